@@ -1,0 +1,222 @@
+// attention.hip - causal grouped-query attention over the float32 KV cache (head_dim 128).
+// Math per transformers eager_attention_forward (oracle/qwen_decoder.py): scores = q.k^T * d^-1/2,
+// float32 softmax, out = P.V; GQA: the n_q/n_kv query heads of a group share one K/V head (repeat_kv).
+//
+// One workgroup = (kv head, query row, key split): the group's G query heads are processed together
+// so each K/V tile is read once per group.  Keys are walked in tiles of 64 with an online softmax:
+//   phase 1  scores: 4 lanes per key (32 dims each, 64-B contiguous per 4 lanes), xor-shuffle reduce
+//   phase 2  one wave per head: tile max / rescale factor / p = exp(s - m) written back to LDS
+//   phase 3  P.V: thread = (dim, key half), V rows read fully coalesced (512 B per 128 lanes)
+// Decode (T = 1) runs n_splits > 1 workgroups per (kv head) to put more CUs on the cache stream and
+// a second kernel merges the (m, l, o) partials; prefill uses n_splits = 1 and normalises in place.
+// The KV cache is float32 on purpose: the parity target is the float32 reference path and the cache
+// is ~1% of decode traffic at the benchmark context.
+#include <math.h>
+
+#include "common.h"
+
+namespace chatts {
+
+constexpr int kMaxGroup = 8;
+constexpr int kTile = 64;
+
+struct AttnParams {
+  const float* qkv;   // [T, (n_q + 2 n_kv) * 128], q already rotated
+  const float* kc;    // [n_kv, max_ctx, 128]
+  const float* vc;
+  float* out;         // [T, n_q * 128]
+  float* part_ml;     // [T, n_q, n_splits, 2]
+  float* part_o;      // [T, n_q, n_splits, 128]
+  const int32_t* pos0_dev;
+  int pos0, t, n_q, n_kv, max_ctx, n_splits;
+};
+
+__global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) float q_s[kMaxGroup * kHeadDim];
+  __shared__ float s_s[kMaxGroup * kTile];
+  __shared__ float alpha_s[kMaxGroup];
+  __shared__ float o_s[kMaxGroup * kHeadDim];
+
+  const int hk = blockIdx.x, row = blockIdx.y, split = blockIdx.z;
+  const int G = p.n_q / p.n_kv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pos = (p.pos0_dev ? *p.pos0_dev : p.pos0) + row;
+  const int heads = p.n_q + 2 * p.n_kv;
+  const float scale = 0.08838834764831845f;   // 128^-1/2
+
+  // q of the G heads of this group -> LDS
+  for (int i = tid; i < G * kHeadDim; i += 256)
+    q_s[i] = p.qkv[((size_t)row * heads + hk * G) * kHeadDim + i];
+  __syncthreads();
+
+  const float* kbase = p.kc + (size_t)hk * p.max_ctx * kHeadDim;
+  const float* vbase = p.vc + (size_t)hk * p.max_ctx * kHeadDim;
+
+  // per-head running statistics live in the wave that owns the head in phase 2 (heads wave, wave+4)
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  float acc[kMaxGroup];
+#pragma unroll
+  for (int g = 0; g < kMaxGroup; ++g) acc[g] = 0.f;
+
+  const int key_l = tid >> 2, quarter = tid & 3;   // phase 1 mapping
+  const int d_o = tid & 127, half = tid >> 7;      // phase 3 mapping
+  const int ntiles = pos / kTile + 1;
+
+  for (int tile = split; tile < ntiles; tile += p.n_splits) {
+    const int j0 = tile * kTile;
+    // ---- phase 1: scores --------------------------------------------------------------------
+    {
+      const int j = j0 + key_l;
+      float dot[kMaxGroup];
+#pragma unroll
+      for (int g = 0; g < kMaxGroup; ++g) dot[g] = 0.f;
+      if (j <= pos) {
+        const float* kr = kbase + (size_t)j * kHeadDim + quarter * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + i * 16);
+#pragma unroll
+          for (int g = 0; g < kMaxGroup; ++g) {
+            if (g < G) {
+              const f32x4 qv = *reinterpret_cast<const f32x4*>(q_s + g * kHeadDim + quarter * 4 + i * 16);
+              dot[g] = fmaf(kv.x, qv.x, dot[g]);
+              dot[g] = fmaf(kv.y, qv.y, dot[g]);
+              dot[g] = fmaf(kv.z, qv.z, dot[g]);
+              dot[g] = fmaf(kv.w, qv.w, dot[g]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < kMaxGroup; ++g) {
+        if (g < G) {
+          float v = dot[g];
+          v += __shfl_xor(v, 1, 64);
+          v += __shfl_xor(v, 2, 64);
+          if (quarter == 0) s_s[g * kTile + key_l] = j <= pos ? v * scale : -INFINITY;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: online softmax statistics, one wave per head ------------------------------------
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      const int g = wave + gi * 4;
+      if (g < G) {
+        const float s = s_s[g * kTile + lane];
+        const float m_new = fmaxf(m_run[gi], wave_max(s));   // finite: key j0 <= pos is always valid
+        const float pr = expf(s - m_new);
+        const float a = expf(m_run[gi] - m_new);             // exp(-inf) = 0 on the first tile
+        l_run[gi] = l_run[gi] * a + wave_sum(pr);
+        m_run[gi] = m_new;
+        s_s[g * kTile + lane] = pr;
+        if (lane == 0) alpha_s[g] = a;
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: o = o * alpha + P.V ---------------------------------------------------------
+    {
+#pragma unroll
+      for (int g = 0; g < kMaxGroup; ++g)
+        if (g < G) acc[g] *= alpha_s[g];
+      const int jb = j0 + half * 32;
+      int jn = pos - jb + 1;
+      if (jn > 32) jn = 32;
+      for (int jj = 0; jj < jn; ++jj) {
+        const float vv = vbase[(size_t)(jb + jj) * kHeadDim + d_o];
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g)
+          if (g < G) acc[g] = fmaf(s_s[g * kTile + half * 32 + jj], vv, acc[g]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- merge the two key halves, then write ------------------------------------------------------
+  if (half == 1) {
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; ++g)
+      if (g < G) o_s[g * kHeadDim + d_o] = acc[g];
+  }
+  // publish l, m through LDS (they live in lanes of the owning wave; every lane holds the same value)
+  if (lane == 0) {
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      const int g = wave + gi * 4;
+      if (g < G) { s_s[g * 2] = m_run[gi]; s_s[g * 2 + 1] = l_run[gi]; }
+    }
+  }
+  __syncthreads();
+  if (half == 0) {
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; ++g) {
+      if (g < G) {
+        const float o = acc[g] + o_s[g * kHeadDim + d_o];
+        const int hq = hk * G + g;
+        if (p.n_splits == 1) {
+          p.out[((size_t)row * p.n_q + hq) * kHeadDim + d_o] = o / s_s[g * 2 + 1];
+        } else {
+          const size_t pi = ((size_t)row * p.n_q + hq) * p.n_splits + split;
+          p.part_o[pi * kHeadDim + d_o] = o;
+          if (d_o == 0) { p.part_ml[pi * 2] = s_s[g * 2]; p.part_ml[pi * 2 + 1] = s_s[g * 2 + 1]; }
+        }
+      }
+    }
+  }
+}
+
+// Merge split partials: out = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s.  One wave-pair per (row, head).
+__global__ __launch_bounds__(128) void attn_combine_kernel(AttnParams p) {
+  const int hq = blockIdx.x, row = blockIdx.y, d = threadIdx.x;
+  const size_t base = ((size_t)row * p.n_q + hq) * p.n_splits;
+  float M = -INFINITY;
+  for (int s = 0; s < p.n_splits; ++s) M = fmaxf(M, p.part_ml[(base + s) * 2]);
+  float num = 0.f, den = 0.f;
+  for (int s = 0; s < p.n_splits; ++s) {
+    const float m = p.part_ml[(base + s) * 2];
+    if (m == -INFINITY) continue;          // split saw no key tile
+    const float w = expf(m - M);
+    num = fmaf(w, p.part_o[(base + s) * kHeadDim + d], num);
+    den = fmaf(w, p.part_ml[(base + s) * 2 + 1], den);
+  }
+  p.out[((size_t)row * p.n_q + hq) * kHeadDim + d] = num / den;
+}
+
+}  // namespace chatts
+
+using namespace chatts;
+
+extern "C" size_t chatts_attn_workspace(int t, int n_q, int n_splits) {
+  if (n_splits <= 1) return 0;
+  return (size_t)t * n_q * n_splits * (kHeadDim + 2) * sizeof(float);
+}
+
+extern "C" int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev,
+                                const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
+                                size_t workspace_bytes, chatts_stream_t stream) {
+  CHATTS_REQUIRE(t >= 0 && n_q > 0 && n_kv > 0 && n_splits >= 1, CHATTS_E_BADARG, "attention: bad sizes");
+  if (t == 0) return CHATTS_OK;
+  CHATTS_REQUIRE(qkv && out && cache && cache->k && cache->v, CHATTS_E_BADARG, "attention: null pointer");
+  CHATTS_REQUIRE(n_q % n_kv == 0 && n_q / n_kv <= kMaxGroup, CHATTS_E_SHAPE,
+                 "attention: GQA group %d/%d unsupported (max %d)", n_q, n_kv, kMaxGroup);
+  if (!pos0_dev)
+    CHATTS_REQUIRE(pos0 >= 0 && pos0 + t <= cache->max_ctx, CHATTS_E_SHAPE, "attention: positions exceed the cache");
+  AttnParams p;
+  p.qkv = qkv; p.kc = cache->k; p.vc = cache->v; p.out = out; p.pos0_dev = pos0_dev; p.pos0 = pos0;
+  p.t = t; p.n_q = n_q; p.n_kv = n_kv; p.max_ctx = cache->max_ctx; p.n_splits = n_splits;
+  p.part_ml = nullptr; p.part_o = nullptr;
+  if (n_splits > 1) {
+    const size_t need = chatts_attn_workspace(t, n_q, n_splits);
+    CHATTS_REQUIRE(workspace && workspace_bytes >= need, CHATTS_E_WORKSPACE,
+                   "attention: needs %zu workspace bytes, got %zu", need, workspace_bytes);
+    p.part_o = reinterpret_cast<float*>(workspace);
+    p.part_ml = p.part_o + (size_t)t * n_q * n_splits * kHeadDim;
+  }
+  hipLaunchKernelGGL(attn_rows_kernel, dim3(n_kv, t, n_splits), dim3(256), 0, as_stream(stream), p);
+  CHATTS_CHECK_LAUNCH("attn_rows");
+  if (n_splits > 1) {
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(n_q, t), dim3(128), 0, as_stream(stream), p);
+    CHATTS_CHECK_LAUNCH("attn_combine");
+  }
+  return CHATTS_OK;
+}

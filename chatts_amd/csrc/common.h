@@ -1,0 +1,91 @@
+// common.h - shared device helpers for the gfx950 kernels (wave64 everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/chatts_amd.h"
+
+namespace chatts {
+
+void set_error(const char* fmt, ...);
+
+#define CHATTS_REQUIRE(cond, code, ...)        \
+  do {                                         \
+    if (!(cond)) {                             \
+      ::chatts::set_error(__VA_ARGS__);        \
+      return (code);                           \
+    }                                          \
+  } while (0)
+
+#define CHATTS_CHECK_LAUNCH(name)                                                  \
+  do {                                                                             \
+    hipError_t e_ = hipGetLastError();                                             \
+    if (e_ != hipSuccess) {                                                        \
+      ::chatts::set_error("%s: launch failed: %s", (name), hipGetErrorString(e_)); \
+      return CHATTS_E_LAUNCH;                                                      \
+    }                                                                              \
+  } while (0)
+
+constexpr int kWave = 64;
+constexpr int kHeadDim = 128;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// round-to-nearest-even float32 -> bfloat16 bits (finite inputs)
+__device__ __host__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  union { float f; uint32_t u; } v;
+  v.f = f;
+  uint32_t u = v.u;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// x = hi + lo (+ eps, |eps| <= 2^-17 |x|): the bf16x2 split of an f32 activation
+__device__ __forceinline__ void split_bf16x2(float x, uint16_t& hi, uint16_t& lo) {
+  hi = f32_to_bf16_rne(x);
+  lo = f32_to_bf16_rne(x - bf16_to_f32(hi));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x == 64*NW; scratch must hold NW floats; all threads get the result
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) scratch[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += scratch[i];
+  __syncthreads();
+  return t;
+}
+
+inline hipStream_t as_stream(chatts_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+int device_cus();
+
+}  // namespace chatts

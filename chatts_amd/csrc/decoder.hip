@@ -1,0 +1,188 @@
+// decoder.hip - host-side composition: chatts_linear dispatch and the Qwen2/Qwen3 decoder schedule.
+// Replaces Qwen2TSForCausalLM.forward / compute_logits (NetManAIOps/ChatTS chatts/vllm/chatts_vllm.py:576-610),
+// whose decoder is vLLM's Qwen2Model (NOT IN REFERENCE); layer math per oracle/qwen_decoder.py.
+// Nothing here allocates device memory or synchronises: every call only enqueues kernels on the
+// caller's stream, so a whole decode step can be captured into one hipGraph and replayed per token.
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace chatts {
+int launch_gemv(const ChattsLinearArgs* a, hipStream_t s);
+int launch_gemm(const ChattsLinearArgs* a, hipStream_t s);
+size_t gemm_workspace(int m, int n, int k);
+}  // namespace chatts
+
+using namespace chatts;
+
+struct ChattsDecoder {
+  ChattsDecoderConfig cfg;
+  ChattsDecoderWeights w;
+  std::vector<ChattsLayerWeights> layers;
+  ChattsDecoderBuffers b;
+};
+
+extern "C" size_t chatts_linear_workspace(int m, int n, int k) { return gemm_workspace(m, n, k); }
+
+extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) {
+  CHATTS_REQUIRE(a != nullptr, CHATTS_E_BADARG, "linear: null args");
+  CHATTS_REQUIRE(a->m >= 0 && a->n > 0 && a->k > 0, CHATTS_E_BADARG, "linear: bad sizes m=%d n=%d k=%d", a->m, a->n, a->k);
+  if (a->m == 0) return CHATTS_OK;
+  CHATTS_REQUIRE(a->a && a->w && a->c, CHATTS_E_BADARG, "linear: null pointer");
+  CHATTS_REQUIRE(a->epilogue >= CHATTS_EPI_NONE && a->epilogue <= CHATTS_EPI_SWIGLU, CHATTS_E_BADARG,
+                 "linear: epilogue %d", a->epilogue);
+  CHATTS_REQUIRE(a->epilogue != CHATTS_EPI_RESID || a->resid, CHATTS_E_BADARG, "linear: EPI_RESID without resid");
+  CHATTS_REQUIRE(a->k % 32 == 0, CHATTS_E_SHAPE, "linear: K=%d must be a multiple of 32 (pad the weight)", a->k);
+  CHATTS_REQUIRE(a->n % 16 == 0 && (a->epilogue != CHATTS_EPI_SWIGLU || a->n % 32 == 0), CHATTS_E_SHAPE,
+                 "linear: N=%d must be a multiple of 16 (32 for SwiGLU)", a->n);
+  CHATTS_REQUIRE(a->lda >= a->k && a->ldw >= a->k && a->lda % 4 == 0 && a->ldw % 8 == 0, CHATTS_E_SHAPE,
+                 "linear: leading dimensions lda=%d ldw=%d", a->lda, a->ldw);
+  const int ncols = a->epilogue == CHATTS_EPI_SWIGLU ? a->n / 2 : a->n;
+  CHATTS_REQUIRE(a->ldc >= ncols, CHATTS_E_SHAPE, "linear: ldc=%d < %d", a->ldc, ncols);
+  CHATTS_REQUIRE(((uintptr_t)a->a % 16) == 0 && ((uintptr_t)a->w % 16) == 0 && ((uintptr_t)a->c % 16) == 0,
+                 CHATTS_E_SHAPE, "linear: pointers must be 16-byte aligned");
+  if (a->m == 1 && a->epilogue != CHATTS_EPI_GELU) return launch_gemv(a, as_stream(stream));
+  CHATTS_REQUIRE(a->norm_w == nullptr, CHATTS_E_BADARG, "linear: fused RMSNorm is only available for M == 1");
+  return launch_gemm(a, as_stream(stream));
+}
+
+extern "C" size_t chatts_decoder_workspace(const ChattsDecoderConfig* c, int t_max, int n_splits_max) {
+  if (!c) return 0;
+  size_t ws = 0;
+  const int qkv_n = (c->n_q + 2 * c->n_kv) * c->head_dim;
+  const int shapes[4][2] = {{qkv_n, c->hidden}, {c->hidden, c->n_q * c->head_dim}, {2 * c->inter, c->hidden},
+                            {c->hidden, c->inter}};
+  for (int t = 2; t <= t_max; ++t) {   // geometry depends on M; take the max over all M (cheap: <= t_max iterations)
+    for (auto& s : shapes) {
+      const size_t w = gemm_workspace(t, s[0], s[1]);
+      if (w > ws) ws = w;
+    }
+  }
+  const size_t aw = chatts_attn_workspace(1, c->n_q, n_splits_max);
+  return (ws > aw ? ws : aw) + 256;
+}
+
+extern "C" ChattsDecoder* chatts_decoder_create(const ChattsDecoderConfig* c, const ChattsDecoderWeights* w,
+                                                const ChattsDecoderBuffers* b) {
+  if (!c || !w || !b || !w->layers) { set_error("decoder_create: null argument"); return nullptr; }
+  if (c->head_dim != kHeadDim) { set_error("decoder_create: head_dim %d != 128", c->head_dim); return nullptr; }
+  if (c->n_q % c->n_kv != 0 || c->n_q / c->n_kv > 8) { set_error("decoder_create: unsupported GQA group"); return nullptr; }
+  if (c->hidden % 32 || c->inter % 32) { set_error("decoder_create: hidden/inter must be multiples of 32"); return nullptr; }
+  ChattsDecoder* d = new (std::nothrow) ChattsDecoder();
+  if (!d) { set_error("decoder_create: out of host memory"); return nullptr; }
+  d->cfg = *c;
+  d->w = *w;
+  d->layers.assign(w->layers, w->layers + c->n_layers);
+  d->w.layers = d->layers.data();
+  d->b = *b;
+  return d;
+}
+
+extern "C" void chatts_decoder_destroy(ChattsDecoder* d) { delete d; }
+
+static ChattsKvCache layer_cache(const ChattsDecoder* d, int layer) {
+  const size_t per = (size_t)d->cfg.n_kv * d->cfg.max_ctx * kHeadDim;
+  ChattsKvCache c;
+  c.k = d->b.kv_k + per * layer;
+  c.v = d->b.kv_v + per * layer;
+  c.max_ctx = d->cfg.max_ctx;
+  return c;
+}
+
+extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, int t, int pos0,
+                                         const int32_t* pos0_dev, int n_splits, chatts_stream_t stream) {
+  CHATTS_REQUIRE(d && layer >= 0 && layer < d->cfg.n_layers && (part == 0 || part == 1), CHATTS_E_BADARG,
+                 "decoder_layer_part: bad arguments");
+  CHATTS_REQUIRE(t >= 1 && t <= d->b.t_max, CHATTS_E_SHAPE, "decoder_layer_part: t=%d exceeds buffers (%d)", t, d->b.t_max);
+  const ChattsDecoderConfig& c = d->cfg;
+  const ChattsLayerWeights& lw = d->layers[layer];
+  const bool tp = c.tp_world > 1;
+  const int H = c.hidden;
+  int rc;
+  ChattsLinearArgs la;
+  if (part == 0) {
+    const int qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim;
+    // RMSNorm -> QKV (+bias).  Decode: norm fused in the GEMV prologue; prefill: separate kernel.
+    la = ChattsLinearArgs{};
+    la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = t; la.n = qkv_n; la.k = H;
+    la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
+    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+    if (t == 1) {
+      la.a = d->b.x; la.norm_w = lw.input_norm; la.norm_eps = c.rms_eps;
+    } else {
+      if ((rc = chatts_rmsnorm(d->b.x, lw.input_norm, d->b.xn, t, H, c.rms_eps, stream)) != 0) return rc;
+      la.a = d->b.xn;
+    }
+    if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+    ChattsKvCache kc = layer_cache(d, layer);
+    if ((rc = chatts_rope_kv_write(d->b.qkv, t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
+                                   d->w.sin_tab, pos0, pos0_dev, &kc, stream)) != 0) return rc;
+    if ((rc = chatts_attention(d->b.qkv, t, c.n_q, c.n_kv, pos0, pos0_dev, &kc, d->b.attn, t == 1 ? n_splits : 1,
+                               d->b.workspace, d->b.workspace_bytes, stream)) != 0) return rc;
+    // o_proj (+ residual, or partial sum for the TP all-reduce)
+    la = ChattsLinearArgs{};
+    la.a = d->b.attn; la.w = lw.o; la.m = t; la.n = H; la.k = c.n_q * kHeadDim;
+    la.lda = la.k; la.ldw = la.k; la.ldc = H;
+    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+    if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
+    else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
+    return chatts_linear(&la, stream);
+  }
+  // part 1: RMSNorm -> gate_up + SwiGLU -> down (+ residual / partial)
+  la = ChattsLinearArgs{};
+  la.w = lw.gate_up; la.c = d->b.act; la.m = t; la.n = 2 * c.inter; la.k = H;
+  la.lda = H; la.ldw = H; la.ldc = c.inter; la.epilogue = CHATTS_EPI_SWIGLU;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  if (t == 1) {
+    la.a = d->b.x; la.norm_w = lw.post_norm; la.norm_eps = c.rms_eps;
+  } else {
+    if ((rc = chatts_rmsnorm(d->b.x, lw.post_norm, d->b.xn, t, H, c.rms_eps, stream)) != 0) return rc;
+    la.a = d->b.xn;
+  }
+  if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+  la = ChattsLinearArgs{};
+  la.a = d->b.act; la.w = lw.down; la.m = t; la.n = H; la.k = c.inter;
+  la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
+  else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
+  return chatts_linear(&la, stream);
+}
+
+extern "C" int chatts_decoder_prefill(ChattsDecoder* d, int t, int pos0, chatts_stream_t stream) {
+  CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_prefill: null decoder");
+  CHATTS_REQUIRE(d->cfg.tp_world == 1, CHATTS_E_BADARG, "decoder_prefill: TP>1 must drive chatts_decoder_layer_part");
+  for (int l = 0; l < d->cfg.n_layers; ++l) {
+    int rc;
+    if ((rc = chatts_decoder_layer_part(d, l, 0, t, pos0, nullptr, 1, stream)) != 0) return rc;
+    if ((rc = chatts_decoder_layer_part(d, l, 1, t, pos0, nullptr, 1, stream)) != 0) return rc;
+  }
+  return CHATTS_OK;
+}
+
+extern "C" int chatts_decoder_logits(ChattsDecoder* d, int row, chatts_stream_t stream) {
+  CHATTS_REQUIRE(d && row >= 0 && row < d->b.t_max, CHATTS_E_BADARG, "decoder_logits: bad row");
+  const ChattsDecoderConfig& c = d->cfg;
+  ChattsLinearArgs la{};
+  la.a = d->b.x + (size_t)row * c.hidden; la.w = d->w.lm_head; la.c = d->b.logits;
+  la.m = 1; la.n = (int)c.vocab_local; la.k = c.hidden; la.lda = c.hidden; la.ldw = c.hidden; la.ldc = (int)c.vocab_local;
+  la.epilogue = CHATTS_EPI_NONE; la.norm_w = d->w.final_norm; la.norm_eps = c.rms_eps;
+  return chatts_linear(&la, stream);
+}
+
+extern "C" int chatts_decoder_decode_step(ChattsDecoder* d, int32_t* pos_dev, int32_t* step_dev, int64_t* token_dev,
+                                          float* token_logit_dev, int64_t* out_tokens, int n_splits,
+                                          chatts_stream_t stream) {
+  CHATTS_REQUIRE(d && pos_dev && step_dev && token_dev, CHATTS_E_BADARG, "decode_step: null argument");
+  CHATTS_REQUIRE(d->cfg.tp_world == 1, CHATTS_E_BADARG, "decode_step: TP>1 must drive chatts_decoder_layer_part");
+  int rc;
+  for (int l = 0; l < d->cfg.n_layers; ++l) {
+    if ((rc = chatts_decoder_layer_part(d, l, 0, 1, 0, pos_dev, n_splits, stream)) != 0) return rc;
+    if ((rc = chatts_decoder_layer_part(d, l, 1, 1, 0, pos_dev, n_splits, stream)) != 0) return rc;
+  }
+  if ((rc = chatts_decoder_logits(d, 0, stream)) != 0) return rc;
+  if ((rc = chatts_argmax(d->b.logits, d->cfg.vocab_local, d->cfg.vocab_offset, token_dev, token_logit_dev, out_tokens,
+                          step_dev, pos_dev, stream)) != 0) return rc;
+  return chatts_embed_token(token_dev, d->w.embed, d->cfg.vocab_offset, d->cfg.vocab_local, d->cfg.hidden, d->b.x, stream);
+}

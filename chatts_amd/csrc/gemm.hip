@@ -1,0 +1,291 @@
+// gemm.hip - prefill / TS-encoder projections:  C[M,N] = epilogue(A[M,K] . W[N,K]^T)
+// A float32 activations, W bfloat16 weights (HF nn.Linear layout, K contiguous for both operands).
+//
+// Precision scheme "bf16x2": the reference path we must match is float32 (1e-3 relative on logits,
+// identical greedy tokens).  Weights are bf16 by definition, so only A needs care: each f32 element
+// is split while it is staged into LDS,  a = hi + lo,  hi = bf16(a), lo = bf16(a - hi), and the
+// wave issues two v_mfma_f32_16x16x32_bf16 per fragment pair (hi.W, lo.W) into ONE f32 accumulator.
+// The W tile is staged and read once; products are exact (8b x 8b mantissas), accumulation is f32.
+//
+// Geometry: 256 threads = 4 waves (WM x WN), tile BM x 128, BK = 32, double-buffered LDS,
+// register-staged global loads issued one K-step ahead, one barrier per K-step.
+// LDS rows are 64 B (32 bf16); 16-byte chunk c of row r lives at chunk c ^ (((r>>3)&1)<<1), which
+// makes every ds_read_b128 fragment read conflict-free (checked exhaustively over the 4 lane groups).
+// Split-K (grid.z) fills the 256 CUs when M is small; partials go to a workspace and a second kernel
+// applies the epilogue.
+#include "common.h"
+
+namespace chatts {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+struct GemmParams {
+  const float* a;
+  const uint16_t* w;
+  const float* bias;
+  const float* resid;
+  float* c;          // final output, or split-K partials [sk][M][N]
+  int m, n, k, lda, ldw, ldc, epilogue;
+  int k_per_split;   // multiple of 32
+  int direct;        // 1: apply epilogue here; 0: write raw partials
+};
+
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu_g(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ int lds_off(int r, int c) {   // byte offset of 16-byte chunk c of row r
+  return r * 64 + ((c ^ (((r >> 3) & 1) << 1)) << 4);
+}
+
+template <int BM, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
+  constexpr int BN = 128, BK = 32;
+  constexpr int TM = BM / WM, TN = BN / WN;     // wave tile
+  constexpr int FM = TM / 16, FN = TN / 16;     // 16x16 fragments per wave
+  constexpr int A_ITERS = (BM * 4 + 255) / 256; // each thread-slot stages 8 floats of one A row
+  constexpr int STAGE = BM * 64 * 2 + BN * 64;  // bytes: A_hi, A_lo, B
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * p.k_per_split;
+  int kend = kbeg + p.k_per_split;
+  if (kend > p.k) kend = p.k;
+  const int nk = (kend - kbeg) / BK;
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging registers
+  f32x4 ra[A_ITERS][2];
+  u32x4 rb[2];
+  const int srow = tid >> 2, schunk = tid & 3;
+
+  auto load_global = [&](int kt) {
+    const int k0 = kbeg + kt * BK + schunk * 8;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int r = srow + i * 64;
+      ra[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      ra[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (r < BM && m0 + r < p.m) {
+        const float* src = p.a + (size_t)(m0 + r) * p.lda + k0;
+        ra[i][0] = *reinterpret_cast<const f32x4*>(src);
+        ra[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = srow + i * 64;
+      rb[i] = (u32x4){0u, 0u, 0u, 0u};
+      if (n0 + r < p.n) rb[i] = *reinterpret_cast<const u32x4*>(p.w + (size_t)(n0 + r) * p.ldw + k0);
+    }
+  };
+
+  auto store_lds = [&](int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int r = srow + i * 64;
+      if (r < BM) {
+        const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w,
+                            ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint16_t h0, l0, h1, l1;
+          split_bf16x2(v[2 * j], h0, l0);
+          split_bf16x2(v[2 * j + 1], h1, l1);
+          hi[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+          lo[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        }
+        const int off = lds_off(r, schunk);
+        *reinterpret_cast<u32x4*>(base + off) = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(base + BM * 64 + off) = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = srow + i * 64;
+      *reinterpret_cast<u32x4*>(base + BM * 128 + lds_off(r, schunk)) = rb[i];
+    }
+  };
+
+  if (nk > 0) {
+    load_global(0);
+    store_lds(0);
+  }
+  __syncthreads();
+
+  const int frow = lane & 15, fchunk = lane >> 4;   // fragment: row (A) / col (B) and 8-wide K chunk
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_global(kt + 1);
+    const char* base = smem + (kt & 1) * STAGE;
+    bf16x8_t bfrag[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      bfrag[j] = *reinterpret_cast<const bf16x8_t*>(base + BM * 128 + lds_off(wn * TN + j * 16 + frow, fchunk));
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int off = lds_off(wm * TM + i * 16 + frow, fchunk);
+      const bf16x8_t ahi = *reinterpret_cast<const bf16x8_t*>(base + off);
+      const bf16x8_t alo = *reinterpret_cast<const bf16x8_t*>(base + BM * 64 + off);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bfrag[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bfrag[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) store_lds((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg -----------
+  const int ccol = lane & 15, crow0 = (lane >> 4) * 4;
+  if (!p.direct) {
+    float* ws = p.c + (size_t)blockIdx.z * p.m * p.n;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wn * TN + j * 16 + ccol;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * TM + i * 16 + crow0 + r;
+          if (row < p.m && col < p.n) ws[(size_t)row * p.n + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  if (p.epilogue == CHATTS_EPI_SWIGLU) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; j += 2) {
+        const int prow = n0 + wn * TN + j * 16 + ccol;   // packed gate row; up row = prow + 16
+        const int ocol = (prow >> 5) * 16 + ccol;
+        if (prow + 16 < p.n) {
+          const float bg = p.bias ? p.bias[prow] : 0.f, bu = p.bias ? p.bias[prow + 16] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * TM + i * 16 + crow0 + r;
+            if (row < p.m) p.c[(size_t)row * p.ldc + ocol] = silu_g(acc[i][j][r] + bg) * (acc[i][j + 1][r] + bu);
+          }
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * TN + j * 16 + ccol;
+      if (col >= p.n) continue;
+      const float b = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * TM + i * 16 + crow0 + r;
+        if (row >= p.m) continue;
+        float v = acc[i][j][r] + b;
+        if (p.epilogue == CHATTS_EPI_GELU) v = gelu_erf_f(v);
+        if (p.epilogue == CHATTS_EPI_RESID) v = p.resid[(size_t)row * p.ldc + col] + v;
+        p.c[(size_t)row * p.ldc + col] = v;
+      }
+    }
+}
+
+// Sum split-K partials in a fixed order and apply the epilogue.  One thread per output element.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ ws, int sk, int m, int n,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ resid, float* __restrict__ c,
+                                                             int ldc, int epilogue) {
+  const int ncols = epilogue == CHATTS_EPI_SWIGLU ? n / 2 : n;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)m * ncols) return;
+  const int row = (int)(idx / ncols), col = (int)(idx % ncols);
+  const size_t plane = (size_t)m * n;
+  if (epilogue == CHATTS_EPI_SWIGLU) {
+    const int prow = (col >> 4) * 32 + (col & 15);
+    float g = 0.f, u = 0.f;
+    for (int s = 0; s < sk; ++s) {
+      g += ws[s * plane + (size_t)row * n + prow];
+      u += ws[s * plane + (size_t)row * n + prow + 16];
+    }
+    if (bias) { g += bias[prow]; u += bias[prow + 16]; }
+    c[(size_t)row * ldc + col] = silu_g(g) * u;
+    return;
+  }
+  float v = 0.f;
+  for (int s = 0; s < sk; ++s) v += ws[s * plane + (size_t)row * n + col];
+  if (bias) v += bias[col];
+  if (epilogue == CHATTS_EPI_GELU) v = gelu_erf_f(v);
+  if (epilogue == CHATTS_EPI_RESID) v = resid[(size_t)row * ldc + col] + v;
+  c[(size_t)row * ldc + col] = v;
+}
+
+static void pick_geometry(int m, int n, int k, int& bm, int& sk) {
+  bm = m > 64 ? 128 : (m > 32 ? 64 : (m > 16 ? 32 : 16));
+  const int tiles = ((m + bm - 1) / bm) * ((n + 127) / 128);
+  const int target = 2 * device_cus();
+  sk = 1;
+  if (tiles < target) {
+    sk = (target + tiles - 1) / tiles;
+    const int max_sk = k / 256 > 0 ? k / 256 : 1;   // keep >= 8 K-steps per split
+    if (sk > max_sk) sk = max_sk;
+    if (sk > 16) sk = 16;
+  }
+}
+
+static int k_per_split(int k, int sk) {
+  int kps = (k + sk - 1) / sk;
+  return ((kps + 31) / 32) * 32;
+}
+
+size_t gemm_workspace(int m, int n, int k) {
+  if (m <= 1) return 0;
+  int bm, sk;
+  pick_geometry(m, n, k, bm, sk);
+  return sk > 1 ? (size_t)sk * m * n * sizeof(float) : 0;
+}
+
+int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
+  int bm, sk;
+  pick_geometry(a->m, a->n, a->k, bm, sk);
+  const int kps = k_per_split(a->k, sk);
+  sk = (a->k + kps - 1) / kps;
+  GemmParams p;
+  p.a = a->a; p.w = a->w; p.bias = a->bias; p.resid = a->resid;
+  p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
+  p.epilogue = a->epilogue; p.k_per_split = kps; p.direct = sk == 1;
+  if (sk > 1) {
+    const size_t need = (size_t)sk * a->m * a->n * sizeof(float);
+    CHATTS_REQUIRE(a->workspace && a->workspace_bytes >= need, CHATTS_E_WORKSPACE,
+                   "linear: split-K needs %zu workspace bytes, got %zu", need, a->workspace_bytes);
+    p.c = reinterpret_cast<float*>(a->workspace);
+  } else {
+    p.c = a->c;
+  }
+  dim3 grid((a->n + 127) / 128, (a->m + bm - 1) / bm, sk), block(256);
+  switch (bm) {
+    case 128: hipLaunchKernelGGL((gemm_bf16x2_kernel<128, 2, 2>), grid, block, 0, s, p); break;
+    case 64: hipLaunchKernelGGL((gemm_bf16x2_kernel<64, 2, 2>), grid, block, 0, s, p); break;
+    case 32: hipLaunchKernelGGL((gemm_bf16x2_kernel<32, 1, 4>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((gemm_bf16x2_kernel<16, 1, 4>), grid, block, 0, s, p); break;
+  }
+  CHATTS_CHECK_LAUNCH("gemm_bf16x2");
+  if (sk > 1) {
+    const int ncols = a->epilogue == CHATTS_EPI_SWIGLU ? a->n / 2 : a->n;
+    const size_t total = (size_t)a->m * ncols;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float*>(a->workspace), sk, a->m, a->n, a->bias, a->resid, a->c,
+                       a->ldc, a->epilogue);
+    CHATTS_CHECK_LAUNCH("splitk_epilogue");
+  }
+  return CHATTS_OK;
+}
+
+}  // namespace chatts

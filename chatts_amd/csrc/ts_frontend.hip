@@ -1,0 +1,115 @@
+// ts_frontend.hip - sp-masked patchify of the padded [N, 2*Lmax] (value, mask) series tensor.
+// Replaces the per-series Python loop of TimeSeriesEmbedding.forward
+// (NetManAIOps/ChatTS chatts/vllm/chatts_vllm.py:93-183): there, 2 .item() host syncs and ~10 tiny
+// torch ops per series; here one wave per series for the mask reduction and one wave per patch for
+// the feature row, no host sync.
+#include "common.h"
+
+namespace chatts {
+
+// One wave per series: valid_len = sum(long(mask)) (chatts_vllm.py:98-99), patch_cnt = ceil(vl/ps).
+// The (value, mask) pairs are read as float2 -> each lane streams 8 B, 512 B per wave instruction.
+__global__ __launch_bounds__(256) void ts_patch_cnt_kernel(const float* __restrict__ series, int n_series,
+                                                          int lmax, int patch, int32_t* __restrict__ vl_out,
+                                                          int64_t* __restrict__ pc_out) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n_series) return;
+  const float2* row = reinterpret_cast<const float2*>(series) + (size_t)wave * lmax;
+  int cnt = 0;
+  for (int t = lane; t < lmax; t += 64) cnt += (int)(long long)row[t].y;  // .long(): truncate toward zero
+  cnt = wave_sum_i(cnt);
+  if (lane == 0) {
+    if (vl_out) vl_out[wave] = cnt;
+    if (pc_out) pc_out[wave] = (int64_t)((cnt + patch - 1) / patch);
+  }
+}
+
+// One wave per output patch row.  Lanes 0..ps-1 own the ps values of the patch; in mode 1 every lane
+// then copies position-embedding elements (ps*emb contiguous floats in the output row).
+// The series owning patch row `p` is found by a binary search over row_off (N+1 ints, L2/L1 resident).
+__global__ __launch_bounds__(256) void ts_patchify_kernel(ChattsPatchifyArgs a) {
+  const int p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (p >= a.total_patches) return;
+  int lo = 0, hi = a.n_series;  // largest s with row_off[s] <= p
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.row_off[mid] <= p) lo = mid; else hi = mid;
+  }
+  const int s = lo;
+  const int vl = a.valid_len[s];
+  const int pp = p - a.row_off[s];          // patch index inside the series
+  const int ps = a.patch_size;
+  const float2* row = reinterpret_cast<const float2*>(a.series) + (size_t)s * a.lmax;
+  float* out = a.out + (size_t)p * a.ld_out;
+  const int t0 = pp * ps;
+  const float last = row[vl - 1].x;          // last VALID value (chatts_vllm.py:122); vl >= 1 here
+  int feat;
+  if (a.mode == 1) {
+    feat = ps + ps * a.emb_dim;
+    if (lane < ps) {
+      const int t = t0 + lane;
+      out[lane] = t < vl ? row[t].x : last;
+    }
+    // out[ps + j*emb + e] = pos_table[idx_j][e], idx_j = t0+j if valid else padding_idx (= max_seq_len)
+    for (int q = lane; q < ps * a.emb_dim; q += 64) {
+      const int j = q / a.emb_dim, e = q - j * a.emb_dim;
+      const int t = t0 + j;
+      const int idx = t < vl ? t : a.max_seq_len;
+      out[ps + q] = a.pos_table[(size_t)idx * a.emb_dim + e];
+    }
+  } else if (a.mode == 2) {
+    feat = 2 * ps;
+    if (lane < ps) {
+      const int t = t0 + lane;
+      const int den = a.max_valid_len - 1 > 1 ? a.max_valid_len - 1 : 1;   // max(1, max_vl-1), :147
+      out[2 * lane] = t < vl ? row[t].x : last;
+      out[2 * lane + 1] = t < vl ? (float)t / (float)den : -1.0f;
+    }
+  } else {
+    feat = ps;
+    if (lane < ps) {
+      const int t = t0 + lane;
+      out[lane] = t < vl ? row[t].x : last;
+    }
+  }
+  for (int q = feat + lane; q < a.ld_out; q += 64) out[q] = 0.f;   // K padding for the MFMA GEMM
+}
+
+}  // namespace chatts
+
+using namespace chatts;
+
+extern "C" int chatts_ts_patch_cnt(const float* series, int n_series, int lmax, int patch_size,
+                                   int32_t* valid_len, int64_t* patch_cnt, chatts_stream_t stream) {
+  CHATTS_REQUIRE(n_series >= 0 && lmax >= 0 && patch_size > 0, CHATTS_E_BADARG,
+                 "ts_patch_cnt: bad sizes n=%d lmax=%d patch=%d", n_series, lmax, patch_size);
+  if (n_series == 0) return CHATTS_OK;
+  CHATTS_REQUIRE(series != nullptr || lmax == 0, CHATTS_E_BADARG, "ts_patch_cnt: null series");
+  CHATTS_REQUIRE(valid_len || patch_cnt, CHATTS_E_BADARG, "ts_patch_cnt: no output");
+  const int blocks = (n_series + 3) / 4;
+  hipLaunchKernelGGL(ts_patch_cnt_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), series, n_series,
+                     lmax, patch_size, valid_len, patch_cnt);
+  CHATTS_CHECK_LAUNCH("ts_patch_cnt");
+  return CHATTS_OK;
+}
+
+extern "C" int chatts_ts_patchify(const ChattsPatchifyArgs* a, chatts_stream_t stream) {
+  CHATTS_REQUIRE(a != nullptr, CHATTS_E_BADARG, "ts_patchify: null args");
+  CHATTS_REQUIRE(a->total_patches >= 0 && a->n_series >= 0, CHATTS_E_BADARG, "ts_patchify: negative size");
+  if (a->total_patches == 0) return CHATTS_OK;
+  CHATTS_REQUIRE(a->series && a->row_off && a->valid_len && a->out, CHATTS_E_BADARG, "ts_patchify: null pointer");
+  CHATTS_REQUIRE(a->patch_size > 0 && a->patch_size <= 64, CHATTS_E_SHAPE, "ts_patchify: patch_size %d not in 1..64",
+                 a->patch_size);
+  CHATTS_REQUIRE(a->mode >= 0 && a->mode <= 2, CHATTS_E_BADARG, "ts_patchify: mode %d", a->mode);
+  const int feat = a->mode == 1 ? a->patch_size * (1 + a->emb_dim) : (a->mode == 2 ? 2 * a->patch_size : a->patch_size);
+  CHATTS_REQUIRE(a->ld_out >= feat, CHATTS_E_SHAPE, "ts_patchify: ld_out %d < features %d", a->ld_out, feat);
+  if (a->mode == 1)
+    CHATTS_REQUIRE(a->pos_table && a->emb_dim > 0 && a->max_seq_len > 0, CHATTS_E_BADARG,
+                   "ts_patchify: position table missing");
+  const int blocks = (a->total_patches + 3) / 4;
+  hipLaunchKernelGGL(ts_patchify_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), *a);
+  CHATTS_CHECK_LAUNCH("ts_patchify");
+  return CHATTS_OK;
+}

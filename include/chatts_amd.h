@@ -1,0 +1,249 @@
+/*
+ * chatts_amd.h - C-ABI of libchatts_amd.so: the MI355X (gfx950) ChatTS inference hot path.
+ *
+ * Every entry point is extern "C", takes plain pointers + sizes + a hipStream_t passed as void*,
+ * NEVER allocates, frees or synchronises (graph-capturable), and returns 0 or a negative
+ * CHATTS_E_* code; chatts_last_error() returns a thread-local message for the last failure.
+ * Device pointers are owned by the caller (PyTorch-ROCm is used purely as the allocator).
+ *
+ * Each function cites the reference interface (file:line under NetManAIOps/ChatTS) it replaces.
+ * Number formats: activations / residual stream / KV cache / logits are float32; weights are
+ * bfloat16 (uint16_t bit patterns) streamed from HBM; every weight x activation product is formed
+ * either exactly on the f32 VALU (decode, M<=4) or by two bf16 MFMA passes over a hi/lo split of the
+ * f32 activation ("bf16x2", prefill) - see DESIGN.md section 3 for why (1e-3 logit tolerance).
+ */
+#ifndef CHATTS_AMD_H
+#define CHATTS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHATTS_OK 0
+#define CHATTS_E_BADARG (-1)          /* null pointer, negative size, unsupported dimension          */
+#define CHATTS_E_SHAPE (-2)           /* shape constraint violated (alignment, head_dim != 128, ...) */
+#define CHATTS_E_COUNT_MISMATCH (-3)  /* #<ts> placeholders != #TS rows (vLLM raises ValueError)     */
+#define CHATTS_E_LAUNCH (-4)          /* hipLaunchKernel / hipGetLastError failed                    */
+#define CHATTS_E_WORKSPACE (-5)       /* caller-supplied workspace too small                         */
+
+typedef void* chatts_stream_t; /* hipStream_t */
+typedef uint16_t chatts_bf16;  /* raw bfloat16 bits */
+
+const char* chatts_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int chatts_abi_version(void);
+/* Number of CUs of the current device (grid sizing), or <0. */
+int chatts_device_cus(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Synthetic weights.  No reference twin: checkpoints cannot travel to the GPU box, so weights are
+ * DEFINED by a counter-based integer hash that oracle/synth.py evaluates bit-identically on the host.
+ *   value(i) = bf16_rne(base + n(i) * 2^-shift),  n(i) = b0+b1+b2+b3-510 over the 4 bytes of
+ *   mix32(lo32(i) ^ mix32(key + hi32(i)*0x85ebca6b)),  i = (row0+r)*full_cols + (col0+c)
+ * Writes a [rows, cols] block (leading dimension ld elements) of the full tensor; out_f32 != 0 stores
+ * the bf16-rounded value widened to float32.
+ * ------------------------------------------------------------------------------------------- */
+int chatts_fill_hash(void* dst, int out_f32, uint32_t key, float base, int shift, int64_t rows,
+                     int64_t cols, int64_t ld, int64_t row0, int64_t col0, int64_t full_cols,
+                     chatts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Time-series encoder front end.
+ * Replaces TimeSeriesEmbedding.forward's per-series Python loop (chatts/vllm/chatts_vllm.py:93-183)
+ * and get_patch_cnt (:198-207).
+ * ------------------------------------------------------------------------------------------- */
+
+/* valid_len[i] = sum(long(mask_i)), patch_cnt[i] = ceil(valid_len/patch) from the padded
+ * [N, 2*Lmax] (value, mask)-interleaved float32 tensor (chatts_vllm.py:94-100 / :198-207).
+ * One wave per series, wave-shuffle reduction.  patch_cnt is int64 like the reference's. */
+int chatts_ts_patch_cnt(const float* series, int n_series, int lmax, int patch_size,
+                        int32_t* valid_len, int64_t* patch_cnt, chatts_stream_t stream);
+
+/* mode: 0 = raw patches [P,16]; 1 = use_position_embedding [P,16+16*emb]; 2 = use_position_idx [P,32] */
+typedef struct ChattsPatchifyArgs {
+  const float* series;     /* [N, 2*Lmax] float32, (value, mask) interleaved, zero padded (:78-84) */
+  const int32_t* row_off;  /* device [N+1]: exclusive scan of patch_cnt (first output row of series i) */
+  const int32_t* valid_len;/* device [N] (from chatts_ts_patch_cnt or the host processor)            */
+  const float* pos_table;  /* mode 1: [max_seq_len+1, emb_dim] float32 (position_embedding.weight)   */
+  float* out;              /* [P, ld_out] float32; columns [feat, ld_out) are zero filled            */
+  int n_series, lmax, patch_size, mode, emb_dim, max_seq_len;
+  int max_valid_len;       /* mode 2 only: max_i valid_len (chatts_vllm.py:146)                      */
+  int total_patches;       /* P = row_off[N], known on the host                                      */
+  int ld_out;              /* >= feature count, multiple of 32 (K padding for the MFMA GEMM)         */
+} ChattsPatchifyArgs;
+/* Builds the MLP input rows: values of patch p of series i, tail padded with the LAST VALID value
+ * (:121-125), followed by the position-embedding rows of indices 16p..16p+15 with padding_idx =
+ * max_seq_len for pad slots (:119,128-129,161-181).  One wave per patch, coalesced row reads. */
+int chatts_ts_patchify(const ChattsPatchifyArgs* args, chatts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Linear layers:  C[M,N] = epilogue(A[M,K] . W[N,K]^T)   A,C float32, W bfloat16 row-major [N,K]
+ * (the HF nn.Linear.weight layout).  Replaces every nn.Linear the path executes:
+ * TimeSeriesEmbedding.mlp (chatts_vllm.py:83-91,188), Qwen2 q/k/v/o/gate/up/down/lm_head
+ * (vLLM / transformers, NOT IN REFERENCE; math per oracle/qwen_decoder.py).
+ * ------------------------------------------------------------------------------------------- */
+#define CHATTS_EPI_NONE 0     /* C = acc (+bias)                                                    */
+#define CHATTS_EPI_GELU 1     /* C = gelu_erf(acc + bias)                (nn.GELU(), :87)           */
+#define CHATTS_EPI_RESID 2    /* C = resid + acc (+bias); C may alias resid                         */
+#define CHATTS_EPI_SWIGLU 3   /* W rows are gate/up interleaved in blocks of 16 rows;               */
+                              /* C[M,N/2] = silu(gate) * up            (Qwen2MLP.forward)           */
+
+typedef struct ChattsLinearArgs {
+  const float* a;          /* [M, lda] */
+  const chatts_bf16* w;    /* [N, ldw] */
+  const float* bias;       /* [N] or NULL (for SWIGLU: interleaved like the rows) */
+  const float* resid;      /* EPI_RESID: [M, ldc] */
+  float* c;                /* [M, ldc]  (SWIGLU: [M, N/2]) */
+  /* optional fused RMSNorm on the rows of A (decode path, M <= 4 only):
+   *   a_used[m,k] = norm_w[k] * (a[m,k] * rsqrt(mean_k(a[m,:]^2) + eps))   (Qwen2RMSNorm.forward) */
+  const float* norm_w;     /* [K] or NULL */
+  float norm_eps;
+  int m, n, k, lda, ldw, ldc, epilogue;
+  void* workspace;         /* split-K partials; may be NULL when chatts_linear_workspace() == 0 */
+  size_t workspace_bytes;
+} ChattsLinearArgs;
+size_t chatts_linear_workspace(int m, int n, int k);
+/* Dispatch: M <= 4 -> weight-streaming GEMV (exact f32 VALU products, HBM-bound);
+ *           M  > 4 -> LDS-tiled MFMA GEMM, v_mfma_f32_16x16x32_bf16, bf16x2 split of A. */
+int chatts_linear(const ChattsLinearArgs* args, chatts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Embedding gather + TS merge.  Replaces get_input_embeddings (chatts_vllm.py:564-574) =
+ * embed_tokens(ids) then vLLM merge_multimodal_embeddings: rows whose id == ts_token_id are
+ * overwritten, in order, by the TS rows.  ids_host (optional) lets the count check run on the host
+ * and return CHATTS_E_COUNT_MISMATCH without a device sync; with ids_host == NULL a mismatch is
+ * recorded in *dev_status (bit 0) instead.  ts_rows == NULL / n_ts_rows == 0: plain gather.
+ * ------------------------------------------------------------------------------------------- */
+int chatts_embed_merge(const int64_t* ids_dev, const int64_t* ids_host, int t, const chatts_bf16* table,
+                       int64_t vocab, int hidden, const float* ts_rows, int n_ts_rows,
+                       int64_t ts_token_id, float* out, int32_t* scratch /* [t+1] */,
+                       int32_t* dev_status, chatts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Decoder pieces (Qwen2 / Qwen3; NOT IN REFERENCE, selected at chatts_vllm.py:483-488,:664-669).
+ * ------------------------------------------------------------------------------------------- */
+
+/* y[t,:] = w * (x[t,:] * rsqrt(mean(x[t,:]^2) + eps))            (Qwen2RMSNorm.forward) */
+int chatts_rmsnorm(const float* x, const float* w, float* y, int t, int hidden, float eps,
+                   chatts_stream_t stream);
+
+typedef struct ChattsKvCache {
+  float* k;                /* [n_kv, max_ctx, 128] float32 of ONE layer of ONE sequence */
+  float* v;
+  int max_ctx;
+} ChattsKvCache;
+
+/* In-place on qkv [T, (n_q+2*n_kv)*128] (after bias): optional per-head RMSNorm of q and k (Qwen3
+ * q_norm/k_norm, NULL for Qwen2), NeoX rotate-half RoPE at positions pos0..pos0+T-1 (pos0 read from
+ * *pos0_dev when pos0_dev != NULL, so a captured graph can be replayed), then k and v rows are
+ * written into the cache at those positions.  cos/sin from the float32 table [max_pos, 64]. */
+int chatts_rope_kv_write(float* qkv, int t, int n_q, int n_kv, const float* q_norm_w,
+                         const float* k_norm_w, float norm_eps, const float* cos_tab,
+                         const float* sin_tab, int pos0, const int32_t* pos0_dev,
+                         const ChattsKvCache* cache, chatts_stream_t stream);
+
+/* Causal GQA attention of T query rows (positions pos0..pos0+T-1) against cache rows [0, pos].
+ * q is read from qkv [T, (n_q+2*n_kv)*128]; out [T, n_q*128].  float32 scores, softmax and PV.
+ * n_splits > 1 (decode): keys are strided over n_splits workgroups per (row, kv-head), partials go
+ * to workspace and are combined by a second kernel.  workspace >= chatts_attn_workspace(). */
+size_t chatts_attn_workspace(int t, int n_q, int n_splits);
+int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev,
+                     const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
+                     size_t workspace_bytes, chatts_stream_t stream);
+
+/* logits [V] float32 -> *token (first index of the maximum, like torch.argmax); optionally also
+ * appends the token to out_tokens[*step_dev] and increments *step_dev and *pos_dev (decode loop
+ * state kept on the device so that a hipGraph of one decode step is replayable). */
+int chatts_argmax(const float* logits, int64_t vocab, int64_t vocab_offset, int64_t* token,
+                  float* token_logit, int64_t* out_tokens, int32_t* step_dev, int32_t* pos_dev,
+                  chatts_stream_t stream);
+
+/* x[h] = float(table[*token, h]) : next-step input embedding, token id read on the device. */
+int chatts_embed_token(const int64_t* token_dev, const chatts_bf16* table, int64_t vocab_offset,
+                       int64_t vocab_rows, int hidden, float* out, chatts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole decoder (TP rank-local).  Replaces Qwen2TSForCausalLM.forward / compute_logits
+ * (chatts_vllm.py:576-610).  Weight pointers are BORROWED for the life of the handle.
+ * Packed layouts (cf. packed_modules_mapping, chatts_vllm.py:454-464):
+ *   qkv  [ (n_q + 2*n_kv)*128, H ]   rows = q heads | k heads | v heads of THIS rank
+ *   gate_up [ 2*I_local, H ]          gate/up interleaved in blocks of 16 rows
+ *   o    [ H, n_q*128 ]  down [ H, I_local ]   (row-parallel: this rank's K-slice, ld = local K)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ChattsLayerWeights {
+  const float* input_norm;      /* [H] */
+  const chatts_bf16* qkv;       /* packed */
+  const float* qkv_bias;        /* [(n_q+2n_kv)*128] or NULL (Qwen3) */
+  const float* q_norm;          /* [128] or NULL (Qwen2) */
+  const float* k_norm;
+  const chatts_bf16* o;
+  const float* post_norm;       /* [H] */
+  const chatts_bf16* gate_up;
+  const chatts_bf16* down;
+} ChattsLayerWeights;
+
+typedef struct ChattsDecoderConfig {
+  int hidden, n_layers, n_q, n_kv, head_dim, inter;   /* n_q, n_kv, inter are RANK-LOCAL sizes */
+  int64_t vocab_local, vocab_offset;                  /* this rank's slice of lm_head / embed   */
+  float rms_eps;
+  int max_ctx, max_pos;
+  int tp_world;                                       /* > 1: o/down outputs are partial sums   */
+} ChattsDecoderConfig;
+
+typedef struct ChattsDecoderWeights {
+  const ChattsLayerWeights* layers;  /* host array [n_layers] */
+  const float* final_norm;           /* [H] */
+  const chatts_bf16* lm_head;        /* [vocab_local, H] */
+  const chatts_bf16* embed;          /* [vocab_local, H] */
+  const float* cos_tab;              /* [max_pos, 64] */
+  const float* sin_tab;
+} ChattsDecoderWeights;
+
+typedef struct ChattsDecoderBuffers {
+  float* kv_k;        /* [n_layers, n_kv, max_ctx, 128] */
+  float* kv_v;
+  float* x;           /* [T_max, H] residual stream */
+  float* xn;          /* [T_max, H] normed scratch (prefill) */
+  float* qkv;         /* [T_max, (n_q+2n_kv)*128] */
+  float* attn;        /* [T_max, n_q*128] */
+  float* act;         /* [T_max, inter] */
+  float* delta;       /* [T_max, H] partial sums when tp_world > 1 */
+  float* logits;      /* [vocab_local] */
+  void* workspace;    /* split-K + attention partials */
+  size_t workspace_bytes;
+  int t_max;
+} ChattsDecoderBuffers;
+
+typedef struct ChattsDecoder ChattsDecoder;  /* opaque; host memory only */
+ChattsDecoder* chatts_decoder_create(const ChattsDecoderConfig*, const ChattsDecoderWeights*,
+                                     const ChattsDecoderBuffers*);
+void chatts_decoder_destroy(ChattsDecoder*);
+size_t chatts_decoder_workspace(const ChattsDecoderConfig*, int t_max, int n_splits_max);
+
+/* One layer, split at the two tensor-parallel exchange points (vLLM: all-reduce after o_proj and
+ * after down_proj).  part 0: x -> norm -> qkv -> rope/cache -> attention -> o_proj;
+ *                    part 1: x -> norm -> gate_up/SwiGLU -> down_proj.
+ * tp_world == 1: the projection adds into x in place.  tp_world > 1: it writes this rank's partial
+ * sum to buffers.delta; the caller all-reduces delta (RCCL) and calls chatts_residual_add. */
+int chatts_decoder_layer_part(ChattsDecoder*, int layer, int part, int t, int pos0,
+                              const int32_t* pos0_dev, int n_splits, chatts_stream_t stream);
+int chatts_residual_add(float* x, const float* delta, int64_t n, chatts_stream_t stream);
+
+/* TP=1 fast paths: all layers back to back on the stream (no host round trip, graph-capturable). */
+int chatts_decoder_prefill(ChattsDecoder*, int t, int pos0, chatts_stream_t stream);
+/* final norm + lm_head on row `row` of x -> buffers.logits */
+int chatts_decoder_logits(ChattsDecoder*, int row, chatts_stream_t stream);
+/* one greedy decode step: x[0,:] holds the input embedding; reads the position from *pos_dev;
+ * runs all layers, logits, argmax (-> out_tokens[*step_dev], step/pos incremented), then loads the
+ * next input embedding into x[0,:].  Fully device-driven: capture once, replay per token. */
+int chatts_decoder_decode_step(ChattsDecoder*, int32_t* pos_dev, int32_t* step_dev,
+                               int64_t* token_dev, float* token_logit_dev, int64_t* out_tokens,
+                               int n_splits, chatts_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHATTS_AMD_H */
