@@ -1,0 +1,141 @@
+"""ctypes binding of libchatts_amd.so (the C-ABI declared in include/chatts_amd.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+OK, E_BADARG, E_SHAPE, E_COUNT_MISMATCH, E_LAUNCH, E_WORKSPACE = 0, -1, -2, -3, -4, -5
+EPI_NONE, EPI_GELU, EPI_RESID, EPI_SWIGLU = 0, 1, 2, 3
+
+c_void_p, c_int, c_int32, c_int64, c_float, c_size_t, c_uint32 = (
+    C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint32)
+
+
+class PatchifyArgs(C.Structure):
+    _fields_ = [("series", c_void_p), ("row_off", c_void_p), ("valid_len", c_void_p), ("pos_table", c_void_p),
+                ("out", c_void_p), ("n_series", c_int), ("lmax", c_int), ("patch_size", c_int), ("mode", c_int),
+                ("emb_dim", c_int), ("max_seq_len", c_int), ("max_valid_len", c_int), ("total_patches", c_int),
+                ("ld_out", c_int)]
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [("a", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("resid", c_void_p), ("c", c_void_p),
+                ("norm_w", c_void_p), ("norm_eps", c_float), ("m", c_int), ("n", c_int), ("k", c_int),
+                ("lda", c_int), ("ldw", c_int), ("ldc", c_int), ("epilogue", c_int), ("workspace", c_void_p),
+                ("workspace_bytes", c_size_t)]
+
+
+class KvCache(C.Structure):
+    _fields_ = [("k", c_void_p), ("v", c_void_p), ("max_ctx", c_int)]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [("input_norm", c_void_p), ("qkv", c_void_p), ("qkv_bias", c_void_p), ("q_norm", c_void_p),
+                ("k_norm", c_void_p), ("o", c_void_p), ("post_norm", c_void_p), ("gate_up", c_void_p),
+                ("down", c_void_p)]
+
+
+class DecoderConfig(C.Structure):
+    _fields_ = [("hidden", c_int), ("n_layers", c_int), ("n_q", c_int), ("n_kv", c_int), ("head_dim", c_int),
+                ("inter", c_int), ("vocab_local", c_int64), ("vocab_offset", c_int64), ("rms_eps", c_float),
+                ("max_ctx", c_int), ("max_pos", c_int), ("tp_world", c_int)]
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [("layers", C.POINTER(LayerWeights)), ("final_norm", c_void_p), ("lm_head", c_void_p),
+                ("embed", c_void_p), ("cos_tab", c_void_p), ("sin_tab", c_void_p)]
+
+
+class DecoderBuffers(C.Structure):
+    _fields_ = [("kv_k", c_void_p), ("kv_v", c_void_p), ("x", c_void_p), ("xn", c_void_p), ("qkv", c_void_p),
+                ("attn", c_void_p), ("act", c_void_p), ("delta", c_void_p), ("logits", c_void_p),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("t_max", c_int)]
+
+
+# name -> (restype, argtypes); this table IS the list of symbols include/chatts_amd.h declares
+SIGNATURES = {
+    "chatts_last_error": (C.c_char_p, []),
+    "chatts_abi_version": (c_int, []),
+    "chatts_device_cus": (c_int, []),
+    "chatts_fill_hash": (c_int, [c_void_p, c_int, c_uint32, c_float, c_int, c_int64, c_int64, c_int64, c_int64,
+                                 c_int64, c_int64, c_void_p]),
+    "chatts_ts_patch_cnt": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "chatts_ts_patchify": (c_int, [C.POINTER(PatchifyArgs), c_void_p]),
+    "chatts_linear_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "chatts_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
+    "chatts_embed_merge": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chatts_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "chatts_rope_kv_write": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                     c_int, c_void_p, C.POINTER(KvCache), c_void_p]),
+    "chatts_attn_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "chatts_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, C.POINTER(KvCache), c_void_p, c_int,
+                                 c_void_p, c_size_t, c_void_p]),
+    "chatts_argmax": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chatts_embed_token": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "chatts_decoder_create": (c_void_p, [C.POINTER(DecoderConfig), C.POINTER(DecoderWeights),
+                                         C.POINTER(DecoderBuffers)]),
+    "chatts_decoder_destroy": (None, [c_void_p]),
+    "chatts_decoder_workspace": (c_size_t, [C.POINTER(DecoderConfig), c_int, c_int]),
+    "chatts_decoder_layer_part": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "chatts_residual_add": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "chatts_decoder_prefill": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "chatts_decoder_logits": (c_int, [c_void_p, c_int, c_void_p]),
+    "chatts_decoder_decode_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_void_p]),
+}
+
+
+class ChattsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libchatts_amd error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the HIP extension has not been built. Run `python -m chatts_amd.build` "
+            "(or __graft_entry__.build()). chatts_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    """Translate a negative return code into the exception type the reference raises in that situation."""
+    if rc == OK:
+        return
+    msg = load().chatts_last_error().decode("utf-8", "replace")
+    if rc == E_COUNT_MISMATCH:
+        raise ValueError(msg)                 # vLLM merge_multimodal_embeddings raises ValueError
+    raise ChattsError(rc, msg)
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,526 @@
+"""ChatTSForCausalLM - the MI355X-native model behind the reference's two call surfaces.
+
+Mirrors (NetManAIOps/ChatTS):
+  HF surface      AutoModelForCausalLM.from_pretrained(...); model.generate(**inputs, max_new_tokens=...)
+                  README.md:88-103, demo/demo_hf.ipynb cells 3-5, chatts/utils/inference_tsmllm_deepspeed.py:89-105
+                  (returned ids begin with the UN-expanded input_ids; model.config.ts['patch_size'] readable)
+  vLLM plugin     Qwen2TSForCausalLM / Qwen3TSForCausalLM hooks, chatts/vllm/chatts_vllm.py:
+                  get_multimodal_embeddings :538-562, get_input_embeddings :564-574, forward :576-599,
+                  compute_logits :601-610, load_weights :612-625, packed_modules_mapping :454-464
+All arithmetic runs in libchatts_amd.so (hand-written HIP, gfx950); torch only owns device memory,
+streams and the RCCL process group.  There is no CPU/PyTorch fallback.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, synth
+from .config import ChatTSConfig, preset
+from .tp import Comm, LocalComm, ShardPlan
+from .ts_encoder import TimeSeriesEmbedding
+
+packed_modules_mapping = {"qkv_proj": ["q_proj", "k_proj", "v_proj"], "gate_up_proj": ["gate_proj", "up_proj"]}
+
+
+def interleave_gate_up(gate, up):
+    """[I,H],[I,H] -> [2I,H] with gate/up alternating in blocks of 16 rows (CHATTS_EPI_SWIGLU layout)."""
+    I, H = gate.shape
+    out = torch.empty((2 * I, H), dtype=gate.dtype, device=gate.device)
+    v = out.view(I // 16, 2, 16, H)
+    v[:, 0] = gate.view(I // 16, 16, H)
+    v[:, 1] = up.view(I // 16, 16, H)
+    return out
+
+
+def rope_tables(cfg, max_pos, device):
+    """float32 cos/sin [max_pos, d/2], computed like Qwen2RotaryEmbedding (inv_freq = theta^(-2i/d), f32)."""
+    d = cfg.head_dim
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    fr = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    return fr.cos().contiguous().to(device), fr.sin().contiguous().to(device)
+
+
+class ChatTSForCausalLM:
+    packed_modules_mapping = packed_modules_mapping
+
+    def __init__(self, config, device="cuda", comm=None, max_ctx=2048, max_prefill_tokens=2048, use_graph=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("chatts_amd needs a ROCm GPU: there is no CPU fallback for the model")
+        self.lib = _lib.load()
+        self.config = config
+        self.device = torch.device(device)
+        self.comm = comm or LocalComm()
+        self.plan = ShardPlan(config, self.comm.rank, self.comm.world)
+        self.max_ctx = int(max_ctx)
+        self.t_max = int(min(max_prefill_tokens, max_ctx))
+        self.use_graph = use_graph
+        self.ts_encoder = TimeSeriesEmbedding(config.ts, device=self.device)
+        self._tensors = {}            # keeps every device tensor alive (the C side borrows pointers)
+        self._decoder = None
+        self._graph = None
+        self.layers = []
+        self.loaded = set()
+
+    # ---------------------------------------------------------------------------------------------
+    # weights
+    # ---------------------------------------------------------------------------------------------
+    @classmethod
+    def from_synthetic(cls, config, seed=0, **kw):
+        """Random-init model whose weights are the counter-hash of chatts_amd/synth.py (bf16-exact)."""
+        if isinstance(config, str):
+            config = preset(config)
+        m = cls(config, **kw)
+        dev, plan, cfg = m.device, m.plan, config
+        specs = {s.name: s for s in synth.all_specs(cfg)}
+
+        def block(name, row0=0, rows=None, col0=0, cols=None, f32=False):
+            s = specs[name]
+            rows = s.rows - row0 if rows is None else rows
+            cols = s.cols - col0 if cols is None else cols
+            t = torch.empty((rows, cols), dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
+            synth.fill_device(t, s, seed, row0=row0, col0=col0, rows=rows, cols=cols)
+            return t[0] if s.is_1d else t
+
+        m._load_with(block, tied=cfg.tie_word_embeddings)
+        m.ts_encoder.load_synthetic(synth.ts_encoder_specs(cfg), seed)
+        m.seed = seed
+        m._finalize()
+        return m
+
+    @classmethod
+    def from_pretrained(cls, path, trust_remote_code=True, device_map=None, torch_dtype=None, **kw):
+        """HF checkpoint directory (config.json + *.safetensors with the names of SURVEY.md section 5)."""
+        import glob
+        import os
+        from safetensors import safe_open
+        cfg = ChatTSConfig.from_pretrained(path)
+        if device_map not in (None, "auto") and "device" not in kw:
+            kw["device"] = device_map if isinstance(device_map, str) else "cuda"
+        m = cls(cfg, **kw)
+        handles, index = [], {}
+        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
+            h = safe_open(f, framework="pt", device="cpu")
+            handles.append(h)
+            for k in h.keys():
+                index[k] = h
+        m.load_weights((k, h.get_tensor(k)) for k, h in index.items())
+        return m
+
+    def load_weights(self, weights):
+        """chatts_vllm.py:612-625: consume (name, tensor) pairs with HF names; q/k/v and gate/up are packed,
+        a missing lm_head means tied embeddings (:619-623).  Returns the set of loaded names."""
+        sd = {}
+        for name, t in weights:
+            if name.startswith("ts_encoder."):
+                self.ts_encoder.load_tensor(name[len("ts_encoder."):], t)
+                self.loaded.add(name)
+            else:
+                sd[name] = t
+        dev = self.device
+
+        def block(name, row0=0, rows=None, col0=0, cols=None, f32=False):
+            t = sd[name]
+            if t.dim() == 1:
+                t = t[col0:(None if cols is None else col0 + cols)]
+            else:
+                t = t[row0:(None if rows is None else row0 + rows), col0:(None if cols is None else col0 + cols)]
+            self.loaded.add(name)
+            return t.to(dev).to(torch.float32 if f32 else torch.bfloat16).contiguous()
+
+        self._load_with(block, tied="lm_head.weight" not in sd)
+        self._finalize()
+        return self.loaded
+
+    def _load_with(self, block, tied):
+        cfg, plan = self.config, self.plan
+        d = cfg.head_dim
+        T = self._tensors
+        T["embed"] = block("model.embed_tokens.weight")
+        if tied:
+            T["lm_head"] = T["embed"][plan.v0:plan.v0 + plan.vocab].contiguous() if plan.world > 1 else T["embed"]
+        else:
+            T["lm_head"] = block("lm_head.weight", row0=plan.v0, rows=plan.vocab)
+        T["final_norm"] = block("model.norm.weight", f32=True)
+        for l in range(cfg.num_hidden_layers):
+            p = f"model.layers.{l}."
+            q = block(p + "self_attn.q_proj.weight", row0=plan.q0 * d, rows=plan.nq * d)
+            k = block(p + "self_attn.k_proj.weight", row0=plan.kv0 * d, rows=plan.nkv * d)
+            v = block(p + "self_attn.v_proj.weight", row0=plan.kv0 * d, rows=plan.nkv * d)
+            L = {"qkv": torch.cat([q, k, v], dim=0).contiguous()}
+            del q, k, v
+            if cfg.attention_bias:
+                L["qkv_bias"] = torch.cat([
+                    block(p + "self_attn.q_proj.bias", col0=plan.q0 * d, cols=plan.nq * d, f32=True),
+                    block(p + "self_attn.k_proj.bias", col0=plan.kv0 * d, cols=plan.nkv * d, f32=True),
+                    block(p + "self_attn.v_proj.bias", col0=plan.kv0 * d, cols=plan.nkv * d, f32=True)]).contiguous()
+            if cfg.qk_norm:
+                L["q_norm"] = block(p + "self_attn.q_norm.weight", f32=True)
+                L["k_norm"] = block(p + "self_attn.k_norm.weight", f32=True)
+            L["o"] = block(p + "self_attn.o_proj.weight", col0=plan.q0 * d, cols=plan.nq * d)
+            g = block(p + "mlp.gate_proj.weight", row0=plan.i0, rows=plan.inter)
+            u = block(p + "mlp.up_proj.weight", row0=plan.i0, rows=plan.inter)
+            L["gate_up"] = interleave_gate_up(g, u)
+            del g, u
+            L["down"] = block(p + "mlp.down_proj.weight", col0=plan.i0, cols=plan.inter)
+            L["input_norm"] = block(p + "input_layernorm.weight", f32=True)
+            L["post_norm"] = block(p + "post_attention_layernorm.weight", f32=True)
+            self.layers.append(L)
+
+    def _finalize(self):
+        """Allocate activations / KV cache and create the C-side decoder handle (borrowing all pointers)."""
+        cfg, plan, dev, lib = self.config, self.plan, self.device, self.lib
+        T = self._tensors
+        H, d = cfg.hidden_size, cfg.head_dim
+        max_pos = max(self.max_ctx, 64)
+        T["cos"], T["sin"] = rope_tables(cfg, max_pos, dev)
+        self.n_splits = max(1, min(32, (self.max_ctx + 63) // 64))
+        dc = _lib.DecoderConfig(hidden=H, n_layers=cfg.num_hidden_layers, n_q=plan.nq, n_kv=plan.nkv, head_dim=d,
+                                inter=plan.inter, vocab_local=plan.vocab, vocab_offset=plan.v0,
+                                rms_eps=cfg.rms_norm_eps, max_ctx=self.max_ctx, max_pos=max_pos, tp_world=plan.world)
+        ws_bytes = int(lib.chatts_decoder_workspace(C.byref(dc), self.t_max, self.n_splits))
+        ws_bytes = max(ws_bytes, int(lib.chatts_linear_workspace(self.t_max, plan.vocab, H)))
+        f32 = dict(dtype=torch.float32, device=dev)
+        qkv_n = (plan.nq + 2 * plan.nkv) * d
+        L = cfg.num_hidden_layers
+        B = {
+            "kv_k": torch.zeros((L, plan.nkv, self.max_ctx, d), **f32),
+            "kv_v": torch.zeros((L, plan.nkv, self.max_ctx, d), **f32),
+            "x": torch.zeros((self.t_max, H), **f32), "xn": torch.zeros((self.t_max, H), **f32),
+            "qkv": torch.zeros((self.t_max, qkv_n), **f32), "attn": torch.zeros((self.t_max, plan.nq * d), **f32),
+            "act": torch.zeros((self.t_max, plan.inter), **f32), "delta": torch.zeros((self.t_max, H), **f32),
+            "logits": torch.zeros(plan.vocab, **f32),
+            "ws": torch.zeros(ws_bytes, dtype=torch.uint8, device=dev),
+            # decode-loop state lives on the device so a captured step can be replayed
+            "pos": torch.zeros(1, dtype=torch.int32, device=dev), "step": torch.zeros(1, dtype=torch.int32, device=dev),
+            "token": torch.zeros(1, dtype=torch.int64, device=dev), "token_logit": torch.zeros(1, **f32),
+            "out_tokens": torch.zeros(self.max_ctx + 8, dtype=torch.int64, device=dev),
+            "scan": torch.zeros(self.t_max + 8, dtype=torch.int32, device=dev),
+            "status": torch.zeros(1, dtype=torch.int32, device=dev),
+        }
+        self.buf = B
+        arr = (_lib.LayerWeights * L)()
+        for i, lw in enumerate(self.layers):
+            arr[i] = _lib.LayerWeights(input_norm=_lib.ptr(lw["input_norm"]), qkv=_lib.ptr(lw["qkv"]),
+                                       qkv_bias=_lib.ptr(lw.get("qkv_bias")), q_norm=_lib.ptr(lw.get("q_norm")),
+                                       k_norm=_lib.ptr(lw.get("k_norm")), o=_lib.ptr(lw["o"]),
+                                       post_norm=_lib.ptr(lw["post_norm"]), gate_up=_lib.ptr(lw["gate_up"]),
+                                       down=_lib.ptr(lw["down"]))
+        self._layer_arr = arr
+        dw = _lib.DecoderWeights(layers=arr, final_norm=_lib.ptr(T["final_norm"]), lm_head=_lib.ptr(T["lm_head"]),
+                                 embed=_lib.ptr(T["embed"]), cos_tab=_lib.ptr(T["cos"]), sin_tab=_lib.ptr(T["sin"]))
+        db = _lib.DecoderBuffers(kv_k=_lib.ptr(B["kv_k"]), kv_v=_lib.ptr(B["kv_v"]), x=_lib.ptr(B["x"]),
+                                 xn=_lib.ptr(B["xn"]), qkv=_lib.ptr(B["qkv"]), attn=_lib.ptr(B["attn"]),
+                                 act=_lib.ptr(B["act"]), delta=_lib.ptr(B["delta"]), logits=_lib.ptr(B["logits"]),
+                                 workspace=_lib.ptr(B["ws"]), workspace_bytes=ws_bytes, t_max=self.t_max)
+        h = lib.chatts_decoder_create(C.byref(dc), C.byref(dw), C.byref(db))
+        if not h:
+            raise _lib.ChattsError(-1, lib.chatts_last_error().decode())
+        self._decoder = C.c_void_p(h)
+        self._graph = None
+
+    def __del__(self):
+        try:
+            if self._decoder:
+                self.lib.chatts_decoder_destroy(self._decoder)
+        except Exception:
+            pass
+
+    def weight_bytes_local(self):
+        n = sum(t.numel() * t.element_size() for lw in self.layers for t in lw.values())
+        return n + self._tensors["lm_head"].numel() * 2 + self._tensors["final_norm"].numel() * 4
+
+    # ---------------------------------------------------------------------------------------------
+    # vLLM-plugin-shaped hooks (same names/order as chatts_vllm.py:538-610)
+    # ---------------------------------------------------------------------------------------------
+    def get_multimodal_embeddings(self, timeseries=None, valid_lengths=None, **kw):
+        """-> list of [patch_cnt_i, H] tensors (empty [0,H] for zero-length series), or None."""
+        if timeseries is None:
+            return None
+        ts = self._parse_and_validate_ts_input(timeseries)
+        feats, patch_cnt = self.ts_encoder(ts, valid_lengths=valid_lengths)
+        if valid_lengths is not None:
+            ps = self.ts_encoder.patch_size
+            counts = [(int(v) + ps - 1) // ps for v in valid_lengths]
+        else:
+            counts = patch_cnt.tolist()
+        out, s = [], 0
+        for c in counts:
+            out.append(feats[s:s + c])
+            s += c
+        return out
+
+    def _parse_and_validate_ts_input(self, timeseries):
+        """chatts_vllm.py:493-536: accept the padded tensor, or a list of (ts_tokens, encoded [1,2L,1]) items."""
+        if isinstance(timeseries, torch.Tensor):
+            return timeseries.to(self.device, dtype=torch.float32)
+        if isinstance(timeseries, (list, tuple)):
+            encs = []
+            for item in timeseries:
+                if isinstance(item, (list, tuple)) and len(item) == 2 and not np.isscalar(item[1]):
+                    encs.append(np.asarray(item[1], dtype=np.float32).reshape(1, -1, 1))
+                else:
+                    encs.append(np.asarray(item, dtype=np.float32).reshape(1, -1, 1))
+            lmax = max(e.shape[1] for e in encs)
+            out = np.zeros((len(encs), lmax, 1), dtype=np.float32)
+            for i, e in enumerate(encs):
+                out[i, :e.shape[1]] = e[0]
+            return torch.from_numpy(out).to(self.device)
+        raise ValueError(f"Incorrect type of ts input features. Got type: {type(timeseries)}")
+
+    def get_input_embeddings(self, input_ids, multimodal_embeddings=None, out=None):
+        """embed_tokens(ids) with rows at ts_token_start_index overwritten in order by the TS rows (:564-574).
+        input_ids: 1-D (already expanded) ids, host list / CPU tensor / device tensor."""
+        ids_host = None
+        if not isinstance(input_ids, torch.Tensor):
+            input_ids = torch.tensor(list(input_ids), dtype=torch.int64)
+        if not input_ids.is_cuda:
+            ids_host = input_ids.to(torch.int64).contiguous()
+            ids_dev = ids_host.to(self.device, non_blocking=True)
+        else:
+            ids_dev = input_ids.to(torch.int64).contiguous()
+        t = ids_dev.numel()
+        H = self.config.hidden_size
+        rows, n_rows = None, 0
+        if multimodal_embeddings is not None:
+            rows = (multimodal_embeddings if isinstance(multimodal_embeddings, torch.Tensor)
+                    else (torch.cat(list(multimodal_embeddings), dim=0) if len(multimodal_embeddings) else
+                          torch.empty((0, H), dtype=torch.float32, device=self.device)))
+            rows = rows.contiguous()
+            n_rows = rows.shape[0]
+        if out is None:
+            out = torch.empty((t, H), dtype=torch.float32, device=self.device)
+        scan = self.buf["scan"] if t + 1 <= self.buf["scan"].numel() else torch.empty(t + 1, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.chatts_embed_merge(
+            _lib.ptr(ids_dev), _lib.ptr(ids_host) if ids_host is not None else None, t, _lib.ptr(self._tensors["embed"]),
+            self.config.vocab_size, H, _lib.ptr(rows) if n_rows else None, n_rows, self.config.ts_token_start_index,
+            _lib.ptr(out), _lib.ptr(scan), _lib.ptr(self.buf["status"]), _lib.stream_ptr()))
+        return out
+
+    def forward(self, input_ids=None, positions=None, intermediate_tensors=None, inputs_embeds=None, **kw):
+        """Prefill `inputs_embeds` [T,H] (or embed input_ids [+ timeseries kw]) at positions pos0..pos0+T-1;
+        returns the residual-stream hidden states [T,H] BEFORE the final norm (compute_logits applies it)."""
+        if inputs_embeds is None:
+            mm = self.get_multimodal_embeddings(**kw)
+            inputs_embeds = self.get_input_embeddings(input_ids, mm)
+        pos0 = 0 if positions is None else int(positions[0])
+        T = inputs_embeds.shape[0]
+        if T > self.t_max:
+            raise ValueError(f"{T} tokens exceed max_prefill_tokens={self.t_max}; use prefill() for chunking")
+        self.buf["x"][:T].copy_(inputs_embeds)
+        self._run_layers(T, pos0)
+        return self.buf["x"][:T]
+
+    def compute_logits(self, hidden_states=None, sampling_metadata=None, row=None):
+        """final RMSNorm + lm_head on ONE row of the residual stream (default: the last) -> [V_local] float32."""
+        if hidden_states is not None and hidden_states.data_ptr() != self.buf["x"].data_ptr():
+            self.buf["x"][:hidden_states.shape[0]].copy_(hidden_states)
+        if row is None:
+            row = (hidden_states.shape[0] - 1) if hidden_states is not None else 0
+        _lib.check(self.lib.chatts_decoder_logits(self._decoder, int(row), _lib.stream_ptr()))
+        return self.buf["logits"]
+
+    # ---------------------------------------------------------------------------------------------
+    # engine
+    # ---------------------------------------------------------------------------------------------
+    def _run_layers(self, T, pos0, pos_dev=None, n_splits=1):
+        lib, st = self.lib, _lib.stream_ptr()
+        if self.plan.world == 1 and pos_dev is None:
+            _lib.check(lib.chatts_decoder_prefill(self._decoder, T, pos0, st))
+            return
+        H = self.config.hidden_size
+        delta = self.buf["delta"][:T]
+        for l in range(self.config.num_hidden_layers):
+            for part in (0, 1):
+                _lib.check(lib.chatts_decoder_layer_part(self._decoder, l, part, T, pos0, _lib.ptr(pos_dev), n_splits, st))
+                if self.plan.world > 1:
+                    self.comm.all_reduce(delta)
+                    _lib.check(lib.chatts_residual_add(_lib.ptr(self.buf["x"]), _lib.ptr(delta), T * H, st))
+
+    def reset(self):
+        self.buf["pos"].zero_()
+        self.buf["step"].zero_()
+
+    def prefill(self, inputs_embeds, pos0=0):
+        """Chunked prefill of [T,H] embeddings starting at cache position pos0; leaves the last chunk in x."""
+        T = inputs_embeds.shape[0]
+        if pos0 + T > self.max_ctx:
+            raise ValueError(f"sequence of {pos0 + T} tokens exceeds max_ctx={self.max_ctx}")
+        done, last = 0, 0
+        while done < T:
+            n = min(self.t_max, T - done)
+            self.buf["x"][:n].copy_(inputs_embeds[done:done + n])
+            self._run_layers(n, pos0 + done)
+            done += n
+            last = n
+        return last
+
+    def _first_token(self, last_rows):
+        """logits of the last prompt row -> greedy token -> next input embedding in x[0]."""
+        lib, st, B = self.lib, _lib.stream_ptr(), self.buf
+        _lib.check(lib.chatts_decoder_logits(self._decoder, last_rows - 1, st))
+        _lib.check(lib.chatts_argmax(_lib.ptr(B["logits"]), self.plan.vocab, self.plan.v0, _lib.ptr(B["token"]),
+                                     _lib.ptr(B["token_logit"]), None, None, None, st))
+        self._finish_token()
+
+    def _finish_token(self):
+        """TP: pick the global argmax; then append to out_tokens, bump step, load the next embedding."""
+        B = self.buf
+        if self.plan.world > 1:
+            B["token"].copy_(self.comm.argmax_pair(B["token_logit"], B["token"]))
+        B["out_tokens"].index_copy_(0, B["step"].to(torch.int64), B["token"])
+        B["step"] += 1
+        _lib.check(self.lib.chatts_embed_token(_lib.ptr(B["token"]), _lib.ptr(self._tensors["embed"]), 0,
+                                               self.config.vocab_size, self.config.hidden_size, _lib.ptr(B["x"]),
+                                               _lib.stream_ptr()))
+
+    def _decode_step_eager(self):
+        lib, st, B = self.lib, _lib.stream_ptr(), self.buf
+        if self.plan.world == 1:
+            _lib.check(lib.chatts_decoder_decode_step(self._decoder, _lib.ptr(B["pos"]), _lib.ptr(B["step"]),
+                                                      _lib.ptr(B["token"]), _lib.ptr(B["token_logit"]),
+                                                      _lib.ptr(B["out_tokens"]), self.n_splits, st))
+            return
+        self._run_layers(1, 0, pos_dev=B["pos"], n_splits=self.n_splits)
+        _lib.check(lib.chatts_decoder_logits(self._decoder, 0, st))
+        _lib.check(lib.chatts_argmax(_lib.ptr(B["logits"]), self.plan.vocab, self.plan.v0, _lib.ptr(B["token"]),
+                                     _lib.ptr(B["token_logit"]), None, None, None, st))
+        B["pos"] += 1
+        self._finish_token()
+
+    def decode_step(self):
+        """One greedy token.  TP=1: a hipGraph of the whole step (captured on first use) is replayed."""
+        if self.use_graph and self.plan.world == 1:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        else:
+            self._decode_step_eager()
+
+    def _capture(self):
+        B = self.buf
+        saved = {k: B[k].clone() for k in ("pos", "step", "token", "token_logit", "x", "out_tokens")}
+        kv = None
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):      # warm-up on a side stream (populates every lazy host-side cache)
+            self._decode_step_eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for k, v in saved.items():
+            B[k].copy_(v)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._decode_step_eager()
+        torch.cuda.synchronize()
+        for k, v in saved.items():          # capture does not execute, but keep the state pristine anyway
+            B[k].copy_(v)
+        self._graph = g
+
+    # ---------------------------------------------------------------------------------------------
+    # HF surface
+    # ---------------------------------------------------------------------------------------------
+    def expand_input_ids(self, ids, patch_counts):
+        """Replace each [<ts>, <ts/>] pair by patch_cnt <ts> placeholders (chatts_vllm.py:402-415, 441)."""
+        ts0 = self.config.ts_token_start_index
+        out, k, i, n = [], 0, 0, len(ids)
+        while i < n:
+            if ids[i] == ts0 and i + 1 < n and ids[i + 1] == ts0 + 1:
+                if k >= len(patch_counts):
+                    raise ValueError("more <ts><ts/> pairs than time series")
+                out.extend([ts0] * int(patch_counts[k]))
+                k += 1
+                i += 2
+            else:
+                out.append(ids[i])
+                i += 1
+        if k != len(patch_counts):
+            raise ValueError(f"{len(patch_counts)} time series but {k} <ts><ts/> pairs in the prompt")
+        return out
+
+    @torch.no_grad()
+    def generate_one(self, ids, series=None, lengths=None, max_new_tokens=64, eos_token_id=None, sync_every=16,
+                     return_logits=False):
+        """ids: un-expanded prompt ids (host list); series: [n, 2*Lmax, 1] tensor of this prompt's series."""
+        cfg = self.config
+        ps = cfg.ts["patch_size"]
+        mm = None
+        counts = []
+        if series is not None and series.shape[0] > 0:
+            series = series.to(self.device, dtype=torch.float32)
+            if lengths is None:
+                lengths = self.ts_encoder.get_patch_cnt(series)[0].tolist()
+            counts = [(int(v) + ps - 1) // ps for v in lengths]
+            mm = self.get_multimodal_embeddings(timeseries=series, valid_lengths=lengths)
+        full = self.expand_input_ids(list(ids), counts)
+        T = len(full)
+        if T + max_new_tokens > self.max_ctx:
+            raise ValueError(f"prompt ({T}) + max_new_tokens ({max_new_tokens}) exceeds max_ctx={self.max_ctx}")
+        emb = self.get_input_embeddings(torch.tensor(full, dtype=torch.int64), mm)
+        self.reset()
+        last = self.prefill(emb, 0)
+        self.buf["pos"].fill_(T)
+        self._first_token(last)
+        logits0 = self.buf["logits"].clone() if return_logits else None
+        eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple, set)) else
+                  ([] if eos_token_id is None else [eos_token_id]))
+        produced = 1
+        toks = None
+        while produced < max_new_tokens:
+            self.decode_step()
+            produced += 1
+            if eos and (produced % sync_every == 0):
+                toks = self.buf["out_tokens"][:produced].tolist()
+                if any(t in eos for t in toks):
+                    break
+        toks = self.buf["out_tokens"][:produced].tolist()
+        if eos:
+            for i, t in enumerate(toks):
+                if t in eos:
+                    toks = toks[:i + 1]
+                    break
+        return (toks, logits0) if return_logits else toks
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, timeseries=None, max_new_tokens=64, max_length=None,
+                 streamer=None, eos_token_id=None, do_sample=False, temperature=None, synced_gpus=False,
+                 valid_lengths=None, **kw):
+        """model.generate(**inputs, max_new_tokens=...) -> LongTensor [B, T_in + new], greedy
+        (README.md:102, demo_hf.ipynb cell 5).  Rows start with the un-expanded input_ids; shorter rows are
+        right-padded with pad_token_id.  A flat `timeseries` tensor is consumed across the batch in prompt order."""
+        if do_sample:
+            raise NotImplementedError("only greedy decoding is implemented (SURVEY.md section 8f item 4)")
+        cfg = self.config
+        ids = input_ids if isinstance(input_ids, torch.Tensor) else torch.tensor(input_ids)
+        if ids.dim() == 1:
+            ids = ids[None]
+        ids = ids.cpu()
+        mask = attention_mask.cpu() if attention_mask is not None else torch.ones_like(ids)
+        if eos_token_id is None:
+            eos_token_id = cfg.eos_token_id
+        ts0 = cfg.ts_token_start_index
+        cursor, rows = 0, []
+        for b in range(ids.shape[0]):
+            seq = ids[b][mask[b].bool()].tolist()
+            n_ts = sum(1 for i in range(len(seq) - 1) if seq[i] == ts0 and seq[i + 1] == ts0 + 1)
+            ser = timeseries[cursor:cursor + n_ts] if (timeseries is not None and n_ts) else None
+            lens = valid_lengths[cursor:cursor + n_ts] if valid_lengths is not None else None
+            cursor += n_ts
+            budget = max_new_tokens if max_length is None else max(1, max_length - len(seq))
+            toks = self.generate_one(seq, ser, lens, budget, eos_token_id)
+            if streamer is not None:
+                streamer.put(torch.tensor(toks))
+            rows.append(ids[b].tolist() + toks)
+        if streamer is not None:
+            streamer.end()
+        n = max(len(r) for r in rows)
+        pad = cfg.pad_token_id
+        return torch.tensor([r + [pad] * (n - len(r)) for r in rows], dtype=torch.long)
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self

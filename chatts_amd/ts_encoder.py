@@ -1,0 +1,166 @@
+"""TimeSeriesEmbedding on MI355X - same constructor / forward contract as the reference class
+(NetManAIOps/ChatTS chatts/vllm/chatts_vllm.py:61-193), executed by the HIP kernels behind the C-ABI:
+
+    forward(x [N, 2*Lmax, 1]) -> (features [P, hidden] float32, patch_cnt [N] int64)
+
+  chatts_ts_patch_cnt   mask reduction, one wave per series      (:94-100)
+  chatts_ts_patchify    patch rows + last-value pad + position-embedding gather -> [P, Kpad]   (:107-183)
+  chatts_linear x n     MLP, bias + exact-erf GELU fused in the epilogue                       (:83-91,188)
+
+Differences that are deliberate: one optional D2H sync per call instead of 2 per series
+(none when the processor's host-side lengths are passed); with use_position_embedding=False the
+reference crashes on ragged tails (AttributeError) - here those modes work.
+"""
+import torch
+
+from . import _lib
+
+
+def _pad32(k):
+    return (k + 31) // 32 * 32
+
+
+class TimeSeriesEmbedding:
+    def __init__(self, config, device="cuda"):
+        self.patch_size = config["patch_size"]
+        self.num_layers = config["num_layers"]
+        self.hidden_size = config["hidden_size"]
+        self.num_features = config["num_features"]
+        self.max_sequence_length = config["max_sequence_length"]
+        self.use_position_embedding = config.get("use_position_embedding", False)
+        self.use_position_idx = config.get("use_position_idx", False)
+        self.embedding_dim = config.get("embedding_dim", 16)
+        if self.num_features != 2:
+            raise ValueError("the sp encoding has exactly 2 features (value, mask)")
+        if self.use_position_embedding:
+            self.mode, self.in_features = 1, self.patch_size * (1 + self.embedding_dim)
+        elif self.use_position_idx:
+            self.mode, self.in_features = 2, 2 * self.patch_size
+        else:
+            self.mode, self.in_features = 0, self.patch_size
+        self.k0 = _pad32(self.in_features)           # K of the first Linear, zero padded for the MFMA GEMM
+        if self.hidden_size % 32:
+            raise ValueError("ts hidden_size must be a multiple of 32")
+        self.device = torch.device(device)
+        self.position_embedding = None               # f32 [max_seq+1, emb]
+        self.weights = [None] * self.num_layers      # bf16 [H, Kpad_l]
+        self.biases = [None] * self.num_layers       # f32 [H]
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def layer_in_features(self, l):
+        return self.in_features if l == 0 else self.hidden_size
+
+    def layer_k(self, l):
+        return self.k0 if l == 0 else self.hidden_size
+
+    def state_names(self):
+        names = ["position_embedding.weight"] if self.mode == 1 else []
+        for l in range(self.num_layers):
+            names += [f"mlp.{2 * l}.weight", f"mlp.{2 * l}.bias"]
+        return names
+
+    def load_tensor(self, name, tensor):
+        """name without the 'ts_encoder.' prefix; tensor: any float dtype, host or device."""
+        t = tensor.to(self.device)
+        if name == "position_embedding.weight":
+            self.position_embedding = t.float().contiguous()
+            return
+        l, kind = int(name.split(".")[1]) // 2, name.split(".")[2]
+        if kind == "bias":
+            self.biases[l] = t.float().contiguous()
+        else:
+            w = torch.zeros((self.hidden_size, self.layer_k(l)), dtype=torch.bfloat16, device=self.device)
+            w[:, :t.shape[1]] = t.to(torch.bfloat16)
+            self.weights[l] = w
+
+    def load_synthetic(self, specs, seed):
+        from . import synth
+        for s in specs:
+            name = s.name[len("ts_encoder."):]
+            if name == "position_embedding.weight":
+                self.position_embedding = synth.fill_device(
+                    torch.empty((s.rows, s.cols), dtype=torch.float32, device=self.device), s, seed)
+                continue
+            l, kind = int(name.split(".")[1]) // 2, name.split(".")[2]
+            if kind == "bias":
+                self.biases[l] = synth.fill_device(torch.empty(s.cols, dtype=torch.float32, device=self.device), s, seed)
+            else:
+                ld = self.layer_k(l)
+                w = torch.zeros((s.rows, ld), dtype=torch.bfloat16, device=self.device)
+                self.weights[l] = synth.fill_device(w, s, seed, ld=ld)
+
+    def weight_bytes(self):
+        n = sum(w.numel() * 2 for w in self.weights) + sum(b.numel() * 4 for b in self.biases)
+        return n
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def get_patch_cnt(self, x):
+        """chatts_vllm.py:198-207 on the device: [N, 2*Lmax, 1] -> (valid_len int32 [N], patch_cnt int64 [N])."""
+        lib = _lib.load()
+        n = x.shape[0]
+        x = x.reshape(n, -1)
+        lmax = x.shape[1] // 2
+        vl = torch.empty(n, dtype=torch.int32, device=x.device)
+        pc = torch.empty(n, dtype=torch.int64, device=x.device)
+        _lib.check(lib.chatts_ts_patch_cnt(_lib.ptr(x), n, lmax, self.patch_size, _lib.ptr(vl), _lib.ptr(pc),
+                                          _lib.stream_ptr()))
+        return vl, pc
+
+    def forward(self, x, valid_lengths=None):
+        """x: [N, 2*Lmax, 1] (value, mask) interleaved, any float dtype, on the GPU.
+
+        valid_lengths: optional host list of the true lengths (from the processor); when given no
+        device->host copy happens at all.
+        """
+        lib = _lib.load()
+        if not x.is_cuda:
+            raise RuntimeError("chatts_amd has no CPU path: move the timeseries tensor to the GPU")
+        n = x.shape[0]
+        x = x.reshape(n, -1).float().contiguous()
+        lmax = x.shape[1] // 2
+        dev = x.device
+        vl_dev, pc_dev = self.get_patch_cnt(x) if n else (torch.empty(0, dtype=torch.int32, device=dev),
+                                                          torch.empty(0, dtype=torch.int64, device=dev))
+        host_given = valid_lengths is not None
+        if not host_given:
+            valid_lengths = vl_dev.tolist()          # the single D2H sync of this path
+        vl_host = [int(v) for v in valid_lengths]
+        if len(vl_host) != n:
+            raise ValueError("valid_lengths does not match the number of series")
+        if any(v > self.max_sequence_length for v in vl_host) and self.mode == 1:
+            raise IndexError("index out of range in self")     # nn.Embedding lookup, chatts_vllm.py:165
+        ps = self.patch_size
+        pcs = [(v + ps - 1) // ps for v in vl_host]
+        row_off = [0]
+        for c in pcs:
+            row_off.append(row_off[-1] + c)
+        P = row_off[-1]
+        if P == 0:
+            return torch.empty((0, self.hidden_size), dtype=torch.float32, device=dev), pc_dev
+        row_off_dev = torch.tensor(row_off, dtype=torch.int32).to(dev, non_blocking=True)
+        if host_given:
+            vl_dev = torch.tensor(vl_host, dtype=torch.int32).to(dev, non_blocking=True)
+        feat = torch.empty((P, self.k0), dtype=torch.float32, device=dev)
+        pa = _lib.PatchifyArgs(series=_lib.ptr(x), row_off=_lib.ptr(row_off_dev), valid_len=_lib.ptr(vl_dev),
+                               pos_table=_lib.ptr(self.position_embedding), out=_lib.ptr(feat), n_series=n, lmax=lmax,
+                               patch_size=ps, mode=self.mode, emb_dim=self.embedding_dim,
+                               max_seq_len=self.max_sequence_length, max_valid_len=max(vl_host) if vl_host else 0,
+                               total_patches=P, ld_out=self.k0)
+        st = _lib.stream_ptr()
+        _lib.check(lib.chatts_ts_patchify(pa, st))
+        ws_bytes = max(lib.chatts_linear_workspace(P, self.hidden_size, self.layer_k(l)) for l in range(self.num_layers))
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        h = feat
+        for l in range(self.num_layers):
+            out = torch.empty((P, self.hidden_size), dtype=torch.float32, device=dev)
+            k = self.layer_k(l)
+            la = _lib.LinearArgs(a=_lib.ptr(h), w=_lib.ptr(self.weights[l]), bias=_lib.ptr(self.biases[l]), resid=None,
+                                 c=_lib.ptr(out), norm_w=None, norm_eps=0.0, m=P, n=self.hidden_size, k=k, lda=k, ldw=k,
+                                 ldc=self.hidden_size,
+                                 epilogue=_lib.EPI_GELU if l < self.num_layers - 1 else _lib.EPI_NONE,
+                                 workspace=_lib.ptr(ws), workspace_bytes=ws_bytes)
+            _lib.check(lib.chatts_linear(la, st))
+            h = out
+        return h, pc_dev
+
+    __call__ = forward

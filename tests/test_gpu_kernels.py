@@ -1,0 +1,357 @@
+"""GPU parity tests, kernel by kernel, through the C-ABI (ctypes) against the CPU oracle / float64 torch.
+
+Tolerances: integer / gather work is bit-exact; float32 reductions 2e-5 relative (summation order only:
+every weight x activation product is exact in these kernels)."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from chatts_amd import _lib, synth
+from oracle import synth as osynth, ts_embedding as ots
+from tests.util import bf16_round, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return _lib.load()
+
+
+def st():
+    return _lib.stream_ptr()
+
+
+# ------------------------------------------------------------------------------------------ fill
+@pytest.mark.parametrize("f32", [False, True])
+def test_fill_hash_bit_exact(lib, f32):
+    spec = synth.TensorSpec("model.layers.3.mlp.up_proj.weight", 300, 1000, 0.0, 13)
+    key = osynth.tensor_key(11, spec.name)
+    dst = torch.empty((37, 264), dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+    synth.fill_device(dst, spec, 11, row0=100, col0=40, rows=37, cols=260, ld=264)
+    torch.cuda.synchronize()
+    bits = osynth.bf16_bits(key, 0.0, 13, 37, 260, row0=100, col0=40, full_cols=1000)
+    got = dst[:, :260].float().cpu().numpy()
+    want = (bits.astype(np.uint32) << 16).view(np.float32)
+    assert np.array_equal(got, want)
+    norm = synth.TensorSpec("model.norm.weight", 1, 512, 1.0, 12, True)
+    t = synth.fill_device(torch.empty(512, dtype=torch.float32, device=DEV), norm, 5)
+    assert np.array_equal(t.cpu().numpy(), osynth.materialize(norm, 5))
+
+
+def test_fill_hash_64bit_index(lib):
+    # rows far enough that i = row*cols + col exceeds 2^32 -> exercises the hi32 term
+    spec = synth.TensorSpec("big", 1 << 22, 2048, 0.0, 13)
+    dst = torch.empty((4, 2048), dtype=torch.bfloat16, device=DEV)
+    synth.fill_device(dst, spec, 1, row0=(1 << 21) + 5, rows=4)
+    bits = osynth.bf16_bits(osynth.tensor_key(1, "big"), 0.0, 13, 4, 2048, row0=(1 << 21) + 5, full_cols=2048)
+    assert np.array_equal(dst.view(torch.int16).cpu().numpy().view(np.uint16), bits)
+
+
+# ------------------------------------------------------------------------------------------ TS front end
+@pytest.mark.parametrize("name", ["posemb", "posidx", "raw", "single"])
+def test_ts_frontend_bit_exact(lib, golden, name):
+    from chatts_amd.ts_encoder import TimeSeriesEmbedding
+    g = golden("ts_embedding_" + name)
+    cfg = json.loads(str(g["config"]))
+    enc = TimeSeriesEmbedding(cfg, device=DEV)
+    x = torch.from_numpy(g["x"]).to(DEV)
+    vl, pc = enc.get_patch_cnt(x)
+    assert np.array_equal(pc.cpu().numpy(), g["patch_cnt"]) and pc.dtype == torch.int64
+    assert np.array_equal(vl.cpu().numpy(), g["lengths"])
+    table = g["w:position_embedding.weight"] if "w:position_embedding.weight" in g.files else None
+    want, _ = ots.patch_features(g["x"], cfg, table)
+    # run patchify alone through the C-ABI
+    lens = g["lengths"].tolist()
+    pcs = [(v + 15) // 16 for v in lens]
+    off = np.concatenate([[0], np.cumsum(pcs)]).astype(np.int32)
+    P = int(off[-1])
+    feat = torch.full((P, enc.k0), 7.0, dtype=torch.float32, device=DEV)
+    tab = torch.from_numpy(table).to(DEV) if table is not None else None
+    pa = _lib.PatchifyArgs(series=x.data_ptr(), row_off=torch.from_numpy(off).to(DEV).data_ptr(),
+                           valid_len=vl.data_ptr(), pos_table=_lib.ptr(tab), out=feat.data_ptr(), n_series=len(lens),
+                           lmax=x.shape[1] // 2, patch_size=16, mode=enc.mode, emb_dim=enc.embedding_dim,
+                           max_seq_len=cfg["max_sequence_length"], max_valid_len=max(lens), total_patches=P,
+                           ld_out=enc.k0)
+    off_dev = torch.from_numpy(off).to(DEV)
+    pa.row_off = off_dev.data_ptr()
+    _lib.check(lib.chatts_ts_patchify(pa, st()))
+    got = feat.cpu().numpy()
+    assert np.array_equal(got[:, :want.shape[1]], want)
+    assert np.all(got[:, want.shape[1]:] == 0)
+
+
+@pytest.mark.parametrize("name", ["posemb", "posidx", "raw", "single"])
+def test_ts_encoder_vs_reference_golden(lib, golden, name):
+    """Full encoder vs (a) the oracle run with the same bf16-rounded weights (tight) and (b) the reference's own
+    float32 output (loose: the only difference is the bf16 rounding of the checkpoint weights)."""
+    from chatts_amd.ts_encoder import TimeSeriesEmbedding
+    g = golden("ts_embedding_" + name)
+    cfg = json.loads(str(g["config"]))
+    enc = TimeSeriesEmbedding(cfg, device=DEV)
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w:")}
+    wr = {k: (bf16_round(v) if k.endswith("weight") and k.startswith("mlp") else v) for k, v in w.items()}
+    for k, v in w.items():
+        enc.load_tensor(k, torch.from_numpy(v))
+    x = torch.from_numpy(g["x"]).to(DEV)
+    for lens in (None, g["lengths"].tolist()):
+        feats, pc = enc(x, valid_lengths=lens)
+        torch.cuda.synchronize()
+        want, wpc = ots.ts_embedding_forward(g["x"], cfg, wr)
+        assert np.array_equal(pc.cpu().numpy(), wpc)
+        assert feats.shape == want.shape
+        assert rel_err(feats.cpu().numpy(), want) < 2e-5
+        assert rel_err(feats.cpu().numpy(), g["features"]) < 2e-2
+
+
+def test_ts_encoder_empty_and_errors(lib):
+    from chatts_amd.ts_encoder import TimeSeriesEmbedding
+    cfg = dict(patch_size=16, num_layers=2, hidden_size=64, num_features=2, max_sequence_length=64,
+               use_position_embedding=True, embedding_dim=16)
+    enc = TimeSeriesEmbedding(cfg, device=DEV)
+    enc.load_synthetic([s for s in synth.ts_encoder_specs(type("C", (), {"ts": cfg})())], 0)
+    feats, pc = enc(torch.zeros((2, 64, 1), device=DEV))                 # all-zero mask -> no patches
+    assert feats.shape == (0, 64) and pc.tolist() == [0, 0]
+    x = torch.ones((1, 2 * 80, 1), device=DEV)                           # 80 valid points > max_sequence_length
+    with pytest.raises(IndexError):
+        enc(x)
+    with pytest.raises(RuntimeError):
+        enc(torch.zeros((1, 32, 1)))                                     # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------------------------------ linear
+def _linear(lib, a, w, bias=None, resid=None, epi=_lib.EPI_NONE, norm_w=None, eps=1e-6):
+    m, k = a.shape
+    n = w.shape[0]
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    out = torch.full((m, ncols), float("nan"), dtype=torch.float32, device=DEV)
+    wsb = int(lib.chatts_linear_workspace(m, n, k))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    la = _lib.LinearArgs(a=a.data_ptr(), w=w.data_ptr(), bias=_lib.ptr(bias), resid=_lib.ptr(resid), c=out.data_ptr(),
+                         norm_w=_lib.ptr(norm_w), norm_eps=eps, m=m, n=n, k=k, lda=k, ldw=k, ldc=ncols, epilogue=epi,
+                         workspace=ws.data_ptr(), workspace_bytes=wsb)
+    _lib.check(lib.chatts_linear(la, st()))
+    torch.cuda.synchronize()
+    return out
+
+
+def _ref_linear(a, w, bias, resid, epi, norm_w=None, eps=1e-6):
+    a64, w64 = a.double().cpu(), w.float().double().cpu()
+    if norm_w is not None:
+        a64 = norm_w.double().cpu() * (a64 * torch.rsqrt(a64.pow(2).mean(-1, keepdim=True) + eps))
+    y = a64 @ w64.T
+    if bias is not None:
+        y = y + bias.double().cpu()
+    if epi == _lib.EPI_GELU:
+        y = torch.nn.functional.gelu(y)
+    elif epi == _lib.EPI_RESID:
+        y = y + resid.double().cpu()
+    elif epi == _lib.EPI_SWIGLU:
+        n = y.shape[1]
+        v = y.view(y.shape[0], n // 32, 2, 16)
+        y = (torch.nn.functional.silu(v[:, :, 0]) * v[:, :, 1]).reshape(y.shape[0], n // 2)
+    return y.numpy()
+
+
+def _rand_problem(m, n, k, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn((m, k), generator=g) * scale).to(DEV)
+    w = (torch.randn((n, k), generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    # asymmetric structure so a transposed / permuted tile cannot pass (guide rule 16)
+    w[:, 0] = torch.linspace(-1, 1, n).to(torch.bfloat16)
+    bias = torch.randn(n, generator=g).to(DEV)
+    resid = torch.randn((m, n), generator=g).to(DEV)
+    norm = (1 + 0.1 * torch.randn(k, generator=g)).to(DEV)
+    return a, w, bias, resid, norm
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("n,k", [(1024, 512), (5120, 5120), (96, 1024), (5120, 13824), (2048, 8 * 32)])
+def test_gemv_parity(lib, epi, norm, n, k):
+    a, w, bias, resid, nw = _rand_problem(1, n, k, seed=n + k + epi)
+    out = _linear(lib, a, w, bias, resid if epi == _lib.EPI_RESID else None, epi, nw if norm else None)
+    want = _ref_linear(a, w, bias, resid, epi, nw if norm else None)
+    assert rel_err(out.cpu().numpy(), want) < 2e-5
+    assert not torch.isnan(out).any()
+
+
+@pytest.mark.parametrize("rows,wk", [(4, 1), (2, 1), (4, 4), (2, 4)])
+def test_gemv_all_geometries(lib, rows, wk, monkeypatch):
+    monkeypatch.setenv("CHATTS_GEMV_ROWS", str(rows))
+    monkeypatch.setenv("CHATTS_GEMV_WK", str(wk))
+    for epi in (_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU):
+        a, w, bias, resid, nw = _rand_problem(1, 1504, 1536 + 64, seed=rows * 10 + wk)
+        out = _linear(lib, a, w, None if epi == _lib.EPI_RESID else bias, resid if epi == _lib.EPI_RESID else None, epi, nw)
+        want = _ref_linear(a, w, None if epi == _lib.EPI_RESID else bias, resid, epi, nw)
+        assert rel_err(out.cpu().numpy(), want) < 2e-5
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k", [(2, 256, 64), (16, 128, 288), (17, 1024, 512), (33, 5120, 288), (70, 384, 1024),
+                                   (128, 5120, 5120), (360, 7168, 5120), (200, 1024, 13824), (1, 256, 512)])
+def test_gemm_bf16x2_parity(lib, epi, m, n, k):
+    if m == 1 and epi != _lib.EPI_GELU:
+        pytest.skip("M=1 non-GELU goes to the GEMV kernel (covered above)")
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
+    out = _linear(lib, a, w, bias, resid if epi == _lib.EPI_RESID else None, epi)
+    want = _ref_linear(a, w, bias, resid, epi)
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu().numpy(), want) < 2e-5       # bf16x2: |eps| <= 2^-17 per product, f32 accumulate
+
+
+def test_linear_argument_errors(lib):
+    a = torch.zeros((2, 48), device=DEV)
+    w = torch.zeros((32, 48), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_lib.ChattsError) as e:
+        _linear(lib, a, w)
+    assert e.value.code == _lib.E_SHAPE and "multiple of 32" in e.value.msg
+
+
+# ------------------------------------------------------------------------------------------ elementwise
+def test_rmsnorm(lib):
+    x = torch.randn((37, 5120), device=DEV) * 3
+    w = 1 + 0.1 * torch.randn(5120, device=DEV)
+    y = torch.empty_like(x)
+    _lib.check(lib.chatts_rmsnorm(x.data_ptr(), w.data_ptr(), y.data_ptr(), 37, 5120, 1e-6, st()))
+    x64 = x.double().cpu()
+    want = w.double().cpu() * (x64 * torch.rsqrt(x64.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert rel_err(y.cpu().numpy(), want.numpy()) < 1e-6
+
+
+def _rope_tables(max_pos, theta=1e6):
+    from oracle.qwen_decoder import rope_cos_sin
+    cos, sin = rope_cos_sin(torch.arange(max_pos), 128, theta)
+    return cos[:, :64].contiguous().to(DEV), sin[:, :64].contiguous().to(DEV)
+
+
+@pytest.mark.parametrize("qk_norm", [False, True])
+def test_rope_kv_write(lib, qk_norm):
+    from oracle.qwen_decoder import rms_norm, rope_cos_sin, rotate_half
+    T, nq, nkv, pos0, max_ctx = 9, 4, 2, 5, 32
+    qkv = torch.randn((T, (nq + 2 * nkv) * 128), device=DEV)
+    orig = qkv.clone().cpu()
+    qn = (1 + 0.1 * torch.randn(128)).to(DEV) if qk_norm else None
+    kn = (1 + 0.1 * torch.randn(128)).to(DEV) if qk_norm else None
+    cos, sin = _rope_tables(64)
+    kc = torch.zeros((nkv, max_ctx, 128), device=DEV)
+    vc = torch.zeros((nkv, max_ctx, 128), device=DEV)
+    cache = _lib.KvCache(k=kc.data_ptr(), v=vc.data_ptr(), max_ctx=max_ctx)
+    _lib.check(lib.chatts_rope_kv_write(qkv.data_ptr(), T, nq, nkv, _lib.ptr(qn), _lib.ptr(kn), 1e-6, cos.data_ptr(),
+                                        sin.data_ptr(), pos0, None, C.byref(cache), st()))
+    torch.cuda.synchronize()
+    o = orig.view(T, nq + 2 * nkv, 128)
+    q, k, v = o[:, :nq], o[:, nq:nq + nkv], o[:, nq + nkv:]
+    if qk_norm:
+        q, k = rms_norm(q, qn.cpu(), 1e-6), rms_norm(k, kn.cpu(), 1e-6)
+    c, s = rope_cos_sin(torch.arange(pos0, pos0 + T), 128, 1e6)
+    q = q * c[:, None] + rotate_half(q) * s[:, None]
+    k = k * c[:, None] + rotate_half(k) * s[:, None]
+    got = qkv.cpu().view(T, nq + 2 * nkv, 128)
+    assert rel_err(got[:, :nq].numpy(), q.numpy()) < 1e-6
+    assert rel_err(kc[:, pos0:pos0 + T].cpu().numpy(), k.transpose(0, 1).numpy()) < 1e-6
+    assert torch.equal(vc[:, pos0:pos0 + T].cpu(), v.transpose(0, 1))
+    assert torch.all(kc[:, :pos0] == 0) and torch.all(kc[:, pos0 + T:] == 0)
+    # device-resident position (graph replay path)
+    pos_dev = torch.tensor([pos0], dtype=torch.int32, device=DEV)
+    qkv2 = orig.clone().to(DEV)
+    kc2, vc2 = torch.zeros_like(kc), torch.zeros_like(vc)
+    cache2 = _lib.KvCache(k=kc2.data_ptr(), v=vc2.data_ptr(), max_ctx=max_ctx)
+    _lib.check(lib.chatts_rope_kv_write(qkv2.data_ptr(), T, nq, nkv, _lib.ptr(qn), _lib.ptr(kn), 1e-6, cos.data_ptr(),
+                                        sin.data_ptr(), 0, pos_dev.data_ptr(), C.byref(cache2), st()))
+    assert torch.equal(kc2, kc) and torch.equal(qkv2, qkv)
+
+
+def _ref_attention(q, kc, vc, pos0):
+    """q [T,nq,128] (rotated), caches [nkv, ctx, 128]; float64 eager attention with causal mask."""
+    T, nq, _ = q.shape
+    nkv = kc.shape[0]
+    g = nq // nkv
+    out = torch.zeros((T, nq, 128), dtype=torch.float64)
+    for t in range(T):
+        pos = pos0 + t
+        for h in range(nq):
+            k = kc[h // g, :pos + 1].double()
+            v = vc[h // g, :pos + 1].double()
+            s = (k @ q[t, h].double()) / np.sqrt(128.0)
+            p = torch.softmax(s, dim=0)
+            out[t, h] = p @ v
+    return out
+
+
+@pytest.mark.parametrize("nq,nkv", [(4, 2), (5, 1), (8, 1), (8, 8)])
+@pytest.mark.parametrize("T,pos0,splits", [(1, 0, 1), (1, 63, 4), (1, 200, 4), (1, 333, 16), (7, 60, 1), (70, 0, 1)])
+def test_attention_parity(lib, nq, nkv, T, pos0, splits):
+    max_ctx = 512
+    g = torch.Generator().manual_seed(nq * 100 + T + pos0)
+    qkv = torch.randn((T, (nq + 2 * nkv) * 128), generator=g)
+    kc = torch.randn((nkv, max_ctx, 128), generator=g)
+    vc = torch.randn((nkv, max_ctx, 128), generator=g)
+    kc[:, 17] *= 4.0     # a spiky key so the online-softmax rescale path is exercised
+    want = _ref_attention(qkv.view(T, nq + 2 * nkv, 128)[:, :nq], kc, vc, pos0)
+    qd, kd, vd = qkv.to(DEV), kc.to(DEV), vc.to(DEV)
+    out = torch.full((T, nq * 128), float("nan"), device=DEV)
+    cache = _lib.KvCache(k=kd.data_ptr(), v=vd.data_ptr(), max_ctx=max_ctx)
+    wsb = int(lib.chatts_attn_workspace(T, nq, splits))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.chatts_attention(qd.data_ptr(), T, nq, nkv, pos0, None, C.byref(cache), out.data_ptr(), splits,
+                                    ws.data_ptr(), wsb, st()))
+    torch.cuda.synchronize()
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu().numpy().reshape(T, nq, 128), want.numpy()) < 1e-5
+
+
+def test_embed_merge_and_argmax(lib):
+    V, H, T = 1000, 256, 50
+    table = torch.randn((V, H)).to(torch.bfloat16).to(DEV)
+    ts_id = 777
+    ids = torch.randint(0, 700, (T,), dtype=torch.int64)
+    where = [3, 4, 5, 20, 49]
+    ids[where] = ts_id
+    rows = torch.randn((len(where), H), device=DEV)
+    out = torch.empty((T, H), device=DEV)
+    scan = torch.empty(T + 1, dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ids_dev = ids.to(DEV)
+    _lib.check(lib.chatts_embed_merge(ids_dev.data_ptr(), ids.data_ptr(), T, table.data_ptr(), V, H, rows.data_ptr(),
+                                      len(where), ts_id, out.data_ptr(), scan.data_ptr(), status.data_ptr(), st()))
+    torch.cuda.synchronize()
+    want = table.float()[ids_dev]
+    want[where] = rows
+    assert torch.equal(out, want) and status.item() == 0
+    # device-side mismatch flag when the host copy of the ids is not supplied
+    _lib.check(lib.chatts_embed_merge(ids_dev.data_ptr(), None, T, table.data_ptr(), V, H, rows.data_ptr(), 4, ts_id,
+                                      out.data_ptr(), scan.data_ptr(), status.data_ptr(), st()))
+    assert status.item() == 1
+    with pytest.raises(ValueError):
+        _lib.check(lib.chatts_embed_merge(ids_dev.data_ptr(), ids.data_ptr(), T, table.data_ptr(), V, H,
+                                          rows.data_ptr(), 4, ts_id, out.data_ptr(), scan.data_ptr(), None, st()))
+    # a long sequence crosses the 1024-wide scan chunk
+    T2 = 3000
+    ids2 = torch.randint(0, 700, (T2,), dtype=torch.int64)
+    sel = torch.rand(T2) < 0.3
+    ids2[sel] = ts_id
+    rows2 = torch.randn((int(sel.sum()), H), device=DEV)
+    out2 = torch.empty((T2, H), device=DEV)
+    scan2 = torch.empty(T2 + 1, dtype=torch.int32, device=DEV)
+    _lib.check(lib.chatts_embed_merge(ids2.to(DEV).data_ptr(), ids2.data_ptr(), T2, table.data_ptr(), V, H,
+                                      rows2.data_ptr(), rows2.shape[0], ts_id, out2.data_ptr(), scan2.data_ptr(), None, st()))
+    want2 = table.float()[ids2.to(DEV)]
+    want2[sel.to(DEV)] = rows2
+    assert torch.equal(out2, want2)
+    # argmax: first index of the maximum
+    logits = torch.randn(152064, device=DEV)
+    logits[[5000, 90000]] = 50.0
+    tok = torch.zeros(1, dtype=torch.int64, device=DEV)
+    val = torch.zeros(1, device=DEV)
+    outt = torch.zeros(8, dtype=torch.int64, device=DEV)
+    step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    pos = torch.tensor([10], dtype=torch.int32, device=DEV)
+    _lib.check(lib.chatts_argmax(logits.data_ptr(), 152064, 1000, tok.data_ptr(), val.data_ptr(), outt.data_ptr(),
+                                 step.data_ptr(), pos.data_ptr(), st()))
+    assert tok.item() == 6000 and val.item() == 50.0 and outt[2].item() == 6000 and step.item() == 3 and pos.item() == 11

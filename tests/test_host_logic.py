@@ -1,0 +1,144 @@
+"""CPU: host-side product logic (processor, tokenizer, protocol expansion, config, shard plan) and the
+C-ABI library: it loads and exports every symbol include/chatts_amd.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from chatts_amd import _lib, config as cfgmod, synth
+from chatts_amd.processing import ChatTSProcessor, sp_normalise
+from chatts_amd.tokenizer import SyntheticTokenizer
+from chatts_amd.tp import ShardPlan
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "chatts_amd.h")).read()
+    declared = set(re.findall(r"\b(chatts_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"chatts_stream_t", "chatts_bf16"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.chatts_abi_version() == 1
+    # host-only validation paths: negative codes + message, no device touched
+    assert lib.chatts_linear(None, None) == _lib.E_BADARG
+    assert b"null args" in lib.chatts_last_error()
+    assert lib.chatts_ts_patchify(None, None) == _lib.E_BADARG
+
+
+def test_embed_merge_count_mismatch_is_value_error():
+    lib = _lib.load()
+    ids = torch.tensor([1, 7, 7, 2], dtype=torch.int64)
+    rc = lib.chatts_embed_merge(None, ids.data_ptr(), 4, None, 100, 64, ctypes.c_void_p(8), 3, 7, None, None, None, None)
+    assert rc == _lib.E_COUNT_MISMATCH
+    with pytest.raises(ValueError, match="Attempted to assign 3 multimodal tokens to 2 placeholders"):
+        _lib.check(rc)
+
+
+def test_processor_matches_reference_vectors(golden):
+    g = golden("sp_encoding")
+    proc = ChatTSProcessor(SyntheticTokenizer(), cfgmod.preset("chatts-14b"), prefix_format="sp")
+    for i in range(int(g["n"])):
+        enc, pfx, meta = proc.encode_series(g[f"in_{i}"])
+        assert pfx == str(g[f"prompt_{i}"])
+        assert np.array_equal(enc[0], g[f"enc_{i}"].astype(np.float32))
+        assert meta["offset"] == float(g[f"offset_{i}"]) and meta["scale_factor"] == float(g[f"scale_{i}"])
+        scaled, _, _ = sp_normalise(g[f"in_{i}"])
+        assert np.array_equal(scaled, g[f"enc_{i}"][0::2, 0])           # float64 bit exact
+    idx = g["batch_idx"]
+    text, encs, lens = proc.splice(str(g["batch_prompt_in"]), [g[f"in_{i}"] for i in idx])
+    assert text == str(g["batch_prompt_out"])
+    assert np.array_equal(proc.pad_stack(encs), g["batch_arr"].astype(np.float32))
+    assert lens == [len(g[f"in_{i}"]) for i in idx]
+
+
+def test_processor_hf_prefix_known_answer():
+    x = np.arange(256)
+    ts1 = np.sin(x / 10) * 5.0
+    ts1[100:] -= 10.0
+    proc = ChatTSProcessor(SyntheticTokenizer(), cfgmod.preset("chatts-14b"))
+    _, pfx, _ = proc.encode_series(ts1)     # /root/reference/demo/demo_lora.ipynb:147
+    assert pfx == "[offset=6.0772|scaling=3.6917|length=256|max=4.9979|min=-15.0000|left=0.0000|right=-8.2047]<ts><ts/>"
+
+
+def test_processor_call_surface():
+    cfg = cfgmod.preset("chatts-14b")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    p1 = "<|im_start|>user\nA: <ts><ts/> B: <ts><ts/><|im_end|><|im_start|>assistant\n"
+    p2 = "<|im_start|>user\nOnly text<|im_end|>"
+    a, b = np.arange(40.0), np.ones(17)
+    out = proc(text=[p1, p2], timeseries=[a, b], padding=True, return_tensors="pt")
+    assert set(out) == {"input_ids", "attention_mask", "timeseries"}
+    assert out["timeseries"].shape == (2, 80, 1) and out["timeseries"].dtype == torch.float32
+    assert out["input_ids"].shape == out["attention_mask"].shape and out["input_ids"].shape[0] == 2
+    assert out["attention_mask"][1, 0] == 0            # left padded
+    assert proc.last_lengths == [40, 17] and proc.last_series_per_prompt == [2, 0]
+    ts0 = cfg.ts_token_start_index
+    row = out["input_ids"][0][out["attention_mask"][0].bool()].tolist()
+    assert sum(1 for i in range(len(row) - 1) if row[i] == ts0 and row[i + 1] == ts0 + 1) == 2
+    with pytest.raises(ValueError):
+        proc(text=[p1], timeseries=[a])
+    with pytest.raises(TypeError):
+        proc(text=["<ts><ts/>"], timeseries=["not a series"])
+    moved = out.to("cpu")
+    assert moved["timeseries"].shape == (2, 80, 1)
+    v = proc(text=[p1], timeseries=[a, b], vllm_flag=True)
+    assert len(v["timeseries"]) == 2 and v["timeseries"][0][1].shape == (1, 80, 1)
+
+
+def test_tokenizer_roundtrip_and_specials():
+    t = SyntheticTokenizer()
+    s = "<|im_start|>system\nYou are a helpful assistant.<|im_end|> TS1 is of length 256: <ts><ts/>; x=-3.25"
+    ids = t.encode(s)
+    assert t.decode(ids) == s
+    assert t.special["<ts/>"] == t.special["<ts>"] + 1 == cfgmod.TS_END_ID
+    assert all(0 <= i < t.vocab_size for i in ids)
+    assert t.decode(ids, skip_special_tokens=True).count("<") == 0
+    small = SyntheticTokenizer.for_config(cfgmod.preset("tiny-qwen2"))
+    assert max(small.encode(s)) < cfgmod.preset("tiny-qwen2").vocab_size
+
+
+def test_config_presets_and_param_counts():
+    c14, c8 = cfgmod.preset("chatts-14b"), cfgmod.preset("chatts-8b")
+    assert c14.param_counts()["layer"] == 275_268_608 - 0
+    assert c14.decode_weight_bytes() == 2 * (48 * 275_268_608 + 778_567_680 + 5120)
+    assert c8.qk_norm and not c8.attention_bias and c14.attention_bias and not c14.qk_norm
+    assert c14.ts["patch_size"] == 16 and c14.ts["hidden_size"] == 5120
+    assert c14.ts_token_end_index == c14.ts_token_start_index + 1
+    rt = cfgmod.ChatTSConfig.from_dict(c8.to_dict())
+    assert rt.to_dict() == c8.to_dict()
+    n_ts = sum(s.rows * s.cols for s in synth.ts_encoder_specs(c14))
+    assert n_ts == 106_406_928                                   # SURVEY.md section 2.1 K3 [PROBED]
+
+
+def test_shard_plan_covers_everything_once():
+    cfg = cfgmod.preset("chatts-14b")
+    for world in (1, 2, 4, 8):
+        plans = [ShardPlan(cfg, r, world) for r in range(world)]
+        assert sum(p.nq for p in plans) == 40 and sum(p.nkv for p in plans) == 8
+        assert [p.q0 for p in plans] == [r * 40 // world for r in range(world)]
+        assert sum(p.inter for p in plans) == 13824 and all(p.inter % 16 == 0 for p in plans)
+        assert sum(p.vocab for p in plans) == 152064 and plans[-1].v0 + plans[-1].vocab == 152064
+    with pytest.raises(ValueError):
+        ShardPlan(cfg, 0, 3)
+
+
+def test_synth_key_and_spec_names():
+    from oracle import synth as osynth
+    for name in ("model.embed_tokens.weight", "ts_encoder.mlp.0.weight", "model.layers.47.mlp.down_proj.weight"):
+        assert synth.tensor_key(3, name) == osynth.tensor_key(3, name)
+    names = [s.name for s in synth.all_specs(cfgmod.preset("tiny-qwen3"))]
+    assert "ts_encoder.position_embedding.weight" in names and "ts_encoder.mlp.8.bias" in names
+    assert "model.layers.2.self_attn.q_norm.weight" in names and "lm_head.weight" in names
+    assert not any("bias" in n for n in names if "self_attn" in n)
+    a = osynth.materialize(synth.TensorSpec("t", 64, 512, 0.0, 13), 1)
+    assert 0.015 < a.std() < 0.021 and abs(a.mean()) < 1e-3
+    assert np.array_equal(a, a.astype(np.float32)) and np.all((a.view(np.uint32) & 0xFFFF) == 0)   # bf16 exact
+    blk = osynth.bf16_bits(osynth.tensor_key(1, "t"), 0.0, 13, 8, 100, row0=5, col0=17, full_cols=512)
+    full = osynth.bf16_bits(osynth.tensor_key(1, "t"), 0.0, 13, 64, 512)
+    assert np.array_equal(blk, full[5:13, 17:117])
