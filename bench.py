@@ -1,0 +1,285 @@
+#!/usr/bin/env python
+"""bench.py - generated tokens/s + p50 TTFT, ChatTS-14B, 8 series x 256 steps, tensor parallel over N GPUs.
+
+    python bench.py --gpus 1 --steps 64 --warmup 8
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE greedy decode step of the whole model (all 48 layers + lm_head + argmax, batch 1) after the
+8x256 prompt has been encoded and prefilled; `value` = steps / max-over-ranks wall time.  Inputs (weights,
+prompt, series tensor) are resident in HBM when the timed region starts.  Extra keys: ttft_ms_p50 (processor +
+H2D + TS encoder + merge + prefill + first token), `roofline` (dominant kernel = the gate_up weight-streaming
+GEMV, timed live with HIP events), `cpu_baseline` (the CPU float32 oracle on this box's host cores, bounded sample).
+Weights are synthetic (counter-hash, bf16-exact) because no checkpoint can reach the box; shapes are the real
+ChatTS-14B ones.  Multi-GPU = tensor parallel (strong scaling), RCCL all-reduce via torch.distributed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def build_inputs(cfg, n_series=8, length=256):
+    import numpy as np
+    from chatts_amd.processing import ChatTSProcessor
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(1234)                       # SURVEY.md section 8d synthetic inputs
+    lengths = [length] * n_series
+    series = [50 + 2 * np.cumsum(rng.standard_normal(L)) for L in lengths]
+    body = f"I have {n_series} time series. " + " ".join(
+        f"TS{i} is of length {L}: <ts><ts/>;" for i, L in enumerate(lengths)) + \
+        " Please analyze the local changes in these time series first and then conclude if these time series " \
+        "show local changes near the same time?"
+    prompt = ("<|im_start|>system\nYou are a helpful assistant.<|im_end|><|im_start|>user\n" + body +
+              "<|im_end|><|im_start|>assistant\n")
+    return proc, prompt, series, lengths
+
+
+def median(xs):
+    s = sorted(xs)
+    return s[len(s) // 2]
+
+
+def roofline_gate_up(model, reps=2):
+    """Dominant kernel: gemv_kernel<.., SWIGLU, NORM> on gate_up (2*I_local x H bf16 per launch).  Launch it once
+    per layer over every layer's own weights (13.6 GB at TP=1: no cache reuse) between two HIP events recorded on
+    the launching stream; achieved = algorithmic bytes per launch / average launch duration."""
+    import torch
+    from chatts_amd import _lib
+    lib, cfg, plan = model.lib, model.config, model.plan
+    H = cfg.hidden_size
+    n = 2 * plan.inter
+    out = torch.empty(plan.inter, dtype=torch.float32, device=model.device)
+    x = torch.randn(H, dtype=torch.float32, device=model.device)
+    stream = torch.cuda.current_stream()
+
+    def sweep():
+        for lw in model.layers:
+            la = _lib.LinearArgs(a=x.data_ptr(), w=lw["gate_up"].data_ptr(), bias=None, resid=None, c=out.data_ptr(),
+                                 norm_w=lw["post_norm"].data_ptr(), norm_eps=cfg.rms_norm_eps, m=1, n=n, k=H, lda=H,
+                                 ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU, workspace=None, workspace_bytes=0)
+            _lib.check(lib.chatts_linear(la, stream.cuda_stream))
+
+    sweep()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        sweep()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    launches = reps * len(model.layers)
+    avg_s = e0.elapsed_time(e1) * 1e-3 / launches
+    # algorithmic bytes per launch: bf16 weights + f32 x in + norm weights + f32 out (SURVEY.md 8d per-unit figure)
+    bytes_per_launch = n * H * 2 + H * 4 + H * 4 + plan.inter * 4
+    return dict(kernel="gemv_kernel<4,1,SWIGLU,NORM> (gate_up_proj + RMSNorm + SwiGLU)", launches=launches,
+                avg_us=avg_s * 1e6, bytes_per_launch=bytes_per_launch, gbs=bytes_per_launch / avg_s / 1e9)
+
+
+def cpu_baseline(model, prompt_tokens, budget_s=30.0):
+    """CPU float32 oracle (the reference's HF float32 path restated, see oracle/) on the host cores of THIS box.
+    Bounded sample: ChatTS-14B widths with 2 and then 4 decoder layers (weights copied back from the GPU, so both
+    arms hold identical values), prefill of the real prompt length + 4 decode tokens each; per-layer and fixed
+    (lm_head) costs are fitted from the two depths and extrapolated to 48 layers."""
+    import torch
+    from oracle.qwen_decoder import QwenOracle
+    cfg = model.config
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    d, nq, nkv, I = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size
+    t_start = time.time()
+    sd = {"model.embed_tokens.weight": model._tensors["embed"][:4096].float().cpu(),       # only ids < 4096 are fed
+          "lm_head.weight": model._tensors["lm_head"].float().cpu(),
+          "model.norm.weight": model._tensors["final_norm"].cpu()}
+    depth = 4
+    for l in range(depth):
+        lw, p = model.layers[l], f"model.layers.{l}."
+        qkv = lw["qkv"].float().cpu()
+        sd[p + "self_attn.q_proj.weight"] = qkv[:nq * d]
+        sd[p + "self_attn.k_proj.weight"] = qkv[nq * d:(nq + nkv) * d]
+        sd[p + "self_attn.v_proj.weight"] = qkv[(nq + nkv) * d:]
+        if "qkv_bias" in lw:
+            b = lw["qkv_bias"].cpu()
+            sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"] = \
+                b[:nq * d], b[nq * d:(nq + nkv) * d], b[(nq + nkv) * d:]
+        if "q_norm" in lw:
+            sd[p + "self_attn.q_norm.weight"], sd[p + "self_attn.k_norm.weight"] = lw["q_norm"].cpu(), lw["k_norm"].cpu()
+        sd[p + "self_attn.o_proj.weight"] = lw["o"].float().cpu()
+        gu = lw["gate_up"].float().cpu().view(I // 16, 2, 16, -1)
+        sd[p + "mlp.gate_proj.weight"] = gu[:, 0].reshape(I, -1).contiguous()
+        sd[p + "mlp.up_proj.weight"] = gu[:, 1].reshape(I, -1).contiguous()
+        sd[p + "mlp.down_proj.weight"] = lw["down"].float().cpu()
+        sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = lw["input_norm"].cpu(), lw["post_norm"].cpu()
+    g = torch.Generator().manual_seed(0)
+    emb = torch.randn((prompt_tokens, cfg.hidden_size), generator=g) * 0.02
+    res = {}
+    for L in (2, depth):
+        o = QwenOracle(cfg.oracle_dict(), sd, num_layers=L)
+        t0 = time.time()
+        logits = o.forward_embeds(emb, return_hidden=True)[-1] @ sd["lm_head.weight"].T   # last row only
+        t_prefill = time.time() - t0
+        times = []
+        for _ in range(4):
+            tok = int(torch.argmax(logits)) % 4096
+            t0 = time.time()
+            logits = o.forward_embeds(o.embed([tok]))[-1]
+            times.append(time.time() - t0)
+        res[L] = (t_prefill, median(times))
+    per_layer_dec = (res[depth][1] - res[2][1]) / (depth - 2)
+    fixed_dec = res[2][1] - 2 * per_layer_dec
+    per_layer_pre = (res[depth][0] - res[2][0]) / (depth - 2)
+    fixed_pre = res[2][0] - 2 * per_layer_pre
+    Lfull = cfg.num_hidden_layers
+    dec_s = fixed_dec + Lfull * per_layer_dec
+    pre_s = fixed_pre + Lfull * per_layer_pre
+    return dict(value=1.0 / dec_s, unit="tokens/s", cores=ncores, kind="port",
+                sample=(f"CPU float32 oracle, ChatTS-14B widths, depths 2 and {depth} of {Lfull} layers measured "
+                        f"(prefill {prompt_tokens} tok + 4 decode tok each), linearly extrapolated to {Lfull} layers; "
+                        f"decode {per_layer_dec * 1e3:.1f} ms/layer + {fixed_dec * 1e3:.0f} ms lm_head"),
+                ttft_s_extrapolated=pre_s, wall_s=time.time() - t_start)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="chatts-14b")
+    ap.add_argument("--series", type=int, default=8)
+    ap.add_argument("--length", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=None, help="debug only: truncate depth (result marked invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--ttft-runs", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from chatts_amd import config as cfgmod
+    from chatts_amd.modeling import ChatTSForCausalLM
+    from chatts_amd.tp import Comm, LocalComm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        comm = Comm()
+    else:
+        comm = LocalComm()
+
+    over = {} if args.layers is None else {"num_hidden_layers": args.layers}
+    cfg = cfgmod.preset(args.model, **over)
+    proc, prompt, series, lengths = build_inputs(cfg, args.series, args.length)
+    t0 = time.time()
+    max_ctx = 2048
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, device=device, comm=comm, max_ctx=max_ctx,
+                                             max_prefill_tokens=1024, use_graph=not args.no_graph)
+    torch.cuda.synchronize()
+    log(f"[bench] {args.model} TP={world} materialised in {time.time() - t0:.1f}s, "
+        f"{model.weight_bytes_local() / 1e9:.2f} GB decoder weights on this rank")
+
+    # ---- TTFT: processor -> H2D -> TS encoder -> merge -> prefill -> first token (p50) ---------------------
+    ttfts, enc_ms = [], []
+    T = None
+    for i in range(args.ttft_runs + 1):
+        comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        inputs = proc(text=[prompt], timeseries=series, padding=True, return_tensors="pt")
+        ids = inputs["input_ids"][0].tolist()
+        ser = inputs["timeseries"].to(device)
+        te0 = time.perf_counter()
+        mm = model.get_multimodal_embeddings(timeseries=ser, valid_lengths=proc.last_lengths)
+        if i > 0:
+            torch.cuda.synchronize()
+            enc_ms.append((time.perf_counter() - te0) * 1e3)
+        full = model.expand_input_ids(ids, [(L + 15) // 16 for L in lengths])
+        T = len(full)
+        emb = model.get_input_embeddings(torch.tensor(full, dtype=torch.int64), mm)
+        model.reset()
+        last = model.prefill(emb, 0)
+        model.buf["pos"].fill_(T)
+        model._first_token(last)
+        first = model.buf["out_tokens"][:1].tolist()
+        dt = (time.perf_counter() - t0) * 1e3
+        if i > 0:                                   # run 0 is the warm-up
+            ttfts.append(dt)
+    ttft = median(ttfts)
+
+    # ---- decode: W warm-up steps (captures the hipGraph), then exactly K timed steps ------------------------
+    for _ in range(args.warmup):
+        model.decode_step()
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.decode_step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    toks = model.buf["out_tokens"][:1 + args.warmup + args.steps].tolist()
+    tok_s = args.steps / dt
+    ms_step = dt / args.steps * 1e3
+
+    roof = roofline_gate_up(model)
+    step_bytes = model.weight_bytes_local()
+    result = {
+        "metric": "generated tokens/sec (greedy, batch 1) + p50 TTFT, ChatTS-14B, 8x256-step TS prompt, TP=N",
+        "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"ChatTS-14B bf16 weights, {args.series} series x {args.length} steps, greedy decode, "
+                               f"TP={world}" if args.model == "chatts-14b" and args.layers is None else
+                               f"DEBUG {args.model} layers={args.layers}",
+                   "model": args.model, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
+                   "parallelism": f"tp{world}", "batch": 1, "decode_graph": bool(model.use_graph and world == 1),
+                   "precision": "bf16 weights; f32 activations, KV cache and accumulation (bf16x2 MFMA split in "
+                                "prefill, exact f32 FMA in decode)",
+                   "first_tokens": toks[:8]},
+        "ttft_ms_p50": ttft, "ts_encode_ms_p50": median(enc_ms),
+        "decode_hbm_gbs_per_gpu": step_bytes / (dt / args.steps) / 1e9,
+        "decode_hbm_frac_of_8TBs": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+        "decode_frac_of_bf16_mfma_roofline": (2.0 * step_bytes / 2 / (dt / args.steps)) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+        "roofline": {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": None, "kernel": roof["kernel"],
+                     "avg_us": roof["avg_us"], "bytes_per_launch": roof["bytes_per_launch"],
+                     "launches_timed": roof["launches"]},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(model, T)
+        except Exception as e:          # the baseline must never take the GPU number down with it
+            result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+                                      "sample": f"failed: {type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -246,7 +246,6 @@ static int k_per_split(int k, int sk) {
 }
 
 size_t gemm_workspace(int m, int n, int k) {
-  if (m <= 1) return 0;
   int bm, sk;
   pick_geometry(m, n, k, bm, sk);
   return sk > 1 ? (size_t)sk * m * n * sizeof(float) : 0;

@@ -149,7 +149,7 @@ if __name__ == "__main__":
                 use_position_embedding=True, embedding_dim=16)
     gen_ts("posemb", base, [256, 17, 0, 64, 1000, 1, 15, 16, 1024], 1)
     gen_ts("single", dict(base, num_layers=1, hidden_size=32), [40, 33], 2)
-    gen_ts("posidx", dict(patch_size=16, num_layers=3, hidden_size=48, num_features=2, max_sequence_length=1024,
+    gen_ts("posidx", dict(patch_size=16, num_layers=3, hidden_size=64, num_features=2, max_sequence_length=1024,
                           use_position_idx=True), [96, 64, 0, 16], 3)   # ragged tails crash the reference here too
     # raw mode: the reference only survives lengths that are multiples of 16 here (AttributeError otherwise)
     gen_ts("raw", dict(patch_size=16, num_layers=2, hidden_size=32, num_features=2, max_sequence_length=1024),
