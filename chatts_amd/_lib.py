@@ -76,6 +76,9 @@ SIGNATURES = {
     "chatts_attn_workspace": (c_size_t, [c_int, c_int, c_int]),
     "chatts_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, C.POINTER(KvCache), c_void_p, c_int,
                                  c_void_p, c_size_t, c_void_p]),
+    "chatts_attention_decode_fused": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                              c_int, c_void_p, C.POINTER(KvCache), c_void_p, c_int, c_void_p,
+                                              c_size_t, c_void_p]),
     "chatts_argmax": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chatts_embed_token": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "chatts_decoder_create": (c_void_p, [C.POINTER(DecoderConfig), C.POINTER(DecoderWeights),

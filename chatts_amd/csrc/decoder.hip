@@ -116,10 +116,16 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     }
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer);
-    if ((rc = chatts_rope_kv_write(d->b.qkv, t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
-                                   d->w.sin_tab, pos0, pos0_dev, &kc, stream)) != 0) return rc;
-    if ((rc = chatts_attention(d->b.qkv, t, c.n_q, c.n_kv, pos0, pos0_dev, &kc, d->b.attn, t == 1 ? n_splits : 1,
-                               d->b.workspace, d->b.workspace_bytes, stream)) != 0) return rc;
+    if (t == 1) {   // decode: RoPE + cache write fused into the attention kernel
+      if ((rc = chatts_attention_decode_fused(d->b.qkv, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
+                                              d->w.sin_tab, pos0, pos0_dev, &kc, d->b.attn, n_splits, d->b.workspace,
+                                              d->b.workspace_bytes, stream)) != 0) return rc;
+    } else {
+      if ((rc = chatts_rope_kv_write(d->b.qkv, t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
+                                     d->w.sin_tab, pos0, pos0_dev, &kc, stream)) != 0) return rc;
+      if ((rc = chatts_attention(d->b.qkv, t, c.n_q, c.n_kv, pos0, pos0_dev, &kc, d->b.attn, 1, d->b.workspace,
+                                 d->b.workspace_bytes, stream)) != 0) return rc;
+    }
     // o_proj (+ residual, or partial sum for the TP all-reduce)
     la = ChattsLinearArgs{};
     la.a = d->b.attn; la.w = lw.o; la.m = t; la.n = H; la.k = c.n_q * kHeadDim;

@@ -97,7 +97,7 @@ typedef struct ChattsLinearArgs {
   const float* bias;       /* [N] or NULL (for SWIGLU: interleaved like the rows) */
   const float* resid;      /* EPI_RESID: [M, ldc] */
   float* c;                /* [M, ldc]  (SWIGLU: [M, N/2]) */
-  /* optional fused RMSNorm on the rows of A (decode path, M <= 4 only):
+  /* optional fused RMSNorm on the rows of A (decode path, M == 1 only):
    *   a_used[m,k] = norm_w[k] * (a[m,k] * rsqrt(mean_k(a[m,:]^2) + eps))   (Qwen2RMSNorm.forward) */
   const float* norm_w;     /* [K] or NULL */
   float norm_eps;
@@ -106,8 +106,8 @@ typedef struct ChattsLinearArgs {
   size_t workspace_bytes;
 } ChattsLinearArgs;
 size_t chatts_linear_workspace(int m, int n, int k);
-/* Dispatch: M <= 4 -> weight-streaming GEMV (exact f32 VALU products, HBM-bound);
- *           M  > 4 -> LDS-tiled MFMA GEMM, v_mfma_f32_16x16x32_bf16, bf16x2 split of A. */
+/* Dispatch: M == 1 -> weight-streaming GEMV (exact f32 VALU products, HBM-bound);
+ *           M  > 1 -> LDS-tiled MFMA GEMM, v_mfma_f32_16x16x32_bf16, bf16x2 split of A. */
 int chatts_linear(const ChattsLinearArgs* args, chatts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -153,6 +153,15 @@ size_t chatts_attn_workspace(int t, int n_q, int n_splits);
 int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev,
                      const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
                      size_t workspace_bytes, chatts_stream_t stream);
+
+/* Decode form (T = 1) that also replaces chatts_rope_kv_write: qkv_raw holds the un-rotated projections
+ * (after bias); the kernel applies the optional per-head q/k RMSNorm + RoPE at position pos (or *pos_dev),
+ * stores the new K/V row into the cache and attends over cache rows [0, pos]. */
+int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int n_kv, const float* q_norm_w,
+                                  const float* k_norm_w, float norm_eps, const float* cos_tab,
+                                  const float* sin_tab, int pos, const int32_t* pos_dev,
+                                  const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
+                                  size_t workspace_bytes, chatts_stream_t stream);
 
 /* logits [V] float32 -> *token (first index of the maximum, like torch.argmax); optionally also
  * appends the token to out_tokens[*step_dev] and increments *step_dev and *pos_dev (decode loop

@@ -181,15 +181,23 @@ def test_gemv_parity(lib, epi, norm, n, k):
     assert not torch.isnan(out).any()
 
 
-@pytest.mark.parametrize("rows,wk", [(4, 1), (2, 1), (4, 4), (2, 4)])
-def test_gemv_all_geometries(lib, rows, wk, monkeypatch):
-    monkeypatch.setenv("CHATTS_GEMV_ROWS", str(rows))
-    monkeypatch.setenv("CHATTS_GEMV_WK", str(wk))
+@pytest.mark.parametrize("geom", [1, 2])       # 1 = x in LDS (one wave per row group), 2 = x in registers (K split)
+@pytest.mark.parametrize("k", [256, 1600, 3072, 5120, 8192, 10240, 13824])   # chunks per wave: 1,1,2,3,4,5->7,7
+def test_gemv_all_geometries(lib, geom, k, monkeypatch):
+    monkeypatch.setenv("CHATTS_GEMV_GEOM", str(geom))
     for epi in (_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU):
-        a, w, bias, resid, nw = _rand_problem(1, 1504, 1536 + 64, seed=rows * 10 + wk)
-        out = _linear(lib, a, w, None if epi == _lib.EPI_RESID else bias, resid if epi == _lib.EPI_RESID else None, epi, nw)
-        want = _ref_linear(a, w, None if epi == _lib.EPI_RESID else bias, resid, epi, nw)
-        assert rel_err(out.cpu().numpy(), want) < 2e-5
+        for n in (1504, 96):
+            a, w, bias, resid, nw = _rand_problem(1, n, k, seed=geom * 10 + k)
+            nob = epi == _lib.EPI_RESID
+            out = _linear(lib, a, w, None if nob else bias, resid if nob else None, epi, nw)
+            want = _ref_linear(a, w, None if nob else bias, resid, epi, nw)
+            assert rel_err(out.cpu().numpy(), want) < 2e-5
+
+
+def test_gemv_is_deterministic(lib):
+    a, w, bias, resid, nw = _rand_problem(1, 5120, 13824, seed=5)
+    outs = [_linear(lib, a, w, bias, resid, _lib.EPI_RESID) for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
 @pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID, _lib.EPI_SWIGLU])
@@ -304,6 +312,46 @@ def test_attention_parity(lib, nq, nkv, T, pos0, splits):
     torch.cuda.synchronize()
     assert not torch.isnan(out).any()
     assert rel_err(out.cpu().numpy().reshape(T, nq, 128), want.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("qk_norm", [False, True])
+@pytest.mark.parametrize("pos,splits", [(0, 1), (5, 4), (63, 4), (64, 4), (200, 3), (333, 16), (130, 32)])
+def test_attention_decode_fused_equals_unfused(lib, qk_norm, pos, splits):
+    """fused kernel (norm + RoPE + cache write + attention) == rope_kv_write followed by attention"""
+    nq, nkv, max_ctx = 10, 2, 512
+    g = torch.Generator().manual_seed(pos * 7 + splits)
+    raw = torch.randn((1, (nq + 2 * nkv) * 128), generator=g).to(DEV)
+    kc0 = torch.randn((nkv, max_ctx, 128), generator=g).to(DEV)
+    vc0 = torch.randn((nkv, max_ctx, 128), generator=g).to(DEV)
+    kc0[:, pos:] = float("nan")      # rows >= pos are not part of the context yet: must never leak into the result
+    vc0[:, pos:] = float("nan")
+    qn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV) if qk_norm else None
+    kn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV) if qk_norm else None
+    cos, sin = _rope_tables(max_ctx)
+    wsb = int(lib.chatts_attn_workspace(1, nq, splits))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    # reference: two-kernel path
+    qkv_a, kc_a, vc_a = raw.clone(), kc0.clone(), vc0.clone()
+    ca = _lib.KvCache(k=kc_a.data_ptr(), v=vc_a.data_ptr(), max_ctx=max_ctx)
+    out_a = torch.empty((1, nq * 128), device=DEV)
+    _lib.check(lib.chatts_rope_kv_write(qkv_a.data_ptr(), 1, nq, nkv, _lib.ptr(qn), _lib.ptr(kn), 1e-6, cos.data_ptr(),
+                                        sin.data_ptr(), pos, None, C.byref(ca), st()))
+    _lib.check(lib.chatts_attention(qkv_a.data_ptr(), 1, nq, nkv, pos, None, C.byref(ca), out_a.data_ptr(), splits,
+                                    ws.data_ptr(), wsb, st()))
+    torch.cuda.synchronize()
+    # fused, position read from the device
+    kc_b, vc_b = kc0.clone(), vc0.clone()
+    cb = _lib.KvCache(k=kc_b.data_ptr(), v=vc_b.data_ptr(), max_ctx=max_ctx)
+    out_b = torch.full((1, nq * 128), float("nan"), device=DEV)
+    pos_dev = torch.tensor([pos], dtype=torch.int32, device=DEV)
+    _lib.check(lib.chatts_attention_decode_fused(raw.data_ptr(), nq, nkv, _lib.ptr(qn), _lib.ptr(kn), 1e-6,
+                                                 cos.data_ptr(), sin.data_ptr(), 0, pos_dev.data_ptr(), C.byref(cb),
+                                                 out_b.data_ptr(), splits, ws.data_ptr(), wsb, st()))
+    torch.cuda.synchronize()
+    assert not torch.isnan(out_b).any()
+    assert torch.equal(kc_b[:, pos], kc_a[:, pos]) and torch.equal(vc_b[:, pos], vc_a[:, pos])
+    assert torch.equal(kc_b[:, :pos], kc0[:, :pos])
+    assert rel_err(out_b.cpu().numpy(), out_a.cpu().numpy()) < 1e-6
 
 
 def test_embed_merge_and_argmax(lib):
