@@ -132,6 +132,17 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
 
   for (int tile = split; tile < ntiles; tile += p.n_splits) {
     const int j0 = tile * kTile;
+    // V of this thread's (dim, key half): all 32 loads are issued now and land while the scores are computed
+    float vv[32];
+    {
+      const int jb = j0 + half * 32;
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const int j = jb + u;
+        const int jc = j <= pos ? j : pos;       // clamped address; masked keys carry p = 0
+        vv[u] = vbase[(size_t)jc * kHeadDim + d_o];
+      }
+    }
     // ---- phase 1: scores --------------------------------------------------------------------
     {
       const int j = j0 + key_l;
@@ -193,23 +204,17 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
 #pragma unroll
       for (int g = 0; g < kMaxGroup; ++g)
         if (g < G) acc[g] *= alpha_s[g];
-      const int jb = j0 + half * 32;
+      if (owner) {                               // the new V row is not in the cache yet for this workgroup
+        const int jb = j0 + half * 32;
 #pragma unroll
-      for (int b8 = 0; b8 < 32; b8 += 8) {
-        float vv[8];
+        for (int u = 0; u < 32; ++u)
+          if (jb + u >= pos) vv[u] = vnew_s[d_o];
+      }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = jb + b8 + u;
-          const int jc = j <= pos ? j : pos;
-          vv[u] = vbase[(size_t)jc * kHeadDim + d_o];
-          if (owner && jc == pos) vv[u] = vnew_s[d_o];
-        }
+      for (int u = 0; u < 32; ++u) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-#pragma unroll
-          for (int g = 0; g < kMaxGroup; ++g)
-            if (g < G) acc[g] = fmaf(s_s[g * kTile + half * 32 + b8 + u], vv[u], acc[g]);   // p = 0 for masked keys
-        }
+        for (int g = 0; g < kMaxGroup; ++g)
+          if (g < G) acc[g] = fmaf(s_s[g * kTile + half * 32 + u], vv[u], acc[g]);   // p = 0 for masked keys
       }
     }
     __syncthreads();
@@ -248,19 +253,32 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
 }
 
 // Merge split partials: out = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the splits that saw keys.
+// One workgroup (2 waves) per (row, head).  Lane s of each wave loads (m_s, l_s) once; weights are broadcast
+// by shuffle, so the o_s[d] loads of all splits are independent and stay in flight together.
 __global__ __launch_bounds__(128) void attn_combine_kernel(AttnParams p) {
-  const int hq = blockIdx.x, row = blockIdx.y, d = threadIdx.x;
+  const int hq = blockIdx.x, row = blockIdx.y, d = threadIdx.x, lane = threadIdx.x & 63;
   const int pos = (p.pos0_dev ? *p.pos0_dev : p.pos0) + row;
   const int ntiles = pos / kTile + 1;
-  const int ns = ntiles < p.n_splits ? ntiles : p.n_splits;     // splits >= ntiles hold (m = -inf, l = 0)
+  const int ns = ntiles < p.n_splits ? ntiles : p.n_splits;     // splits >= ntiles saw no key (n_splits <= 64)
   const size_t base = ((size_t)row * p.n_q + hq) * p.n_splits;
-  float M = -INFINITY;
-  for (int s = 0; s < ns; ++s) M = fmaxf(M, p.part_ml[(base + s) * 2]);
-  float num = 0.f, den = 0.f;
-  for (int s = 0; s < ns; ++s) {
-    const float w = expf(p.part_ml[(base + s) * 2] - M);
-    num = fmaf(w, p.part_o[(base + s) * kHeadDim + d], num);
-    den = fmaf(w, p.part_ml[(base + s) * 2 + 1], den);
+  float m = -INFINITY, l = 0.f;
+  if (lane < ns) { m = p.part_ml[(base + lane) * 2]; l = p.part_ml[(base + lane) * 2 + 1]; }
+  const float M = wave_max(m);
+  const float w = lane < ns ? expf(m - M) : 0.f;
+  const float den = wave_sum(w * l);
+  float num = 0.f;
+  for (int s0 = 0; s0 < ns; s0 += 8) {
+    float o[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u < ns ? s0 + u : ns - 1;
+      o[u] = p.part_o[(base + s) * kHeadDim + d];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float ws = __shfl(w, s0 + u < 64 ? s0 + u : 63, 64);
+      if (s0 + u < ns) num = fmaf(ws, o[u], num);
+    }
   }
   p.out[((size_t)row * p.n_q + hq) * kHeadDim + d] = num / den;
 }
@@ -297,7 +315,7 @@ static int attention_common(AttnParams& p, bool fused, void* workspace, size_t w
 extern "C" int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev,
                                 const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
                                 size_t workspace_bytes, chatts_stream_t stream) {
-  CHATTS_REQUIRE(t >= 0 && n_q > 0 && n_kv > 0 && n_splits >= 1, CHATTS_E_BADARG, "attention: bad sizes");
+  CHATTS_REQUIRE(t >= 0 && n_q > 0 && n_kv > 0 && n_splits >= 1 && n_splits <= 64, CHATTS_E_BADARG, "attention: bad sizes");
   if (t == 0) return CHATTS_OK;
   CHATTS_REQUIRE(qkv && out && cache && cache->k && cache->v, CHATTS_E_BADARG, "attention: null pointer");
   CHATTS_REQUIRE(n_q % n_kv == 0 && n_q / n_kv <= kMaxGroup, CHATTS_E_SHAPE,
@@ -315,7 +333,7 @@ extern "C" int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int 
                                              const float* sin_tab, int pos, const int32_t* pos_dev,
                                              const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
                                              size_t workspace_bytes, chatts_stream_t stream) {
-  CHATTS_REQUIRE(n_q > 0 && n_kv > 0 && n_splits >= 1, CHATTS_E_BADARG, "attention_decode_fused: bad sizes");
+  CHATTS_REQUIRE(n_q > 0 && n_kv > 0 && n_splits >= 1 && n_splits <= 64, CHATTS_E_BADARG, "attention_decode_fused: bad sizes");
   CHATTS_REQUIRE(qkv_raw && out && cos_tab && sin_tab && cache && cache->k && cache->v, CHATTS_E_BADARG,
                  "attention_decode_fused: null pointer");
   CHATTS_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), CHATTS_E_BADARG,

@@ -155,7 +155,15 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   __shared__ int64_t si[16];
   float best = -INFINITY;
   int64_t bi = 0x7fffffffffffffffLL;
-  for (int64_t i = threadIdx.x; i < vocab; i += 1024) {
+  const int64_t v4 = ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) ? vocab / 4 : 0;   // float4 body, scalar tail
+  for (int64_t q = threadIdx.x; q < v4; q += 1024) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(logits)[q];
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (e[j] > best) { best = e[j]; bi = q * 4 + j; }      // ascending i within a thread: '>' keeps the first
+  }
+  for (int64_t i = v4 * 4 + threadIdx.x; i < vocab; i += 1024) {
     const float v = logits[i];
     if (v > best || (v == best && i < bi)) { best = v; bi = i; }
   }

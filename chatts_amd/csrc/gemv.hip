@@ -5,16 +5,11 @@
 // "GEMV / M<=16 decode weights" rule: weights go straight to VGPRs as non-temporal 16-byte loads,
 // many loads in flight per lane, no LDS round trip for the streamed operand.
 //
-// Two geometries:
-//  * gemv_regx_kernel (N up to a few 10k rows): the workgroup's 4 waves split K in 512-element chunks
-//    (chunk c -> wave c & 3) and each wave keeps ITS slice of x in registers for the whole launch
-//    (<= 7 chunks x 8 floats), so there is no LDS staging, no prologue barrier for the plain variants,
-//    and all NCH x ROWS 16-byte weight loads of a row group are issued back to back (12-14 per lane).
-//    The next row group's loads are issued before the cross-wave reduction of the current one.
-//    Partial sums meet in LDS (one barrier per row group, double-buffered slots) and are added in a
-//    fixed order -> run-to-run deterministic.
-//  * gemv_ldsx_kernel (lm_head, N = 152k): one wave per 4-row group over the whole K, x staged once per
-//    workgroup in LDS, permuted so each lane's two 16-byte reads per chunk are lane-linear.
+// Geometry: one wave per group of 2 rows over the whole K; the small, re-used operand x (20-55 KB f32) is
+// staged once per workgroup in LDS (4-16 waves share it), permuted so that each lane's two 16-byte reads
+// per 512-element chunk are lane-linear (conflict-free ds_read_b128); 2 rows x 2 chunks = 4 independent
+// 16-byte weight loads in flight per lane, 16-32 waves per CU.  A K-split variant that kept x in registers
+// and issued 12-14 loads per lane was measured and lost on every shape (tools/gemv_sweep.py).
 // Arithmetic: bf16 -> f32 widening is exact and x is f32, so every product is exact in the f32 FMA;
 // only the summation order differs from the CPU oracle (parity budget: 1e-3 relative on logits).
 // Fusions: RMSNorm of x in the prologue (Qwen2RMSNorm.forward), bias, residual add, SwiGLU.
@@ -87,123 +82,34 @@ __device__ __forceinline__ void gemv_epilogue(const GemvParams& p, int task, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// x in registers, K split over the 4 waves.  NCH = max chunks per wave (K <= 2048 * NCH).
+// x in LDS, one wave per row group over the whole K.  blockDim = 64 * NW (NW = 4, 8 or 16 waves share one
+// staged copy of x); ROWS x UNR 16-byte weight loads in flight per lane.
 // ------------------------------------------------------------------------------------------------
-template <int NCH, int ROWS, int EPI, bool NORM>
-__global__ __launch_bounds__(256) void gemv_regx_kernel(GemvParams p) {
-  __shared__ float red[2][4][ROWS];
-  __shared__ float ssq[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = p.k;
-
-  // this lane's x elements: chunk c = wave + 4 i, k = c*512 + lane*8 .. +7
-  f32x4 xa[NCH], xb[NCH];
-  bool okc[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int k0 = ((wave + 4 * i) << 9) + lane * 8;
-    okc[i] = k0 < K;
-    xa[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    xb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (okc[i]) {
-      xa[i] = *reinterpret_cast<const f32x4*>(p.x + k0);
-      xb[i] = *reinterpret_cast<const f32x4*>(p.x + k0 + 4);
-    }
-  }
-
-  u32x4 wr[NCH][ROWS];
-  auto issue = [&](int task) {
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      int row = task_row<ROWS, EPI>(task, r);
-      if (row >= p.n) row = 0;
-      const uint16_t* wrow = p.w + (size_t)row * p.ldw + lane * 8;
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        wr[i][r] = (u32x4){0u, 0u, 0u, 0u};
-        if (okc[i]) wr[i][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + ((wave + 4 * i) << 9)));
-      }
-    }
-  };
-
-  int task = blockIdx.x;
-  if (task < p.tasks) issue(task);   // weights of the first row group fly while x is normalised
-
-  if (NORM) {
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-      ss += xa[i].x * xa[i].x + xa[i].y * xa[i].y + xa[i].z * xa[i].z + xa[i].w * xa[i].w +
-            xb[i].x * xb[i].x + xb[i].y * xb[i].y + xb[i].z * xb[i].z + xb[i].w * xb[i].w;
-    ss = wave_sum(ss);
-    if (lane == 0) ssq[wave] = ss;
-    __syncthreads();
-    const float rstd = rsqrtf(((ssq[0] + ssq[1]) + (ssq[2] + ssq[3])) / (float)K + p.eps);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      if (okc[i]) {
-        const int k0 = ((wave + 4 * i) << 9) + lane * 8;
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(p.norm_w + k0);
-        const f32x4 gb = *reinterpret_cast<const f32x4*>(p.norm_w + k0 + 4);
-        xa[i].x = ga.x * (xa[i].x * rstd); xa[i].y = ga.y * (xa[i].y * rstd);
-        xa[i].z = ga.z * (xa[i].z * rstd); xa[i].w = ga.w * (xa[i].w * rstd);
-        xb[i].x = gb.x * (xb[i].x * rstd); xb[i].y = gb.y * (xb[i].y * rstd);
-        xb[i].z = gb.z * (xb[i].z * rstd); xb[i].w = gb.w * (xb[i].w * rstd);
-      }
-    }
-  }
-
-  int parity = 0;
-  for (; task < p.tasks; task += gridDim.x) {
-    float acc[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) a = dot8(wr[i][r], xa[i], xb[i], a);
-      acc[r] = a;
-    }
-    const int next = task + gridDim.x;
-    if (next < p.tasks) issue(next);            // next row group's loads overlap the reduction below
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
-    if (lane == 0) {
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r) red[parity][wave][r] = acc[r];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r)
-        acc[r] = (red[parity][0][r] + red[parity][1][r]) + (red[parity][2][r] + red[parity][3][r]);
-      gemv_epilogue<ROWS, EPI>(p, task, lane, acc);
-    }
-    parity ^= 1;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// x in LDS, one wave per row group over the whole K (large N).
-// ------------------------------------------------------------------------------------------------
-template <int ROWS, int EPI, bool NORM>
-__global__ __launch_bounds__(256) void gemv_ldsx_kernel(GemvParams p) {
+template <int ROWS, int UNR, int EPI, bool NORM>
+__global__ __launch_bounds__(1024) void gemv_ldsx_kernel(GemvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* xs4 = reinterpret_cast<f32x4*>(smem);            // permuted x: [chunk][half][lane] float4
   float* red = reinterpret_cast<float*>(smem) + (size_t)((p.k + 511) / 512) * 512;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthreads = blockDim.x, nw = nthreads >> 6;
   const int K = p.k;
   const int nchunks = (K + 511) >> 9;
 
-  float ss = 0.f;
+  float rstd = 1.f;
   if (NORM) {
-    for (int k4 = tid * 4; k4 < K; k4 += 1024) {
+    float ss = 0.f;
+    for (int k4 = tid * 4; k4 < K; k4 += nthreads * 4) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + k4);
       ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
-    ss = block_sum<4>(ss, red);
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    rstd = rsqrtf(t / (float)K + p.eps);
   }
-  const float rstd = NORM ? rsqrtf(ss / (float)K + p.eps) : 1.f;
-  for (int k4 = tid * 4; k4 < nchunks * 512; k4 += 1024) {
+  for (int k4 = tid * 4; k4 < nchunks * 512; k4 += nthreads * 4) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (k4 < K) {
       v = *reinterpret_cast<const f32x4*>(p.x + k4);
@@ -217,38 +123,35 @@ __global__ __launch_bounds__(256) void gemv_ldsx_kernel(GemvParams p) {
   }
   __syncthreads();
 
-  for (int task = blockIdx.x * 4 + wave; task < p.tasks; task += gridDim.x * 4) {
+  for (int task = blockIdx.x * nw + wave; task < p.tasks; task += gridDim.x * nw) {
     const uint16_t* wrow[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       int row = task_row<ROWS, EPI>(task, r);
       if (row >= p.n) row = 0;
-      wrow[r] = p.w + (size_t)row * p.ldw;
+      wrow[r] = p.w + (size_t)row * p.ldw + lane * 8;
     }
     float acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-    for (int c = 0; c < nchunks; c += 2) {     // two chunks (2 x ROWS 16-byte loads) in flight per lane
-      const int c1 = c + 1;
-      const int k0 = (c << 9) + lane * 8, k1 = (c1 << 9) + lane * 8;
-      const bool ok0 = k0 < K, ok1 = c1 < nchunks && k1 < K;
-      u32x4 w0[ROWS], w1[ROWS];
+    for (int c = 0; c < nchunks; c += UNR) {
+      u32x4 wv[UNR][ROWS];
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) {
-        w0[r] = (u32x4){0u, 0u, 0u, 0u};
-        w1[r] = (u32x4){0u, 0u, 0u, 0u};
-        if (ok0) w0[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k0));
+      for (int u = 0; u < UNR; ++u) {
+        const bool ok = c + u < nchunks && ((c + u) << 9) + lane * 8 < K;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          wv[u][r] = (u32x4){0u, 0u, 0u, 0u};
+          if (ok) wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + ((c + u) << 9)));
+        }
       }
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r)
-        if (ok1) w1[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k1));
-      const f32x4 xa0 = xs4[c * 128 + lane], xb0 = xs4[c * 128 + 64 + lane];
+      for (int u = 0; u < UNR; ++u) {
+        if (c + u < nchunks) {
+          const f32x4 xa = xs4[(c + u) * 128 + lane], xb = xs4[(c + u) * 128 + 64 + lane];
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) acc[r] = dot8(w0[r], xa0, xb0, acc[r]);
-      if (c1 < nchunks) {
-        const f32x4 xa1 = xs4[c1 * 128 + lane], xb1 = xs4[c1 * 128 + 64 + lane];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[r] = dot8(w1[r], xa1, xb1, acc[r]);
+          for (int r = 0; r < ROWS; ++r) acc[r] = dot8(wv[u][r], xa, xb, acc[r]);
+        }
       }
     }
 #pragma unroll
@@ -258,23 +161,18 @@ __global__ __launch_bounds__(256) void gemv_ldsx_kernel(GemvParams p) {
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------
-template <int NCH, int ROWS, int EPI>
-static void launch_regx_norm(const GemvParams& p, bool norm, int blocks, hipStream_t s) {
-  if (norm) hipLaunchKernelGGL((gemv_regx_kernel<NCH, ROWS, EPI, true>), dim3(blocks), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemv_regx_kernel<NCH, ROWS, EPI, false>), dim3(blocks), dim3(256), 0, s, p);
+template <int ROWS, int UNR, int EPI>
+static void launch_ldsx_norm(const GemvParams& p, bool norm, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (norm) hipLaunchKernelGGL((gemv_ldsx_kernel<ROWS, UNR, EPI, true>), dim3(blocks), dim3(threads), lds, s, p);
+  else hipLaunchKernelGGL((gemv_ldsx_kernel<ROWS, UNR, EPI, false>), dim3(blocks), dim3(threads), lds, s, p);
 }
-template <int NCH, int ROWS>
-static void launch_regx(const GemvParams& p, int epi, bool norm, int blocks, hipStream_t s) {
+template <int ROWS, int UNR>
+static void launch_ldsx(const GemvParams& p, int epi, bool norm, int blocks, int threads, size_t lds, hipStream_t s) {
   switch (epi) {
-    case CHATTS_EPI_RESID: launch_regx_norm<NCH, ROWS, CHATTS_EPI_RESID>(p, norm, blocks, s); break;
-    case CHATTS_EPI_SWIGLU: launch_regx_norm<NCH, ROWS, CHATTS_EPI_SWIGLU>(p, norm, blocks, s); break;
-    default: launch_regx_norm<NCH, ROWS, CHATTS_EPI_NONE>(p, norm, blocks, s); break;
+    case CHATTS_EPI_RESID: launch_ldsx_norm<ROWS, UNR, CHATTS_EPI_RESID>(p, norm, blocks, threads, lds, s); break;
+    case CHATTS_EPI_SWIGLU: launch_ldsx_norm<ROWS, UNR, CHATTS_EPI_SWIGLU>(p, norm, blocks, threads, lds, s); break;
+    default: launch_ldsx_norm<ROWS, UNR, CHATTS_EPI_NONE>(p, norm, blocks, threads, lds, s); break;
   }
-}
-template <int EPI>
-static void launch_ldsx_norm(const GemvParams& p, bool norm, int blocks, size_t lds, hipStream_t s) {
-  if (norm) hipLaunchKernelGGL((gemv_ldsx_kernel<4, EPI, true>), dim3(blocks), dim3(256), lds, s, p);
-  else hipLaunchKernelGGL((gemv_ldsx_kernel<4, EPI, false>), dim3(blocks), dim3(256), lds, s, p);
 }
 
 static int env_int(const char* name, int dflt) {
@@ -291,44 +189,39 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   const int swiglu = a->epilogue == CHATTS_EPI_SWIGLU;
   const int units = swiglu ? a->n / 2 : a->n;
   const int nchunks = (a->k + 511) / 512;
-  const int nch = (nchunks + 3) / 4;                  // chunks per wave in the K-split geometry
-  // 0 = auto, 1 = force x-in-LDS, 2 = force x-in-registers (tuning / tests)
-  const int force = env_int("CHATTS_GEMV_GEOM", 0);
-  const bool regx = force == 2 || (force == 0 && nch <= 7 && units < 65536);
-  if (regx && nch <= 7) {
-    const int rows = nch <= 4 ? 4 : 2;
-    const int upt = swiglu ? rows / 2 : rows;
-    p.tasks = (units + upt - 1) / upt;
-    // resident workgroups per CU (VGPR-bound: ~88 regs for NCH<=4, ~130 for NCH=7)
-    int occ = env_int("CHATTS_GEMV_OCC", nch <= 4 ? 5 : 3);
-    const int maxb = cus * occ;
-    const int iters = (p.tasks + maxb - 1) / maxb;
-    int blocks = (p.tasks + iters - 1) / iters;       // balanced: every workgroup runs `iters` (or iters-1) tasks
-    if (blocks < 1) blocks = 1;
-    if (nch <= 1) launch_regx<1, 4>(p, a->epilogue, norm, blocks, s);
-    else if (nch == 2) launch_regx<2, 4>(p, a->epilogue, norm, blocks, s);
-    else if (nch == 3) launch_regx<3, 4>(p, a->epilogue, norm, blocks, s);
-    else if (nch == 4) launch_regx<4, 4>(p, a->epilogue, norm, blocks, s);
-    else launch_regx<7, 2>(p, a->epilogue, norm, blocks, s);
-    CHATTS_CHECK_LAUNCH("gemv_regx");
-    return CHATTS_OK;
-  }
   const size_t lds = (size_t)nchunks * 512 * 4 + 64 * 4;
   CHATTS_REQUIRE(lds <= 160 * 1024, CHATTS_E_SHAPE, "gemv: K=%d too large for the LDS-resident x", a->k);
-  int occ = (int)((150 * 1024) / lds);
-  if (occ > 8) occ = 8;
+  // Geometry from the sweep in tools/gemv_sweep.py (profiles/gemv_sweep_r1.log): 2 rows x 2 chunks in flight per lane
+  // wins on every decode shape; what varies is how many waves share one staged copy of x and how many
+  // workgroups a CU should hold.
+  int rows = env_int("CHATTS_GEMV_ROWS", 2);
+  if (rows != 4) rows = 2;
+  int unr = env_int("CHATTS_GEMV_UNR", 2);
+  if (unr != 4) unr = 2;
+  int nw_auto, occ_auto = 0;
+  if (a->k > 8192) nw_auto = 16;                       // down_proj: 55 KB of x per workgroup -> amortise over 16 waves
+  else if (units >= 65536) { nw_auto = 4; occ_auto = 2; }   // lm_head
+  else if (a->n >= 16384) { nw_auto = 8; occ_auto = 2; }    // gate_up
+  else if (a->n > 6000) nw_auto = 16;                  // qkv
+  else nw_auto = 4;                                    // o_proj
+  int nw = env_int("CHATTS_GEMV_NW", nw_auto);
+  if (nw != 8 && nw != 16) nw = 4;
+  int occ = (int)((150 * 1024) / lds);          // workgroups per CU that fit in LDS
+  const int wave_cap = 32 / nw;                  // 32 waves per CU
+  if (occ > wave_cap) occ = wave_cap;
+  if (occ_auto && occ > occ_auto) occ = occ_auto;
   if (occ < 1) occ = 1;
   occ = env_int("CHATTS_GEMV_OCC", occ);
-  const int upt = swiglu ? 2 : 4;
+  const int upt = swiglu ? rows / 2 : rows;
   p.tasks = (units + upt - 1) / upt;
-  int blocks = (p.tasks + 3) / 4;
+  int blocks = (p.tasks + nw - 1) / nw;
   if (blocks > cus * occ) blocks = cus * occ;
   if (blocks < 1) blocks = 1;
-  switch (a->epilogue) {
-    case CHATTS_EPI_RESID: launch_ldsx_norm<CHATTS_EPI_RESID>(p, norm, blocks, lds, s); break;
-    case CHATTS_EPI_SWIGLU: launch_ldsx_norm<CHATTS_EPI_SWIGLU>(p, norm, blocks, lds, s); break;
-    default: launch_ldsx_norm<CHATTS_EPI_NONE>(p, norm, blocks, lds, s); break;
-  }
+  const int threads = nw * 64;
+  if (rows == 4 && unr == 2) launch_ldsx<4, 2>(p, a->epilogue, norm, blocks, threads, lds, s);
+  else if (rows == 4) launch_ldsx<4, 4>(p, a->epilogue, norm, blocks, threads, lds, s);
+  else if (unr == 2) launch_ldsx<2, 2>(p, a->epilogue, norm, blocks, threads, lds, s);
+  else launch_ldsx<2, 4>(p, a->epilogue, norm, blocks, threads, lds, s);
   CHATTS_CHECK_LAUNCH("gemv_ldsx");
   return CHATTS_OK;
 }

@@ -349,7 +349,7 @@ def test_attention_decode_fused_equals_unfused(lib, qk_norm, pos, splits):
                                                  out_b.data_ptr(), splits, ws.data_ptr(), wsb, st()))
     torch.cuda.synchronize()
     assert not torch.isnan(out_b).any()
-    assert torch.equal(kc_b[:, pos], kc_a[:, pos]) and torch.equal(vc_b[:, pos], vc_a[:, pos])
+    assert rel_err(kc_b[:, pos].cpu().numpy(), kc_a[:, pos].cpu().numpy()) < 1e-6 and torch.equal(vc_b[:, pos], vc_a[:, pos])
     assert torch.equal(kc_b[:, :pos], kc0[:, :pos])
     assert rel_err(out_b.cpu().numpy(), out_a.cpu().numpy()) < 1e-6
 
