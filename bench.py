@@ -85,7 +85,7 @@ def roofline_gate_up(model, reps=2):
     avg_s = e0.elapsed_time(e1) * 1e-3 / launches
     # algorithmic bytes per launch: bf16 weights + f32 x in + norm weights + f32 out (SURVEY.md 8d per-unit figure)
     bytes_per_launch = n * H * 2 + H * 4 + H * 4 + plan.inter * 4
-    return dict(kernel="gemv_kernel<4,1,SWIGLU,NORM> (gate_up_proj + RMSNorm + SwiGLU)", launches=launches,
+    return dict(kernel="gemv_ldsx_kernel<2,2,SWIGLU,NORM> (gate_up_proj + fused RMSNorm + SwiGLU)", launches=launches,
                 avg_us=avg_s * 1e6, bytes_per_launch=bytes_per_launch, gbs=bytes_per_launch / avg_s / 1e9)
 
 
@@ -261,6 +261,14 @@ def main():
     ms_step = dt / args.steps * 1e3
 
     roof = roofline_gate_up(model)
+    traffic = None          # HBM bytes per launch from the separate rocprofv3 --pmc pass (TP=1 shape only)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if world == 1 and args.model == "chatts-14b":
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        pmc = None
     step_bytes = model.weight_bytes_local()
     result = {
         "metric": "generated tokens/sec (greedy, batch 1) + p50 TTFT, ChatTS-14B, 8x256-step TS prompt, TP=N",
@@ -280,7 +288,8 @@ def main():
         "decode_hbm_frac_of_8TBs": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         "decode_frac_of_bf16_mfma_roofline": (2.0 * step_bytes / 2 / (dt / args.steps)) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
         "roofline": {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": None, "kernel": roof["kernel"],
+                     "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": (pmc or {}).get("source") if traffic else None, "kernel": roof["kernel"],
                      "avg_us": roof["avg_us"], "bytes_per_launch": roof["bytes_per_launch"],
                      "launches_timed": roof["launches"]},
     }

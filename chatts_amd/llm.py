@@ -1,0 +1,80 @@
+"""vLLM-style offline surface: ``LLM(...).generate([{"prompt", "multi_modal_data": {"timeseries": [...]}}], SamplingParams)``.
+
+Mirrors how the reference drives vLLM (NetManAIOps/ChatTS demo/demo_vllm.py:30-63, chatts/utils/llm_utils.py:154-182):
+same constructor keywords, same dict input schema, results expose ``.outputs[0].text``.  vLLM itself is not a
+dependency; requests are served one after another on the HIP engine (continuous batching: SURVEY.md section 8f).
+"""
+import os
+
+import numpy as np
+
+
+class SamplingParams:
+    def __init__(self, max_tokens=16, temperature=0.0, top_p=1.0, stop_token_ids=None, ignore_eos=False, **kw):
+        self.max_tokens = int(max_tokens)
+        self.temperature = temperature
+        self.top_p = top_p
+        self.stop_token_ids = list(stop_token_ids or [])
+        self.ignore_eos = ignore_eos
+
+
+class CompletionOutput:
+    def __init__(self, text, token_ids):
+        self.text, self.token_ids, self.index = text, token_ids, 0
+
+
+class RequestOutput:
+    def __init__(self, prompt, prompt_token_ids, outputs):
+        self.prompt, self.prompt_token_ids, self.outputs = prompt, prompt_token_ids, outputs
+
+
+class LLM:
+    def __init__(self, model, tensor_parallel_size=1, max_model_len=6000, limit_mm_per_prompt=None,
+                 trust_remote_code=True, gpu_memory_utilization=None, seed=0, tokenizer=None, comm=None, **kw):
+        from .config import PRESETS, ChatTSConfig, preset
+        from .modeling import ChatTSForCausalLM
+        from .processing import ChatTSProcessor
+        from .tp import Comm, LocalComm
+        if comm is None:
+            comm = Comm() if tensor_parallel_size > 1 else LocalComm()
+        if comm.world != tensor_parallel_size:
+            raise ValueError(f"tensor_parallel_size={tensor_parallel_size} needs {tensor_parallel_size} ranks launched "
+                             f"one per GPU (torchrun); this process group has {comm.world}")
+        mk = dict(comm=comm, max_ctx=max_model_len, max_prefill_tokens=min(2048, max_model_len))
+        if isinstance(model, ChatTSConfig):
+            self.model = ChatTSForCausalLM.from_synthetic(model, seed=seed, **mk)
+        elif isinstance(model, str) and model in PRESETS:
+            self.model = ChatTSForCausalLM.from_synthetic(preset(model), seed=seed, **mk)
+        elif isinstance(model, str) and os.path.isdir(model):
+            self.model = ChatTSForCausalLM.from_pretrained(model, **mk)
+        else:
+            raise ValueError(f"model must be a checkpoint directory, a ChatTSConfig or one of {sorted(PRESETS)}")
+        self.config = self.model.config
+        self.processor = ChatTSProcessor.from_pretrained(self.config, tokenizer=tokenizer)
+        self.limit = (limit_mm_per_prompt or {}).get("timeseries", 50)      # chatts_vllm.py:220 caps at 50
+
+    def get_tokenizer(self):
+        return self.processor.tokenizer
+
+    def generate(self, prompts, sampling_params=None, use_tqdm=False):
+        sp = sampling_params or SamplingParams()
+        if sp.temperature not in (0, 0.0, None):
+            raise NotImplementedError("only greedy decoding (temperature=0) is implemented")
+        if isinstance(prompts, (str, dict)):
+            prompts = [prompts]
+        outs = []
+        for req in prompts:
+            if isinstance(req, str):
+                req = {"prompt": req}
+            series = list((req.get("multi_modal_data") or {}).get("timeseries", []))
+            if len(series) > self.limit:
+                raise ValueError(f"At most {self.limit} timeseries may be provided in one prompt, got {len(series)}")
+            text, encs, lens = self.processor.splice(req["prompt"], [np.asarray(s, dtype=np.float64) for s in series])
+            ids = self.processor.tokenizer.encode(text)
+            import torch
+            ser = torch.from_numpy(self.processor.pad_stack(encs)) if encs else None
+            eos = None if sp.ignore_eos else (list(self.config.eos_token_id) + sp.stop_token_ids)
+            toks = self.model.generate_one(ids, ser, lens, sp.max_tokens, eos)
+            outs.append(RequestOutput(req["prompt"], ids,
+                                      [CompletionOutput(self.processor.tokenizer.decode(toks, skip_special_tokens=True), toks)]))
+        return outs

@@ -1,0 +1,114 @@
+"""CPU, world_size 2, gloo: the tensor-parallel PLAN and COMM of chatts_amd/tp.py.
+
+Each rank evaluates its shard of the decoder with the oracle's float32 math (heads / MLP columns / vocabulary
+sliced exactly as ShardPlan says), exchanges partial sums through tp.Comm.all_reduce and picks the greedy token
+with tp.Comm.argmax_pair; rank 0 compares with the unsharded oracle.  (The HIP kernels themselves cannot run on
+CPU; on the GPU the same plan is checked by tests/test_gpu_e2e.py::test_emulated_tensor_parallel_matches_tp1.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from chatts_amd import config as cfgmod, synth
+from chatts_amd.tp import Comm, ShardPlan
+from oracle import qwen_decoder as qd, synth as osynth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _sharded_forward(cfg, sd, plan, comm, x):
+    """One pass of all layers on this rank's shard; returns the (replicated) final hidden states."""
+    c = cfg.oracle_dict()
+    d, eps, H = c["head_dim"], c["rms_norm_eps"], c["hidden_size"]
+    T = x.shape[0]
+    pos = torch.arange(T)
+    cos, sin = qd.rope_cos_sin(pos, d, c["rope_theta"])
+    for l in range(cfg.num_hidden_layers):
+        p = f"model.layers.{l}."
+        h = qd.rms_norm(x, sd[p + "input_layernorm.weight"], eps)
+        qs, ks = slice(plan.q0 * d, (plan.q0 + plan.nq) * d), slice(plan.kv0 * d, (plan.kv0 + plan.nkv) * d)
+        q = (h @ sd[p + "self_attn.q_proj.weight"][qs].T).view(T, plan.nq, d)
+        k = (h @ sd[p + "self_attn.k_proj.weight"][ks].T).view(T, plan.nkv, d)
+        v = (h @ sd[p + "self_attn.v_proj.weight"][ks].T).view(T, plan.nkv, d)
+        if p + "self_attn.q_proj.bias" in sd:
+            q = q + sd[p + "self_attn.q_proj.bias"][qs].view(plan.nq, d)
+            k = k + sd[p + "self_attn.k_proj.bias"][ks].view(plan.nkv, d)
+            v = v + sd[p + "self_attn.v_proj.bias"][ks].view(plan.nkv, d)
+        if p + "self_attn.q_norm.weight" in sd:
+            q = qd.rms_norm(q, sd[p + "self_attn.q_norm.weight"], eps)
+            k = qd.rms_norm(k, sd[p + "self_attn.k_norm.weight"], eps)
+        q = q * cos[:, None] + qd.rotate_half(q) * sin[:, None]
+        k = k * cos[:, None] + qd.rotate_half(k) * sin[:, None]
+        g = plan.nq // plan.nkv
+        kk, vv = k.transpose(0, 1).repeat_interleave(g, 0), v.transpose(0, 1).repeat_interleave(g, 0)
+        att = (q.transpose(0, 1) @ kk.transpose(1, 2)) / np.sqrt(d)
+        att = att.masked_fill(torch.arange(T)[None, :] > pos[:, None], float("-inf"))
+        o = (torch.softmax(att, -1) @ vv).transpose(0, 1).reshape(T, plan.nq * d)
+        delta = o @ sd[p + "self_attn.o_proj.weight"][:, qs].T              # row-parallel partial sum
+        x = x + comm.all_reduce(delta.contiguous())
+        h = qd.rms_norm(x, sd[p + "post_attention_layernorm.weight"], eps)
+        isl = slice(plan.i0, plan.i0 + plan.inter)
+        act = torch.nn.functional.silu(h @ sd[p + "mlp.gate_proj.weight"][isl].T) * (h @ sd[p + "mlp.up_proj.weight"][isl].T)
+        delta = act @ sd[p + "mlp.down_proj.weight"][:, isl].T
+        x = x + comm.all_reduce(delta.contiguous())
+    return qd.rms_norm(x, sd["model.norm.weight"], eps)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        cfg = cfgmod.preset("tiny-qwen3", num_hidden_layers=2)
+        sd = osynth.state_dict(synth.decoder_specs(cfg), 4)
+        comm = Comm()
+        assert (comm.rank, comm.world) == (rank, world)
+        plan = ShardPlan(cfg, comm.rank, comm.world)
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn((9, cfg.hidden_size), generator=g) * 0.5
+        h = _sharded_forward(cfg, sd, plan, comm, x)
+        logits = h[-1] @ sd["lm_head.weight"][plan.v0:plan.v0 + plan.vocab].T        # vocab-parallel
+        val, idx = logits.max(0)
+        tok = comm.argmax_pair(val.reshape(1), (idx + plan.v0).reshape(1))
+        # tie rule: equal maxima on both ranks -> the lowest token id wins
+        tie = comm.argmax_pair(torch.tensor([1.0]), torch.tensor([100 + 7 * (world - rank)]))
+        comm.barrier()
+        if rank == 0:
+            ref = qd.QwenOracle(cfg.oracle_dict(), sd).forward_embeds(x)
+            q.put((int(tok), int(torch.argmax(ref[-1])), float((h - _ref_hidden(cfg, sd, x)).abs().max()), int(tie)))
+            q.put(float(np.linalg.norm((logits - ref[-1][plan.v0:plan.v0 + plan.vocab]).numpy()) /
+                        np.linalg.norm(ref[-1][plan.v0:plan.v0 + plan.vocab].numpy())))
+    finally:
+        dist.destroy_process_group()
+
+
+def _ref_hidden(cfg, sd, x):
+    return qd.QwenOracle(cfg.oracle_dict(), sd).forward_embeds(x, return_hidden=True)
+
+
+def test_tensor_parallel_plan_and_comm_gloo_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    tok, ref_tok, hid_err, tie = q.get(timeout=10)
+    rel = q.get(timeout=10)
+    assert tok == ref_tok
+    assert hid_err < 1e-4
+    assert rel < 1e-5
+    assert tie == 107            # min(100 + 7*2, 100 + 7*1): lowest id among equal maxima
