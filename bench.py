@@ -192,12 +192,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # test hooks (functional TP check on a single-GPU box): CHATTS_FORCE_DEVICE pins every rank to one device,
+    # CHATTS_DIST_BACKEND=gloo replaces RCCL.  Never set by the driver.
+    dev_index = int(os.environ.get("CHATTS_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        backend = os.environ.get("CHATTS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend=backend)
         comm = Comm()
     else:
         comm = LocalComm()

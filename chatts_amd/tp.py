@@ -49,10 +49,11 @@ class Comm:
         Ties resolve to the lowest token id, like torch.argmax over the full vocabulary."""
         if self.world == 1:
             return token
-        vals = torch.empty(self.world, dtype=logit.dtype, device=logit.device)
-        idxs = torch.empty(self.world, dtype=token.dtype, device=token.device)
-        self.dist.all_gather_into_tensor(vals, logit.reshape(1), group=self.group)
-        self.dist.all_gather_into_tensor(idxs, token.reshape(1), group=self.group)
+        vl = [torch.empty(1, dtype=logit.dtype, device=logit.device) for _ in range(self.world)]
+        il = [torch.empty(1, dtype=token.dtype, device=token.device) for _ in range(self.world)]
+        self.dist.all_gather(vl, logit.reshape(1).contiguous(), group=self.group)     # list form: works on nccl and gloo
+        self.dist.all_gather(il, token.reshape(1).contiguous(), group=self.group)
+        vals, idxs = torch.cat(vl), torch.cat(il)
         best = vals.max()
         cand = torch.where(vals == best, idxs, torch.full_like(idxs, torch.iinfo(torch.int64).max))
         return cand.min().reshape(1)
