@@ -147,8 +147,8 @@ int chatts_rope_kv_write(float* qkv, int t, int n_q, int n_kv, const float* q_no
 
 /* Causal GQA attention of T query rows (positions pos0..pos0+T-1) against cache rows [0, pos].
  * q is read from qkv [T, (n_q+2*n_kv)*128]; out [T, n_q*128].  float32 scores, softmax and PV.
- * n_splits > 1 (decode): keys are strided over n_splits workgroups per (row, kv-head), partials go
- * to workspace and are combined by a second kernel.  workspace >= chatts_attn_workspace(). */
+ * n_splits > 1: key tiles are strided over n_splits workgroups per (row, kv-head), partials go to workspace and
+ * are combined by a second kernel.  workspace >= chatts_attn_workspace() (needed whenever n_splits > 1). */
 size_t chatts_attn_workspace(int t, int n_q, int n_splits);
 int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev,
                      const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
@@ -156,7 +156,9 @@ int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int pos0, const
 
 /* Decode form (T = 1) that also replaces chatts_rope_kv_write: qkv_raw holds the un-rotated projections
  * (after bias); the kernel applies the optional per-head q/k RMSNorm + RoPE at position pos (or *pos_dev),
- * stores the new K/V row into the cache and attends over cache rows [0, pos]. */
+ * stores the new K/V row into the cache and attends over cache rows [0, pos].  One wave per (kv head, 16-key
+ * tile); n_splits (<= 256) is the number of tile slots, slot s walks tiles s, s+n_splits, ...; the workspace
+ * (chatts_attn_workspace(1, n_q, n_splits) bytes) is always required. */
 int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int n_kv, const float* q_norm_w,
                                   const float* k_norm_w, float norm_eps, const float* cos_tab,
                                   const float* sin_tab, int pos, const int32_t* pos_dev,
