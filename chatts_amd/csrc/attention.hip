@@ -23,7 +23,7 @@ namespace chatts {
 constexpr int kMaxGroup = 8;
 constexpr int kTile = 64;    // prefill kernel: keys per tile
 constexpr int kDTile = 16;   // decode kernel: keys per wave-tile
-constexpr int kMaxSlots = 256;
+constexpr int kMaxSlots = 64;    // decode: tile slots per kv head (one lane of the combine wave each)
 
 struct AttnParams {
   const float* qkv;   // [T, (n_q + 2 n_kv) * 128]; q already rotated for attn_rows, raw for attn_decode
@@ -74,6 +74,28 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
   if (slot >= ntiles) return;                  // the combine only reads slots < min(ntiles, NS)
   const bool owner = ((pos / kDTile) % NS) == slot;
   const float scale = 0.08838834764831845f;    // 128^-1/2
+  const float* kbase = p.kc + (size_t)hk * p.max_ctx * kHeadDim;
+  const float* vbase = p.vc + (size_t)hk * p.max_ctx * kHeadDim;
+  const int key_l = lane >> 2, quarter = lane & 3;
+
+  // K and V of the first tile only depend on `pos`: issue them before the q prologue so that the cache rows,
+  // q, cos/sin all travel in the same memory round trip.
+  f32x4 kv[8];
+  float2 vv[kDTile];
+  auto load_tile = [&](int tile) {
+    const int j0 = tile * kDTile;
+    const int j = j0 + key_l;
+    const int jc = j <= pos ? j : pos;          // clamped address; masked below
+    const float* kr = kbase + (size_t)jc * kHeadDim + quarter * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
+#pragma unroll
+    for (int u = 0; u < kDTile; ++u) {
+      const int ju = j0 + u <= pos ? j0 + u : pos;
+      vv[u] = *reinterpret_cast<const float2*>(vbase + (size_t)ju * kHeadDim + lane * 2);
+    }
+  };
+  load_tile(slot);
 
   {
     const float c = p.cos_tab[(size_t)pos * 64 + lane], s = p.sin_tab[(size_t)pos * 64 + lane];
@@ -107,28 +129,15 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
   }
   __syncthreads();                              // single wave: orders the LDS writes above
 
-  const float* kbase = p.kc + (size_t)hk * p.max_ctx * kHeadDim;
-  const float* vbase = p.vc + (size_t)hk * p.max_ctx * kHeadDim;
-  const int key_l = lane >> 2, quarter = lane & 3;
-
   float m_run[kMaxGroup], l_run[kMaxGroup], acc0[kMaxGroup], acc1[kMaxGroup];
 #pragma unroll
   for (int g = 0; g < kMaxGroup; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.f; acc0[g] = 0.f; acc1[g] = 0.f; }
 
   for (int tile = slot; tile < ntiles; tile += NS) {
+    if (tile != slot) load_tile(tile);
     const int j0 = tile * kDTile;
     const int j = j0 + key_l;
-    const int jc = j <= pos ? j : pos;          // clamped address; masked below
-    const float* kr = kbase + (size_t)jc * kHeadDim + quarter * 4;
-    f32x4 kv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
-    float2 vv[kDTile];
-#pragma unroll
-    for (int u = 0; u < kDTile; ++u) {
-      const int ju = j0 + u <= pos ? j0 + u : pos;
-      vv[u] = *reinterpret_cast<const float2*>(vbase + (size_t)ju * kHeadDim + lane * 2);
-    }
+    const int jc = j <= pos ? j : pos;
     if (owner && jc == pos) {                   // the row just produced is not in the cache for this wave yet
 #pragma unroll
       for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(knew_s + quarter * 4 + i * 16);
@@ -202,41 +211,33 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
   }
 }
 
-// out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys.  One workgroup (2 waves)
-// per head; the weights go through LDS so that the o_s[d] loads of all slots are independent of each other.
+// out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots).  One workgroup
+// (2 waves) per head; lane s of each wave holds (m_s, l_s), weights are broadcast by shuffle, and 16 independent
+// o_s[d] loads are in flight per thread: no LDS, no barrier.
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnParams p) {
-  __shared__ float w_s[kMaxSlots];
-  __shared__ float red[4];
-  const int hq = blockIdx.x, d = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hq = blockIdx.x, d = threadIdx.x, lane = threadIdx.x & 63;
   const int pos = p.pos0_dev ? *p.pos0_dev : p.pos0;
   const int ntiles = pos / kDTile + 1;
   const int ns = ntiles < p.n_splits ? ntiles : p.n_splits;
   const size_t base = (size_t)hq * p.n_splits;
-  float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;      // slots d and d + 128
-  if (d < ns) { m0 = p.part_ml[(base + d) * 2]; l0 = p.part_ml[(base + d) * 2 + 1]; }
-  if (d + 128 < ns) { m1 = p.part_ml[(base + d + 128) * 2]; l1 = p.part_ml[(base + d + 128) * 2 + 1]; }
-  float M = wave_max(fmaxf(m0, m1));
-  if (lane == 0) red[wave] = M;
-  __syncthreads();
-  M = fmaxf(red[0], red[1]);
-  const float w0 = d < ns ? expf(m0 - M) : 0.f, w1 = d + 128 < ns ? expf(m1 - M) : 0.f;
-  w_s[d] = w0;
-  w_s[d + 128] = w1;
-  const float dl = wave_sum(w0 * l0 + w1 * l1);
-  if (lane == 0) red[2 + wave] = dl;
-  __syncthreads();
-  const float den = red[2] + red[3];
+  float m = -INFINITY, l = 0.f;
+  if (lane < ns) { m = p.part_ml[(base + lane) * 2]; l = p.part_ml[(base + lane) * 2 + 1]; }
+  const float M = wave_max(m);
+  const float w = lane < ns ? expf(m - M) : 0.f;
+  const float den = wave_sum(w * l);
   float num = 0.f;
-  for (int s0 = 0; s0 < ns; s0 += 8) {
-    float o[8];
+  for (int s0 = 0; s0 < ns; s0 += 16) {
+    float o[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int s = s0 + u < ns ? s0 + u : ns - 1;
       o[u] = p.part_o[(base + s) * kHeadDim + d];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (s0 + u < ns) num = fmaf(w_s[s0 + u], o[u], num);
+    for (int u = 0; u < 16; ++u) {
+      const float ws = __shfl(w, (s0 + u) & 63, 64);     // 0 for slots >= ns
+      num = fmaf(ws, o[u], num);
+    }
   }
   p.out[(size_t)hq * kHeadDim + d] = num / den;
 }

@@ -176,7 +176,7 @@ class ChatTSForCausalLM:
         max_pos = max(self.max_ctx, 64)
         T["cos"], T["sin"] = rope_tables(cfg, max_pos, dev)
         # decode attention: one wave per 16-key tile; slots beyond the live context exit immediately
-        self.n_splits = max(1, min(256, (self.max_ctx + 15) // 16))
+        self.n_splits = max(1, min(64, (self.max_ctx + 15) // 16))
         dc = _lib.DecoderConfig(hidden=H, n_layers=cfg.num_hidden_layers, n_q=plan.nq, n_kv=plan.nkv, head_dim=d,
                                 inter=plan.inter, vocab_local=plan.vocab, vocab_offset=plan.v0,
                                 rms_eps=cfg.rms_norm_eps, max_ctx=self.max_ctx, max_pos=max_pos, tp_world=plan.world)

@@ -157,7 +157,7 @@ int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int pos0, const
 /* Decode form (T = 1) that also replaces chatts_rope_kv_write: qkv_raw holds the un-rotated projections
  * (after bias); the kernel applies the optional per-head q/k RMSNorm + RoPE at position pos (or *pos_dev),
  * stores the new K/V row into the cache and attends over cache rows [0, pos].  One wave per (kv head, 16-key
- * tile); n_splits (<= 256) is the number of tile slots, slot s walks tiles s, s+n_splits, ...; the workspace
+ * tile); n_splits (<= 64) is the number of tile slots, slot s walks tiles s, s+n_splits, ...; the workspace
  * (chatts_attn_workspace(1, n_q, n_splits) bytes) is always required. */
 int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int n_kv, const float* q_norm_w,
                                   const float* k_norm_w, float norm_eps, const float* cos_tab,
