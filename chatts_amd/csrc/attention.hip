@@ -381,6 +381,134 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// prefill, flash style on the exact-f32 matrix cores (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate, bitwise an
+// fmaf chain - the parity target is the float32 reference, and attention is ~3 % of prefill FLOPs, so the f32 MFMA
+// rate (155 TF) is enough).  grid (ceil(T/64), n_q), 256 threads: wave w owns query rows q0+16w .. +15 of ONE q head.
+//   Q fragment  A[i = lane&15][k = lane>>4 + 4j]: 32 floats per lane, loaded once
+//   K tile      [KT][130] f32 in LDS (row stride 130 floats: the B-fragment reads K[n = lane&15][k] are conflict-free)
+//   S = Q.K^T   KT/16 accumulators in C layout (col = lane&15 = key, row = 4*(lane>>4) + reg)
+//   softmax     online, per C-layout row: 16-lane xor shuffles for max and sum
+//   P           C layout -> wave-private LDS [16][KT+2] -> A layout (row = lane&15, k = lane>>4 + 4j)
+//   O += P.V    V tile [KT][144] f32 in LDS (stride 144: rows k and k+1 land 16 banks apart), 8 accumulators
+// Heaviest query tiles (most key tiles under the causal mask) are scheduled first.
+// ---------------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(AttnParams p) {
+  constexpr int KS = 130, VS = 144, PS = KT + 2, NB = KT / 16;
+  __shared__ __attribute__((aligned(16))) float v_s[KT * VS];
+  __shared__ __attribute__((aligned(16))) float k_s[KT * KS];
+  __shared__ float p_all[4 * 16 * PS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = gridDim.x - 1 - blockIdx.x, hq = blockIdx.y;
+  const int G = p.n_q / p.n_kv, hk = hq / G;
+  const int heads = p.n_q + 2 * p.n_kv;
+  const int T = p.t, pos0 = p.pos0_dev ? *p.pos0_dev : p.pos0;
+  const int q0 = qt * 64;
+  const int arow = lane & 15, kq = lane >> 4;              // A/B fragment coordinates
+  const int ccol = lane & 15, crow0 = (lane >> 4) * 4;     // C layout
+  const float scale = 0.08838834764831845f;
+  float* p_s = p_all + wave * 16 * PS;
+
+  float qreg[32];
+  {
+    int qrow = q0 + wave * 16 + arow;
+    if (qrow > T - 1) qrow = T - 1;                         // padded rows compute garbage that is never stored
+    const float* qp = p.qkv + ((size_t)qrow * heads + hq) * kHeadDim + kq;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) qreg[j] = qp[4 * j];
+  }
+  int qpos[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) qpos[r] = pos0 + q0 + wave * 16 + crow0 + r;
+  float m_run[4], l_run[4];
+  f32x4 o_acc[8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+#pragma unroll
+  for (int db = 0; db < 8; ++db) o_acc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int last_q = q0 + 63 < T - 1 ? q0 + 63 : T - 1;
+  const int kmax = pos0 + last_q;                           // last key any row of this workgroup may see
+  const int nkt = kmax / KT + 1;
+  const float* kbase = p.kc + (size_t)hk * p.max_ctx * kHeadDim;
+  const float* vbase = p.vc + (size_t)hk * p.max_ctx * kHeadDim;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int k0 = kt * KT;
+    __syncthreads();                                        // the previous tile has been consumed by every wave
+    for (int idx = tid; idx < KT * 32; idx += 256) {
+      const int key = idx >> 5, c4 = idx & 31;
+      const int kr = k0 + key <= kmax ? k0 + key : kmax;    // clamped address; masked by key index below
+      const f32x4 kvv = *reinterpret_cast<const f32x4*>(kbase + (size_t)kr * kHeadDim + c4 * 4);
+      const f32x4 vvv = *reinterpret_cast<const f32x4*>(vbase + (size_t)kr * kHeadDim + c4 * 4);
+      float2* kd = reinterpret_cast<float2*>(k_s + key * KS + c4 * 4);
+      kd[0] = make_float2(kvv.x, kvv.y);
+      kd[1] = make_float2(kvv.z, kvv.w);
+      *reinterpret_cast<f32x4*>(v_s + key * VS + c4 * 4) = vvv;
+    }
+    __syncthreads();
+
+    f32x4 s_acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) s_acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        s_acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(qreg[j], k_s[(nb * 16 + arow) * KS + kq + 4 * j], s_acc[nb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float s = s_acc[nb][r] * scale;
+        if (k0 + nb * 16 + ccol > qpos[r]) s = -INFINITY;   // causal mask
+        s_acc[nb][r] = s;
+        mx = fmaxf(mx, s);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float m_new = fmaxf(m_run[r], mx);              // finite from the first tile on (key 0 is always visible)
+      const float alpha = expf(m_run[r] - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float e = expf(s_acc[nb][r] - m_new);
+        s_acc[nb][r] = e;
+        ps += e;
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) ps += __shfl_xor(ps, o, 64);
+      l_run[r] = l_run[r] * alpha + ps;
+      m_run[r] = m_new;
+#pragma unroll
+      for (int db = 0; db < 8; ++db) o_acc[db][r] *= alpha;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) p_s[(crow0 + r) * PS + nb * 16 + ccol] = s_acc[nb][r];
+    }
+    __builtin_amdgcn_wave_barrier();                        // P is wave private: LDS ops of one wave stay in order
+#pragma unroll
+    for (int j = 0; j < KT / 4; ++j) {
+      const float pa = p_s[arow * PS + kq + 4 * j];
+#pragma unroll
+      for (int db = 0; db < 8; ++db)
+        o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, v_s[(kq + 4 * j) * VS + db * 16 + arow], o_acc[db], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qrow = q0 + wave * 16 + crow0 + r;
+    if (qrow < T) {
+      const float inv = 1.0f / l_run[r];
+      float* dst = p.out + ((size_t)qrow * p.n_q + hq) * kHeadDim + ccol;
+#pragma unroll
+      for (int db = 0; db < 8; ++db) dst[db * 16] = o_acc[db][r] * inv;
+    }
+  }
+}
+
 // merge the split partials of attn_rows_kernel (splits that saw no tile hold m = -inf, l = 0)
 __global__ __launch_bounds__(128) void attn_combine_kernel(AttnParams p) {
   const int hq = blockIdx.x, row = blockIdx.y, d = threadIdx.x;
@@ -433,6 +561,12 @@ extern "C" int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int 
   if (n_splits > 1) {
     const int rc = bind_workspace(p, workspace, workspace_bytes);
     if (rc) return rc;
+  }
+  static const bool force_rows = getenv("CHATTS_ATTN_ROWS") != nullptr;   // debugging aid: VALU kernel for every T
+  if (t >= 16 && n_splits == 1 && !force_rows) {
+    hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, dim3((t + 63) / 64, n_q), dim3(256), 0, as_stream(stream), p);
+    CHATTS_CHECK_LAUNCH("attn_prefill_mfma");
+    return CHATTS_OK;
   }
   hipLaunchKernelGGL(attn_rows_kernel, dim3(n_kv, t, n_splits), dim3(256), 0, as_stream(stream), p);
   CHATTS_CHECK_LAUNCH("attn_rows");

@@ -48,7 +48,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed; used for speed only).  All M-tiles of one
+  // W panel (N-tile) are given to the same XCD, adjacent in dispatch order, so the panel is fetched from HBM once
+  // into that XCD's L2 instead of once per M-tile (profiles/r1_bench_pmc_fetch_size.txt showed ~7x re-fetch).
+  const int mt_count = (p.m + BM - 1) / BM, nt_count = (p.n + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int nt = (local / mt_count) * 8 + xcd, mt = local % mt_count;
+  if (nt >= nt_count) return;                    // padding slot (N-tiles not a multiple of 8); uniform exit
+  const int m0 = mt * BM, n0 = nt * BN;
   const int kbeg = blockIdx.z * p.k_per_split;
   int kend = kbeg + p.k_per_split;
   if (kend > p.k) kend = p.k;
@@ -268,7 +275,8 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   } else {
     p.c = a->c;
   }
-  dim3 grid((a->n + 127) / 128, (a->m + bm - 1) / bm, sk), block(256);
+  const int nt_count = (a->n + 127) / 128, mt_count = (a->m + bm - 1) / bm;
+  dim3 grid(8 * ((nt_count + 7) / 8) * mt_count, 1, sk), block(256);
   switch (bm) {
     case 128: hipLaunchKernelGGL((gemm_bf16x2_kernel<128, 2, 2>), grid, block, 0, s, p); break;
     case 64: hipLaunchKernelGGL((gemm_bf16x2_kernel<64, 2, 2>), grid, block, 0, s, p); break;

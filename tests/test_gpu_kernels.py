@@ -293,7 +293,8 @@ def _ref_attention(q, kc, vc, pos0):
 
 
 @pytest.mark.parametrize("nq,nkv", [(4, 2), (5, 1), (8, 1), (8, 8)])
-@pytest.mark.parametrize("T,pos0,splits", [(1, 0, 1), (1, 63, 4), (1, 200, 4), (1, 333, 16), (7, 60, 1), (70, 0, 1)])
+@pytest.mark.parametrize("T,pos0,splits", [(1, 0, 1), (1, 63, 4), (1, 200, 4), (1, 333, 16), (7, 60, 1), (70, 0, 1),
+                                           (16, 0, 1), (64, 0, 1), (65, 31, 1), (130, 100, 1), (200, 0, 1)])
 def test_attention_parity(lib, nq, nkv, T, pos0, splits):
     max_ctx = 512
     g = torch.Generator().manual_seed(nq * 100 + T + pos0)
