@@ -115,6 +115,10 @@ def load():
         raise RuntimeError(
             f"{path} is missing: the HIP extension has not been built. Run `python -m chatts_amd.build` "
             "(or __graft_entry__.build()). chatts_amd has no CPU fallback.")
+    # torch must be imported BEFORE the .so: both link libamdhip64, and torch ships its own copy.  Whichever is loaded
+    # first serves the whole process; if ours pulled in /opt/rocm's runtime first, torch's allocations and our launches
+    # would live in two HIP runtimes ("no ROCm-capable device is detected" on the first launch).
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
