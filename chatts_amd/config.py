@@ -59,6 +59,7 @@ class ChatTSConfig:
     # --- HF-style helpers -------------------------------------------------------------------------
     def to_dict(self):
         d = {k: copy.deepcopy(v) for k, v in self.__dict__.items() if k != "extra"}
+        d.update(copy.deepcopy(self.extra))       # unknown keys round-trip (e.g. im_start_token_id of the tiny presets)
         return d
 
     @classmethod

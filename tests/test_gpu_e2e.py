@@ -198,3 +198,74 @@ def test_full_width_layers_vs_oracle():
         model.decode_step()
         assert rel_err(model.buf["logits"].cpu().numpy(), cur.numpy()) < TIGHT_TOL
     assert model.buf["out_tokens"][:3].tolist() == toks
+
+
+def test_chunked_prefill_matches_single_pass():
+    """Prompts longer than max_prefill_tokens are prefilled in chunks (positions continue, attention sees the cache)."""
+    cfg = cfgmod.preset("tiny-qwen3")
+    a = ChatTSForCausalLM.from_synthetic(cfg, seed=2, max_ctx=512, max_prefill_tokens=512)
+    b = ChatTSForCausalLM.from_synthetic(cfg, seed=2, max_ctx=512, max_prefill_tokens=48)     # forces 5 chunks
+    g = torch.Generator().manual_seed(1)
+    emb = (torch.randn((201, cfg.hidden_size), generator=g) * 0.5).cuda()
+    outs = []
+    for m in (a, b):
+        m.reset()
+        last = m.prefill(emb, 0)
+        m.buf["pos"].fill_(201)
+        m._first_token(last)
+        lg = m.buf["logits"].clone()
+        toks = [int(m.buf["out_tokens"][0])]
+        for _ in range(4):
+            m.decode_step()
+        outs.append((lg, m.buf["out_tokens"][:5].tolist()))
+    assert rel_err(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy()) < 1e-5
+    assert outs[0][1] == outs[1][1]
+
+
+@pytest.mark.parametrize("tied", [False, True])
+def test_from_pretrained_safetensors_roundtrip(tmp_path, tied):
+    """load_weights (chatts_vllm.py:612-625): HF-named safetensors -> packed qkv / interleaved gate_up; a checkpoint
+    without lm_head.weight means tied embeddings (:619-623).  Compared with the oracle on the same tensors."""
+    from safetensors.torch import save_file
+    cfg = cfgmod.preset("tiny-qwen2", tie_word_embeddings=tied)
+    sd = osynth.state_dict(synth.all_specs(cfg), 11)
+    ckpt = tmp_path / "ckpt"
+    cfg.save_pretrained(str(ckpt))
+    names = list(sd)
+    half = len(names) // 2                       # two shards, like the reference's multi-file checkpoints
+    save_file({k: sd[k].to(torch.bfloat16).contiguous() for k in names[:half]}, str(ckpt / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].to(torch.bfloat16).contiguous() for k in names[half:]}, str(ckpt / "model-00002-of-00002.safetensors"))
+    model = ChatTSForCausalLM.from_pretrained(str(ckpt), device_map="cuda:0", max_ctx=256, max_prefill_tokens=256)
+    assert model.config.ts["patch_size"] == 16
+    assert "ts_encoder.mlp.0.weight" in model.loaded and "model.layers.1.mlp.down_proj.weight" in model.loaded
+    proc = ChatTSProcessor.from_pretrained(str(ckpt))
+    rng = np.random.default_rng(5)
+    series = [random_walk_series(rng, 40)]
+    inputs = proc(text=[chat_prompt([40])], timeseries=series, return_tensors="pt")
+    ids = inputs["input_ids"][0].tolist()
+    if tied:
+        sd = dict(sd)
+        sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
+    want = pipeline.generate(cfg, sd, ids, inputs["timeseries"].numpy(), 6)
+    out = model.generate(**inputs.to("cuda"), max_new_tokens=6, eos_token_id=[])
+    assert out[0, len(ids):].tolist() == want["tokens"]
+
+
+def test_llm_surface_matches_generate():
+    from chatts_amd import LLM, SamplingParams
+    cfg = cfgmod.preset("tiny-qwen2")
+    llm = LLM(cfg, tensor_parallel_size=1, max_model_len=512, limit_mm_per_prompt={"timeseries": 2}, seed=3)
+    rng = np.random.default_rng(1234)
+    lengths = [64, 30]
+    series = [random_walk_series(rng, L) for L in lengths]
+    prompt = chat_prompt(lengths)
+    outs = llm.generate([{"prompt": prompt, "multi_modal_data": {"timeseries": [s.tolist() for s in series]}}] * 2,
+                        sampling_params=SamplingParams(max_tokens=6, ignore_eos=True))
+    assert len(outs) == 2 and outs[0].outputs[0].token_ids == outs[1].outputs[0].token_ids
+    assert isinstance(outs[0].outputs[0].text, str)
+    sd = osynth.state_dict(synth.all_specs(cfg), 3)
+    inputs = llm.processor(text=[prompt], timeseries=series, return_tensors="pt")
+    want = pipeline.generate(cfg, sd, inputs["input_ids"][0].tolist(), inputs["timeseries"].numpy(), 6)
+    assert outs[0].outputs[0].token_ids == want["tokens"]
+    with pytest.raises(ValueError):
+        llm.generate([{"prompt": "<ts><ts/><ts><ts/><ts><ts/>", "multi_modal_data": {"timeseries": [[1.0, 2.0]] * 3}}])
