@@ -101,18 +101,17 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
       if (r < BM) {
         const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w,
                             ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
-        uint32_t hi[4], lo[4];
+        // native __bf16 conversions: the compiler selects v_cvt_pk_bf16_f32 (RNE), ~3 VALU per element instead of ~10
+        bf16x8_t hv, lv;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          uint16_t h0, l0, h1, l1;
-          split_bf16x2(v[2 * j], h0, l0);
-          split_bf16x2(v[2 * j + 1], h1, l1);
-          hi[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-          lo[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        for (int j = 0; j < 8; ++j) {
+          const __bf16 h = (__bf16)v[j];
+          hv[j] = h;
+          lv[j] = (__bf16)(v[j] - (float)h);
         }
         const int off = lds_off(r, schunk);
-        *reinterpret_cast<u32x4*>(base + off) = (u32x4){hi[0], hi[1], hi[2], hi[3]};
-        *reinterpret_cast<u32x4*>(base + BM * 64 + off) = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+        *reinterpret_cast<bf16x8_t*>(base + off) = hv;
+        *reinterpret_cast<bf16x8_t*>(base + BM * 64 + off) = lv;
       }
     }
 #pragma unroll
@@ -136,17 +135,26 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j)
       bfrag[j] = *reinterpret_cast<const bf16x8_t*>(base + BM * 128 + lds_off(wn * TN + j * 16 + frow, fchunk));
+    // Two sweeps over all FM x FN accumulators (lo pass, then hi pass): consecutive MFMAs never touch the same
+    // accumulator, so none waits on the previous one's result (back-to-back lo/hi on one accumulator held the
+    // matrix pipe at 41 % busy: SQ_WAIT_INST_ANY 44 %, profiles/r1_pmc_sq_gemm.txt).
+    bf16x8_t afrag[FM];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int off = lds_off(wm * TM + i * 16 + frow, fchunk);
-      const bf16x8_t ahi = *reinterpret_cast<const bf16x8_t*>(base + off);
-      const bf16x8_t alo = *reinterpret_cast<const bf16x8_t*>(base + BM * 64 + off);
+    for (int i = 0; i < FM; ++i)
+      afrag[i] = *reinterpret_cast<const bf16x8_t*>(base + BM * 64 + lds_off(wm * TM + i * 16 + frow, fchunk));
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bfrag[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bfrag[j], acc[i][j], 0, 0, 0);
-      }
-    }
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[i], bfrag[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+      afrag[i] = *reinterpret_cast<const bf16x8_t*>(base + lds_off(wm * TM + i * 16 + frow, fchunk));
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[i], bfrag[j], acc[i][j], 0, 0, 0);
     if (kt + 1 < nk) store_lds((kt + 1) & 1);
     __syncthreads();
   }
