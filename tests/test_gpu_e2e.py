@@ -269,3 +269,63 @@ def test_llm_surface_matches_generate():
     assert outs[0].outputs[0].token_ids == want["tokens"]
     with pytest.raises(ValueError):
         llm.generate([{"prompt": "<ts><ts/><ts><ts/><ts><ts/>", "multi_modal_data": {"timeseries": [[1.0, 2.0]] * 3}}])
+
+
+def test_config4_like_30_series_mixed_lengths_chunked():
+    """BASELINE.json config 4 shape on a tiny decoder: 30 series with mixed lengths 64..1024 (ragged tails included),
+    prompt longer than max_prefill_tokens (chunked prefill), vs the oracle."""
+    cfg = cfgmod.preset("tiny-qwen2")
+    rng = np.random.default_rng(1234)
+    lengths = [int(v) for v in rng.integers(64, 1025, 30)]
+    lengths[3], lengths[17] = 1000, 65                      # make sure L % 16 != 0 cases are in
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    series = [random_walk_series(rng, L) for L in lengths]
+    inputs = proc(text=[chat_prompt(lengths)], timeseries=series, padding=True, return_tensors="pt")
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=8, max_ctx=4096, max_prefill_tokens=1024)
+    sd = osynth.state_dict(synth.all_specs(cfg), 8)
+    ids = inputs["input_ids"][0].tolist()
+    want = pipeline.generate(cfg, sd, ids, inputs["timeseries"].numpy(), 6)
+    assert len(want["expanded_ids"]) > 2048                 # really exercises >2 prefill chunks
+    toks, lg = model.generate_one(ids, inputs["timeseries"].cuda(), proc.last_lengths, 6, return_logits=True)
+    assert rel_err(lg.cpu().numpy(), want["logits"][0].numpy()) < LOGIT_TOL
+    assert toks == want["tokens"]
+
+
+def test_full_size_14b_properties():
+    """ChatTS-14B at FULL size (48 layers, 28 GB of weights): size-independent properties instead of an oracle run.
+    (a) hipGraph replay == eager launches, token for token and bit for bit on the logits;
+    (b) generation is deterministic across runs;
+    (c) TS encoder: permuting the series permutes the patch-row blocks (rows are independent units);
+    (d) prefilling the prompt in chunks == prefilling it at once (first-token logits)."""
+    cfg = cfgmod.preset("chatts-14b")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(1234)
+    lengths = [256] * 8
+    series = [random_walk_series(rng, L) for L in lengths]
+    inputs = proc(text=[chat_prompt(lengths)], timeseries=series, padding=True, return_tensors="pt")
+    ids = inputs["input_ids"][0].tolist()
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, max_ctx=1024, max_prefill_tokens=1024)
+    ser = inputs["timeseries"].cuda()
+    model.use_graph = True
+    t1, l1 = model.generate_one(ids, ser, proc.last_lengths, 6, return_logits=True)
+    g_last = model.buf["logits"].clone()
+    t2 = model.generate_one(ids, ser, proc.last_lengths, 6)
+    model.use_graph = False
+    t3, l3 = model.generate_one(ids, ser, proc.last_lengths, 6, return_logits=True)
+    assert t1 == t2 == t3 and torch.equal(l1, l3) and torch.equal(g_last, model.buf["logits"])
+    assert torch.isfinite(l1).all() and len(set(t1)) > 1
+    # (c)
+    perm = [3, 0, 7, 1, 6, 2, 5, 4]
+    f0 = torch.cat(model.get_multimodal_embeddings(timeseries=ser, valid_lengths=lengths))
+    f1 = torch.cat(model.get_multimodal_embeddings(timeseries=ser[perm], valid_lengths=lengths))
+    assert rel_err(f1.view(8, 16, -1).cpu().numpy(), f0.view(8, 16, -1)[perm].cpu().numpy()) < 1e-6
+    # (d)
+    mm = model.get_multimodal_embeddings(timeseries=ser, valid_lengths=lengths)
+    emb = model.get_input_embeddings(torch.tensor(model.expand_input_ids(ids, [16] * 8)), mm)
+    model.reset()
+    model.prefill(emb[:300], 0)
+    last = model.prefill(emb[300:], 300)
+    model.buf["pos"].fill_(emb.shape[0])
+    model._first_token(last)
+    assert rel_err(model.buf["logits"].cpu().numpy(), l1.cpu().numpy()) < 1e-5
+    assert int(model.buf["out_tokens"][0]) == t1[0]
