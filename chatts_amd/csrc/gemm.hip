@@ -242,17 +242,34 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   c[(size_t)row * ldc + col] = v;
 }
 
+static int gemm_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
 static void pick_geometry(int m, int n, int k, int& bm, int& sk) {
   bm = m > 64 ? 128 : (m > 32 ? 64 : (m > 16 ? 32 : 16));
+  const int force_bm = gemm_env_int("CHATTS_GEMM_BM", 0);          // tuning / tests only
+  if (force_bm == 16 || force_bm == 32 || force_bm == 64 || force_bm == 128) bm = force_bm;
   const int tiles = ((m + bm - 1) / bm) * ((n + 127) / 128);
-  const int target = 2 * device_cus();
+  // Split-K so that the workgroups fill whole "rounds" of the resident slots (3 workgroups of 48 KB LDS per CU):
+  // efficiency of a launch = blocks / (slots * ceil(blocks / slots)); split-K costs a partials round trip + an
+  // epilogue launch, hence the small penalty.  (tools/gemm_sweep.py: qkv @ M=798 wants 3, o/down 2, gate_up 1.)
+  const int slots = 3 * device_cus();
+  int max_sk = k / 256 > 0 ? (k / 256 < 16 ? k / 256 : 16) : 1;   // keep >= 8 K-steps per split
+  const int traffic_cap = k / (2 * m) > 1 ? k / (2 * m) : 1;        // partials (sk*M*N*8 B) <= 2x the weight bytes
+  if (max_sk > traffic_cap) max_sk = traffic_cap;
   sk = 1;
-  if (tiles < target) {
-    sk = (target + tiles - 1) / tiles;
-    const int max_sk = k / 256 > 0 ? k / 256 : 1;   // keep >= 8 K-steps per split
-    if (sk > max_sk) sk = max_sk;
-    if (sk > 16) sk = 16;
+  float best = -1.f;
+  for (int cand = 1; cand <= max_sk; ++cand) {
+    const int blocks = tiles * cand;
+    const int rounds = (blocks + slots - 1) / slots;
+    const float eff = (float)blocks / (float)(slots * rounds);
+    const float score = eff - 0.06f * (m < 800 ? (float)m / 800.f : 1.f) * (cand - 1);   // partials cost grows with M
+    if (score > best) { best = score; sk = cand; }
   }
+  const int force_sk = gemm_env_int("CHATTS_GEMM_SK", 0);
+  if (force_sk > 0 && force_sk <= 16 && k / force_sk >= 32) sk = force_sk;
 }
 
 static int k_per_split(int k, int sk) {
