@@ -54,7 +54,7 @@ class DecoderWeights(C.Structure):
 class DecoderBuffers(C.Structure):
     _fields_ = [("kv_k", c_void_p), ("kv_v", c_void_p), ("x", c_void_p), ("xn", c_void_p), ("qkv", c_void_p),
                 ("attn", c_void_p), ("act", c_void_p), ("delta", c_void_p), ("logits", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("t_max", c_int)]
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("t_max", c_int), ("max_batch", c_int)]
 
 
 # name -> (restype, argtypes); this table IS the list of symbols include/chatts_amd.h declares
@@ -79,6 +79,16 @@ SIGNATURES = {
     "chatts_attention_decode_fused": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                               c_int, c_void_p, C.POINTER(KvCache), c_void_p, c_int, c_void_p,
                                               c_size_t, c_void_p]),
+    "chatts_attention_decode_batched": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
+                                                c_void_p, c_int, c_void_p, C.POINTER(KvCache), c_size_t, c_void_p, c_int,
+                                                c_void_p, c_size_t, c_void_p]),
+    "chatts_argmax_batched": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                      c_void_p, c_void_p, c_int, c_void_p]),
+    "chatts_embed_token_batched": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "chatts_decoder_select_sequence": (c_int, [c_void_p, c_int]),
+    "chatts_decoder_layer_part_batched": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "chatts_decoder_decode_step_batched": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                   c_int64, c_void_p, c_int, c_void_p]),
     "chatts_argmax": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chatts_embed_token": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "chatts_decoder_create": (c_void_p, [C.POINTER(DecoderConfig), C.POINTER(DecoderWeights),

@@ -40,6 +40,7 @@ struct AttnParams {
   const float* cos_tab;
   const float* sin_tab;
   float eps;
+  size_t seq_stride;   // batched decode: floats between the caches of consecutive sequences (same layer)
 };
 
 // rotate one 128-wide head held as (a = x[lane], b = x[lane+64]) by the wave; optional RMSNorm first
@@ -66,16 +67,19 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) float q_s[kMaxGroup * kHeadDim];
   __shared__ __attribute__((aligned(16))) float knew_s[kHeadDim];
   __shared__ __attribute__((aligned(16))) float vnew_s[kHeadDim];
-  const int hk = blockIdx.x, slot = blockIdx.y, NS = p.n_splits;
+  const int hk = blockIdx.x, slot = blockIdx.y, NS = p.n_splits, seq = blockIdx.z;
   const int lane = threadIdx.x;
   const int G = p.n_q / p.n_kv;
-  const int pos = p.pos0_dev ? *p.pos0_dev : p.pos0;
+  const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;     // batched decode: one position per sequence
   const int ntiles = pos / kDTile + 1;
   if (slot >= ntiles) return;                  // the combine only reads slots < min(ntiles, NS)
+  const float* qkv = p.qkv + (size_t)seq * (p.n_q + 2 * p.n_kv) * kHeadDim;
+  float* kcache = p.kc + (size_t)seq * p.seq_stride;
+  float* vcache = p.vc + (size_t)seq * p.seq_stride;
   const bool owner = ((pos / kDTile) % NS) == slot;
   const float scale = 0.08838834764831845f;    // 128^-1/2
-  const float* kbase = p.kc + (size_t)hk * p.max_ctx * kHeadDim;
-  const float* vbase = p.vc + (size_t)hk * p.max_ctx * kHeadDim;
+  const float* kbase = kcache + (size_t)hk * p.max_ctx * kHeadDim;
+  const float* vbase = vcache + (size_t)hk * p.max_ctx * kHeadDim;
   const int key_l = lane >> 2, quarter = lane & 3;
 
   // K and V of the first tile only depend on `pos`: issue them before the q prologue so that the cache rows,
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
 #pragma unroll
     for (int g = 0; g < kMaxGroup; ++g) {
       if (g < G) {
-        const float* src = p.qkv + (size_t)(hk * G + g) * kHeadDim;
+        const float* src = qkv + (size_t)(hk * G + g) * kHeadDim;
         float a = src[lane], b = src[lane + 64];
         norm_rope(a, b, p.q_norm_w, p.eps, c, s, lane);
         q_s[g * kHeadDim + lane] = a;
@@ -110,19 +114,19 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
       }
     }
     if (owner) {                                // the new K/V row: to the cache and to LDS
-      const float* ks = p.qkv + (size_t)(p.n_q + hk) * kHeadDim;
+      const float* ks = qkv + (size_t)(p.n_q + hk) * kHeadDim;
       float a = ks[lane], b = ks[lane + 64];
       norm_rope(a, b, p.k_norm_w, p.eps, c, s, lane);
       knew_s[lane] = a;
       knew_s[lane + 64] = b;
-      float* kd = p.kc + ((size_t)hk * p.max_ctx + pos) * kHeadDim;
+      float* kd = kcache + ((size_t)hk * p.max_ctx + pos) * kHeadDim;
       kd[lane] = a;
       kd[lane + 64] = b;
-      const float* vs = p.qkv + (size_t)(p.n_q + p.n_kv + hk) * kHeadDim;
+      const float* vs = qkv + (size_t)(p.n_q + p.n_kv + hk) * kHeadDim;
       const float va = vs[lane], vb = vs[lane + 64];
       vnew_s[lane] = va;
       vnew_s[lane + 64] = vb;
-      float* vd = p.vc + ((size_t)hk * p.max_ctx + pos) * kHeadDim;
+      float* vd = vcache + ((size_t)hk * p.max_ctx + pos) * kHeadDim;
       vd[lane] = va;
       vd[lane + 64] = vb;
     }
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
 #pragma unroll
   for (int g = 0; g < kMaxGroup; ++g) {
     if (g < G) {
-      const size_t pi = (size_t)(hk * G + g) * NS + slot;
+      const size_t pi = ((size_t)seq * p.n_q + hk * G + g) * NS + slot;
       *reinterpret_cast<float2*>(p.part_o + pi * kHeadDim + lane * 2) = make_float2(acc0[g], acc1[g]);
       if (lane == 0) { p.part_ml[pi * 2] = m_run[g]; p.part_ml[pi * 2 + 1] = l_run[g]; }
     }
@@ -215,11 +219,11 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
 // (2 waves) per head; lane s of each wave holds (m_s, l_s), weights are broadcast by shuffle, and 16 independent
 // o_s[d] loads are in flight per thread: no LDS, no barrier.
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnParams p) {
-  const int hq = blockIdx.x, d = threadIdx.x, lane = threadIdx.x & 63;
-  const int pos = p.pos0_dev ? *p.pos0_dev : p.pos0;
+  const int hq = blockIdx.x, seq = blockIdx.y, d = threadIdx.x, lane = threadIdx.x & 63;
+  const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;
   const int ntiles = pos / kDTile + 1;
   const int ns = ntiles < p.n_splits ? ntiles : p.n_splits;
-  const size_t base = (size_t)hq * p.n_splits;
+  const size_t base = ((size_t)seq * p.n_q + hq) * p.n_splits;
   float m = -INFINITY, l = 0.f;
   if (lane < ns) { m = p.part_ml[(base + lane) * 2]; l = p.part_ml[(base + lane) * 2 + 1]; }
   const float M = wave_max(m);
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnParams p) 
       num = fmaf(ws, o[u], num);
     }
   }
-  p.out[(size_t)hq * kHeadDim + d] = num / den;
+  p.out[((size_t)seq * p.n_q + hq) * kHeadDim + d] = num / den;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -577,30 +581,41 @@ extern "C" int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int 
   return CHATTS_OK;
 }
 
+extern "C" int chatts_attention_decode_batched(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w,
+                                               const float* k_norm_w, float norm_eps, const float* cos_tab,
+                                               const float* sin_tab, int pos, const int32_t* pos_dev,
+                                               const ChattsKvCache* cache, size_t seq_stride, float* out, int n_splits,
+                                               void* workspace, size_t workspace_bytes, chatts_stream_t stream) {
+  CHATTS_REQUIRE(batch >= 1 && n_q > 0 && n_kv > 0 && n_splits >= 1 && n_splits <= kMaxSlots, CHATTS_E_BADARG,
+                 "attention_decode: bad sizes (batch >= 1, 1 <= n_splits <= %d)", kMaxSlots);
+  CHATTS_REQUIRE(qkv_raw && out && cos_tab && sin_tab && cache && cache->k && cache->v, CHATTS_E_BADARG,
+                 "attention_decode: null pointer");
+  CHATTS_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), CHATTS_E_BADARG,
+                 "attention_decode: q_norm and k_norm must both be set or both be null");
+  CHATTS_REQUIRE(n_q % n_kv == 0 && n_q / n_kv <= kMaxGroup, CHATTS_E_SHAPE,
+                 "attention: GQA group %d/%d unsupported (max %d)", n_q, n_kv, kMaxGroup);
+  CHATTS_REQUIRE(batch == 1 || pos_dev, CHATTS_E_BADARG, "attention_decode: batch > 1 needs per-sequence positions on the device");
+  if (!pos_dev)
+    CHATTS_REQUIRE(pos >= 0 && pos < cache->max_ctx, CHATTS_E_SHAPE, "attention_decode: position exceeds the cache");
+  AttnParams p{};
+  p.qkv = qkv_raw; p.kc = cache->k; p.vc = cache->v; p.out = out; p.pos0_dev = pos_dev; p.pos0 = pos;
+  p.t = batch; p.n_q = n_q; p.n_kv = n_kv; p.max_ctx = cache->max_ctx; p.n_splits = n_splits;
+  p.q_norm_w = q_norm_w; p.k_norm_w = k_norm_w; p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.eps = norm_eps;
+  p.seq_stride = seq_stride;
+  const int rc = bind_workspace(p, workspace, workspace_bytes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(n_kv, n_splits, batch), dim3(64), 0, as_stream(stream), p);
+  CHATTS_CHECK_LAUNCH("attn_decode");
+  hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(n_q, batch), dim3(128), 0, as_stream(stream), p);
+  CHATTS_CHECK_LAUNCH("attn_decode_combine");
+  return CHATTS_OK;
+}
+
 extern "C" int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int n_kv, const float* q_norm_w,
                                              const float* k_norm_w, float norm_eps, const float* cos_tab,
                                              const float* sin_tab, int pos, const int32_t* pos_dev,
                                              const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
                                              size_t workspace_bytes, chatts_stream_t stream) {
-  CHATTS_REQUIRE(n_q > 0 && n_kv > 0 && n_splits >= 1 && n_splits <= kMaxSlots, CHATTS_E_BADARG,
-                 "attention_decode_fused: bad sizes (1 <= n_splits <= %d)", kMaxSlots);
-  CHATTS_REQUIRE(qkv_raw && out && cos_tab && sin_tab && cache && cache->k && cache->v, CHATTS_E_BADARG,
-                 "attention_decode_fused: null pointer");
-  CHATTS_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), CHATTS_E_BADARG,
-                 "attention_decode_fused: q_norm and k_norm must both be set or both be null");
-  CHATTS_REQUIRE(n_q % n_kv == 0 && n_q / n_kv <= kMaxGroup, CHATTS_E_SHAPE,
-                 "attention: GQA group %d/%d unsupported (max %d)", n_q, n_kv, kMaxGroup);
-  if (!pos_dev)
-    CHATTS_REQUIRE(pos >= 0 && pos < cache->max_ctx, CHATTS_E_SHAPE, "attention_decode_fused: position exceeds the cache");
-  AttnParams p{};
-  p.qkv = qkv_raw; p.kc = cache->k; p.vc = cache->v; p.out = out; p.pos0_dev = pos_dev; p.pos0 = pos;
-  p.t = 1; p.n_q = n_q; p.n_kv = n_kv; p.max_ctx = cache->max_ctx; p.n_splits = n_splits;
-  p.q_norm_w = q_norm_w; p.k_norm_w = k_norm_w; p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.eps = norm_eps;
-  const int rc = bind_workspace(p, workspace, workspace_bytes);
-  if (rc) return rc;
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(n_kv, n_splits), dim3(64), 0, as_stream(stream), p);
-  CHATTS_CHECK_LAUNCH("attn_decode");
-  hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(n_q), dim3(128), 0, as_stream(stream), p);
-  CHATTS_CHECK_LAUNCH("attn_decode_combine");
-  return CHATTS_OK;
+  return chatts_attention_decode_batched(qkv_raw, 1, n_q, n_kv, q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos, pos_dev,
+                                         cache, 0, out, n_splits, workspace, workspace_bytes, stream);
 }

@@ -21,6 +21,7 @@ struct ChattsDecoder {
   ChattsDecoderWeights w;
   std::vector<ChattsLayerWeights> layers;
   ChattsDecoderBuffers b;
+  int cur_seq = 0;          // sequence (KV-cache slot) the single-sequence entry points operate on
 };
 
 extern "C" size_t chatts_linear_workspace(int m, int n, int k) { return gemm_workspace(m, n, k); }
@@ -81,13 +82,24 @@ extern "C" ChattsDecoder* chatts_decoder_create(const ChattsDecoderConfig* c, co
 
 extern "C" void chatts_decoder_destroy(ChattsDecoder* d) { delete d; }
 
-static ChattsKvCache layer_cache(const ChattsDecoder* d, int layer) {
+static size_t seq_stride(const ChattsDecoder* d) {      // floats between the caches of consecutive sequences
+  return (size_t)d->cfg.n_layers * d->cfg.n_kv * d->cfg.max_ctx * kHeadDim;
+}
+
+static ChattsKvCache layer_cache(const ChattsDecoder* d, int layer, int seq) {
   const size_t per = (size_t)d->cfg.n_kv * d->cfg.max_ctx * kHeadDim;
   ChattsKvCache c;
-  c.k = d->b.kv_k + per * layer;
-  c.v = d->b.kv_v + per * layer;
+  c.k = d->b.kv_k + seq_stride(d) * seq + per * layer;
+  c.v = d->b.kv_v + seq_stride(d) * seq + per * layer;
   c.max_ctx = d->cfg.max_ctx;
   return c;
+}
+
+extern "C" int chatts_decoder_select_sequence(ChattsDecoder* d, int seq) {
+  CHATTS_REQUIRE(d && seq >= 0 && seq < (d->b.max_batch > 0 ? d->b.max_batch : 1), CHATTS_E_BADARG,
+                 "decoder_select_sequence: slot %d out of range", seq);
+  d->cur_seq = seq;
+  return CHATTS_OK;
 }
 
 extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, int t, int pos0,
@@ -115,7 +127,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
       la.a = d->b.xn;
     }
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
-    ChattsKvCache kc = layer_cache(d, layer);
+    ChattsKvCache kc = layer_cache(d, layer, d->cur_seq);
     if (t == 1) {   // decode: RoPE + cache write fused into the attention kernel
       if ((rc = chatts_attention_decode_fused(d->b.qkv, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
                                               d->w.sin_tab, pos0, pos0_dev, &kc, d->b.attn, n_splits, d->b.workspace,
@@ -154,6 +166,86 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
   return chatts_linear(&la, stream);
+}
+
+// Batched decode: `batch` sequences advance one token each.  Row b of x / qkv / attn /
+// act belongs to sequence b (cache slot b, position pos_dev[b]).  The projections run as M = batch GEMMs (bf16x2
+// MFMA, weights streamed once for the whole batch); attention runs per sequence on its own cache.
+extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, int part, int batch,
+                                                 const int32_t* pos_dev, int n_splits, chatts_stream_t stream) {
+  CHATTS_REQUIRE(d && layer >= 0 && layer < d->cfg.n_layers && (part == 0 || part == 1) && pos_dev, CHATTS_E_BADARG,
+                 "decoder_layer_part_batched: bad arguments");
+  const int maxb = d->b.max_batch > 0 ? d->b.max_batch : 1;
+  CHATTS_REQUIRE(batch >= 1 && batch <= maxb && batch <= d->b.t_max, CHATTS_E_SHAPE,
+                 "decoder_layer_part_batched: batch %d exceeds max_batch %d", batch, maxb);
+  const ChattsDecoderConfig& c = d->cfg;
+  const ChattsLayerWeights& lw = d->layers[layer];
+  const bool tp = c.tp_world > 1;
+  const int H = c.hidden;
+  int rc;
+  ChattsLinearArgs la;
+  if (part == 0) {
+    const int qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim;
+    if ((rc = chatts_rmsnorm(d->b.x, lw.input_norm, d->b.xn, batch, H, c.rms_eps, stream)) != 0) return rc;
+    la = ChattsLinearArgs{};
+    la.a = d->b.xn; la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = batch; la.n = qkv_n; la.k = H;
+    la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
+    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+    if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+    ChattsKvCache kc = layer_cache(d, layer, 0);
+    if ((rc = chatts_attention_decode_batched(d->b.qkv, batch, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps,
+                                              d->w.cos_tab, d->w.sin_tab, 0, pos_dev, &kc, seq_stride(d), d->b.attn,
+                                              n_splits, d->b.workspace, d->b.workspace_bytes, stream)) != 0) return rc;
+    la = ChattsLinearArgs{};
+    la.a = d->b.attn; la.w = lw.o; la.m = batch; la.n = H; la.k = c.n_q * kHeadDim;
+    la.lda = la.k; la.ldw = la.k; la.ldc = H;
+    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+    if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
+    else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
+    return chatts_linear(&la, stream);
+  }
+  if ((rc = chatts_rmsnorm(d->b.x, lw.post_norm, d->b.xn, batch, H, c.rms_eps, stream)) != 0) return rc;
+  la = ChattsLinearArgs{};
+  la.a = d->b.xn; la.w = lw.gate_up; la.c = d->b.act; la.m = batch; la.n = 2 * c.inter; la.k = H;
+  la.lda = H; la.ldw = H; la.ldc = c.inter; la.epilogue = CHATTS_EPI_SWIGLU;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+  la = ChattsLinearArgs{};
+  la.a = d->b.act; la.w = lw.down; la.m = batch; la.n = H; la.k = c.inter;
+  la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
+  else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
+  return chatts_linear(&la, stream);
+}
+
+// One greedy step for `batch` sequences (TP = 1): all layers, final norm + lm_head for every row, per-sequence
+// argmax (token / step / pos / out_tokens rows advance independently; pos saturates at max_ctx - 1).
+// logits_all: [batch, vocab_local] float32 scratch owned by the caller.
+extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, int32_t* pos_dev, int32_t* step_dev,
+                                                  int64_t* token_dev, float* token_logit_dev, int64_t* out_tokens,
+                                                  int64_t out_stride, float* logits_all, int n_splits,
+                                                  chatts_stream_t stream) {
+  CHATTS_REQUIRE(d && pos_dev && step_dev && token_dev && logits_all, CHATTS_E_BADARG, "decode_step_batched: null argument");
+  CHATTS_REQUIRE(d->cfg.tp_world == 1, CHATTS_E_BADARG, "decode_step_batched: TP>1 must drive chatts_decoder_layer_part_batched");
+  int rc;
+  const ChattsDecoderConfig& c = d->cfg;
+  // the step STARTS by loading the input embeddings from the current tokens (so a prefill of another request may
+  // use x between two steps) and ENDS with the per-sequence argmax
+  if ((rc = chatts_embed_token_batched(token_dev, batch, d->w.embed, c.vocab_offset, c.vocab_local, c.hidden, d->b.x,
+                                       stream)) != 0) return rc;
+  for (int l = 0; l < c.n_layers; ++l) {
+    if ((rc = chatts_decoder_layer_part_batched(d, l, 0, batch, pos_dev, n_splits, stream)) != 0) return rc;
+    if ((rc = chatts_decoder_layer_part_batched(d, l, 1, batch, pos_dev, n_splits, stream)) != 0) return rc;
+  }
+  if ((rc = chatts_rmsnorm(d->b.x, d->w.final_norm, d->b.xn, batch, c.hidden, c.rms_eps, stream)) != 0) return rc;
+  ChattsLinearArgs la{};
+  la.a = d->b.xn; la.w = d->w.lm_head; la.c = logits_all; la.m = batch; la.n = (int)c.vocab_local; la.k = c.hidden;
+  la.lda = c.hidden; la.ldw = c.hidden; la.ldc = (int)c.vocab_local; la.epilogue = CHATTS_EPI_NONE;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+  return chatts_argmax_batched(logits_all, batch, c.vocab_local, c.vocab_local, c.vocab_offset, token_dev, token_logit_dev,
+                               out_tokens, out_stride, step_dev, pos_dev, c.max_ctx - 1, stream);
 }
 
 extern "C" int chatts_decoder_prefill(ChattsDecoder* d, int t, int pos0, chatts_stream_t stream) {

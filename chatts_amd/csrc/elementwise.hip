@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void embed_merge_kernel(const int64_t* __restr
 __global__ __launch_bounds__(256) void embed_token_kernel(const int64_t* __restrict__ token, const uint16_t* __restrict__ table,
                                                          int64_t vocab_offset, int64_t vocab_rows, int hidden,
                                                          float* __restrict__ out) {
-  const int64_t id = *token - vocab_offset;
+  const int seq = blockIdx.y;                       // batched decode: one token / output row per sequence
+  const int64_t id = token[seq] - vocab_offset;
   const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (k >= hidden) return;
   f32x4 f = {0.f, 0.f, 0.f, 0.f};
@@ -143,16 +144,26 @@ __global__ __launch_bounds__(256) void embed_token_kernel(const int64_t* __restr
     const u32x2 v = *reinterpret_cast<const u32x2*>(table + (size_t)id * hidden + k);
     f = (f32x4){bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y)};
   }
-  *reinterpret_cast<f32x4*>(out + k) = f;
+  *reinterpret_cast<f32x4*>(out + (size_t)seq * hidden + k) = f;
 }
 
 // ---- argmax: one workgroup of 1024; first index of the maximum (torch.argmax tie rule) -------------
-__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int64_t vocab,
-                                                     int64_t vocab_offset, int64_t* __restrict__ token,
-                                                     float* __restrict__ token_logit, int64_t* __restrict__ out_tokens,
-                                                     int32_t* __restrict__ step_dev, int32_t* __restrict__ pos_dev) {
+// One workgroup per sequence (blockIdx.x): batched decode keeps token / step / pos / out_tokens per sequence.
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits_all, int64_t logits_stride,
+                                                     int64_t vocab, int64_t vocab_offset, int64_t* __restrict__ token_all,
+                                                     float* __restrict__ token_logit_all,
+                                                     int64_t* __restrict__ out_tokens_all, int64_t out_stride,
+                                                     int32_t* __restrict__ step_all, int32_t* __restrict__ pos_all,
+                                                     int pos_limit) {
   __shared__ float sv[16];
   __shared__ int64_t si[16];
+  const int seq = blockIdx.x;
+  const float* logits = logits_all + (size_t)seq * logits_stride;
+  int64_t* token = token_all ? token_all + seq : nullptr;
+  float* token_logit = token_logit_all ? token_logit_all + seq : nullptr;
+  int64_t* out_tokens = out_tokens_all ? out_tokens_all + (size_t)seq * out_stride : nullptr;
+  int32_t* step_dev = step_all ? step_all + seq : nullptr;
+  int32_t* pos_dev = pos_all ? pos_all + seq : nullptr;
   float best = -INFINITY;
   int64_t bi = 0x7fffffffffffffffLL;
   const int64_t v4 = ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) ? vocab / 4 : 0;   // float4 body, scalar tail
@@ -182,9 +193,9 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     const int64_t tok = bi + vocab_offset;
     if (token) *token = tok;
     if (token_logit) *token_logit = best;
-    if (out_tokens && step_dev) out_tokens[*step_dev] = tok;
+    if (out_tokens && step_dev && (out_stride == 0 || *step_dev < out_stride)) out_tokens[*step_dev] = tok;
     if (step_dev) *step_dev += 1;
-    if (pos_dev) *pos_dev += 1;
+    if (pos_dev && (pos_limit <= 0 || *pos_dev < pos_limit)) *pos_dev += 1;     // idle batch slots saturate, never overflow
   }
 }
 
@@ -261,23 +272,38 @@ extern "C" int chatts_embed_merge(const int64_t* ids_dev, const int64_t* ids_hos
   return CHATTS_OK;
 }
 
+extern "C" int chatts_argmax_batched(const float* logits, int batch, int64_t logits_stride, int64_t vocab,
+                                     int64_t vocab_offset, int64_t* token, float* token_logit, int64_t* out_tokens,
+                                     int64_t out_stride, int32_t* step_dev, int32_t* pos_dev, int pos_limit,
+                                     chatts_stream_t stream) {
+  CHATTS_REQUIRE(logits && vocab > 0 && batch >= 1 && logits_stride >= vocab, CHATTS_E_BADARG, "argmax: bad arguments");
+  hipLaunchKernelGGL(argmax_kernel, dim3(batch), dim3(1024), 0, as_stream(stream), logits, logits_stride, vocab,
+                     vocab_offset, token, token_logit, out_tokens, out_stride, step_dev, pos_dev, pos_limit);
+  CHATTS_CHECK_LAUNCH("argmax");
+  return CHATTS_OK;
+}
+
 extern "C" int chatts_argmax(const float* logits, int64_t vocab, int64_t vocab_offset, int64_t* token,
                              float* token_logit, int64_t* out_tokens, int32_t* step_dev, int32_t* pos_dev,
                              chatts_stream_t stream) {
-  CHATTS_REQUIRE(logits && vocab > 0, CHATTS_E_BADARG, "argmax: bad arguments");
-  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, as_stream(stream), logits, vocab, vocab_offset, token,
-                     token_logit, out_tokens, step_dev, pos_dev);
-  CHATTS_CHECK_LAUNCH("argmax");
+  return chatts_argmax_batched(logits, 1, vocab, vocab, vocab_offset, token, token_logit, out_tokens, 0, step_dev, pos_dev,
+                               0, stream);
+}
+
+extern "C" int chatts_embed_token_batched(const int64_t* token_dev, int batch, const chatts_bf16* table,
+                                          int64_t vocab_offset, int64_t vocab_rows, int hidden, float* out,
+                                          chatts_stream_t stream) {
+  CHATTS_REQUIRE(token_dev && table && out && hidden > 0 && hidden % 4 == 0 && batch >= 1, CHATTS_E_BADARG,
+                 "embed_token: bad arguments");
+  hipLaunchKernelGGL(embed_token_kernel, dim3((hidden / 4 + 255) / 256, batch), dim3(256), 0, as_stream(stream), token_dev,
+                     table, vocab_offset, vocab_rows, hidden, out);
+  CHATTS_CHECK_LAUNCH("embed_token");
   return CHATTS_OK;
 }
 
 extern "C" int chatts_embed_token(const int64_t* token_dev, const chatts_bf16* table, int64_t vocab_offset,
                                   int64_t vocab_rows, int hidden, float* out, chatts_stream_t stream) {
-  CHATTS_REQUIRE(token_dev && table && out && hidden > 0 && hidden % 4 == 0, CHATTS_E_BADARG, "embed_token: bad arguments");
-  hipLaunchKernelGGL(embed_token_kernel, dim3((hidden / 4 + 255) / 256), dim3(256), 0, as_stream(stream), token_dev,
-                     table, vocab_offset, vocab_rows, hidden, out);
-  CHATTS_CHECK_LAUNCH("embed_token");
-  return CHATTS_OK;
+  return chatts_embed_token_batched(token_dev, 1, table, vocab_offset, vocab_rows, hidden, out, stream);
 }
 
 extern "C" int chatts_residual_add(float* x, const float* delta, int64_t n, chatts_stream_t stream) {

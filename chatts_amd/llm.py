@@ -30,7 +30,8 @@ class RequestOutput:
 
 class LLM:
     def __init__(self, model, tensor_parallel_size=1, max_model_len=6000, limit_mm_per_prompt=None,
-                 trust_remote_code=True, gpu_memory_utilization=None, seed=0, tokenizer=None, comm=None, **kw):
+                 trust_remote_code=True, gpu_memory_utilization=None, seed=0, tokenizer=None, comm=None,
+                 max_num_seqs=1, **kw):
         from .config import PRESETS, ChatTSConfig, preset
         from .modeling import ChatTSForCausalLM
         from .processing import ChatTSProcessor
@@ -40,7 +41,9 @@ class LLM:
         if comm.world != tensor_parallel_size:
             raise ValueError(f"tensor_parallel_size={tensor_parallel_size} needs {tensor_parallel_size} ranks launched "
                              f"one per GPU (torchrun); this process group has {comm.world}")
-        mk = dict(comm=comm, max_ctx=max_model_len, max_prefill_tokens=min(2048, max_model_len))
+        # max_num_seqs (vLLM's name): cache slots decoded together (continuous batching); 1 = one request at a time
+        mk = dict(comm=comm, max_ctx=max_model_len, max_prefill_tokens=min(2048, max_model_len),
+                  max_batch=max(1, int(max_num_seqs)) if tensor_parallel_size == 1 else 1)
         if isinstance(model, ChatTSConfig):
             self.model = ChatTSForCausalLM.from_synthetic(model, seed=seed, **mk)
         elif isinstance(model, str) and model in PRESETS:
@@ -62,7 +65,8 @@ class LLM:
             raise NotImplementedError("only greedy decoding (temperature=0) is implemented")
         if isinstance(prompts, (str, dict)):
             prompts = [prompts]
-        outs = []
+        import torch
+        reqs, metas = [], []
         for req in prompts:
             if isinstance(req, str):
                 req = {"prompt": req}
@@ -71,10 +75,11 @@ class LLM:
                 raise ValueError(f"At most {self.limit} timeseries may be provided in one prompt, got {len(series)}")
             text, encs, lens = self.processor.splice(req["prompt"], [np.asarray(s, dtype=np.float64) for s in series])
             ids = self.processor.tokenizer.encode(text)
-            import torch
             ser = torch.from_numpy(self.processor.pad_stack(encs)) if encs else None
-            eos = None if sp.ignore_eos else (list(self.config.eos_token_id) + sp.stop_token_ids)
-            toks = self.model.generate_one(ids, ser, lens, sp.max_tokens, eos)
-            outs.append(RequestOutput(req["prompt"], ids,
-                                      [CompletionOutput(self.processor.tokenizer.decode(toks, skip_special_tokens=True), toks)]))
-        return outs
+            reqs.append((ids, ser, lens))
+            metas.append((req["prompt"], ids))
+        eos = None if sp.ignore_eos else (list(self.config.eos_token_id) + sp.stop_token_ids)
+        toks_all = self.model.generate_batch(reqs, sp.max_tokens, eos)      # sequential when max_num_seqs == 1
+        tok = self.processor.tokenizer
+        return [RequestOutput(p, ids, [CompletionOutput(tok.decode(t, skip_special_tokens=True), t)])
+                for (p, ids), t in zip(metas, toks_all)]

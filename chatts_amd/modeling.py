@@ -45,7 +45,8 @@ def rope_tables(cfg, max_pos, device):
 class ChatTSForCausalLM:
     packed_modules_mapping = packed_modules_mapping
 
-    def __init__(self, config, device="cuda", comm=None, max_ctx=2048, max_prefill_tokens=2048, use_graph=True):
+    def __init__(self, config, device="cuda", comm=None, max_ctx=2048, max_prefill_tokens=2048, use_graph=True,
+                 max_batch=1):
         if not torch.cuda.is_available():
             raise RuntimeError("chatts_amd needs a ROCm GPU: there is no CPU fallback for the model")
         self.lib = _lib.load()
@@ -54,7 +55,8 @@ class ChatTSForCausalLM:
         self.comm = comm or LocalComm()
         self.plan = ShardPlan(config, self.comm.rank, self.comm.world)
         self.max_ctx = int(max_ctx)
-        self.t_max = int(min(max_prefill_tokens, max_ctx))
+        self.max_batch = int(max_batch)          # KV-cache slots for batched decode (continuous batching)
+        self.t_max = int(max(min(max_prefill_tokens, max_ctx), self.max_batch))
         self.use_graph = use_graph
         self.ts_encoder = TimeSeriesEmbedding(config.ts, device=self.device)
         self._tensors = {}            # keeps every device tensor alive (the C side borrows pointers)
@@ -182,24 +184,32 @@ class ChatTSForCausalLM:
                                 rms_eps=cfg.rms_norm_eps, max_ctx=self.max_ctx, max_pos=max_pos, tp_world=plan.world)
         ws_bytes = int(lib.chatts_decoder_workspace(C.byref(dc), self.t_max, self.n_splits))
         ws_bytes = max(ws_bytes, int(lib.chatts_linear_workspace(self.t_max, plan.vocab, H)))
+        for m in range(2, self.max_batch + 1):     # batched lm_head
+            ws_bytes = max(ws_bytes, int(lib.chatts_linear_workspace(m, plan.vocab, H)))
+        ws_bytes = max(ws_bytes, int(lib.chatts_attn_workspace(self.max_batch, plan.nq, self.n_splits)) + 256)
+        MB = self.max_batch
         f32 = dict(dtype=torch.float32, device=dev)
         qkv_n = (plan.nq + 2 * plan.nkv) * d
         L = cfg.num_hidden_layers
         B = {
-            "kv_k": torch.zeros((L, plan.nkv, self.max_ctx, d), **f32),
-            "kv_v": torch.zeros((L, plan.nkv, self.max_ctx, d), **f32),
+            "kv_k": torch.zeros((MB, L, plan.nkv, self.max_ctx, d), **f32),      # slot-major: one cache per sequence
+            "kv_v": torch.zeros((MB, L, plan.nkv, self.max_ctx, d), **f32),
             "x": torch.zeros((self.t_max, H), **f32), "xn": torch.zeros((self.t_max, H), **f32),
             "qkv": torch.zeros((self.t_max, qkv_n), **f32), "attn": torch.zeros((self.t_max, plan.nq * d), **f32),
             "act": torch.zeros((self.t_max, plan.inter), **f32), "delta": torch.zeros((self.t_max, H), **f32),
             "logits": torch.zeros(plan.vocab, **f32),
             "ws": torch.zeros(ws_bytes, dtype=torch.uint8, device=dev),
             # decode-loop state lives on the device so a captured step can be replayed
-            "pos": torch.zeros(1, dtype=torch.int32, device=dev), "step": torch.zeros(1, dtype=torch.int32, device=dev),
-            "token": torch.zeros(1, dtype=torch.int64, device=dev), "token_logit": torch.zeros(1, **f32),
-            "out_tokens": torch.zeros(self.max_ctx + 8, dtype=torch.int64, device=dev),
+            "pos_all": torch.zeros(MB, dtype=torch.int32, device=dev), "step_all": torch.zeros(MB, dtype=torch.int32, device=dev),
+            "token_all": torch.zeros(MB, dtype=torch.int64, device=dev), "token_logit_all": torch.zeros(MB, **f32),
+            "out_tokens_all": torch.zeros((MB, self.max_ctx + 8), dtype=torch.int64, device=dev),
+            "logits_all": torch.zeros((MB, plan.vocab), **f32) if MB > 1 else None,
             "scan": torch.zeros(self.t_max + 8, dtype=torch.int32, device=dev),
             "status": torch.zeros(1, dtype=torch.int32, device=dev),
         }
+        # single-sequence views (slot 0): the batch-1 fast path and its hipGraph use these
+        B["pos"], B["step"], B["token"], B["token_logit"] = B["pos_all"][:1], B["step_all"][:1], B["token_all"][:1], B["token_logit_all"][:1]
+        B["out_tokens"] = B["out_tokens_all"][0]
         self.buf = B
         arr = (_lib.LayerWeights * L)()
         for i, lw in enumerate(self.layers):
@@ -214,12 +224,14 @@ class ChatTSForCausalLM:
         db = _lib.DecoderBuffers(kv_k=_lib.ptr(B["kv_k"]), kv_v=_lib.ptr(B["kv_v"]), x=_lib.ptr(B["x"]),
                                  xn=_lib.ptr(B["xn"]), qkv=_lib.ptr(B["qkv"]), attn=_lib.ptr(B["attn"]),
                                  act=_lib.ptr(B["act"]), delta=_lib.ptr(B["delta"]), logits=_lib.ptr(B["logits"]),
-                                 workspace=_lib.ptr(B["ws"]), workspace_bytes=ws_bytes, t_max=self.t_max)
+                                 workspace=_lib.ptr(B["ws"]), workspace_bytes=ws_bytes, t_max=self.t_max,
+                                 max_batch=self.max_batch)
         h = lib.chatts_decoder_create(C.byref(dc), C.byref(dw), C.byref(db))
         if not h:
             raise _lib.ChattsError(-1, lib.chatts_last_error().decode())
         self._decoder = C.c_void_p(h)
         self._graph = None
+        self._graph_batched = None
 
     def __del__(self):
         try:
@@ -421,6 +433,125 @@ class ChatTSForCausalLM:
         self._graph = g
 
     # ---------------------------------------------------------------------------------------------
+    # batched decode / continuous batching (TP = 1)
+    # ---------------------------------------------------------------------------------------------
+    def select_sequence(self, slot):
+        _lib.check(self.lib.chatts_decoder_select_sequence(self._decoder, int(slot)))
+
+    def _batched_step_eager(self):
+        B = self.buf
+        _lib.check(self.lib.chatts_decoder_decode_step_batched(
+            self._decoder, self.max_batch, _lib.ptr(B["pos_all"]), _lib.ptr(B["step_all"]), _lib.ptr(B["token_all"]),
+            _lib.ptr(B["token_logit_all"]), _lib.ptr(B["out_tokens_all"]), B["out_tokens_all"].shape[1],
+            _lib.ptr(B["logits_all"]), self.n_splits, _lib.stream_ptr()))
+
+    def batched_step(self):
+        """One greedy token for EVERY cache slot (idle slots compute harmlessly; their position saturates)."""
+        if self.plan.world != 1:
+            raise NotImplementedError("batched decode is implemented for tensor_parallel_size=1")
+        if not self.use_graph:
+            return self._batched_step_eager()
+        if self._graph_batched is None:
+            B = self.buf
+            keys = ("pos_all", "step_all", "token_all", "token_logit_all", "out_tokens_all")
+            saved = {k: B[k].clone() for k in keys}
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._batched_step_eager()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for k in keys:
+                B[k].copy_(saved[k])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._batched_step_eager()
+            torch.cuda.synchronize()
+            for k in keys:
+                B[k].copy_(saved[k])
+            self._graph_batched = g
+        self._graph_batched.replay()
+
+    def _admit(self, slot, ids, series, lengths):
+        """Prefill one request into cache slot `slot` and produce its first token (out_tokens_all[slot, 0])."""
+        cfg, B = self.config, self.buf
+        ps = cfg.ts["patch_size"]
+        mm, counts = None, []
+        if series is not None and series.shape[0] > 0:
+            series = series.to(self.device, dtype=torch.float32)
+            if lengths is None:
+                lengths = self.ts_encoder.get_patch_cnt(series)[0].tolist()
+            counts = [(int(v) + ps - 1) // ps for v in lengths]
+            mm = self.get_multimodal_embeddings(timeseries=series, valid_lengths=lengths)
+        full = self.expand_input_ids(list(ids), counts)
+        T = len(full)
+        if T + 1 > self.max_ctx:
+            raise ValueError(f"prompt ({T}) exceeds max_ctx={self.max_ctx}")
+        emb = self.get_input_embeddings(torch.tensor(full, dtype=torch.int64), mm)
+        self.select_sequence(slot)
+        last = self.prefill(emb, 0)
+        st = _lib.stream_ptr()
+        _lib.check(self.lib.chatts_decoder_logits(self._decoder, last - 1, st))
+        B["pos_all"][slot] = T
+        B["step_all"][slot] = 0
+        _lib.check(self.lib.chatts_argmax_batched(
+            _lib.ptr(B["logits"]), 1, self.plan.vocab, self.plan.vocab, self.plan.v0,
+            B["token_all"][slot:].data_ptr(), B["token_logit_all"][slot:].data_ptr(), B["out_tokens_all"][slot].data_ptr(),
+            B["out_tokens_all"].shape[1], B["step_all"][slot:].data_ptr(), None, 0, st))
+        self.select_sequence(0)
+        return T
+
+    @torch.no_grad()
+    def generate_batch(self, requests, max_new_tokens=64, eos_token_id=None, sync_every=8):
+        """Continuous batching over `max_batch` cache slots.  requests: list of (ids, series [n,2Lmax,1] | None,
+        lengths | None).  A finished sequence frees its slot for the next waiting request at the next sync point.
+        Returns the list of generated token lists, in request order."""
+        if self.max_batch < 2:
+            return [self.generate_one(i, s, l, max_new_tokens, eos_token_id) for (i, s, l) in requests]
+        eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple, set)) else
+                  ([] if eos_token_id is None else [eos_token_id]))
+        B = self.buf
+        results = [None] * len(requests)
+        waiting = list(range(len(requests)))[::-1]
+        slots = [None] * self.max_batch              # request index per slot
+        produced = [0] * self.max_batch
+        B["pos_all"].zero_(); B["step_all"].zero_(); B["token_all"].zero_()
+        steps_since_sync = 0
+
+        def harvest(final=False):
+            toks_all = B["out_tokens_all"].cpu()
+            for s, r in enumerate(slots):
+                if r is None:
+                    continue
+                toks = toks_all[s, :produced[s]].tolist()
+                cut = next((i + 1 for i, t in enumerate(toks) if t in eos), None) if eos else None
+                if cut is not None or produced[s] >= max_new_tokens or final:
+                    results[r] = toks[:cut] if cut is not None else toks[:max_new_tokens]
+                    slots[s] = None
+                    B["pos_all"][s] = 0          # an idle slot attends over one key, not over its stale context
+
+        while waiting or any(r is not None for r in slots):
+            for s in range(self.max_batch):
+                if slots[s] is None and waiting:
+                    r = waiting.pop()
+                    ids, series, lengths = requests[r]
+                    self._admit(s, ids, series, lengths)
+                    slots[s], produced[s] = r, 1
+            if all(r is None or produced[s] >= max_new_tokens for s, r in enumerate(slots)):
+                harvest()
+                continue
+            self.batched_step()
+            for s, r in enumerate(slots):
+                if r is not None and produced[s] < max_new_tokens:
+                    produced[s] += 1
+            steps_since_sync += 1
+            if steps_since_sync >= sync_every or all(r is None or produced[s] >= max_new_tokens for s, r in enumerate(slots)):
+                harvest()
+                steps_since_sync = 0
+        return results
+
+    # ---------------------------------------------------------------------------------------------
     # HF surface
     # ---------------------------------------------------------------------------------------------
     def expand_input_ids(self, ids, patch_counts):
@@ -502,18 +633,25 @@ class ChatTSForCausalLM:
         if eos_token_id is None:
             eos_token_id = cfg.eos_token_id
         ts0 = cfg.ts_token_start_index
-        cursor, rows = 0, []
+        cursor, rows, reqs = 0, [], []
         for b in range(ids.shape[0]):
             seq = ids[b][mask[b].bool()].tolist()
             n_ts = sum(1 for i in range(len(seq) - 1) if seq[i] == ts0 and seq[i + 1] == ts0 + 1)
             ser = timeseries[cursor:cursor + n_ts] if (timeseries is not None and n_ts) else None
             lens = valid_lengths[cursor:cursor + n_ts] if valid_lengths is not None else None
             cursor += n_ts
-            budget = max_new_tokens if max_length is None else max(1, max_length - len(seq))
-            toks = self.generate_one(seq, ser, lens, budget, eos_token_id)
-            if streamer is not None:
-                streamer.put(torch.tensor(toks))
-            rows.append(ids[b].tolist() + toks)
+            reqs.append((seq, ser, lens))
+        budget = max_new_tokens if max_length is None else max(1, max_length - max(len(r[0]) for r in reqs))
+        if self.max_batch > 1 and len(reqs) > 1 and streamer is None and self.plan.world == 1:
+            outs = self.generate_batch(reqs, budget, eos_token_id)          # continuous batching over the cache slots
+        else:
+            outs = []
+            for seq, ser, lens in reqs:
+                toks = self.generate_one(seq, ser, lens, budget, eos_token_id)
+                if streamer is not None:
+                    streamer.put(torch.tensor(toks))
+                outs.append(toks)
+        rows = [ids[b].tolist() + outs[b] for b in range(ids.shape[0])]
         if streamer is not None:
             streamer.end()
         n = max(len(r) for r in rows)

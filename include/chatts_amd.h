@@ -165,12 +165,29 @@ int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int n_kv, const
                                   const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
                                   size_t workspace_bytes, chatts_stream_t stream);
 
+/* Batched form of the above: `batch` sequences, one decode token each; row b of qkv_raw / out and pos_dev[b] belong
+ * to sequence b, whose cache is `cache` advanced by b * seq_stride floats (same layer). */
+int chatts_attention_decode_batched(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w,
+                                    const float* k_norm_w, float norm_eps, const float* cos_tab,
+                                    const float* sin_tab, int pos, const int32_t* pos_dev,
+                                    const ChattsKvCache* cache, size_t seq_stride, float* out, int n_splits,
+                                    void* workspace, size_t workspace_bytes, chatts_stream_t stream);
+
 /* logits [V] float32 -> *token (first index of the maximum, like torch.argmax); optionally also
  * appends the token to out_tokens[*step_dev] and increments *step_dev and *pos_dev (decode loop
  * state kept on the device so that a hipGraph of one decode step is replayable). */
 int chatts_argmax(const float* logits, int64_t vocab, int64_t vocab_offset, int64_t* token,
                   float* token_logit, int64_t* out_tokens, int32_t* step_dev, int32_t* pos_dev,
                   chatts_stream_t stream);
+
+/* Per-sequence form: logits [batch, logits_stride], token/token_logit/step_dev/pos_dev are arrays of `batch`,
+ * out_tokens is [batch, out_stride]; sequence b appends at out_tokens[b][step_dev[b]]. */
+int chatts_argmax_batched(const float* logits, int batch, int64_t logits_stride, int64_t vocab, int64_t vocab_offset,
+                          int64_t* token, float* token_logit, int64_t* out_tokens, int64_t out_stride,
+                          int32_t* step_dev, int32_t* pos_dev, int pos_limit /* pos saturates here; 0 = none */,
+                          chatts_stream_t stream);
+int chatts_embed_token_batched(const int64_t* token_dev, int batch, const chatts_bf16* table, int64_t vocab_offset,
+                               int64_t vocab_rows, int hidden, float* out /* [batch, hidden] */, chatts_stream_t stream);
 
 /* x[h] = float(table[*token, h]) : next-step input embedding, token id read on the device. */
 int chatts_embed_token(const int64_t* token_dev, const chatts_bf16* table, int64_t vocab_offset,
@@ -226,6 +243,7 @@ typedef struct ChattsDecoderBuffers {
   void* workspace;    /* split-K + attention partials */
   size_t workspace_bytes;
   int t_max;
+  int max_batch;      /* KV caches are [max_batch, n_layers, n_kv, max_ctx, 128]; 0 or 1 = single sequence */
 } ChattsDecoderBuffers;
 
 typedef struct ChattsDecoder ChattsDecoder;  /* opaque; host memory only */
@@ -242,6 +260,17 @@ size_t chatts_decoder_workspace(const ChattsDecoderConfig*, int t_max, int n_spl
 int chatts_decoder_layer_part(ChattsDecoder*, int layer, int part, int t, int pos0,
                               const int32_t* pos0_dev, int n_splits, chatts_stream_t stream);
 int chatts_residual_add(float* x, const float* delta, int64_t n, chatts_stream_t stream);
+
+/* KV-cache slot (sequence) used by the single-sequence entry points (layer_part, prefill, decode_step). */
+int chatts_decoder_select_sequence(ChattsDecoder*, int seq);
+/* Batched decode (continuous batching): `batch` sequences advance one token each; row b of
+ * the activation buffers and pos_dev[b] belong to cache slot b.  Projections run as M = batch MFMA GEMMs. */
+int chatts_decoder_layer_part_batched(ChattsDecoder*, int layer, int part, int batch, const int32_t* pos_dev,
+                                      int n_splits, chatts_stream_t stream);
+int chatts_decoder_decode_step_batched(ChattsDecoder*, int batch, int32_t* pos_dev, int32_t* step_dev,
+                                       int64_t* token_dev, float* token_logit_dev, int64_t* out_tokens,
+                                       int64_t out_stride, float* logits_all /* [batch, vocab_local] */, int n_splits,
+                                       chatts_stream_t stream);
 
 /* TP=1 fast paths: all layers back to back on the stream (no host round trip, graph-capturable). */
 int chatts_decoder_prefill(ChattsDecoder*, int t, int pos0, chatts_stream_t stream);

@@ -330,3 +330,40 @@ def test_full_size_14b_properties():
     err = rel_err(model.buf["logits"].cpu().numpy(), l1.cpu().numpy())
     assert err < 2e-4, err          # 48 layers of re-ordered f32 sums (different GEMM tiling per chunk size)
     assert int(model.buf["out_tokens"][0]) == t1[0]
+
+
+def test_continuous_batching_matches_oracle():
+    """5 requests of different shapes through 3 cache slots (continuous batching): every request's greedy tokens equal
+    the oracle's, independent of which slot / which neighbours it was decoded with."""
+    cfg = cfgmod.preset("tiny-qwen2")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=5, max_ctx=512, max_prefill_tokens=256, max_batch=3)
+    sd = osynth.state_dict(synth.all_specs(cfg), 5)
+    rng = np.random.default_rng(77)
+    specs = [[64], [17, 40], [], [256], [30]]
+    reqs, wants = [], []
+    for lengths in specs:
+        series = [random_walk_series(rng, L) for L in lengths]
+        prompt = chat_prompt(lengths) if lengths else "<|im_start|>user\nJust words, no series.<|im_end|><|im_start|>assistant\n"
+        inp = proc(text=[prompt], timeseries=series if series else None, return_tensors="pt")
+        ids = inp["input_ids"][0].tolist()
+        reqs.append((ids, inp["timeseries"] if series else None, list(lengths) if series else None))
+        wants.append(pipeline.generate(cfg, sd, ids, inp["timeseries"].numpy() if series else None, 9)["tokens"])
+    for use_graph in (False, True):
+        model.use_graph = use_graph
+        outs = model.generate_batch(reqs, max_new_tokens=9, eos_token_id=None, sync_every=4)
+        assert outs == wants
+    # early stop: treat each request's 3rd oracle token as its EOS -> result is cut right after it, slot is reused
+    eos = [w[2] for w in wants]
+    outs = model.generate_batch(reqs, max_new_tokens=9, eos_token_id=eos, sync_every=2)
+    for o, w in zip(outs, wants):
+        cut = next(i + 1 for i, t in enumerate(w) if t in eos)
+        assert o == w[:cut]
+    # the HF surface batches through the same path
+    prompts = [chat_prompt([64]), chat_prompt([48])]
+    ser = [random_walk_series(rng, 64), random_walk_series(rng, 48)]
+    inputs = proc(text=prompts, timeseries=ser, padding=True, return_tensors="pt")
+    out = model.generate(**inputs.to("cuda"), max_new_tokens=4, eos_token_id=[])
+    model1 = ChatTSForCausalLM.from_synthetic(cfg, seed=5, max_ctx=512, max_prefill_tokens=256)
+    ref = model1.generate(**inputs.to("cuda"), max_new_tokens=4, eos_token_id=[])
+    assert torch.equal(out, ref)

@@ -404,3 +404,38 @@ def test_embed_merge_and_argmax(lib):
     _lib.check(lib.chatts_argmax(logits.data_ptr(), 152064, 1000, tok.data_ptr(), val.data_ptr(), outt.data_ptr(),
                                  step.data_ptr(), pos.data_ptr(), st()))
     assert tok.item() == 6000 and val.item() == 50.0 and outt[2].item() == 6000 and step.item() == 3 and pos.item() == 11
+
+
+def test_attention_decode_batched_equals_per_sequence(lib):
+    """batched decode attention (one position / cache slot per sequence) == the single-sequence call per slot"""
+    nq, nkv, max_ctx, L, B, splits = 10, 2, 256, 3, 4, 16
+    g = torch.Generator().manual_seed(42)
+    raw = torch.randn((B, (nq + 2 * nkv) * 128), generator=g).to(DEV)
+    kc0 = torch.randn((B, L, nkv, max_ctx, 128), generator=g).to(DEV)
+    vc0 = torch.randn((B, L, nkv, max_ctx, 128), generator=g).to(DEV)
+    pos = [0, 37, 200, 16]
+    layer = 1
+    cos, sin = _rope_tables(max_ctx)
+    wsb = int(lib.chatts_attn_workspace(B, nq, splits))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    seq_stride = L * nkv * max_ctx * 128
+    kc_b, vc_b = kc0.clone(), vc0.clone()
+    cache = _lib.KvCache(k=kc_b[0, layer].data_ptr(), v=vc_b[0, layer].data_ptr(), max_ctx=max_ctx)
+    out_b = torch.full((B, nq * 128), float("nan"), device=DEV)
+    pos_dev = torch.tensor(pos, dtype=torch.int32, device=DEV)
+    _lib.check(lib.chatts_attention_decode_batched(raw.data_ptr(), B, nq, nkv, None, None, 1e-6, cos.data_ptr(),
+                                                   sin.data_ptr(), 0, pos_dev.data_ptr(), C.byref(cache), seq_stride,
+                                                   out_b.data_ptr(), splits, ws.data_ptr(), wsb, st()))
+    torch.cuda.synchronize()
+    for b in range(B):
+        kc_a, vc_a = kc0[b, layer].clone(), vc0[b, layer].clone()
+        ca = _lib.KvCache(k=kc_a.data_ptr(), v=vc_a.data_ptr(), max_ctx=max_ctx)
+        out_a = torch.empty((1, nq * 128), device=DEV)
+        _lib.check(lib.chatts_attention_decode_fused(raw[b:b + 1].contiguous().data_ptr(), nq, nkv, None, None, 1e-6,
+                                                     cos.data_ptr(), sin.data_ptr(), pos[b], None, C.byref(ca),
+                                                     out_a.data_ptr(), splits, ws.data_ptr(), wsb, st()))
+        torch.cuda.synchronize()
+        assert torch.equal(out_b[b], out_a[0])
+        assert torch.equal(kc_b[b, layer], kc_a) and torch.equal(vc_b[b, layer], vc_a)
+    # other layers / untouched
+    assert torch.equal(kc_b[:, 0], kc0[:, 0]) and torch.equal(kc_b[:, 2], kc0[:, 2])
