@@ -70,7 +70,8 @@ def roofline_gate_up(model, reps=2):
         for lw in model.layers:
             la = _lib.LinearArgs(a=x.data_ptr(), w=lw["gate_up"].data_ptr(), bias=None, resid=None, c=out.data_ptr(),
                                  norm_w=lw["post_norm"].data_ptr(), norm_eps=cfg.rms_norm_eps, m=1, n=n, k=H, lda=H,
-                                 ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU, workspace=None, workspace_bytes=0)
+                                 ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU, workspace=None, workspace_bytes=0,
+                                 w8=_lib.ptr(lw.get("gate_up8")), w8_scale=_lib.ptr(lw.get("gate_up8_scale")), ldw8=H)
             _lib.check(lib.chatts_linear(la, stream.cuda_stream))
 
     sweep()
@@ -84,8 +85,10 @@ def roofline_gate_up(model, reps=2):
     launches = reps * len(model.layers)
     avg_s = e0.elapsed_time(e1) * 1e-3 / launches
     # algorithmic bytes per launch: bf16 weights + f32 x in + norm weights + f32 out (SURVEY.md 8d per-unit figure)
-    bytes_per_launch = n * H * 2 + H * 4 + H * 4 + plan.inter * 4
-    return dict(kernel="gemv_ldsx_kernel<2,2,SWIGLU,NORM> (gate_up_proj + fused RMSNorm + SwiGLU)", launches=launches,
+    fp8 = "gate_up8" in model.layers[0]
+    bytes_per_launch = n * H * (1 if fp8 else 2) + (n * 4 if fp8 else 0) + H * 4 + H * 4 + plan.inter * 4
+    return dict(kernel=("gemv8_ldsx_kernel" if fp8 else "gemv_ldsx_kernel") +
+                "<2,2,SWIGLU,NORM> (gate_up_proj + fused RMSNorm + SwiGLU)", launches=launches,
                 avg_us=avg_s * 1e6, bytes_per_launch=bytes_per_launch, gbs=bytes_per_launch / avg_s / 1e9)
 
 
@@ -179,6 +182,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ttft-runs", type=int, default=5)
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8 = BASELINE.json config 5 weight format (NOT the headline: reported as a separate workload)")
     args = ap.parse_args()
 
     import torch
@@ -215,7 +220,8 @@ def main():
     t0 = time.time()
     max_ctx = 2048
     model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, device=device, comm=comm, max_ctx=max_ctx,
-                                             max_prefill_tokens=1024, use_graph=not args.no_graph)
+                                             max_prefill_tokens=1024, use_graph=not args.no_graph,
+                                             weight_format=args.weights)
     torch.cuda.synchronize()
     log(f"[bench] {args.model} TP={world} materialised in {time.time() - t0:.1f}s, "
         f"{model.weight_bytes_local() / 1e9:.2f} GB decoder weights on this rank")
@@ -272,7 +278,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        if world == 1 and args.model == "chatts-14b":
+        if world == 1 and args.model == "chatts-14b" and args.weights == "bf16":
             traffic = pmc["hbm_bytes_per_launch"]
     except Exception:
         pmc = None
@@ -281,8 +287,8 @@ def main():
         "metric": "generated tokens/sec (greedy, batch 1) + p50 TTFT, ChatTS-14B, 8x256-step TS prompt, TP=N",
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"ChatTS-14B bf16 weights, {args.series} series x {args.length} steps, greedy decode, "
+        "dtype": "bf16" if args.weights == "bf16" else "fp8-e4m3 weights (pow2 row scales), f32 math", "data": "synthetic",
+        "config": {"workload": f"ChatTS-14B {args.weights} weights, {args.series} series x {args.length} steps, greedy decode, "
                                f"TP={world}" if args.model == "chatts-14b" and args.layers is None else
                                f"DEBUG {args.model} layers={args.layers}",
                    "model": args.model, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),

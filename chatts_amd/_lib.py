@@ -27,7 +27,7 @@ class LinearArgs(C.Structure):
     _fields_ = [("a", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("resid", c_void_p), ("c", c_void_p),
                 ("norm_w", c_void_p), ("norm_eps", c_float), ("m", c_int), ("n", c_int), ("k", c_int),
                 ("lda", c_int), ("ldw", c_int), ("ldc", c_int), ("epilogue", c_int), ("workspace", c_void_p),
-                ("workspace_bytes", c_size_t)]
+                ("workspace_bytes", c_size_t), ("w8", c_void_p), ("w8_scale", c_void_p), ("ldw8", c_int)]
 
 
 class KvCache(C.Structure):
@@ -37,7 +37,9 @@ class KvCache(C.Structure):
 class LayerWeights(C.Structure):
     _fields_ = [("input_norm", c_void_p), ("qkv", c_void_p), ("qkv_bias", c_void_p), ("q_norm", c_void_p),
                 ("k_norm", c_void_p), ("o", c_void_p), ("post_norm", c_void_p), ("gate_up", c_void_p),
-                ("down", c_void_p)]
+                ("down", c_void_p), ("qkv8", c_void_p), ("qkv8_scale", c_void_p), ("o8", c_void_p),
+                ("o8_scale", c_void_p), ("gate_up8", c_void_p), ("gate_up8_scale", c_void_p), ("down8", c_void_p),
+                ("down8_scale", c_void_p)]
 
 
 class DecoderConfig(C.Structure):
@@ -48,6 +50,7 @@ class DecoderConfig(C.Structure):
 
 class DecoderWeights(C.Structure):
     _fields_ = [("layers", C.POINTER(LayerWeights)), ("final_norm", c_void_p), ("lm_head", c_void_p),
+                ("lm_head8", c_void_p), ("lm_head8_scale", c_void_p),
                 ("embed", c_void_p), ("cos_tab", c_void_p), ("sin_tab", c_void_p)]
 
 

@@ -43,6 +43,9 @@ extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) 
   CHATTS_REQUIRE(a->ldc >= ncols, CHATTS_E_SHAPE, "linear: ldc=%d < %d", a->ldc, ncols);
   CHATTS_REQUIRE(((uintptr_t)a->a % 16) == 0 && ((uintptr_t)a->w % 16) == 0 && ((uintptr_t)a->c % 16) == 0,
                  CHATTS_E_SHAPE, "linear: pointers must be 16-byte aligned");
+  if (a->w8)
+    CHATTS_REQUIRE(a->w8_scale && a->ldw8 >= a->k && a->ldw8 % 16 == 0 && ((uintptr_t)a->w8 % 16) == 0 && a->k % 16 == 0,
+                   CHATTS_E_SHAPE, "linear: fp8 weights need a scale, ldw8 >= K, 16-byte alignment");
   if (a->m == 1 && a->epilogue != CHATTS_EPI_GELU) return launch_gemv(a, as_stream(stream));
   CHATTS_REQUIRE(a->norm_w == nullptr, CHATTS_E_BADARG, "linear: fused RMSNorm is only available for M == 1");
   return launch_gemm(a, as_stream(stream));
@@ -122,6 +125,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if (t == 1) {
       la.a = d->b.x; la.norm_w = lw.input_norm; la.norm_eps = c.rms_eps;
+      la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H;
     } else {
       if ((rc = chatts_rmsnorm(d->b.x, lw.input_norm, d->b.xn, t, H, c.rms_eps, stream)) != 0) return rc;
       la.a = d->b.xn;
@@ -143,6 +147,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     la.a = d->b.attn; la.w = lw.o; la.m = t; la.n = H; la.k = c.n_q * kHeadDim;
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+    if (t == 1) { la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k; }
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
     return chatts_linear(&la, stream);
@@ -154,6 +159,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if (t == 1) {
     la.a = d->b.x; la.norm_w = lw.post_norm; la.norm_eps = c.rms_eps;
+    la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H;
   } else {
     if ((rc = chatts_rmsnorm(d->b.x, lw.post_norm, d->b.xn, t, H, c.rms_eps, stream)) != 0) return rc;
     la.a = d->b.xn;
@@ -163,6 +169,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   la.a = d->b.act; la.w = lw.down; la.m = t; la.n = H; la.k = c.inter;
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  if (t == 1) { la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter; }
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
   return chatts_linear(&la, stream);
@@ -266,6 +273,7 @@ extern "C" int chatts_decoder_logits(ChattsDecoder* d, int row, chatts_stream_t 
   la.a = d->b.x + (size_t)row * c.hidden; la.w = d->w.lm_head; la.c = d->b.logits;
   la.m = 1; la.n = (int)c.vocab_local; la.k = c.hidden; la.lda = c.hidden; la.ldw = c.hidden; la.ldc = (int)c.vocab_local;
   la.epilogue = CHATTS_EPI_NONE; la.norm_w = d->w.final_norm; la.norm_eps = c.rms_eps;
+  la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden;
   return chatts_linear(&la, stream);
 }
 

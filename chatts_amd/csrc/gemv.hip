@@ -29,6 +29,9 @@ struct GemvParams {
   int k;
   int ldw;
   int tasks;   // number of row-group tasks
+  const uint8_t* w8;      // fp8 (OCP e4m3fn) weights [N, ldw8] or NULL
+  const float* w8_scale;  // per-row power-of-two scale: w = scale[row] * float(w8)
+  int ldw8;
 };
 
 __device__ __forceinline__ float dot8(const u32x4 wv, const f32x4 xa, const f32x4 xb, float acc) {
@@ -160,6 +163,106 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(GemvParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp8 weights (OCP e4m3fn, CDNA4 v_cvt_pk_f32_fp8): the same geometry with 16 weights per 16-byte load, so a
+// chunk is 1024 elements and x is staged as [chunk][quarter][lane] float4.  Each row carries a power-of-two
+// scale, w = scale[row] * float(q): the dequantised weight is exactly representable in bf16, i.e. the fp8 copy
+// is a lossless encoding of the bf16 matrix the prefill GEMM streams.  Halves the decode weight traffic.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float dot16_fp8(const u32x4 wv, const f32x4 x0, const f32x4 x1, const f32x4 x2, const f32x4 x3,
+                                            float acc) {
+  f32x2 a;
+  a = __builtin_amdgcn_cvt_pk_f32_fp8(wv.x, false); acc = fmaf(a.x, x0.x, acc); acc = fmaf(a.y, x0.y, acc);
+  a = __builtin_amdgcn_cvt_pk_f32_fp8(wv.x, true);  acc = fmaf(a.x, x0.z, acc); acc = fmaf(a.y, x0.w, acc);
+  a = __builtin_amdgcn_cvt_pk_f32_fp8(wv.y, false); acc = fmaf(a.x, x1.x, acc); acc = fmaf(a.y, x1.y, acc);
+  a = __builtin_amdgcn_cvt_pk_f32_fp8(wv.y, true);  acc = fmaf(a.x, x1.z, acc); acc = fmaf(a.y, x1.w, acc);
+  a = __builtin_amdgcn_cvt_pk_f32_fp8(wv.z, false); acc = fmaf(a.x, x2.x, acc); acc = fmaf(a.y, x2.y, acc);
+  a = __builtin_amdgcn_cvt_pk_f32_fp8(wv.z, true);  acc = fmaf(a.x, x2.z, acc); acc = fmaf(a.y, x2.w, acc);
+  a = __builtin_amdgcn_cvt_pk_f32_fp8(wv.w, false); acc = fmaf(a.x, x3.x, acc); acc = fmaf(a.y, x3.y, acc);
+  a = __builtin_amdgcn_cvt_pk_f32_fp8(wv.w, true);  acc = fmaf(a.x, x3.z, acc); acc = fmaf(a.y, x3.w, acc);
+  return acc;
+}
+
+template <int ROWS, int UNR, int EPI, bool NORM>
+__global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* xs4 = reinterpret_cast<f32x4*>(smem);            // permuted x: [chunk][quarter][lane] float4
+  const int K = p.k;
+  const int nchunks = (K + 1023) >> 10;
+  float* red = reinterpret_cast<float*>(smem) + (size_t)nchunks * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthreads = blockDim.x, nw = nthreads >> 6;
+
+  float rstd = 1.f;
+  if (NORM) {
+    float ss = 0.f;
+    for (int k4 = tid * 4; k4 < K; k4 += nthreads * 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + k4);
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    rstd = rsqrtf(t / (float)K + p.eps);
+  }
+  for (int k4 = tid * 4; k4 < nchunks * 1024; k4 += nthreads * 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k4 < K) {
+      v = *reinterpret_cast<const f32x4*>(p.x + k4);
+      if (NORM) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
+        v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
+      }
+    }
+    const int chunk = k4 >> 10, within = k4 & 1023;
+    xs4[chunk * 256 + ((within >> 2) & 3) * 64 + (within >> 4)] = v;
+  }
+  __syncthreads();
+
+  for (int task = blockIdx.x * nw + wave; task < p.tasks; task += gridDim.x * nw) {
+    const uint8_t* wrow[ROWS];
+    float scale[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      int row = task_row<ROWS, EPI>(task, r);
+      if (row >= p.n) row = 0;
+      wrow[r] = p.w8 + (size_t)row * p.ldw8 + lane * 16;
+      scale[r] = p.w8_scale[row];
+    }
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+    for (int c = 0; c < nchunks; c += UNR) {
+      u32x4 wv[UNR][ROWS];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const bool ok = c + u < nchunks && ((c + u) << 10) + lane * 16 < K;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          wv[u][r] = (u32x4){0u, 0u, 0u, 0u};
+          if (ok) wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + ((c + u) << 10)));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (c + u < nchunks) {
+          const f32x4* xb = xs4 + (c + u) * 256 + lane;
+          const f32x4 x0 = xb[0], x1 = xb[64], x2 = xb[128], x3 = xb[192];
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) acc[r] = dot16_fp8(wv[u][r], x0, x1, x2, x3, acc[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]) * scale[r];     // power-of-two scale: exact
+    gemv_epilogue<ROWS, EPI>(p, task, lane, acc);
+  }
+}
+
 // ---- dispatch ------------------------------------------------------------------------------------
 template <int ROWS, int UNR, int EPI>
 static void launch_ldsx_norm(const GemvParams& p, bool norm, int blocks, int threads, size_t lds, hipStream_t s) {
@@ -175,6 +278,12 @@ static void launch_ldsx(const GemvParams& p, int epi, bool norm, int blocks, int
   }
 }
 
+template <int EPI>
+static void launch8_norm(const GemvParams& p, bool norm, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (norm) hipLaunchKernelGGL((gemv8_ldsx_kernel<2, 2, EPI, true>), dim3(blocks), dim3(threads), lds, s, p);
+  else hipLaunchKernelGGL((gemv8_ldsx_kernel<2, 2, EPI, false>), dim3(blocks), dim3(threads), lds, s, p);
+}
+
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -184,6 +293,7 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   GemvParams p;
   p.w = a->w; p.x = a->a; p.bias = a->bias; p.resid = a->resid; p.out = a->c;
   p.norm_w = a->norm_w; p.eps = a->norm_eps; p.n = a->n; p.k = a->k; p.ldw = a->ldw;
+  p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8;
   const bool norm = a->norm_w != nullptr;
   const int cus = device_cus();
   const int swiglu = a->epilogue == CHATTS_EPI_SWIGLU;
@@ -218,6 +328,21 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   if (blocks > cus * occ) blocks = cus * occ;
   if (blocks < 1) blocks = 1;
   const int threads = nw * 64;
+  if (a->w8 != nullptr) {                       // fp8 weights: 2 rows x 2 chunks of 1024 elements in flight
+    const int nchunks8 = (a->k + 1023) / 1024;
+    const size_t lds8 = (size_t)nchunks8 * 1024 * 4 + 64 * 4;
+    p.tasks = (units + (swiglu ? 1 : 2) - 1) / (swiglu ? 1 : 2);
+    int blocks8 = (p.tasks + nw - 1) / nw;
+    if (blocks8 > cus * occ) blocks8 = cus * occ;
+    if (blocks8 < 1) blocks8 = 1;
+    switch (a->epilogue) {
+      case CHATTS_EPI_RESID: launch8_norm<CHATTS_EPI_RESID>(p, norm, blocks8, threads, lds8, s); break;
+      case CHATTS_EPI_SWIGLU: launch8_norm<CHATTS_EPI_SWIGLU>(p, norm, blocks8, threads, lds8, s); break;
+      default: launch8_norm<CHATTS_EPI_NONE>(p, norm, blocks8, threads, lds8, s); break;
+    }
+    CHATTS_CHECK_LAUNCH("gemv8_ldsx");
+    return CHATTS_OK;
+  }
   if (rows == 4 && unr == 2) launch_ldsx<4, 2>(p, a->epilogue, norm, blocks, threads, lds, s);
   else if (rows == 4) launch_ldsx<4, 4>(p, a->epilogue, norm, blocks, threads, lds, s);
   else if (unr == 2) launch_ldsx<2, 2>(p, a->epilogue, norm, blocks, threads, lds, s);

@@ -34,6 +34,20 @@ def interleave_gate_up(gate, up):
     return out
 
 
+def quantize_fp8_rows(w):
+    """[N,K] bf16 -> (q uint8 view of float8_e4m3fn [N,K], scale f32 [N] (powers of two), deq bf16 [N,K]).
+
+    w ~= scale[n] * float(q[n,k]) with scale a power of two, so the dequantised value has <= 4 significant bits and is
+    EXACTLY representable in bf16: `deq` replaces the bf16 weight and both copies describe the same matrix."""
+    wf = w.float()
+    amax = wf.abs().amax(dim=1).clamp_min(1e-30)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / 448.0)))
+    scale = torch.where(amax / scale > 448.0, scale * 2.0, scale)          # guard log2 rounding: never overflow e4m3
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    deq = (q.float() * scale[:, None]).to(torch.bfloat16)
+    return q.view(torch.uint8).contiguous(), scale.contiguous(), deq.contiguous()
+
+
 def rope_tables(cfg, max_pos, device):
     """float32 cos/sin [max_pos, d/2], computed like Qwen2RotaryEmbedding (inv_freq = theta^(-2i/d), f32)."""
     d = cfg.head_dim
@@ -46,7 +60,7 @@ class ChatTSForCausalLM:
     packed_modules_mapping = packed_modules_mapping
 
     def __init__(self, config, device="cuda", comm=None, max_ctx=2048, max_prefill_tokens=2048, use_graph=True,
-                 max_batch=1):
+                 max_batch=1, weight_format="bf16"):
         if not torch.cuda.is_available():
             raise RuntimeError("chatts_amd needs a ROCm GPU: there is no CPU fallback for the model")
         self.lib = _lib.load()
@@ -55,6 +69,9 @@ class ChatTSForCausalLM:
         self.comm = comm or LocalComm()
         self.plan = ShardPlan(config, self.comm.rank, self.comm.world)
         self.max_ctx = int(max_ctx)
+        if weight_format not in ("bf16", "fp8"):
+            raise ValueError("weight_format must be 'bf16' or 'fp8'")
+        self.weight_format = weight_format       # "fp8": decode GEMVs stream an e4m3 copy (BASELINE.json config 5)
         self.max_batch = int(max_batch)          # KV-cache slots for batched decode (continuous batching)
         self.t_max = int(max(min(max_prefill_tokens, max_ctx), self.max_batch))
         self.use_graph = use_graph
@@ -177,6 +194,17 @@ class ChatTSForCausalLM:
         H, d = cfg.hidden_size, cfg.head_dim
         max_pos = max(self.max_ctx, 64)
         T["cos"], T["sin"] = rope_tables(cfg, max_pos, dev)
+        if self.weight_format == "fp8" and "lm_head8" not in T:
+            # quantise every decoder projection once; the bf16 tensors are REPLACED by the (bf16-exact) dequantised
+            # values so prefill (bf16 MFMA GEMM), batched decode and the fp8 decode GEMV all see the same weights
+            for lw in self.layers:
+                for name in ("qkv", "o", "gate_up", "down"):
+                    lw[name + "8"], lw[name + "8_scale"], lw[name] = quantize_fp8_rows(lw[name])
+            tied = T["lm_head"].data_ptr() == T["embed"].data_ptr()
+            T["lm_head8"], T["lm_head8_scale"], deq = quantize_fp8_rows(T["lm_head"])
+            T["lm_head"] = deq
+            if tied:
+                T["embed"] = deq
         # decode attention: one wave per 16-key tile; slots beyond the live context exit immediately
         self.n_splits = max(1, min(64, (self.max_ctx + 15) // 16))
         dc = _lib.DecoderConfig(hidden=H, n_layers=cfg.num_hidden_layers, n_q=plan.nq, n_kv=plan.nkv, head_dim=d,
@@ -217,9 +245,14 @@ class ChatTSForCausalLM:
                                        qkv_bias=_lib.ptr(lw.get("qkv_bias")), q_norm=_lib.ptr(lw.get("q_norm")),
                                        k_norm=_lib.ptr(lw.get("k_norm")), o=_lib.ptr(lw["o"]),
                                        post_norm=_lib.ptr(lw["post_norm"]), gate_up=_lib.ptr(lw["gate_up"]),
-                                       down=_lib.ptr(lw["down"]))
+                                       down=_lib.ptr(lw["down"]),
+                                       qkv8=_lib.ptr(lw.get("qkv8")), qkv8_scale=_lib.ptr(lw.get("qkv8_scale")),
+                                       o8=_lib.ptr(lw.get("o8")), o8_scale=_lib.ptr(lw.get("o8_scale")),
+                                       gate_up8=_lib.ptr(lw.get("gate_up8")), gate_up8_scale=_lib.ptr(lw.get("gate_up8_scale")),
+                                       down8=_lib.ptr(lw.get("down8")), down8_scale=_lib.ptr(lw.get("down8_scale")))
         self._layer_arr = arr
         dw = _lib.DecoderWeights(layers=arr, final_norm=_lib.ptr(T["final_norm"]), lm_head=_lib.ptr(T["lm_head"]),
+                                 lm_head8=_lib.ptr(T.get("lm_head8")), lm_head8_scale=_lib.ptr(T.get("lm_head8_scale")),
                                  embed=_lib.ptr(T["embed"]), cos_tab=_lib.ptr(T["cos"]), sin_tab=_lib.ptr(T["sin"]))
         db = _lib.DecoderBuffers(kv_k=_lib.ptr(B["kv_k"]), kv_v=_lib.ptr(B["kv_v"]), x=_lib.ptr(B["x"]),
                                  xn=_lib.ptr(B["xn"]), qkv=_lib.ptr(B["qkv"]), attn=_lib.ptr(B["attn"]),
@@ -241,8 +274,16 @@ class ChatTSForCausalLM:
             pass
 
     def weight_bytes_local(self):
-        n = sum(t.numel() * t.element_size() for lw in self.layers for t in lw.values())
-        return n + self._tensors["lm_head"].numel() * 2 + self._tensors["final_norm"].numel() * 4
+        """Bytes one batch-1 decode step streams on this rank (fp8 copies replace their bf16 twins when present)."""
+        n = 0
+        for lw in self.layers:
+            for k, t in lw.items():
+                if k + "8" in lw:
+                    continue                       # the fp8 copy is the one the decode GEMV reads
+                n += t.numel() * t.element_size()
+        T = self._tensors
+        head = (T["lm_head8"].numel() + T["lm_head8_scale"].numel() * 4) if "lm_head8" in T else T["lm_head"].numel() * 2
+        return n + head + T["final_norm"].numel() * 4
 
     # ---------------------------------------------------------------------------------------------
     # vLLM-plugin-shaped hooks (same names/order as chatts_vllm.py:538-610)

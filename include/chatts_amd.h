@@ -104,6 +104,12 @@ typedef struct ChattsLinearArgs {
   int m, n, k, lda, ldw, ldc, epilogue;
   void* workspace;         /* split-K partials; may be NULL when chatts_linear_workspace() == 0 */
   size_t workspace_bytes;
+  /* optional fp8 copy of W (OCP e4m3fn, [N, ldw8]) with a per-row power-of-two scale, w = w8_scale[n] * fp8: a
+   * lossless encoding of the bf16 matrix (so both copies describe the same weights).  Used by the M == 1 decode
+   * GEMV to halve the streamed bytes (BASELINE.json config 5); the MFMA GEMM keeps streaming the bf16 copy. */
+  const uint8_t* w8;
+  const float* w8_scale;
+  int ldw8;
 } ChattsLinearArgs;
 size_t chatts_linear_workspace(int m, int n, int k);
 /* Dispatch: M == 1 -> weight-streaming GEMV (exact f32 VALU products, HBM-bound);
@@ -211,6 +217,11 @@ typedef struct ChattsLayerWeights {
   const float* post_norm;       /* [H] */
   const chatts_bf16* gate_up;
   const chatts_bf16* down;
+  /* optional fp8 copies (see ChattsLinearArgs.w8): NULL = stream bf16 in decode too */
+  const uint8_t* qkv8; const float* qkv8_scale;
+  const uint8_t* o8; const float* o8_scale;
+  const uint8_t* gate_up8; const float* gate_up8_scale;
+  const uint8_t* down8; const float* down8_scale;
 } ChattsLayerWeights;
 
 typedef struct ChattsDecoderConfig {
@@ -225,6 +236,8 @@ typedef struct ChattsDecoderWeights {
   const ChattsLayerWeights* layers;  /* host array [n_layers] */
   const float* final_norm;           /* [H] */
   const chatts_bf16* lm_head;        /* [vocab_local, H] */
+  const uint8_t* lm_head8;           /* optional fp8 copy + per-row scale */
+  const float* lm_head8_scale;
   const chatts_bf16* embed;          /* [vocab_local, H] */
   const float* cos_tab;              /* [max_pos, 64] */
   const float* sin_tab;

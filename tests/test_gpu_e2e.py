@@ -367,3 +367,28 @@ def test_continuous_batching_matches_oracle():
     model1 = ChatTSForCausalLM.from_synthetic(cfg, seed=5, max_ctx=512, max_prefill_tokens=256)
     ref = model1.generate(**inputs.to("cuda"), max_new_tokens=4, eos_token_id=[])
     assert torch.equal(out, ref)
+
+
+def test_fp8_weight_format_matches_oracle_on_dequantised_weights():
+    """weight_format='fp8' (BASELINE.json config 5): decode streams e4m3 weights with power-of-two row scales.  The
+    oracle runs on the dequantised values (the fp8 copy is a lossless encoding of them), same tolerance as bf16."""
+    from chatts_amd.modeling import quantize_fp8_rows
+    cfg = cfgmod.preset("tiny-qwen2")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(3)
+    lengths = [64, 21]
+    series = [random_walk_series(rng, L) for L in lengths]
+    inputs = proc(text=[chat_prompt(lengths)], timeseries=series, return_tensors="pt")
+    ids = inputs["input_ids"][0].tolist()
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=4, max_ctx=512, max_prefill_tokens=512, weight_format="fp8")
+    assert model.weight_bytes_local() < 0.62 * ChatTSForCausalLM.from_synthetic(cfg, seed=4, max_ctx=64, max_prefill_tokens=64).weight_bytes_local()
+    sd = osynth.state_dict(synth.all_specs(cfg), 4)
+    for name in list(sd):
+        if name.endswith("_proj.weight") or name == "lm_head.weight":
+            sd[name] = quantize_fp8_rows(sd[name].to(torch.bfloat16))[2].float()
+    # the device holds exactly these dequantised values
+    assert torch.equal(model.layers[1]["down"].float().cpu(), sd["model.layers.1.mlp.down_proj.weight"])
+    want = pipeline.generate(cfg, sd, ids, inputs["timeseries"].numpy(), 10)
+    toks, lg = model.generate_one(ids, inputs["timeseries"].cuda(), proc.last_lengths, 10, return_logits=True)
+    assert rel_err(lg.cpu().numpy(), want["logits"][0].numpy()) < TIGHT_TOL
+    assert toks == want["tokens"]

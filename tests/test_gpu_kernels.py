@@ -439,3 +439,33 @@ def test_attention_decode_batched_equals_per_sequence(lib):
         assert torch.equal(kc_b[b, layer], kc_a) and torch.equal(vc_b[b, layer], vc_a)
     # other layers / untouched
     assert torch.equal(kc_b[:, 0], kc0[:, 0]) and torch.equal(kc_b[:, 2], kc0[:, 2])
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("n,k", [(1024, 512), (5120, 5120), (96, 2048), (5120, 13824), (2048, 16 * 17)])
+def test_gemv_fp8_weights_parity(lib, epi, norm, n, k):
+    """decode GEMV streaming the fp8 (e4m3fn + per-row power-of-two scale) copy == float64 math on the dequantised
+    weights; and == the bf16 GEMV on the dequantised bf16 copy up to summation order."""
+    from chatts_amd.modeling import quantize_fp8_rows
+    a, w, bias, resid, nw = _rand_problem(1, n, k if k % 32 == 0 else k + (32 - k % 32), seed=n + k + epi)
+    k = a.shape[1]
+    w[7] *= 37.0                                    # rows with very different scales
+    w[11] = 0
+    q, scale, deq = quantize_fp8_rows(w)
+    assert torch.equal(deq.float(), q.view(torch.float8_e4m3fn).float() * scale[:, None])
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    outs = []
+    for use8 in (True, False):
+        out = torch.full((1, ncols), float("nan"), device=DEV)
+        la = _lib.LinearArgs(a=a.data_ptr(), w=deq.data_ptr(), bias=bias.data_ptr(),
+                             resid=resid.data_ptr() if epi == _lib.EPI_RESID else None, c=out.data_ptr(),
+                             norm_w=nw.data_ptr() if norm else None, norm_eps=1e-6, m=1, n=n, k=k, lda=k, ldw=k, ldc=ncols,
+                             epilogue=epi, workspace=None, workspace_bytes=0,
+                             w8=q.data_ptr() if use8 else None, w8_scale=scale.data_ptr() if use8 else None, ldw8=k)
+        _lib.check(lib.chatts_linear(la, st()))
+        torch.cuda.synchronize()
+        outs.append(out)
+    want = _ref_linear(a, deq, bias, resid, epi, nw if norm else None)
+    assert rel_err(outs[0].cpu().numpy(), want) < 2e-5
+    assert rel_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 2e-5
