@@ -197,6 +197,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     la = ChattsLinearArgs{};
     la.a = d->b.xn; la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = batch; la.n = qkv_n; la.k = H;
     la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
+    la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, 0);
@@ -206,6 +207,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     la = ChattsLinearArgs{};
     la.a = d->b.attn; la.w = lw.o; la.m = batch; la.n = H; la.k = c.n_q * kHeadDim;
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
+    la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
@@ -215,11 +217,13 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   la = ChattsLinearArgs{};
   la.a = d->b.xn; la.w = lw.gate_up; la.c = d->b.act; la.m = batch; la.n = 2 * c.inter; la.k = H;
   la.lda = H; la.ldw = H; la.ldc = c.inter; la.epilogue = CHATTS_EPI_SWIGLU;
+  la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
   la = ChattsLinearArgs{};
   la.a = d->b.act; la.w = lw.down; la.m = batch; la.n = H; la.k = c.inter;
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
+  la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
@@ -250,6 +254,7 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
   la.a = d->b.xn; la.w = d->w.lm_head; la.c = logits_all; la.m = batch; la.n = (int)c.vocab_local; la.k = c.hidden;
   la.lda = c.hidden; la.ldw = c.hidden; la.ldc = (int)c.vocab_local; la.epilogue = CHATTS_EPI_NONE;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden;
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
   return chatts_argmax_batched(logits_all, batch, c.vocab_local, c.vocab_local, c.vocab_offset, token_dev, token_logit_dev,
                                out_tokens, out_stride, step_dev, pos_dev, c.max_ctx - 1, stream);

@@ -28,6 +28,9 @@ struct GemmParams {
   int m, n, k, lda, ldw, ldc, epilogue;
   int k_per_split;   // multiple of 32
   int direct;        // 1: apply epilogue here; 0: write raw partials
+  const uint8_t* w8;     // optional fp8 (e4m3fn) copy of W: streamed instead of the bf16 copy, widened (exactly) to
+  const float* w8_scale; // bf16 while it is staged to LDS; the per-row power-of-two scale is applied in the epilogue
+  int ldw8;
 };
 
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -89,7 +92,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
     for (int i = 0; i < 2; ++i) {
       const int r = srow + i * 64;
       rb[i] = (u32x4){0u, 0u, 0u, 0u};
-      if (n0 + r < p.n) rb[i] = *reinterpret_cast<const u32x4*>(p.w + (size_t)(n0 + r) * p.ldw + k0);
+      if (n0 + r < p.n) {
+        if (p.w8) {
+          const u32x2 q = *reinterpret_cast<const u32x2*>(p.w8 + (size_t)(n0 + r) * p.ldw8 + k0);   // 8 fp8 weights
+          rb[i].x = q.x;
+          rb[i].y = q.y;
+        } else {
+          rb[i] = *reinterpret_cast<const u32x4*>(p.w + (size_t)(n0 + r) * p.ldw + k0);
+        }
+      }
     }
   };
 
@@ -117,7 +128,17 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = srow + i * 64;
-      *reinterpret_cast<u32x4*>(base + BM * 128 + lds_off(r, schunk)) = rb[i];
+      if (p.w8) {                                  // e4m3 -> f32 -> bf16: both steps exact
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t f0 = __builtin_amdgcn_cvt_pk_f32_fp8(rb[i].x, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(rb[i].x, true);
+        const f32x2_t f2 = __builtin_amdgcn_cvt_pk_f32_fp8(rb[i].y, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(rb[i].y, true);
+        bf16x8_t bv;
+        bv[0] = (__bf16)f0.x; bv[1] = (__bf16)f0.y; bv[2] = (__bf16)f1.x; bv[3] = (__bf16)f1.y;
+        bv[4] = (__bf16)f2.x; bv[5] = (__bf16)f2.y; bv[6] = (__bf16)f3.x; bv[7] = (__bf16)f3.y;
+        *reinterpret_cast<bf16x8_t*>(base + BM * 128 + lds_off(r, schunk)) = bv;
+      } else {
+        *reinterpret_cast<u32x4*>(base + BM * 128 + lds_off(r, schunk)) = rb[i];
+      }
     }
   };
 
@@ -185,10 +206,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
         const int ocol = (prow >> 5) * 16 + ccol;
         if (prow + 16 < p.n) {
           const float bg = p.bias ? p.bias[prow] : 0.f, bu = p.bias ? p.bias[prow + 16] : 0.f;
+          const float sg = p.w8 ? p.w8_scale[prow] : 1.f, su = p.w8 ? p.w8_scale[prow + 16] : 1.f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm * TM + i * 16 + crow0 + r;
-            if (row < p.m) p.c[(size_t)row * p.ldc + ocol] = silu_g(acc[i][j][r] + bg) * (acc[i][j + 1][r] + bu);
+            if (row < p.m) p.c[(size_t)row * p.ldc + ocol] = silu_g(acc[i][j][r] * sg + bg) * (acc[i][j + 1][r] * su + bu);
           }
         }
       }
@@ -201,11 +223,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
       const int col = n0 + wn * TN + j * 16 + ccol;
       if (col >= p.n) continue;
       const float b = p.bias ? p.bias[col] : 0.f;
+      const float sc = p.w8 ? p.w8_scale[col] : 1.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * TM + i * 16 + crow0 + r;
         if (row >= p.m) continue;
-        float v = acc[i][j][r] + b;
+        float v = acc[i][j][r] * sc + b;
         if (p.epilogue == CHATTS_EPI_GELU) v = gelu_erf_f(v);
         if (p.epilogue == CHATTS_EPI_RESID) v = p.resid[(size_t)row * p.ldc + col] + v;
         p.c[(size_t)row * p.ldc + col] = v;
@@ -217,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ ws, int sk, int m, int n,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ resid, float* __restrict__ c,
-                                                             int ldc, int epilogue) {
+                                                             int ldc, int epilogue, const float* __restrict__ scale) {
   const int ncols = epilogue == CHATTS_EPI_SWIGLU ? n / 2 : n;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)m * ncols) return;
@@ -230,12 +253,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
       g += ws[s * plane + (size_t)row * n + prow];
       u += ws[s * plane + (size_t)row * n + prow + 16];
     }
+    if (scale) { g *= scale[prow]; u *= scale[prow + 16]; }
     if (bias) { g += bias[prow]; u += bias[prow + 16]; }
     c[(size_t)row * ldc + col] = silu_g(g) * u;
     return;
   }
   float v = 0.f;
   for (int s = 0; s < sk; ++s) v += ws[s * plane + (size_t)row * n + col];
+  if (scale) v *= scale[col];
   if (bias) v += bias[col];
   if (epilogue == CHATTS_EPI_GELU) v = gelu_erf_f(v);
   if (epilogue == CHATTS_EPI_RESID) v = resid[(size_t)row * ldc + col] + v;
@@ -292,6 +317,7 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   p.a = a->a; p.w = a->w; p.bias = a->bias; p.resid = a->resid;
   p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
   p.epilogue = a->epilogue; p.k_per_split = kps; p.direct = sk == 1;
+  p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8;
   if (sk > 1) {
     const size_t need = (size_t)sk * a->m * a->n * sizeof(float);
     CHATTS_REQUIRE(a->workspace && a->workspace_bytes >= need, CHATTS_E_WORKSPACE,
@@ -314,7 +340,7 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
     const size_t total = (size_t)a->m * ncols;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float*>(a->workspace), sk, a->m, a->n, a->bias, a->resid, a->c,
-                       a->ldc, a->epilogue);
+                       a->ldc, a->epilogue, a->w8 ? a->w8_scale : nullptr);
     CHATTS_CHECK_LAUNCH("splitk_epilogue");
   }
   return CHATTS_OK;

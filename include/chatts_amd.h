@@ -105,8 +105,9 @@ typedef struct ChattsLinearArgs {
   void* workspace;         /* split-K partials; may be NULL when chatts_linear_workspace() == 0 */
   size_t workspace_bytes;
   /* optional fp8 copy of W (OCP e4m3fn, [N, ldw8]) with a per-row power-of-two scale, w = w8_scale[n] * fp8: a
-   * lossless encoding of the bf16 matrix (so both copies describe the same weights).  Used by the M == 1 decode
-   * GEMV to halve the streamed bytes (BASELINE.json config 5); the MFMA GEMM keeps streaming the bf16 copy. */
+   * lossless encoding of the bf16 matrix (so both copies describe the same weights).  When set it is the copy that
+   * is streamed (BASELINE.json config 5): the decode GEMV widens it on the VALU, the MFMA GEMM widens it to bf16
+   * while staging to LDS; the row scale is applied in the epilogue.  The prefill path passes NULL (MFMA-bound). */
   const uint8_t* w8;
   const float* w8_scale;
   int ldw8;

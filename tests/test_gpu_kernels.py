@@ -469,3 +469,26 @@ def test_gemv_fp8_weights_parity(lib, epi, norm, n, k):
     want = _ref_linear(a, deq, bias, resid, epi, nw if norm else None)
     assert rel_err(outs[0].cpu().numpy(), want) < 2e-5
     assert rel_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k", [(2, 256, 64), (16, 5120, 5120), (33, 1024, 512), (200, 384, 1024)])
+def test_gemm_fp8_weights_parity(lib, epi, m, n, k):
+    """MFMA GEMM streaming the fp8 copy of W (widened to bf16 in the LDS staging, row scale in the epilogue)"""
+    from chatts_amd.modeling import quantize_fp8_rows
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
+    w[5] *= 50.0
+    q, scale, deq = quantize_fp8_rows(w)
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    out = torch.full((m, ncols), float("nan"), device=DEV)
+    wsb = int(lib.chatts_linear_workspace(m, n, k))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    la = _lib.LinearArgs(a=a.data_ptr(), w=deq.data_ptr(), bias=bias.data_ptr(),
+                         resid=resid.data_ptr() if epi == _lib.EPI_RESID else None, c=out.data_ptr(), norm_w=None,
+                         norm_eps=0.0, m=m, n=n, k=k, lda=k, ldw=k, ldc=ncols, epilogue=epi, workspace=ws.data_ptr(),
+                         workspace_bytes=wsb, w8=q.data_ptr(), w8_scale=scale.data_ptr(), ldw8=k)
+    _lib.check(lib.chatts_linear(la, st()))
+    torch.cuda.synchronize()
+    want = _ref_linear(a, deq, bias, resid, epi)
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu().numpy(), want) < 2e-5

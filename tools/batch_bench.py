@@ -15,8 +15,11 @@ cfg = cfgmod.preset("chatts-14b")
 proc, prompt, series, lengths = build_inputs(cfg)
 inp = proc(text=[prompt], timeseries=series, return_tensors="pt")
 ids, ser = inp["input_ids"][0].tolist(), inp["timeseries"]
-for B in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 16]:
-    model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, max_ctx=1024, max_prefill_tokens=1024, max_batch=B)
+FMT = "fp8" if "fp8" in sys.argv[1:] else "bf16"
+print(f"# weight_format = {FMT}")
+for B in [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 2, 4, 8, 16]:
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, max_ctx=1024, max_prefill_tokens=1024, max_batch=B,
+                                             weight_format=FMT)
     reqs = [(ids, ser, lengths)] * B
     new = 48
     model.generate_batch(reqs, max_new_tokens=4)          # warm-up + graph capture
