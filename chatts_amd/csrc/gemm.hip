@@ -276,6 +276,8 @@ static void pick_geometry(int m, int n, int k, int& bm, int& sk) {
   bm = m > 64 ? 128 : (m > 32 ? 64 : (m > 16 ? 32 : 16));
   const int force_bm = gemm_env_int("CHATTS_GEMM_BM", 0);          // tuning / tests only
   if (force_bm == 16 || force_bm == 32 || force_bm == 64 || force_bm == 128) bm = force_bm;
+  // short K (no split-K possible, e.g. the first TS-MLP layer, K = 288) and few tiles: smaller M-tiles fill more CUs
+  if (!force_bm && k < 512 && ((m + bm - 1) / bm) * ((n + 127) / 128) * 4 <= device_cus() && bm > 32) bm = 32;
   const int tiles = ((m + bm - 1) / bm) * ((n + 127) / 128);
   // Split-K so that the workgroups fill whole "rounds" of the resident slots (3 workgroups of 48 KB LDS per CU):
   // efficiency of a launch = blocks / (slots * ceil(blocks / slots)); split-K costs a partials round trip + an

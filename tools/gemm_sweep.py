@@ -12,7 +12,7 @@ from chatts_amd import _lib  # noqa: E402
 lib = _lib.load()
 DEV = "cuda"
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 798
-SHAPES = {"qkv": (7168, 5120, _lib.EPI_NONE), "o": (5120, 5120, _lib.EPI_RESID), "gate_up": (27648, 5120, _lib.EPI_SWIGLU),
+SHAPES = {"ts_l0": (5120, 288, _lib.EPI_GELU), "ts_mid": (5120, 5120, _lib.EPI_GELU), "qkv": (7168, 5120, _lib.EPI_NONE), "o": (5120, 5120, _lib.EPI_RESID), "gate_up": (27648, 5120, _lib.EPI_SWIGLU),
           "down": (5120, 13824, _lib.EPI_RESID)}
 st = torch.cuda.current_stream()
 
@@ -51,7 +51,10 @@ def bench(name, env):
 
 for name in SHAPES:
     print(f"== {name} M={M} N={SHAPES[name][0]} K={SHAPES[name][1]}")
-    for env in ({}, {"CHATTS_GEMM_BM": 64}, {"CHATTS_GEMM_BM": 128, "CHATTS_GEMM_SK": 1}, {"CHATTS_GEMM_BM": 64, "CHATTS_GEMM_SK": 1},
-                {"CHATTS_GEMM_BM": 128, "CHATTS_GEMM_SK": 2}, {"CHATTS_GEMM_BM": 128, "CHATTS_GEMM_SK": 3}):
+    envs = [{}, {"CHATTS_GEMM_BM": 64}, {"CHATTS_GEMM_BM": 128, "CHATTS_GEMM_SK": 1}, {"CHATTS_GEMM_BM": 64, "CHATTS_GEMM_SK": 1},
+            {"CHATTS_GEMM_BM": 128, "CHATTS_GEMM_SK": 2}, {"CHATTS_GEMM_BM": 128, "CHATTS_GEMM_SK": 3}]
+    if M <= 128:
+        envs = [{}] + [{"CHATTS_GEMM_BM": bm, "CHATTS_GEMM_SK": sk} for bm in (32, 64, 128) for sk in (1, 4, 8, 16)]
+    for env in envs:
         us, tf = bench(name, env)
         print(f"   {us:8.1f} us  {tf:6.0f} TF useful  " + " ".join(f"{k.replace('CHATTS_GEMM_', '')}={v}" for k, v in env.items()))
