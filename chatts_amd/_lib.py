@@ -23,6 +23,12 @@ class PatchifyArgs(C.Structure):
                 ("ld_out", c_int)]
 
 
+class TsWeights(C.Structure):
+    _fields_ = [("patch_size", c_int), ("num_layers", c_int), ("hidden", c_int), ("mode", c_int), ("emb_dim", c_int),
+                ("max_seq_len", c_int), ("in_features_pad", c_int), ("pos_table", c_void_p), ("w", c_void_p * 8),
+                ("b", c_void_p * 8)]
+
+
 class LinearArgs(C.Structure):
     _fields_ = [("a", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("resid", c_void_p), ("c", c_void_p),
                 ("norm_w", c_void_p), ("norm_eps", c_float), ("m", c_int), ("n", c_int), ("k", c_int),
@@ -69,6 +75,8 @@ SIGNATURES = {
                                  c_int64, c_int64, c_void_p]),
     "chatts_ts_patch_cnt": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "chatts_ts_patchify": (c_int, [C.POINTER(PatchifyArgs), c_void_p]),
+    "chatts_ts_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(TsWeights), c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chatts_linear_workspace": (c_size_t, [c_int, c_int, c_int]),
     "chatts_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
     "chatts_embed_merge": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64,

@@ -113,3 +113,35 @@ extern "C" int chatts_ts_patchify(const ChattsPatchifyArgs* a, chatts_stream_t s
   CHATTS_CHECK_LAUNCH("ts_patchify");
   return CHATTS_OK;
 }
+
+// Whole encoder in one call (the C-ABI SURVEY.md section 8b proposes for a3 + a4): patchify, then the MLP
+// (Linear + exact-erf GELU) x (n-1) + Linear, ping-ponging between two caller-owned [P, H] buffers.
+extern "C" int chatts_ts_encode(const float* series, const int32_t* row_off, const int32_t* valid_len, int n_series, int lmax,
+                                int max_valid_len, int total_patches, const ChattsTsWeights* w, float* feat, float* h0,
+                                float* h1, float* out, void* workspace, size_t workspace_bytes, chatts_stream_t stream) {
+  CHATTS_REQUIRE(w != nullptr && w->num_layers >= 1 && w->num_layers <= 8, CHATTS_E_BADARG, "ts_encode: bad weights");
+  if (total_patches == 0) return CHATTS_OK;
+  CHATTS_REQUIRE(feat && out && (w->num_layers < 2 || h0) && (w->num_layers < 3 || h1), CHATTS_E_BADARG,
+                 "ts_encode: null buffer");
+  ChattsPatchifyArgs pa{};
+  pa.series = series; pa.row_off = row_off; pa.valid_len = valid_len; pa.pos_table = w->pos_table; pa.out = feat;
+  pa.n_series = n_series; pa.lmax = lmax; pa.patch_size = w->patch_size; pa.mode = w->mode; pa.emb_dim = w->emb_dim;
+  pa.max_seq_len = w->max_seq_len; pa.max_valid_len = max_valid_len; pa.total_patches = total_patches;
+  pa.ld_out = w->in_features_pad;
+  int rc = chatts_ts_patchify(&pa, stream);
+  if (rc) return rc;
+  const float* cur = feat;
+  int k = w->in_features_pad;
+  for (int l = 0; l < w->num_layers; ++l) {
+    const bool last = l == w->num_layers - 1;
+    float* dst = last ? out : ((l & 1) ? h1 : h0);
+    ChattsLinearArgs la{};
+    la.a = cur; la.w = w->w[l]; la.bias = w->b[l]; la.c = dst; la.m = total_patches; la.n = w->hidden; la.k = k;
+    la.lda = k; la.ldw = k; la.ldc = w->hidden; la.epilogue = last ? CHATTS_EPI_NONE : CHATTS_EPI_GELU;
+    la.workspace = workspace; la.workspace_bytes = workspace_bytes;
+    if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+    cur = dst;
+    k = w->hidden;
+  }
+  return CHATTS_OK;
+}

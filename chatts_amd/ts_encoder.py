@@ -61,6 +61,7 @@ class TimeSeriesEmbedding:
 
     def load_tensor(self, name, tensor):
         """name without the 'ts_encoder.' prefix; tensor: any float dtype, host or device."""
+        self._tsw = None
         t = tensor.to(self.device)
         if name == "position_embedding.weight":
             self.position_embedding = t.float().contiguous()
@@ -75,6 +76,7 @@ class TimeSeriesEmbedding:
 
     def load_synthetic(self, specs, seed):
         from . import synth
+        self._tsw = None
         for s in specs:
             name = s.name[len("ts_encoder."):]
             if name == "position_embedding.weight":
@@ -140,27 +142,33 @@ class TimeSeriesEmbedding:
         row_off_dev = torch.tensor(row_off, dtype=torch.int32).to(dev, non_blocking=True)
         if host_given:
             vl_dev = torch.tensor(vl_host, dtype=torch.int32).to(dev, non_blocking=True)
-        feat = torch.empty((P, self.k0), dtype=torch.float32, device=dev)
-        pa = _lib.PatchifyArgs(series=_lib.ptr(x), row_off=_lib.ptr(row_off_dev), valid_len=_lib.ptr(vl_dev),
-                               pos_table=_lib.ptr(self.position_embedding), out=_lib.ptr(feat), n_series=n, lmax=lmax,
-                               patch_size=ps, mode=self.mode, emb_dim=self.embedding_dim,
-                               max_seq_len=self.max_sequence_length, max_valid_len=max(vl_host) if vl_host else 0,
-                               total_patches=P, ld_out=self.k0)
-        st = _lib.stream_ptr()
-        _lib.check(lib.chatts_ts_patchify(pa, st))
-        ws_bytes = max(lib.chatts_linear_workspace(P, self.hidden_size, self.layer_k(l)) for l in range(self.num_layers))
-        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-        h = feat
-        for l in range(self.num_layers):
-            out = torch.empty((P, self.hidden_size), dtype=torch.float32, device=dev)
-            k = self.layer_k(l)
-            la = _lib.LinearArgs(a=_lib.ptr(h), w=_lib.ptr(self.weights[l]), bias=_lib.ptr(self.biases[l]), resid=None,
-                                 c=_lib.ptr(out), norm_w=None, norm_eps=0.0, m=P, n=self.hidden_size, k=k, lda=k, ldw=k,
-                                 ldc=self.hidden_size,
-                                 epilogue=_lib.EPI_GELU if l < self.num_layers - 1 else _lib.EPI_NONE,
-                                 workspace=_lib.ptr(ws), workspace_bytes=ws_bytes)
-            _lib.check(lib.chatts_linear(la, st))
-            h = out
-        return h, pc_dev
+        # one C call: patchify + the whole MLP (chatts_ts_encode); buffers are cached per patch count
+        key = (P, dev)
+        if getattr(self, "_buf_key", None) != key:
+            H = self.hidden_size
+            ws_bytes = max(int(lib.chatts_linear_workspace(P, H, self.layer_k(l))) for l in range(self.num_layers))
+            self._bufs = dict(feat=torch.empty((P, self.k0), dtype=torch.float32, device=dev),
+                              h0=torch.empty((P, H), dtype=torch.float32, device=dev),
+                              h1=torch.empty((P, H), dtype=torch.float32, device=dev),
+                              ws=torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev), ws_bytes=ws_bytes)
+            self._buf_key = key
+        if getattr(self, "_tsw", None) is None:
+            if self.num_layers > 8:
+                raise ValueError("ts num_layers > 8 is not supported")
+            tw = _lib.TsWeights(patch_size=ps, num_layers=self.num_layers, hidden=self.hidden_size, mode=self.mode,
+                                emb_dim=self.embedding_dim, max_seq_len=self.max_sequence_length, in_features_pad=self.k0,
+                                pos_table=_lib.ptr(self.position_embedding))
+            for l in range(self.num_layers):
+                tw.w[l] = _lib.ptr(self.weights[l])
+                tw.b[l] = _lib.ptr(self.biases[l])
+            self._tsw = tw
+        B = self._bufs
+        out = torch.empty((P, self.hidden_size), dtype=torch.float32, device=dev)
+        import ctypes as C
+        _lib.check(lib.chatts_ts_encode(_lib.ptr(x), _lib.ptr(row_off_dev), _lib.ptr(vl_dev), n, lmax,
+                                        max(vl_host) if vl_host else 0, P, C.byref(self._tsw), _lib.ptr(B["feat"]),
+                                        _lib.ptr(B["h0"]), _lib.ptr(B["h1"]), _lib.ptr(out), _lib.ptr(B["ws"]),
+                                        B["ws_bytes"], _lib.stream_ptr()))
+        return out, pc_dev
 
     __call__ = forward

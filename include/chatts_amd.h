@@ -79,6 +79,21 @@ typedef struct ChattsPatchifyArgs {
  * max_seq_len for pad slots (:119,128-129,161-181).  One wave per patch, coalesced row reads. */
 int chatts_ts_patchify(const ChattsPatchifyArgs* args, chatts_stream_t stream);
 
+/* Whole encoder in one call = _parse_and_validate_ts_input + TimeSeriesEmbedding.forward (chatts_vllm.py:493-536,
+ * 93-193) after the host computed the row offsets: patchify into feat [P, in_features_pad], then the MLP
+ * (Linear + exact-erf GELU) x (n-1) + Linear through the ping-pong buffers h0/h1 [P, hidden] into out [P, hidden].
+ * workspace >= max_l chatts_linear_workspace(P, hidden, K_l).  Declared after ChattsLinearArgs users below. */
+typedef struct ChattsTsWeights {
+  int patch_size, num_layers, hidden, mode, emb_dim, max_seq_len;
+  int in_features_pad;         /* K of layer 0, padded to a multiple of 32 (288 for 16 + 16*16) */
+  const float* pos_table;      /* mode 1 */
+  const chatts_bf16* w[8];     /* [hidden, K_l] bf16 */
+  const float* b[8];           /* [hidden] */
+} ChattsTsWeights;
+int chatts_ts_encode(const float* series, const int32_t* row_off, const int32_t* valid_len, int n_series, int lmax,
+                     int max_valid_len, int total_patches, const ChattsTsWeights* weights, float* feat, float* h0,
+                     float* h1, float* out, void* workspace, size_t workspace_bytes, chatts_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Linear layers:  C[M,N] = epilogue(A[M,K] . W[N,K]^T)   A,C float32, W bfloat16 row-major [N,K]
  * (the HF nn.Linear.weight layout).  Replaces every nn.Linear the path executes:
