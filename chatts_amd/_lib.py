@@ -33,7 +33,8 @@ class LinearArgs(C.Structure):
     _fields_ = [("a", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("resid", c_void_p), ("c", c_void_p),
                 ("norm_w", c_void_p), ("norm_eps", c_float), ("m", c_int), ("n", c_int), ("k", c_int),
                 ("lda", c_int), ("ldw", c_int), ("ldc", c_int), ("epilogue", c_int), ("workspace", c_void_p),
-                ("workspace_bytes", c_size_t), ("w8", c_void_p), ("w8_scale", c_void_p), ("ldw8", c_int)]
+                ("workspace_bytes", c_size_t), ("w8", c_void_p), ("w8_scale", c_void_p), ("ldw8", c_int),
+                ("a_hi", c_void_p), ("a_lo", c_void_p), ("ld_planes", c_int)]
 
 
 class KvCache(C.Structure):
@@ -63,7 +64,8 @@ class DecoderWeights(C.Structure):
 class DecoderBuffers(C.Structure):
     _fields_ = [("kv_k", c_void_p), ("kv_v", c_void_p), ("x", c_void_p), ("xn", c_void_p), ("qkv", c_void_p),
                 ("attn", c_void_p), ("act", c_void_p), ("delta", c_void_p), ("logits", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("t_max", c_int), ("max_batch", c_int)]
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("t_max", c_int), ("max_batch", c_int),
+                ("planes_hi", c_void_p), ("planes_lo", c_void_p)]
 
 
 # name -> (restype, argtypes); this table IS the list of symbols include/chatts_amd.h declares
@@ -79,6 +81,7 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chatts_linear_workspace": (c_size_t, [c_int, c_int, c_int]),
     "chatts_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
+    "chatts_split_bf16x2": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "chatts_embed_merge": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "chatts_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -11,6 +11,7 @@
 namespace chatts {
 int launch_gemv(const ChattsLinearArgs* a, hipStream_t s);
 int launch_gemm(const ChattsLinearArgs* a, hipStream_t s);
+int launch_split_bf16x2(const float* x, int m, int k, int ldx, uint16_t* hi, uint16_t* lo, int ldp, hipStream_t s);
 size_t gemm_workspace(int m, int n, int k);
 }  // namespace chatts
 
@@ -30,14 +31,19 @@ extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) 
   CHATTS_REQUIRE(a != nullptr, CHATTS_E_BADARG, "linear: null args");
   CHATTS_REQUIRE(a->m >= 0 && a->n > 0 && a->k > 0, CHATTS_E_BADARG, "linear: bad sizes m=%d n=%d k=%d", a->m, a->n, a->k);
   if (a->m == 0) return CHATTS_OK;
-  CHATTS_REQUIRE(a->a && a->w && a->c, CHATTS_E_BADARG, "linear: null pointer");
+  const bool planes = a->a_hi || a->a_lo;
+  CHATTS_REQUIRE((a->a || planes) && a->w && a->c, CHATTS_E_BADARG, "linear: null pointer");
+  if (planes)
+    CHATTS_REQUIRE(a->a_hi && a->a_lo && a->ld_planes >= a->k && a->ld_planes % 8 == 0 && ((uintptr_t)a->a_hi % 16) == 0 &&
+                       ((uintptr_t)a->a_lo % 16) == 0 && a->m > 1 && !a->w8 && !a->norm_w,
+                   CHATTS_E_SHAPE, "linear: pre-split A needs both planes, ld_planes >= K and %% 8, 16-byte alignment, M > 1");
   CHATTS_REQUIRE(a->epilogue >= CHATTS_EPI_NONE && a->epilogue <= CHATTS_EPI_SWIGLU, CHATTS_E_BADARG,
                  "linear: epilogue %d", a->epilogue);
   CHATTS_REQUIRE(a->epilogue != CHATTS_EPI_RESID || a->resid, CHATTS_E_BADARG, "linear: EPI_RESID without resid");
   CHATTS_REQUIRE(a->k % 32 == 0, CHATTS_E_SHAPE, "linear: K=%d must be a multiple of 32 (pad the weight)", a->k);
   CHATTS_REQUIRE(a->n % 16 == 0 && (a->epilogue != CHATTS_EPI_SWIGLU || a->n % 32 == 0), CHATTS_E_SHAPE,
                  "linear: N=%d must be a multiple of 16 (32 for SwiGLU)", a->n);
-  CHATTS_REQUIRE(a->lda >= a->k && a->ldw >= a->k && a->lda % 4 == 0 && a->ldw % 8 == 0, CHATTS_E_SHAPE,
+  CHATTS_REQUIRE((!a->a || (a->lda >= a->k && a->lda % 4 == 0)) && a->ldw >= a->k && a->ldw % 8 == 0, CHATTS_E_SHAPE,
                  "linear: leading dimensions lda=%d ldw=%d", a->lda, a->ldw);
   const int ncols = a->epilogue == CHATTS_EPI_SWIGLU ? a->n / 2 : a->n;
   CHATTS_REQUIRE(a->ldc >= ncols, CHATTS_E_SHAPE, "linear: ldc=%d < %d", a->ldc, ncols);
@@ -49,6 +55,18 @@ extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) 
   if (a->m == 1 && a->epilogue != CHATTS_EPI_GELU) return launch_gemv(a, as_stream(stream));
   CHATTS_REQUIRE(a->norm_w == nullptr, CHATTS_E_BADARG, "linear: fused RMSNorm is only available for M == 1");
   return launch_gemm(a, as_stream(stream));
+}
+
+extern "C" int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, chatts_bf16* lo, int ld_planes,
+                                   chatts_stream_t stream) {
+  CHATTS_REQUIRE(m >= 0 && k >= 0 && k % 8 == 0, CHATTS_E_SHAPE, "split_bf16x2: m=%d k=%d (K must be a multiple of 8)", m, k);
+  if (m == 0 || k == 0) return CHATTS_OK;
+  CHATTS_REQUIRE(x && hi && lo, CHATTS_E_BADARG, "split_bf16x2: null pointer");
+  CHATTS_REQUIRE(ldx >= k && ldx % 4 == 0 && ld_planes >= k && ld_planes % 8 == 0, CHATTS_E_SHAPE,
+                 "split_bf16x2: leading dimensions ldx=%d ld_planes=%d", ldx, ld_planes);
+  CHATTS_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)hi % 16) == 0 && ((uintptr_t)lo % 16) == 0, CHATTS_E_SHAPE,
+                 "split_bf16x2: pointers must be 16-byte aligned");
+  return launch_split_bf16x2(x, m, k, ldx, hi, lo, ld_planes, as_stream(stream));
 }
 
 extern "C" size_t chatts_decoder_workspace(const ChattsDecoderConfig* c, int t_max, int n_splits_max) {
@@ -98,6 +116,16 @@ static ChattsKvCache layer_cache(const ChattsDecoder* d, int layer, int seq) {
   return c;
 }
 
+// Prefill: hand the projection its input as bf16 hi / lo planes as well, so that chatts_linear can take the LDS-DMA
+// GEMM (M >= 96, K a multiple of 64; otherwise it reads `a` as before).
+static int with_planes(ChattsDecoder* d, ChattsLinearArgs* la, chatts_stream_t stream) {
+  if (!d->b.planes_hi || !d->b.planes_lo || la->m < 96 || la->k % 64 != 0) return CHATTS_OK;
+  const int rc = chatts_split_bf16x2(la->a, la->m, la->k, la->lda, d->b.planes_hi, d->b.planes_lo, la->k, stream);
+  if (rc) return rc;
+  la->a_hi = d->b.planes_hi; la->a_lo = d->b.planes_lo; la->ld_planes = la->k;
+  return CHATTS_OK;
+}
+
 extern "C" int chatts_decoder_select_sequence(ChattsDecoder* d, int seq) {
   CHATTS_REQUIRE(d && seq >= 0 && seq < (d->b.max_batch > 0 ? d->b.max_batch : 1), CHATTS_E_BADARG,
                  "decoder_select_sequence: slot %d out of range", seq);
@@ -129,6 +157,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     } else {
       if ((rc = chatts_rmsnorm(d->b.x, lw.input_norm, d->b.xn, t, H, c.rms_eps, stream)) != 0) return rc;
       la.a = d->b.xn;
+      if ((rc = with_planes(d, &la, stream)) != 0) return rc;
     }
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, d->cur_seq);
@@ -148,6 +177,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if (t == 1) { la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k; }
+    else if ((rc = with_planes(d, &la, stream)) != 0) return rc;
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
     return chatts_linear(&la, stream);
@@ -163,6 +193,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   } else {
     if ((rc = chatts_rmsnorm(d->b.x, lw.post_norm, d->b.xn, t, H, c.rms_eps, stream)) != 0) return rc;
     la.a = d->b.xn;
+    if ((rc = with_planes(d, &la, stream)) != 0) return rc;
   }
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
   la = ChattsLinearArgs{};
@@ -170,6 +201,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if (t == 1) { la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter; }
+  else if ((rc = with_planes(d, &la, stream)) != 0) return rc;
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
   return chatts_linear(&la, stream);

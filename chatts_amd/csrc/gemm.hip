@@ -40,6 +40,66 @@ __device__ __forceinline__ int lds_off(int r, int c) {   // byte offset of 16-by
   return r * 64 + ((c ^ (((r >> 3) & 1) << 1)) << 4);
 }
 
+// Epilogue shared by the GEMM kernels.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
+template <int FM, int FN, int TM, int TN, bool W8>
+__device__ __forceinline__ void gemm_store(const GemmParams& p, const f32x4 (&acc)[FM][FN], int m0, int n0, int wm, int wn,
+                                           int lane, int split) {
+  // ---- epilogue.  C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg -----------
+  const int ccol = lane & 15, crow0 = (lane >> 4) * 4;
+  if (!p.direct) {
+    float* ws = p.c + (size_t)split * p.m * p.n;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wn * TN + j * 16 + ccol;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * TM + i * 16 + crow0 + r;
+          if (row < p.m && col < p.n) ws[(size_t)row * p.n + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  if (p.epilogue == CHATTS_EPI_SWIGLU) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; j += 2) {
+        const int prow = n0 + wn * TN + j * 16 + ccol;   // packed gate row; up row = prow + 16
+        const int ocol = (prow >> 5) * 16 + ccol;
+        if (prow + 16 < p.n) {
+          const float bg = p.bias ? p.bias[prow] : 0.f, bu = p.bias ? p.bias[prow + 16] : 0.f;
+          const float sg = W8 ? p.w8_scale[prow] : 1.f, su = W8 ? p.w8_scale[prow + 16] : 1.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * TM + i * 16 + crow0 + r;
+            if (row < p.m) p.c[(size_t)row * p.ldc + ocol] = silu_g(acc[i][j][r] * sg + bg) * (acc[i][j + 1][r] * su + bu);
+          }
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * TN + j * 16 + ccol;
+      if (col >= p.n) continue;
+      const float b = p.bias ? p.bias[col] : 0.f;
+      const float sc = W8 ? p.w8_scale[col] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * TM + i * 16 + crow0 + r;
+        if (row >= p.m) continue;
+        float v = acc[i][j][r] * sc + b;
+        if (p.epilogue == CHATTS_EPI_GELU) v = gelu_erf_f(v);
+        if (p.epilogue == CHATTS_EPI_RESID) v = p.resid[(size_t)row * p.ldc + col] + v;
+        p.c[(size_t)row * p.ldc + col] = v;
+      }
+    }
+}
+
 // W8: W is streamed from its fp8 copy (compile-time switch: a runtime branch in the K-loop cost 18 % on the bf16 path)
 template <int BM, int WM, int WN, bool W8>
 __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
@@ -181,60 +241,213 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue.  C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg -----------
-  const int ccol = lane & 15, crow0 = (lane >> 4) * 4;
-  if (!p.direct) {
-    float* ws = p.c + (size_t)blockIdx.z * p.m * p.n;
+  gemm_store<FM, FN, TM, TN, W8>(p, acc, m0, n0, wm, wn, lane, blockIdx.z);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA kernel (prefill, M large): A arrives already split into bf16 hi / lo planes (split_bf16x2_kernel, or a
+// producer that writes planes directly), so all three operand tiles are plain bf16 rows and are staged by
+// global_load_lds_dwordx4: 16 B per lane from global memory straight into LDS - no staging registers, no VALU
+// conversion, no ds_write.  One wave instruction fills 1 KB of LDS (M0 base + lane * 16) = 8 tile rows x 128 B, i.e.
+// every lane-octet fetches one whole 128-byte line.
+//
+// Why this shape (measurements: tools/gemm_dma_sweep.py, tools/probes/*.hip, profiles/r1_gemm_dma_*.txt).
+//  * The 128 x 128 tile of the register-staged kernel moves 24 KB per 32-deep K-step and CU-side fetch, not the MFMA
+//    pipe or LDS, paces it.  Flops per fetched byte = 2*BM*BN / (2*BM + BN) (A counts twice: hi and lo): 85 for
+//    128 x 128, 128 for 128 x 256.  Hence 128 x 256 x 64: eight compute waves as 2 x 4, each a 64 x 64 wave tile,
+//    64 MFMAs per wave and K-step.
+//  * An LDS-DMA instruction holds its wave's issue port for ~100 cycles.  When the compute waves issue their own
+//    pieces right behind the step's barrier, both waves of every SIMD do so at the same moment and the matrix pipe
+//    drains (57 % busy).  So the DMA is issued by four LOADER waves (one per SIMD, 16 pieces each per K-step): their
+//    VMEM issue overlaps the compute waves' MFMAs, and the compute waves' stream is ds_read + MFMA only.
+//    12 waves = 3 per SIMD -> 168 VGPRs per wave, which the read schedule below is built to fit.
+//  * L2 prefetching of the W panel (by the compute waves, by a ninth wave, or by the panel's first M-tile only) was
+//    measured and does not pay: the in-order VMEM return queue or the doubled L2 request count cost more than the
+//    HBM latency they hide.
+//
+// LDS: two 64 KB stages (A_hi | A_lo | W, rows of 128 B); 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7),
+// applied on the SOURCE side of the DMA (lane l of a piece fetches global chunk (l & 7) ^ swizzle(row)); conflict-free
+// for the ds_read_b128 fragment reads (brute-forced over the four lane groups and both K halves).
+//
+// Compute-wave pipeline (K-step kt; W and A_lo/A_hi fragments of K-half 0 already in registers):
+//   lo sweep h0 | read W,A_lo of h1 | hi sweep h0 | read A_hi of h1 | lo sweep h1 | lgkmcnt(0) + s_barrier |
+//   read h0 of stage kt+1 | hi sweep h1
+// The barrier sits INSIDE the MFMA stream: the loaders arrive at it once stage kt+1 has landed, the compute waves once
+// they have read the last fragment of stage kt, whose slot the loaders refill right behind it.  The next step's
+// first fragments land underneath the last 16 MFMAs.
+// Rows past M / N are clamped to the last valid row (the epilogue masks them): the loop has no bounds checks.
+//
+// XCD mapping: workgroup b runs on XCD b % 8.  The (N-panel major, M-tile minor) tile sequence is cut into 8 contiguous,
+// equally long ranges, one per XCD: the M-tiles of a W panel stay adjacent on one XCD (its L2 fetches the panel once),
+// and no XCD gets a whole panel more than another (108 panels over 8 XCDs as 14/13 cost a 4th round of workgroups).
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ int lds_off128(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+constexpr int kDmaBN = 256, kDmaBK = 64, kDmaLds = 2 * (2 * 128 * 128 + kDmaBN * 128), kDmaThreads = 768;
+
+__global__ __launch_bounds__(kDmaThreads) void gemm_dma_kernel(GemmParams p, const uint16_t* __restrict__ a_hi,
+                                                               const uint16_t* __restrict__ a_lo, int ldp) {
+  constexpr int BM = 128, BN = kDmaBN, BK = kDmaBK, WN = 4, NCOMPUTE = 8, NLOAD = 4;
+  constexpr int TM = 64, TN = 64, FM = 4, FN = 4;
+  constexpr int A_PLANE = BM * 128, STAGE = 2 * A_PLANE + BN * 128;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt_count = (p.m + BM - 1) / BM, nt_count = (p.n + BN - 1) / BN;
+  const int total = mt_count * nt_count, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int share = total >> 3, rem = total & 7;
+  if (local >= share + (xcd < rem)) return;                          // uniform exit of the padding workgroups
+  const int idx = xcd * share + (xcd < rem ? xcd : rem) + local;
+  const int nt = idx / mt_count, mt = idx - nt * mt_count;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int kbeg = blockIdx.z * p.k_per_split;
+  int kend = kbeg + p.k_per_split;
+  if (kend > p.k) kend = p.k;
+  const int nk = (kend - kbeg) / BK;           // the launcher makes k_per_split a multiple of 64; nk >= 1
+
+  if (wave >= NCOMPUTE) {
+    // ---- loader wave L: 1 KB pieces (8 rows x 128 B) {L, L+4, ...} of each plane, 16 per stage.  Piece q = rows
+    // 8q .. 8q+7, so (r >> 1) & 7 = ((q & 1) << 2) | (lrow >> 1), and q & 1 == L & 1.
+    constexpr int NA = 16 / NLOAD, NW = BN / 8 / NLOAD;
+    const int L = wave - NCOMPUTE;
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ (((L & 1) << 2) | (lrow >> 1));
+    const uint16_t* src[2 * NA + NW];
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int h = 0; h < NA; ++h) {
+      int am = m0 + (L + NLOAD * h) * 8 + lrow;
+      if (am > p.m - 1) am = p.m - 1;
+      src[h] = a_hi + (size_t)am * ldp + kbeg + lchunk * 8;
+      src[NA + h] = a_lo + (size_t)am * ldp + kbeg + lchunk * 8;
+    }
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int col = n0 + wn * TN + j * 16 + ccol;
+    for (int h = 0; h < NW; ++h) {
+      int wr = n0 + (L + NLOAD * h) * 8 + lrow;
+      if (wr > p.n - 1) wr = p.n - 1;
+      src[2 * NA + h] = p.w + (size_t)wr * p.ldw + kbeg + lchunk * 8;
+    }
+    auto issue = [&](int kt) {   // stage kt -> slot kt & 1
+      char* base = smem + (kt & 1) * STAGE + L * 1024;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = m0 + wm * TM + i * 16 + crow0 + r;
-          if (row < p.m && col < p.n) ws[(size_t)row * p.n + col] = acc[i][j][r];
-        }
+      for (int h = 0; h < NA; ++h) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + (size_t)kt * BK), (lptr_t)(base + h * NLOAD * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[NA + h] + (size_t)kt * BK), (lptr_t)(base + A_PLANE + h * NLOAD * 1024),
+                                         16, 0, 0);
       }
+#pragma unroll
+      for (int h = 0; h < NW; ++h)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[2 * NA + h] + (size_t)kt * BK),
+                                         (lptr_t)(base + 2 * A_PLANE + h * NLOAD * 1024), 16, 0, 0);
+    };
+    static_assert(2 * NA + NW == 16, "vmcnt(16) below = the pieces of one stage");
+    issue(0);
+    if (nk > 1) {
+      issue(1);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");            // stage 0 landed, stage 1 may be in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                   // publishes stage 0
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // stage kt+1 landed (issued a whole K-step ago)
+      __builtin_amdgcn_s_barrier();                                 // ... published; slot of stage kt retired
+      if (kt + 2 < nk) issue(kt + 2);
+    }
     return;
   }
-  if (p.epilogue == CHATTS_EPI_SWIGLU) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; j += 2) {
-        const int prow = n0 + wn * TN + j * 16 + ccol;   // packed gate row; up row = prow + 16
-        const int ocol = (prow >> 5) * 16 + ccol;
-        if (prow + 16 < p.n) {
-          const float bg = p.bias ? p.bias[prow] : 0.f, bu = p.bias ? p.bias[prow + 16] : 0.f;
-          const float sg = W8 ? p.w8_scale[prow] : 1.f, su = W8 ? p.w8_scale[prow + 16] : 1.f;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * TM + i * 16 + crow0 + r;
-            if (row < p.m) p.c[(size_t)row * p.ldc + ocol] = silu_g(acc[i][j][r] * sg + bg) * (acc[i][j + 1][r] * su + bu);
-          }
-        }
-      }
-    return;
-  }
+
+  // ---- compute wave
+  const int wm = wave / WN, wn = wave % WN;
+  f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = n0 + wn * TN + j * 16 + ccol;
-      if (col >= p.n) continue;
-      const float b = p.bias ? p.bias[col] : 0.f;
-      const float sc = W8 ? p.w8_scale[col] : 1.f;
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  bf16x8_t bfrag[2][FN], alo[2][FM], ahi[2][FM];
+  auto read_b = [&](int kt, int h) {
+    const char* base = smem + (kt & 1) * STAGE + 2 * A_PLANE;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * TM + i * 16 + crow0 + r;
-        if (row >= p.m) continue;
-        float v = acc[i][j][r] * sc + b;
-        if (p.epilogue == CHATTS_EPI_GELU) v = gelu_erf_f(v);
-        if (p.epilogue == CHATTS_EPI_RESID) v = p.resid[(size_t)row * p.ldc + col] + v;
-        p.c[(size_t)row * p.ldc + col] = v;
-      }
+    for (int j = 0; j < FN; ++j)
+      bfrag[h][j] = *reinterpret_cast<const bf16x8_t*>(base + lds_off128(wn * TN + j * 16 + frow, h * 4 + fchunk));
+  };
+  auto read_a = [&](int kt, int h, int plane, bf16x8_t (&dst)[FM]) {
+    const char* base = smem + (kt & 1) * STAGE + plane * A_PLANE;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+      dst[i] = *reinterpret_cast<const bf16x8_t*>(base + lds_off128(wm * TM + i * 16 + frow, h * 4 + fchunk));
+  };
+  auto sweep = [&](const bf16x8_t (&af)[FM], const bf16x8_t (&bf)[FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  };
+
+  __builtin_amdgcn_s_barrier();                // stage 0 published
+  read_b(0, 0);
+  read_a(0, 0, 1, alo[0]);
+  read_a(0, 0, 0, ahi[0]);
+  // (the last K-step is peeled: with the `more` test inside the loop the register allocator stops accumulating in place
+  // and spills fragments)
+  auto step = [&](int kt, bool more) {
+    __builtin_amdgcn_sched_barrier(0);
+    sweep(alo[0], bfrag[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(kt, 1);
+    read_a(kt, 1, 1, alo[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    sweep(ahi[0], bfrag[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(kt, 1, 0, ahi[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    sweep(alo[1], bfrag[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of slot kt has returned
+      __builtin_amdgcn_s_barrier();
+      read_b(kt + 1, 0);
+      read_a(kt + 1, 0, 1, alo[0]);
+      read_a(kt + 1, 0, 0, ahi[0]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    sweep(ahi[1], bfrag[1]);
+  };
+  for (int kt = 0; kt + 1 < nk; ++kt) step(kt, true);
+  step(nk - 1, false);
+  gemm_store<FM, FN, TM, TN, false>(p, acc, m0, n0, wm, wn, lane, blockIdx.z);
+}
+
+// x = hi + lo (to 16 mantissa bits): one thread per 8 consecutive elements.
+__global__ __launch_bounds__(256) void split_bf16x2_kernel(const float* __restrict__ x, int m, int k, int ldx,
+                                                          uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int ldp) {
+  const int kc = k >> 3;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)m * kc) return;
+  const int row = (int)(idx / kc), c = (int)(idx % kc);
+  const float* src = x + (size_t)row * ldx + c * 8;
+  const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+  const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  bf16x8_t hv, lv;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    hv[j] = h;
+    lv[j] = (__bf16)(v[j] - (float)h);
+  }
+  *reinterpret_cast<bf16x8_t*>(hi + (size_t)row * ldp + c * 8) = hv;
+  *reinterpret_cast<bf16x8_t*>(lo + (size_t)row * ldp + c * 8) = lv;
+}
+
+int launch_split_bf16x2(const float* x, int m, int k, int ldx, uint16_t* hi, uint16_t* lo, int ldp, hipStream_t s) {
+  const size_t total = (size_t)m * (k >> 3);
+  hipLaunchKernelGGL(split_bf16x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, m, k, ldx, hi, lo, ldp);
+  CHATTS_CHECK_LAUNCH("split_bf16x2");
+  return CHATTS_OK;
 }
 
 // Sum split-K partials in a fixed order and apply the epilogue.  One thread per output element.
@@ -273,17 +486,17 @@ static int gemm_env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-static void pick_geometry(int m, int n, int k, int& bm, int& sk) {
+static void pick_geometry(int m, int n, int k, int& bm, int& sk, int slots_per_cu = 3, int bn = 128) {
   bm = m > 64 ? 128 : (m > 32 ? 64 : (m > 16 ? 32 : 16));
   const int force_bm = gemm_env_int("CHATTS_GEMM_BM", 0);          // tuning / tests only
   if (force_bm == 16 || force_bm == 32 || force_bm == 64 || force_bm == 128) bm = force_bm;
   // short K (no split-K possible, e.g. the first TS-MLP layer, K = 288) and few tiles: smaller M-tiles fill more CUs
   if (!force_bm && k < 512 && ((m + bm - 1) / bm) * ((n + 127) / 128) * 4 <= device_cus() && bm > 32) bm = 32;
-  const int tiles = ((m + bm - 1) / bm) * ((n + 127) / 128);
+  const int tiles = ((m + bm - 1) / bm) * ((n + bn - 1) / bn);
   // Split-K so that the workgroups fill whole "rounds" of the resident slots (3 workgroups of 48 KB LDS per CU):
   // efficiency of a launch = blocks / (slots * ceil(blocks / slots)); split-K costs a partials round trip + an
   // epilogue launch, hence the small penalty.  (tools/gemm_sweep.py: qkv @ M=798 wants 3, o/down 2, gate_up 1.)
-  const int slots = 3 * device_cus();
+  const int slots = slots_per_cu * device_cus();
   int max_sk = k / 256 > 0 ? (k / 256 < 16 ? k / 256 : 16) : 1;   // keep >= 8 K-steps per split
   const int traffic_cap = k / (2 * m) > 1 ? k / (2 * m) : 1;        // partials (sk*M*N*8 B) <= 2x the weight bytes
   if (max_sk > traffic_cap) max_sk = traffic_cap;
@@ -300,21 +513,60 @@ static void pick_geometry(int m, int n, int k, int& bm, int& sk) {
   if (force_sk > 0 && force_sk <= 16 && k / force_sk >= 32) sk = force_sk;
 }
 
-static int k_per_split(int k, int sk) {
+static int k_per_split(int k, int sk, int bk = 32) {
   int kps = (k + sk - 1) / sk;
-  return ((kps + 31) / 32) * 32;
+  return ((kps + bk - 1) / bk) * bk;
+}
+
+// The LDS-DMA kernel runs when the caller supplies the pre-split planes and either M >= kDmaMinM (its M-tile is a
+// fixed 128 rows) or there is no float32 A to fall back on.
+constexpr int kDmaMinM = 96;
+
+static bool use_dma(const ChattsLinearArgs* a) {
+  if (!a->a_hi || !a->a_lo || a->k % kDmaBK != 0) return false;
+  if (!a->a) return true;
+  return a->m >= gemm_env_int("CHATTS_GEMM_DMA_MIN_M", kDmaMinM) && gemm_env_int("CHATTS_GEMM_DMA", 1) != 0;
+}
+
+// DMA geometry: 128 x 256 tiles, one 8-wave workgroup per CU.
+static void pick_dma_geometry(int m, int n, int k, int& sk) {
+  int bm;
+  pick_geometry(m < 128 ? 128 : m, n, k, bm, sk, 1, kDmaBN);
 }
 
 size_t gemm_workspace(int m, int n, int k) {
-  int bm, sk;
+  int bm, sk, sk2;
   pick_geometry(m, n, k, bm, sk);
+  pick_dma_geometry(m, n, k, sk2);
+  if (sk2 > sk) sk = sk2;
   return sk > 1 ? (size_t)sk * m * n * sizeof(float) : 0;
+}
+
+static int launch_dma(const GemmParams& p, const ChattsLinearArgs* a, int sk, hipStream_t s) {
+  static bool configured = false;     // > 64 KB of dynamic LDS must be opted into once
+  if (!configured) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds);
+    CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "gemm_dma: cannot reserve %d bytes of LDS: %s", kDmaLds, hipGetErrorString(e));
+    configured = true;
+  }
+  const int tiles = ((a->n + kDmaBN - 1) / kDmaBN) * ((a->m + 127) / 128);
+  dim3 grid(8 * ((tiles + 7) / 8), 1, sk), block(kDmaThreads);
+  hipLaunchKernelGGL(gemm_dma_kernel, grid, block, kDmaLds, s, p, a->a_hi, a->a_lo, a->ld_planes);
+  return CHATTS_OK;
 }
 
 int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   int bm, sk;
-  pick_geometry(a->m, a->n, a->k, bm, sk);
-  const int kps = k_per_split(a->k, sk);
+  const bool dma = use_dma(a);
+  if (dma) {
+    pick_dma_geometry(a->m, a->n, a->k, sk);
+    bm = 128;
+  } else {
+    CHATTS_REQUIRE(a->a, CHATTS_E_SHAPE, "linear: a == NULL needs K %% %d == 0 (K=%d) for the plane path", kDmaBK, a->k);
+    pick_geometry(a->m, a->n, a->k, bm, sk);
+  }
+  const int kps = k_per_split(a->k, sk, dma ? kDmaBK : 32);
   sk = (a->k + kps - 1) / kps;
   GemmParams p;
   p.a = a->a; p.w = a->w; p.bias = a->bias; p.resid = a->resid;
@@ -331,7 +583,10 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   }
   const int nt_count = (a->n + 127) / 128, mt_count = (a->m + bm - 1) / bm;
   dim3 grid(8 * ((nt_count + 7) / 8) * mt_count, 1, sk), block(256);
-  if (a->w8) {
+  if (dma) {
+    const int rc = launch_dma(p, a, sk, s);
+    if (rc) return rc;
+  } else if (a->w8) {
     switch (bm) {
       case 128: hipLaunchKernelGGL((gemm_bf16x2_kernel<128, 2, 2, true>), grid, block, 0, s, p); break;
       case 64: hipLaunchKernelGGL((gemm_bf16x2_kernel<64, 2, 2, true>), grid, block, 0, s, p); break;

@@ -226,6 +226,8 @@ class ChatTSForCausalLM:
             "qkv": torch.zeros((self.t_max, qkv_n), **f32), "attn": torch.zeros((self.t_max, plan.nq * d), **f32),
             "act": torch.zeros((self.t_max, plan.inter), **f32), "delta": torch.zeros((self.t_max, H), **f32),
             "logits": torch.zeros(plan.vocab, **f32),
+            # bf16 hi / lo planes of the current projection input (prefill: LDS-DMA GEMM operands)
+            "planes": torch.zeros((2, self.t_max, max(H, plan.nq * d, plan.inter)), dtype=torch.bfloat16, device=dev),
             "ws": torch.zeros(ws_bytes, dtype=torch.uint8, device=dev),
             # decode-loop state lives on the device so a captured step can be replayed
             "pos_all": torch.zeros(MB, dtype=torch.int32, device=dev), "step_all": torch.zeros(MB, dtype=torch.int32, device=dev),
@@ -258,7 +260,8 @@ class ChatTSForCausalLM:
                                  xn=_lib.ptr(B["xn"]), qkv=_lib.ptr(B["qkv"]), attn=_lib.ptr(B["attn"]),
                                  act=_lib.ptr(B["act"]), delta=_lib.ptr(B["delta"]), logits=_lib.ptr(B["logits"]),
                                  workspace=_lib.ptr(B["ws"]), workspace_bytes=ws_bytes, t_max=self.t_max,
-                                 max_batch=self.max_batch)
+                                 max_batch=self.max_batch, planes_hi=_lib.ptr(B["planes"][0]),
+                                 planes_lo=_lib.ptr(B["planes"][1]))
         h = lib.chatts_decoder_create(C.byref(dc), C.byref(dw), C.byref(db))
         if not h:
             raise _lib.ChattsError(-1, lib.chatts_last_error().decode())

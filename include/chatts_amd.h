@@ -126,8 +126,18 @@ typedef struct ChattsLinearArgs {
   const uint8_t* w8;
   const float* w8_scale;
   int ldw8;
+  /* optional pre-split A (see chatts_split_bf16x2): a == a_hi + a_lo exactly to 16 mantissa bits, both planes bf16
+   * [M, ld_planes].  When set (and M > 1, fp8 copy absent) the GEMM stages all three operand tiles with LDS-DMA
+   * (global_load_lds) through a 3-deep ring instead of splitting A on the VALU per tile; `a` may then be NULL.
+   * Same products, same accumulation order -> bit-identical results to the `a` path. */
+  const chatts_bf16* a_hi;
+  const chatts_bf16* a_lo;
+  int ld_planes;
 } ChattsLinearArgs;
 size_t chatts_linear_workspace(int m, int n, int k);
+/* hi = bf16(x) (RNE), lo = bf16(x - hi): the operand split of the bf16x2 GEMM, done once per activation matrix. */
+int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, chatts_bf16* lo, int ld_planes,
+                        chatts_stream_t stream);
 /* Dispatch: M == 1 -> weight-streaming GEMV (exact f32 VALU products, HBM-bound);
  *           M  > 1 -> LDS-tiled MFMA GEMM, v_mfma_f32_16x16x32_bf16, bf16x2 split of A. */
 int chatts_linear(const ChattsLinearArgs* args, chatts_stream_t stream);
@@ -273,6 +283,10 @@ typedef struct ChattsDecoderBuffers {
   size_t workspace_bytes;
   int t_max;
   int max_batch;      /* KV caches are [max_batch, n_layers, n_kv, max_ctx, 128]; 0 or 1 = single sequence */
+  /* optional: bf16 hi / lo planes of the current projection input, each [T_max, max(H, n_q*128, inter)]
+   * (ChattsLinearArgs.a_hi / a_lo).  When both are set, prefill chunks of >= 96 rows run the LDS-DMA GEMM. */
+  chatts_bf16* planes_hi;
+  chatts_bf16* planes_lo;
 } ChattsDecoderBuffers;
 
 typedef struct ChattsDecoder ChattsDecoder;  /* opaque; host memory only */

@@ -213,6 +213,79 @@ def test_gemm_bf16x2_parity(lib, epi, m, n, k):
     assert rel_err(out.cpu().numpy(), want) < 2e-5       # bf16x2: |eps| <= 2^-17 per product, f32 accumulate
 
 
+def _split_planes(lib, a, ld=None):
+    m, k = a.shape
+    ld = ld or k
+    hi = torch.full((m, ld), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lo = torch.full((m, ld), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.chatts_split_bf16x2(a.data_ptr(), m, k, k, hi.data_ptr(), lo.data_ptr(), ld, st()))
+    torch.cuda.synchronize()
+    return hi, lo
+
+
+def test_split_bf16x2_bit_exact(lib):
+    g = torch.Generator().manual_seed(3)
+    a = (torch.randn((37, 320), generator=g) * torch.logspace(-20, 20, 320)).to(DEV)    # wide exponent range
+    a[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-30, 65504.0])
+    hi, lo = _split_planes(lib, a, ld=328)
+    want_hi = a.to(torch.bfloat16)
+    want_lo = (a - want_hi.float()).to(torch.bfloat16)
+    assert torch.equal(hi[:, :320], want_hi) and torch.equal(lo[:, :320], want_lo)
+    # hi + lo carries 16 mantissa bits of a
+    rec = hi[:, :320].float().double() + lo[:, :320].float().double()
+    ok = a.abs() > 1e-30
+    assert ((rec - a.double()).abs()[ok] <= a.double().abs()[ok] * 2.0 ** -16).all()
+
+
+def _linear_planes(lib, a, w, bias, resid, epi, with_a=True, ld=None):
+    m, k = a.shape
+    n = w.shape[0]
+    hi, lo = _split_planes(lib, a, ld)
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    out = torch.full((m, ncols), float("nan"), dtype=torch.float32, device=DEV)
+    wsb = int(lib.chatts_linear_workspace(m, n, k))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    la = _lib.LinearArgs(a=a.data_ptr() if with_a else None, w=w.data_ptr(), bias=_lib.ptr(bias), resid=_lib.ptr(resid),
+                         c=out.data_ptr(), norm_w=None, norm_eps=0.0, m=m, n=n, k=k, lda=k, ldw=k, ldc=ncols, epilogue=epi,
+                         workspace=ws.data_ptr(), workspace_bytes=wsb, a_hi=hi.data_ptr(), a_lo=lo.data_ptr(),
+                         ld_planes=ld or k)
+    _lib.check(lib.chatts_linear(la, st()))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k", [(96, 256, 64), (128, 5120, 5120), (130, 384, 1024), (360, 7168, 5120), (200, 1024, 13824),
+                                   (798, 2080, 640), (513, 96, 192)])
+def test_gemm_dma_parity(lib, epi, m, n, k):
+    """LDS-DMA GEMM on pre-split planes (ragged M and N tiles, K = 1..216 steps of 64, split-K) vs float64."""
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
+    out = _linear_planes(lib, a, w, bias, resid if epi == _lib.EPI_RESID else None, epi, with_a=False, ld=k + 64)
+    want = _ref_linear(a, w, bias, resid, epi)
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu().numpy(), want) < 2e-5
+
+
+@pytest.mark.parametrize("sk", [1, 2, 3])
+def test_gemm_dma_equals_register_staged_bitwise(lib, sk, monkeypatch):
+    """Same products, same accumulation order: with the split-K factor pinned the two GEMM kernels agree bit for bit."""
+    monkeypatch.setenv("CHATTS_GEMM_SK", str(sk))
+    monkeypatch.setenv("CHATTS_GEMM_BM", "128")
+    for epi, (m, n, k) in ((_lib.EPI_RESID, (300, 640, 1536)), (_lib.EPI_SWIGLU, (257, 1024, 768))):
+        a, w, bias, resid, _ = _rand_problem(m, n, k, seed=sk + m, scale=2.0)
+        r = resid if epi == _lib.EPI_RESID else None
+        assert torch.equal(_linear_planes(lib, a, w, bias, r, epi), _linear(lib, a, w, bias, r, epi))
+
+
+def test_gemm_dma_small_m_and_odd_k_fall_back(lib):
+    a, w, bias, resid, _ = _rand_problem(40, 256, 512, seed=9)
+    assert torch.equal(_linear_planes(lib, a, w, bias, None, _lib.EPI_NONE), _linear(lib, a, w, bias, None, _lib.EPI_NONE))
+    a, w, bias, resid, _ = _rand_problem(200, 256, 96, seed=10)          # K % 64 != 0: the planes are ignored
+    assert torch.equal(_linear_planes(lib, a, w, bias, None, _lib.EPI_NONE), _linear(lib, a, w, bias, None, _lib.EPI_NONE))
+    with pytest.raises(_lib.ChattsError):                                 # ... and without `a` there is nothing to fall back on
+        _linear_planes(lib, a, w, bias, None, _lib.EPI_NONE, with_a=False)
+
+
 def test_linear_argument_errors(lib):
     a = torch.zeros((2, 48), device=DEV)
     w = torch.zeros((32, 48), dtype=torch.bfloat16, device=DEV)
