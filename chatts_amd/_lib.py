@@ -34,7 +34,8 @@ class LinearArgs(C.Structure):
                 ("norm_w", c_void_p), ("norm_eps", c_float), ("m", c_int), ("n", c_int), ("k", c_int),
                 ("lda", c_int), ("ldw", c_int), ("ldc", c_int), ("epilogue", c_int), ("workspace", c_void_p),
                 ("workspace_bytes", c_size_t), ("w8", c_void_p), ("w8_scale", c_void_p), ("ldw8", c_int),
-                ("a_hi", c_void_p), ("a_lo", c_void_p), ("ld_planes", c_int)]
+                ("a_hi", c_void_p), ("a_lo", c_void_p), ("ld_planes", c_int),
+                ("c_hi", c_void_p), ("c_lo", c_void_p), ("ld_cplanes", c_int)]
 
 
 class KvCache(C.Structure):
@@ -65,7 +66,7 @@ class DecoderBuffers(C.Structure):
     _fields_ = [("kv_k", c_void_p), ("kv_v", c_void_p), ("x", c_void_p), ("xn", c_void_p), ("qkv", c_void_p),
                 ("attn", c_void_p), ("act", c_void_p), ("delta", c_void_p), ("logits", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("t_max", c_int), ("max_batch", c_int),
-                ("planes_hi", c_void_p), ("planes_lo", c_void_p)]
+                ("planes_hi", c_void_p), ("planes_lo", c_void_p), ("planes2_hi", c_void_p), ("planes2_lo", c_void_p)]
 
 
 # name -> (restype, argtypes); this table IS the list of symbols include/chatts_amd.h declares
@@ -85,6 +86,7 @@ SIGNATURES = {
     "chatts_embed_merge": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "chatts_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "chatts_rmsnorm_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "chatts_rope_kv_write": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                      c_int, c_void_p, C.POINTER(KvCache), c_void_p]),
     "chatts_attn_workspace": (c_size_t, [c_int, c_int, c_int]),

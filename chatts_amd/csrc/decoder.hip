@@ -32,7 +32,11 @@ extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) 
   CHATTS_REQUIRE(a->m >= 0 && a->n > 0 && a->k > 0, CHATTS_E_BADARG, "linear: bad sizes m=%d n=%d k=%d", a->m, a->n, a->k);
   if (a->m == 0) return CHATTS_OK;
   const bool planes = a->a_hi || a->a_lo;
-  CHATTS_REQUIRE((a->a || planes) && a->w && a->c, CHATTS_E_BADARG, "linear: null pointer");
+  const bool cplanes = a->c_hi || a->c_lo;
+  CHATTS_REQUIRE((a->a || planes) && a->w && (a->c || cplanes), CHATTS_E_BADARG, "linear: null pointer");
+  if (cplanes)
+    CHATTS_REQUIRE(a->c_hi && a->c_lo && a->m > 1 && a->ld_cplanes >= (a->epilogue == CHATTS_EPI_SWIGLU ? a->n / 2 : a->n),
+                   CHATTS_E_SHAPE, "linear: plane output needs both planes, M > 1 and ld_cplanes >= the output width");
   if (planes)
     CHATTS_REQUIRE(a->a_hi && a->a_lo && a->ld_planes >= a->k && a->ld_planes % 8 == 0 && ((uintptr_t)a->a_hi % 16) == 0 &&
                        ((uintptr_t)a->a_lo % 16) == 0 && a->m > 1 && !a->w8 && !a->norm_w,
@@ -46,7 +50,7 @@ extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) 
   CHATTS_REQUIRE((!a->a || (a->lda >= a->k && a->lda % 4 == 0)) && a->ldw >= a->k && a->ldw % 8 == 0, CHATTS_E_SHAPE,
                  "linear: leading dimensions lda=%d ldw=%d", a->lda, a->ldw);
   const int ncols = a->epilogue == CHATTS_EPI_SWIGLU ? a->n / 2 : a->n;
-  CHATTS_REQUIRE(a->ldc >= ncols, CHATTS_E_SHAPE, "linear: ldc=%d < %d", a->ldc, ncols);
+  CHATTS_REQUIRE(a->ldc >= ncols || (cplanes && a->epilogue != CHATTS_EPI_RESID), CHATTS_E_SHAPE, "linear: ldc=%d < %d", a->ldc, ncols);
   CHATTS_REQUIRE(((uintptr_t)a->a % 16) == 0 && ((uintptr_t)a->w % 16) == 0 && ((uintptr_t)a->c % 16) == 0,
                  CHATTS_E_SHAPE, "linear: pointers must be 16-byte aligned");
   if (a->w8)
@@ -116,14 +120,19 @@ static ChattsKvCache layer_cache(const ChattsDecoder* d, int layer, int seq) {
   return c;
 }
 
-// Prefill: hand the projection its input as bf16 hi / lo planes as well, so that chatts_linear can take the LDS-DMA
-// GEMM (M >= 96, K a multiple of 64; otherwise it reads `a` as before).
-static int with_planes(ChattsDecoder* d, ChattsLinearArgs* la, chatts_stream_t stream) {
-  if (!d->b.planes_hi || !d->b.planes_lo || la->m < 96 || la->k % 64 != 0) return CHATTS_OK;
-  const int rc = chatts_split_bf16x2(la->a, la->m, la->k, la->lda, d->b.planes_hi, d->b.planes_lo, la->k, stream);
-  if (rc) return rc;
-  la->a_hi = d->b.planes_hi; la->a_lo = d->b.planes_lo; la->ld_planes = la->k;
-  return CHATTS_OK;
+// Prefill chunks of >= 96 rows run the projections on the LDS-DMA GEMM, whose A operand is a pair of bf16 hi / lo planes.
+static bool planes_path(const ChattsDecoder* d, int m, int k) {
+  return d->b.planes_hi && d->b.planes_lo && d->b.planes2_hi && d->b.planes2_lo && m >= 96 && k % 64 == 0;
+}
+
+// x -> RMSNorm -> la's input: planes written by the norm kernel itself (plane path) or float32 xn.
+static int norm_into(ChattsDecoder* d, const float* norm_w, ChattsLinearArgs* la, chatts_stream_t stream) {
+  if (planes_path(d, la->m, la->k)) {
+    la->a = nullptr; la->a_hi = d->b.planes_hi; la->a_lo = d->b.planes_lo; la->ld_planes = la->k;
+    return chatts_rmsnorm_planes(d->b.x, norm_w, d->b.planes_hi, d->b.planes_lo, la->k, la->m, la->k, d->cfg.rms_eps, stream);
+  }
+  la->a = d->b.xn;
+  return chatts_rmsnorm(d->b.x, norm_w, d->b.xn, la->m, la->k, d->cfg.rms_eps, stream);
 }
 
 extern "C" int chatts_decoder_select_sequence(ChattsDecoder* d, int seq) {
@@ -155,9 +164,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
       la.a = d->b.x; la.norm_w = lw.input_norm; la.norm_eps = c.rms_eps;
       la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H;
     } else {
-      if ((rc = chatts_rmsnorm(d->b.x, lw.input_norm, d->b.xn, t, H, c.rms_eps, stream)) != 0) return rc;
-      la.a = d->b.xn;
-      if ((rc = with_planes(d, &la, stream)) != 0) return rc;
+      if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
     }
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, d->cur_seq);
@@ -176,8 +183,12 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     la.a = d->b.attn; la.w = lw.o; la.m = t; la.n = H; la.k = c.n_q * kHeadDim;
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
-    if (t == 1) { la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k; }
-    else if ((rc = with_planes(d, &la, stream)) != 0) return rc;
+    if (t == 1) {
+      la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k;
+    } else if (planes_path(d, t, la.k)) {      // the attention kernel writes float32: split it
+      if ((rc = chatts_split_bf16x2(d->b.attn, t, la.k, la.k, d->b.planes_hi, d->b.planes_lo, la.k, stream)) != 0) return rc;
+      la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k;
+    }
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
     return chatts_linear(&la, stream);
@@ -191,17 +202,17 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     la.a = d->b.x; la.norm_w = lw.post_norm; la.norm_eps = c.rms_eps;
     la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H;
   } else {
-    if ((rc = chatts_rmsnorm(d->b.x, lw.post_norm, d->b.xn, t, H, c.rms_eps, stream)) != 0) return rc;
-    la.a = d->b.xn;
-    if ((rc = with_planes(d, &la, stream)) != 0) return rc;
+    if ((rc = norm_into(d, lw.post_norm, &la, stream)) != 0) return rc;
   }
+  const bool act_planes = t > 1 && planes_path(d, t, c.inter);   // SwiGLU output goes straight into down_proj's operand format
+  if (act_planes) { la.c = nullptr; la.c_hi = d->b.planes2_hi; la.c_lo = d->b.planes2_lo; la.ld_cplanes = c.inter; }
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
   la = ChattsLinearArgs{};
   la.a = d->b.act; la.w = lw.down; la.m = t; la.n = H; la.k = c.inter;
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if (t == 1) { la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter; }
-  else if ((rc = with_planes(d, &la, stream)) != 0) return rc;
+  if (act_planes) { la.a = nullptr; la.a_hi = d->b.planes2_hi; la.a_lo = d->b.planes2_lo; la.ld_planes = c.inter; }
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
   return chatts_linear(&la, stream);

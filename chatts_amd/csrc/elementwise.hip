@@ -6,11 +6,14 @@ namespace chatts {
 
 // ---- RMSNorm: one workgroup per row, float4 loads, wave-shuffle + LDS reduction --------------------
 // y = w * (x * rsqrt(mean(x^2) + eps))     (Qwen2RMSNorm.forward; same op order as the oracle)
+// PLANES: the row goes out as bf16 hi / lo planes (hi = bf16(y), lo = bf16(y - hi)), the LDS-DMA GEMM's operand format.
+template <bool PLANES>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                     float* __restrict__ y, int hidden, float eps) {
+                                                     float* __restrict__ y, int hidden, float eps,
+                                                     uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int ldp) {
   __shared__ float red[4];
   const float* xr = x + (size_t)blockIdx.x * hidden;
-  float* yr = y + (size_t)blockIdx.x * hidden;
+  float* yr = PLANES ? nullptr : y + (size_t)blockIdx.x * hidden;
   float ss = 0.f;
   for (int k = threadIdx.x * 4; k < hidden; k += 1024) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
@@ -23,7 +26,23 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     const f32x4 g = *reinterpret_cast<const f32x4*>(w + k);
     f32x4 o;
     o.x = g.x * (v.x * rstd); o.y = g.y * (v.y * rstd); o.z = g.z * (v.z * rstd); o.w = g.w * (v.w * rstd);
-    *reinterpret_cast<f32x4*>(yr + k) = o;
+    if (PLANES) {
+      // no contraction: o is a product, and folding it into the subtraction as an FMA would make lo differ from the split of
+      // the ROUNDED float32 value that the float32 variant stores
+#pragma clang fp contract(off)
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      bf16x4_t hv, lv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const __bf16 h = (__bf16)o[j];
+        hv[j] = h;
+        lv[j] = (__bf16)(o[j] - (float)h);
+      }
+      *reinterpret_cast<bf16x4_t*>(hi + (size_t)blockIdx.x * ldp + k) = hv;
+      *reinterpret_cast<bf16x4_t*>(lo + (size_t)blockIdx.x * ldp + k) = lv;
+    } else {
+      *reinterpret_cast<f32x4*>(yr + k) = o;
+    }
   }
 }
 
@@ -218,8 +237,21 @@ extern "C" int chatts_rmsnorm(const float* x, const float* w, float* y, int t, i
   if (t == 0) return CHATTS_OK;
   CHATTS_REQUIRE(x && w && y, CHATTS_E_BADARG, "rmsnorm: null pointer");
   CHATTS_REQUIRE(hidden % 4 == 0, CHATTS_E_SHAPE, "rmsnorm: hidden %d not a multiple of 4", hidden);
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3(t), dim3(256), 0, as_stream(stream), x, w, y, hidden, eps);
+  hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3(t), dim3(256), 0, as_stream(stream), x, w, y, hidden, eps, nullptr, nullptr, 0);
   CHATTS_CHECK_LAUNCH("rmsnorm");
+  return CHATTS_OK;
+}
+
+extern "C" int chatts_rmsnorm_planes(const float* x, const float* w, chatts_bf16* hi, chatts_bf16* lo, int ld_planes, int t,
+                                     int hidden, float eps, chatts_stream_t stream) {
+  CHATTS_REQUIRE(t >= 0 && hidden > 0, CHATTS_E_BADARG, "rmsnorm_planes: bad sizes t=%d hidden=%d", t, hidden);
+  if (t == 0) return CHATTS_OK;
+  CHATTS_REQUIRE(x && w && hi && lo, CHATTS_E_BADARG, "rmsnorm_planes: null pointer");
+  CHATTS_REQUIRE(hidden % 4 == 0 && ld_planes >= hidden && ld_planes % 4 == 0, CHATTS_E_SHAPE,
+                 "rmsnorm_planes: hidden %d / ld_planes %d must be multiples of 4, ld_planes >= hidden", hidden, ld_planes);
+  hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3(t), dim3(256), 0, as_stream(stream), x, w, nullptr, hidden, eps, hi, lo,
+                     ld_planes);
+  CHATTS_CHECK_LAUNCH("rmsnorm_planes");
   return CHATTS_OK;
 }
 

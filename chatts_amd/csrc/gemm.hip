@@ -31,7 +31,20 @@ struct GemmParams {
   const uint8_t* w8;     // optional fp8 (e4m3fn) copy of W: streamed instead of the bf16 copy, widened (exactly) to
   const float* w8_scale; // bf16 while it is staged to LDS; the per-row power-of-two scale is applied in the epilogue
   int ldw8;
+  uint16_t* c_hi;        // optional: the output goes out as bf16 hi / lo planes [M, ldcp] (the next GEMM's operand
+  uint16_t* c_lo;        // format) instead of float32 c
+  int ldcp;
 };
+
+__device__ __forceinline__ void store_planes(uint16_t* hi, uint16_t* lo, size_t off, float v) {
+  // no contraction: when v is a product (SwiGLU) the compiler would otherwise fold it into the subtraction as an FMA and
+  // lo would no longer be the split of the ROUNDED float32 value the float32 path stores
+#pragma clang fp contract(off)
+  const __bf16 h = (__bf16)v;
+  const __bf16 l = (__bf16)(v - (float)h);
+  hi[off] = __builtin_bit_cast(uint16_t, h);
+  lo[off] = __builtin_bit_cast(uint16_t, l);
+}
 
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu_g(float x) { return x / (1.0f + expf(-x)); }
@@ -74,7 +87,11 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, const f32x4 (&ac
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm * TM + i * 16 + crow0 + r;
-            if (row < p.m) p.c[(size_t)row * p.ldc + ocol] = silu_g(acc[i][j][r] * sg + bg) * (acc[i][j + 1][r] * su + bu);
+            if (row < p.m) {
+              const float v = silu_g(acc[i][j][r] * sg + bg) * (acc[i][j + 1][r] * su + bu);
+              if (p.c_hi) store_planes(p.c_hi, p.c_lo, (size_t)row * p.ldcp + ocol, v);
+              else p.c[(size_t)row * p.ldc + ocol] = v;
+            }
           }
         }
       }
@@ -95,7 +112,8 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, const f32x4 (&ac
         float v = acc[i][j][r] * sc + b;
         if (p.epilogue == CHATTS_EPI_GELU) v = gelu_erf_f(v);
         if (p.epilogue == CHATTS_EPI_RESID) v = p.resid[(size_t)row * p.ldc + col] + v;
-        p.c[(size_t)row * p.ldc + col] = v;
+        if (p.c_hi) store_planes(p.c_hi, p.c_lo, (size_t)row * p.ldcp + col, v);
+        else p.c[(size_t)row * p.ldc + col] = v;
       }
     }
 }
@@ -454,7 +472,8 @@ int launch_split_bf16x2(const float* x, int m, int k, int ldx, uint16_t* hi, uin
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ ws, int sk, int m, int n,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ resid, float* __restrict__ c,
-                                                             int ldc, int epilogue, const float* __restrict__ scale) {
+                                                             int ldc, int epilogue, const float* __restrict__ scale,
+                                                             uint16_t* __restrict__ c_hi, uint16_t* __restrict__ c_lo, int ldcp) {
   const int ncols = epilogue == CHATTS_EPI_SWIGLU ? n / 2 : n;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)m * ncols) return;
@@ -469,7 +488,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     }
     if (scale) { g *= scale[prow]; u *= scale[prow + 16]; }
     if (bias) { g += bias[prow]; u += bias[prow + 16]; }
-    c[(size_t)row * ldc + col] = silu_g(g) * u;
+    if (c_hi) store_planes(c_hi, c_lo, (size_t)row * ldcp + col, silu_g(g) * u);
+    else c[(size_t)row * ldc + col] = silu_g(g) * u;
     return;
   }
   float v = 0.f;
@@ -478,7 +498,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   if (bias) v += bias[col];
   if (epilogue == CHATTS_EPI_GELU) v = gelu_erf_f(v);
   if (epilogue == CHATTS_EPI_RESID) v = resid[(size_t)row * ldc + col] + v;
-  c[(size_t)row * ldc + col] = v;
+  if (c_hi) store_planes(c_hi, c_lo, (size_t)row * ldcp + col, v);
+  else c[(size_t)row * ldc + col] = v;
 }
 
 static int gemm_env_int(const char* name, int dflt) {
@@ -573,6 +594,7 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
   p.epilogue = a->epilogue; p.k_per_split = kps; p.direct = sk == 1;
   p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8;
+  p.c_hi = a->c_hi; p.c_lo = a->c_lo; p.ldcp = a->ld_cplanes;
   if (sk > 1) {
     const size_t need = (size_t)sk * a->m * a->n * sizeof(float);
     CHATTS_REQUIRE(a->workspace && a->workspace_bytes >= need, CHATTS_E_WORKSPACE,
@@ -607,7 +629,7 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
     const size_t total = (size_t)a->m * ncols;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float*>(a->workspace), sk, a->m, a->n, a->bias, a->resid, a->c,
-                       a->ldc, a->epilogue, a->w8 ? a->w8_scale : nullptr);
+                       a->ldc, a->epilogue, a->w8 ? a->w8_scale : nullptr, a->c_hi, a->c_lo, a->ld_cplanes);
     CHATTS_CHECK_LAUNCH("splitk_epilogue");
   }
   return CHATTS_OK;

@@ -226,8 +226,8 @@ class ChatTSForCausalLM:
             "qkv": torch.zeros((self.t_max, qkv_n), **f32), "attn": torch.zeros((self.t_max, plan.nq * d), **f32),
             "act": torch.zeros((self.t_max, plan.inter), **f32), "delta": torch.zeros((self.t_max, H), **f32),
             "logits": torch.zeros(plan.vocab, **f32),
-            # bf16 hi / lo planes of the current projection input (prefill: LDS-DMA GEMM operands)
-            "planes": torch.zeros((2, self.t_max, max(H, plan.nq * d, plan.inter)), dtype=torch.bfloat16, device=dev),
+            # two pairs of bf16 hi / lo planes (prefill: LDS-DMA GEMM operands; pair 0 = projection input, pair 1 = SwiGLU out)
+            "planes": torch.zeros((4, self.t_max, max(H, plan.nq * d, plan.inter)), dtype=torch.bfloat16, device=dev),
             "ws": torch.zeros(ws_bytes, dtype=torch.uint8, device=dev),
             # decode-loop state lives on the device so a captured step can be replayed
             "pos_all": torch.zeros(MB, dtype=torch.int32, device=dev), "step_all": torch.zeros(MB, dtype=torch.int32, device=dev),
@@ -261,7 +261,8 @@ class ChatTSForCausalLM:
                                  act=_lib.ptr(B["act"]), delta=_lib.ptr(B["delta"]), logits=_lib.ptr(B["logits"]),
                                  workspace=_lib.ptr(B["ws"]), workspace_bytes=ws_bytes, t_max=self.t_max,
                                  max_batch=self.max_batch, planes_hi=_lib.ptr(B["planes"][0]),
-                                 planes_lo=_lib.ptr(B["planes"][1]))
+                                 planes_lo=_lib.ptr(B["planes"][1]), planes2_hi=_lib.ptr(B["planes"][2]),
+                                 planes2_lo=_lib.ptr(B["planes"][3]))
         h = lib.chatts_decoder_create(C.byref(dc), C.byref(dw), C.byref(db))
         if not h:
             raise _lib.ChattsError(-1, lib.chatts_last_error().decode())

@@ -133,6 +133,11 @@ typedef struct ChattsLinearArgs {
   const chatts_bf16* a_hi;
   const chatts_bf16* a_lo;
   int ld_planes;
+  /* optional (M > 1): write the result as bf16 hi / lo planes [M, ld_cplanes] - the operand format of the next
+   * projection - instead of float32 `c` (which may then be NULL).  Same values as chatts_split_bf16x2(c). */
+  chatts_bf16* c_hi;
+  chatts_bf16* c_lo;
+  int ld_cplanes;
 } ChattsLinearArgs;
 size_t chatts_linear_workspace(int m, int n, int k);
 /* hi = bf16(x) (RNE), lo = bf16(x - hi): the operand split of the bf16x2 GEMM, done once per activation matrix. */
@@ -161,6 +166,9 @@ int chatts_embed_merge(const int64_t* ids_dev, const int64_t* ids_host, int t, c
 /* y[t,:] = w * (x[t,:] * rsqrt(mean(x[t,:]^2) + eps))            (Qwen2RMSNorm.forward) */
 int chatts_rmsnorm(const float* x, const float* w, float* y, int t, int hidden, float eps,
                    chatts_stream_t stream);
+/* The same, with the result written as bf16 hi / lo planes (== chatts_split_bf16x2(chatts_rmsnorm(x))). */
+int chatts_rmsnorm_planes(const float* x, const float* w, chatts_bf16* hi, chatts_bf16* lo, int ld_planes, int t, int hidden,
+                          float eps, chatts_stream_t stream);
 
 typedef struct ChattsKvCache {
   float* k;                /* [n_kv, max_ctx, 128] float32 of ONE layer of ONE sequence */
@@ -283,10 +291,13 @@ typedef struct ChattsDecoderBuffers {
   size_t workspace_bytes;
   int t_max;
   int max_batch;      /* KV caches are [max_batch, n_layers, n_kv, max_ctx, 128]; 0 or 1 = single sequence */
-  /* optional: bf16 hi / lo planes of the current projection input, each [T_max, max(H, n_q*128, inter)]
-   * (ChattsLinearArgs.a_hi / a_lo).  When both are set, prefill chunks of >= 96 rows run the LDS-DMA GEMM. */
+  /* optional: two pairs of bf16 hi / lo planes, each plane [T_max, max(H, n_q*128, inter)] (ChattsLinearArgs.a_hi /
+   * a_lo / c_hi / c_lo).  When all four are set, prefill chunks of >= 96 rows run the LDS-DMA GEMM: the RMSNorms and
+   * the SwiGLU epilogue write planes directly (pair 0 = projection input, pair 1 = gate_up output). */
   chatts_bf16* planes_hi;
   chatts_bf16* planes_lo;
+  chatts_bf16* planes2_hi;
+  chatts_bf16* planes2_lo;
 } ChattsDecoderBuffers;
 
 typedef struct ChattsDecoder ChattsDecoder;  /* opaque; host memory only */

@@ -277,6 +277,47 @@ def test_gemm_dma_equals_register_staged_bitwise(lib, sk, monkeypatch):
         assert torch.equal(_linear_planes(lib, a, w, bias, r, epi), _linear(lib, a, w, bias, r, epi))
 
 
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k,planes_in", [(300, 640, 1536, True), (130, 1024, 768, True), (40, 512, 256, False),
+                                             (17, 256, 2048, False)])
+def test_linear_plane_output_equals_split_of_f32_output(lib, epi, m, n, k, planes_in):
+    """c_hi / c_lo: the epilogue writes what chatts_split_bf16x2 would make of the float32 result (direct and split-K)."""
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + k + epi, scale=2.0)
+    r = resid if epi == _lib.EPI_RESID else None
+    want = _linear_planes(lib, a, w, bias, r, epi) if planes_in else _linear(lib, a, w, bias, r, epi)
+    want_hi, want_lo = _split_planes(lib, want)
+    ncols = want.shape[1]
+    hi = torch.full((m, ncols + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lo = torch.full((m, ncols + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ahi, alo = _split_planes(lib, a)
+    wsb = int(lib.chatts_linear_workspace(m, n, k))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    la = _lib.LinearArgs(a=a.data_ptr(), w=w.data_ptr(), bias=_lib.ptr(bias), resid=_lib.ptr(r), c=None, norm_w=None,
+                         norm_eps=0.0, m=m, n=n, k=k, lda=k, ldw=k, ldc=ncols, epilogue=epi, workspace=ws.data_ptr(),
+                         workspace_bytes=wsb, c_hi=hi.data_ptr(), c_lo=lo.data_ptr(), ld_cplanes=ncols + 8)
+    if planes_in:
+        la.a_hi, la.a_lo, la.ld_planes = ahi.data_ptr(), alo.data_ptr(), k
+    _lib.check(lib.chatts_linear(la, st()))
+    torch.cuda.synchronize()
+    assert torch.equal(hi[:, :ncols], want_hi) and torch.equal(lo[:, :ncols], want_lo)
+    assert torch.isnan(hi[:, ncols:].float()).all()                      # padding columns untouched
+
+
+def test_rmsnorm_planes_equals_split_of_rmsnorm(lib):
+    g = torch.Generator().manual_seed(11)
+    t, h = 37, 5120
+    x = (torch.randn((t, h), generator=g) * 3).to(DEV)
+    w = (1 + 0.1 * torch.randn(h, generator=g)).to(DEV)
+    y = torch.empty_like(x)
+    _lib.check(lib.chatts_rmsnorm(x.data_ptr(), w.data_ptr(), y.data_ptr(), t, h, 1e-6, st()))
+    hi = torch.full((t, h + 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lo = torch.full((t, h + 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.chatts_rmsnorm_planes(x.data_ptr(), w.data_ptr(), hi.data_ptr(), lo.data_ptr(), h + 64, t, h, 1e-6, st()))
+    torch.cuda.synchronize()
+    want_hi, want_lo = _split_planes(lib, y)
+    assert torch.equal(hi[:, :h], want_hi) and torch.equal(lo[:, :h], want_lo)
+
+
 def test_gemm_dma_small_m_and_odd_k_fall_back(lib):
     a, w, bias, resid, _ = _rand_problem(40, 256, 512, seed=9)
     assert torch.equal(_linear_planes(lib, a, w, bias, None, _lib.EPI_NONE), _linear(lib, a, w, bias, None, _lib.EPI_NONE))
