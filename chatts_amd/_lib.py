@@ -50,6 +50,11 @@ class LayerWeights(C.Structure):
                 ("down8_scale", c_void_p)]
 
 
+class SamplingArgs(C.Structure):
+    _fields_ = [("temperature", c_float), ("top_k", c_int), ("top_p", c_float), ("seed", c_uint32), ("n_kept", c_void_p),
+                ("kept_mass", c_void_p)]
+
+
 class DecoderConfig(C.Structure):
     _fields_ = [("hidden", c_int), ("n_layers", c_int), ("n_q", c_int), ("n_kv", c_int), ("head_dim", c_int),
                 ("inter", c_int), ("vocab_local", c_int64), ("vocab_offset", c_int64), ("rms_eps", c_float),
@@ -100,8 +105,11 @@ SIGNATURES = {
                                                 c_void_p, c_size_t, c_void_p]),
     "chatts_argmax_batched": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_int, c_void_p]),
+    "chatts_sample_batched": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, C.POINTER(SamplingArgs), c_void_p, c_void_p,
+                                      c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     "chatts_embed_token_batched": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "chatts_decoder_select_sequence": (c_int, [c_void_p, c_int]),
+    "chatts_decoder_set_sampling": (c_int, [c_void_p, C.POINTER(SamplingArgs)]),
     "chatts_decoder_layer_part_batched": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "chatts_decoder_decode_step_batched": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                    c_int64, c_void_p, c_int, c_void_p]),

@@ -23,6 +23,8 @@ struct ChattsDecoder {
   std::vector<ChattsLayerWeights> layers;
   ChattsDecoderBuffers b;
   int cur_seq = 0;          // sequence (KV-cache slot) the single-sequence entry points operate on
+  bool sampling = false;    // token selection of the decode steps: greedy argmax, or the sampler with `sa`
+  ChattsSamplingArgs sa{};
 };
 
 extern "C" size_t chatts_linear_workspace(int m, int n, int k) { return gemm_workspace(m, n, k); }
@@ -133,6 +135,16 @@ static int norm_into(ChattsDecoder* d, const float* norm_w, ChattsLinearArgs* la
   }
   la->a = d->b.xn;
   return chatts_rmsnorm(d->b.x, norm_w, d->b.xn, la->m, la->k, d->cfg.rms_eps, stream);
+}
+
+extern "C" int chatts_decoder_set_sampling(ChattsDecoder* d, const ChattsSamplingArgs* sa) {
+  CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_set_sampling: null decoder");
+  if (sa) CHATTS_REQUIRE(sa->temperature > 0.f && sa->top_p > 0.f, CHATTS_E_BADARG,
+                         "decoder_set_sampling: temperature %g / top_p %g must be positive (pass NULL for greedy)",
+                         (double)sa->temperature, (double)sa->top_p);
+  d->sampling = sa != nullptr;
+  if (sa) d->sa = *sa;
+  return CHATTS_OK;
 }
 
 extern "C" int chatts_decoder_select_sequence(ChattsDecoder* d, int seq) {
@@ -299,6 +311,9 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden;
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+  if (d->sampling)
+    return chatts_sample_batched(logits_all, batch, c.vocab_local, c.vocab_local, c.vocab_offset, &d->sa, token_dev,
+                                 token_logit_dev, out_tokens, out_stride, step_dev, pos_dev, c.max_ctx - 1, stream);
   return chatts_argmax_batched(logits_all, batch, c.vocab_local, c.vocab_local, c.vocab_offset, token_dev, token_logit_dev,
                                out_tokens, out_stride, step_dev, pos_dev, c.max_ctx - 1, stream);
 }
@@ -336,7 +351,12 @@ extern "C" int chatts_decoder_decode_step(ChattsDecoder* d, int32_t* pos_dev, in
     if ((rc = chatts_decoder_layer_part(d, l, 1, 1, 0, pos_dev, n_splits, stream)) != 0) return rc;
   }
   if ((rc = chatts_decoder_logits(d, 0, stream)) != 0) return rc;
-  if ((rc = chatts_argmax(d->b.logits, d->cfg.vocab_local, d->cfg.vocab_offset, token_dev, token_logit_dev, out_tokens,
-                          step_dev, pos_dev, stream)) != 0) return rc;
+  if (d->sampling)
+    rc = chatts_sample_batched(d->b.logits, 1, d->cfg.vocab_local, d->cfg.vocab_local, d->cfg.vocab_offset, &d->sa, token_dev,
+                               token_logit_dev, out_tokens, 0, step_dev, pos_dev, 0, stream);
+  else
+    rc = chatts_argmax(d->b.logits, d->cfg.vocab_local, d->cfg.vocab_offset, token_dev, token_logit_dev, out_tokens, step_dev,
+                       pos_dev, stream);
+  if (rc) return rc;
   return chatts_embed_token(token_dev, d->w.embed, d->cfg.vocab_offset, d->cfg.vocab_local, d->cfg.hidden, d->b.x, stream);
 }

@@ -10,10 +10,13 @@ import numpy as np
 
 
 class SamplingParams:
-    def __init__(self, max_tokens=16, temperature=0.0, top_p=1.0, stop_token_ids=None, ignore_eos=False, **kw):
+    def __init__(self, max_tokens=16, temperature=0.0, top_p=1.0, top_k=-1, seed=None, stop_token_ids=None,
+                 ignore_eos=False, **kw):
         self.max_tokens = int(max_tokens)
-        self.temperature = temperature
+        self.temperature = temperature          # 0 = greedy (this engine's default; the reference's drivers pass 0.2 / 0.5)
         self.top_p = top_p
+        self.top_k = top_k                      # -1 / 0 = off, like vLLM
+        self.seed = seed
         self.stop_token_ids = list(stop_token_ids or [])
         self.ignore_eos = ignore_eos
 
@@ -36,6 +39,7 @@ class LLM:
         from .modeling import ChatTSForCausalLM
         from .processing import ChatTSProcessor
         from .tp import Comm, LocalComm
+        self._seed = int(seed)              # also the default seed of sampled generation (SamplingParams.seed overrides)
         if comm is None:
             comm = Comm() if tensor_parallel_size > 1 else LocalComm()
         if comm.world != tensor_parallel_size:
@@ -61,8 +65,8 @@ class LLM:
 
     def generate(self, prompts, sampling_params=None, use_tqdm=False):
         sp = sampling_params or SamplingParams()
-        if sp.temperature not in (0, 0.0, None):
-            raise NotImplementedError("only greedy decoding (temperature=0) is implemented")
+        self.model.set_sampling(sp.temperature or 0.0, max(int(sp.top_k or 0), 0), sp.top_p,
+                                self._seed if sp.seed is None else sp.seed)
         if isinstance(prompts, (str, dict)):
             prompts = [prompts]
         import torch

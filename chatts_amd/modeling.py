@@ -414,21 +414,59 @@ class ChatTSForCausalLM:
             last = n
         return last
 
-    def _first_token(self, last_rows):
-        """logits of the last prompt row -> greedy token -> next input embedding in x[0]."""
-        lib, st, B = self.lib, _lib.stream_ptr(), self.buf
-        _lib.check(lib.chatts_decoder_logits(self._decoder, last_rows - 1, st))
-        _lib.check(lib.chatts_argmax(_lib.ptr(B["logits"]), self.plan.vocab, self.plan.v0, _lib.ptr(B["token"]),
-                                     _lib.ptr(B["token_logit"]), None, None, None, st))
-        self._finish_token()
+    def set_sampling(self, temperature=0.0, top_k=0, top_p=1.0, seed=0):
+        """Token selection of every following step: greedy (temperature 0 / None, the default) or temperature / top-k /
+        top-p sampling on the GPU (chatts_sample_batched).  Same seed + same prompt => same tokens."""
+        if not temperature:
+            args = None
+        else:
+            if temperature < 0 or not (0.0 < top_p <= 1.0):
+                raise ValueError(f"temperature={temperature} must be >= 0 and top_p={top_p} in (0, 1]")
+            args = _lib.SamplingArgs(temperature=float(temperature), top_k=int(top_k or 0), top_p=float(top_p),
+                                     seed=int(seed) & 0xFFFFFFFF, n_kept=None, kept_mass=None)
+        key = None if args is None else (args.temperature, args.top_k, args.top_p, args.seed)
+        if key == getattr(self, "_sampling_key", None):
+            return
+        _lib.check(self.lib.chatts_decoder_set_sampling(self._decoder, None if args is None else C.byref(args)))
+        self._sampling, self._sampling_key = args, key
+        self._graph = None               # the captured steps have the old selection kernel baked in
+        self._graph_batched = None
 
-    def _finish_token(self):
-        """TP: pick the global argmax; then append to out_tokens, bump step, load the next embedding."""
-        B = self.buf
-        if self.plan.world > 1:
+    def _select_token(self):
+        """logits of this rank -> next token in B['token'] (appended to out_tokens, step bumped) on every rank."""
+        lib, st, B = self.lib, _lib.stream_ptr(), self.buf
+        sa = getattr(self, "_sampling", None)
+        if self.plan.world == 1:
+            if sa is None:
+                _lib.check(lib.chatts_argmax(_lib.ptr(B["logits"]), self.plan.vocab, self.plan.v0, _lib.ptr(B["token"]),
+                                             _lib.ptr(B["token_logit"]), _lib.ptr(B["out_tokens"]), _lib.ptr(B["step"]),
+                                             None, st))
+            else:
+                _lib.check(lib.chatts_sample_batched(_lib.ptr(B["logits"]), 1, self.plan.vocab, self.plan.vocab, self.plan.v0,
+                                                     C.byref(sa), _lib.ptr(B["token"]), _lib.ptr(B["token_logit"]),
+                                                     _lib.ptr(B["out_tokens"]), 0, _lib.ptr(B["step"]), None, 0, st))
+            return
+        if sa is None:      # TP greedy: one (logit, index) pair per rank instead of the [V / W] logits
+            _lib.check(lib.chatts_argmax(_lib.ptr(B["logits"]), self.plan.vocab, self.plan.v0, _lib.ptr(B["token"]),
+                                         _lib.ptr(B["token_logit"]), None, None, None, st))
             B["token"].copy_(self.comm.argmax_pair(B["token_logit"], B["token"]))
-        B["out_tokens"].index_copy_(0, B["step"].to(torch.int64), B["token"])
-        B["step"] += 1
+            B["out_tokens"].index_copy_(0, B["step"].to(torch.int64), B["token"])
+            B["step"] += 1
+            return
+        # TP sampling: every rank draws from the gathered full-vocabulary logits with the same seed -> the same token
+        full = self.comm.all_gather_cat(B["logits"])
+        _lib.check(lib.chatts_sample_batched(_lib.ptr(full), 1, full.numel(), full.numel(), 0, C.byref(sa),
+                                             _lib.ptr(B["token"]), _lib.ptr(B["token_logit"]), _lib.ptr(B["out_tokens"]), 0,
+                                             _lib.ptr(B["step"]), None, 0, st))
+
+    def _first_token(self, last_rows):
+        """logits of the last prompt row -> first generated token -> next input embedding in x[0]."""
+        _lib.check(self.lib.chatts_decoder_logits(self._decoder, last_rows - 1, _lib.stream_ptr()))
+        self._select_token()
+        self._load_token_embedding()
+
+    def _load_token_embedding(self):
+        B = self.buf
         _lib.check(self.lib.chatts_embed_token(_lib.ptr(B["token"]), _lib.ptr(self._tensors["embed"]), 0,
                                                self.config.vocab_size, self.config.hidden_size, _lib.ptr(B["x"]),
                                                _lib.stream_ptr()))
@@ -442,10 +480,9 @@ class ChatTSForCausalLM:
             return
         self._run_layers(1, 0, pos_dev=B["pos"], n_splits=self.n_splits)
         _lib.check(lib.chatts_decoder_logits(self._decoder, 0, st))
-        _lib.check(lib.chatts_argmax(_lib.ptr(B["logits"]), self.plan.vocab, self.plan.v0, _lib.ptr(B["token"]),
-                                     _lib.ptr(B["token_logit"]), None, None, None, st))
         B["pos"] += 1
-        self._finish_token()
+        self._select_token()
+        self._load_token_embedding()
 
     def decode_step(self):
         """One greedy token.  TP=1: a hipGraph of the whole step (captured on first use) is replayed."""
@@ -540,10 +577,19 @@ class ChatTSForCausalLM:
         _lib.check(self.lib.chatts_decoder_logits(self._decoder, last - 1, st))
         B["pos_all"][slot] = T
         B["step_all"][slot] = 0
-        _lib.check(self.lib.chatts_argmax_batched(
-            _lib.ptr(B["logits"]), 1, self.plan.vocab, self.plan.vocab, self.plan.v0,
-            B["token_all"][slot:].data_ptr(), B["token_logit_all"][slot:].data_ptr(), B["out_tokens_all"][slot].data_ptr(),
-            B["out_tokens_all"].shape[1], B["step_all"][slot:].data_ptr(), None, 0, st))
+        sa = getattr(self, "_sampling", None)
+        if sa is None:
+            _lib.check(self.lib.chatts_argmax_batched(
+                _lib.ptr(B["logits"]), 1, self.plan.vocab, self.plan.vocab, self.plan.v0,
+                B["token_all"][slot:].data_ptr(), B["token_logit_all"][slot:].data_ptr(), B["out_tokens_all"][slot].data_ptr(),
+                B["out_tokens_all"].shape[1], B["step_all"][slot:].data_ptr(), None, 0, st))
+        else:   # the batched steps draw with (seed, slot, step); this single-row call would see slot 0: fold the slot into the seed
+            sa1 = _lib.SamplingArgs(temperature=sa.temperature, top_k=sa.top_k, top_p=sa.top_p,
+                                    seed=(sa.seed ^ (0x51ED27 * (slot + 1))) & 0xFFFFFFFF, n_kept=None, kept_mass=None)
+            _lib.check(self.lib.chatts_sample_batched(
+                _lib.ptr(B["logits"]), 1, self.plan.vocab, self.plan.vocab, self.plan.v0, C.byref(sa1),
+                B["token_all"][slot:].data_ptr(), B["token_logit_all"][slot:].data_ptr(), B["out_tokens_all"][slot].data_ptr(),
+                B["out_tokens_all"].shape[1], B["step_all"][slot:].data_ptr(), None, 0, st))
         self.select_sequence(0)
         return T
 
@@ -662,13 +708,18 @@ class ChatTSForCausalLM:
 
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, timeseries=None, max_new_tokens=64, max_length=None,
-                 streamer=None, eos_token_id=None, do_sample=False, temperature=None, synced_gpus=False,
-                 valid_lengths=None, **kw):
-        """model.generate(**inputs, max_new_tokens=...) -> LongTensor [B, T_in + new], greedy
-        (README.md:102, demo_hf.ipynb cell 5).  Rows start with the un-expanded input_ids; shorter rows are
+                 streamer=None, eos_token_id=None, do_sample=False, temperature=None, top_k=None, top_p=None,
+                 seed=0, synced_gpus=False, valid_lengths=None, **kw):
+        """model.generate(**inputs, max_new_tokens=...) -> LongTensor [B, T_in + new] (README.md:102, demo_hf.ipynb
+        cell 5).  Greedy unless do_sample=True, like HF; with do_sample the HF GenerationConfig defaults apply to what is
+        not given (temperature 1.0, top_k 50, top_p 1.0; the reference's deepspeed driver passes temperature=0.2,
+        inference_tsmllm_deepspeed.py:95-100).  Rows start with the un-expanded input_ids; shorter rows are
         right-padded with pad_token_id.  A flat `timeseries` tensor is consumed across the batch in prompt order."""
         if do_sample:
-            raise NotImplementedError("only greedy decoding is implemented (SURVEY.md section 8f item 4)")
+            self.set_sampling(1.0 if temperature is None else temperature, 50 if top_k is None else top_k,
+                              1.0 if top_p is None else top_p, seed)
+        else:
+            self.set_sampling(0.0)
         cfg = self.config
         ids = input_ids if isinstance(input_ids, torch.Tensor) else torch.tensor(input_ids)
         if ids.dim() == 1:

@@ -58,6 +58,14 @@ class Comm:
         cand = torch.where(vals == best, idxs, torch.full_like(idxs, torch.iinfo(torch.int64).max))
         return cand.min().reshape(1)
 
+    def all_gather_cat(self, t):
+        """Concatenation of every rank's 1-D tensor in rank order (vocab-parallel logits -> full vocabulary)."""
+        if self.world == 1:
+            return t
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t.contiguous(), group=self.group)
+        return torch.cat(parts)
+
     def barrier(self):
         if self.world > 1:
             self.dist.barrier(group=self.group)

@@ -230,6 +230,28 @@ int chatts_embed_token_batched(const int64_t* token_dev, int batch, const chatts
                                int64_t vocab_rows, int hidden, float* out /* [batch, hidden] */, chatts_stream_t stream);
 
 /* x[h] = float(table[*token, h]) : next-step input embedding, token id read on the device. */
+/* ---------------------------------------------------------------------------------------------
+ * Sampling (temperature / top-k / top-p): what the reference's evaluation drivers ask of vLLM / HF -
+ * SamplingParams(temperature=0.2) (chatts/utils/inference_tsmllm_vllm.py:43-46), temperature=0.5 + top_p=0.95
+ * (chatts/utils/llm_utils.py:94,153).  Rule (vLLM's, restated in oracle/sampler.py): logits / temperature; keep the
+ * top_k largest; of those the smallest set of most probable tokens whose mass reaches top_p; renormalise; draw.
+ * Ties at either cut are kept.  The uniform variate is a counter-based hash of (seed, sequence, step_dev[sequence]),
+ * so a captured decode step replays with fresh draws and the same seed reproduces the same tokens.
+ * Same side effects as chatts_argmax_batched (token, logit, out_tokens[step], ++step, ++pos).
+ * temperature == 0 is greedy decoding: call chatts_argmax.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ChattsSamplingArgs {
+  float temperature;   /* > 0 */
+  int top_k;           /* <= 0 or >= vocab: off */
+  float top_p;         /* (0, 1]; 1 = off */
+  uint32_t seed;
+  int32_t* n_kept;     /* optional diagnostics [batch]: size of the renormalised set ...            */
+  float* kept_mass;    /* ... and its share of the (top-k) probability mass                          */
+} ChattsSamplingArgs;
+int chatts_sample_batched(const float* logits, int batch, int64_t logits_stride, int64_t vocab, int64_t vocab_offset,
+                          const ChattsSamplingArgs* args, int64_t* token, float* token_logit, int64_t* out_tokens,
+                          int64_t out_stride, int32_t* step_dev, int32_t* pos_dev, int pos_limit, chatts_stream_t stream);
+
 int chatts_embed_token(const int64_t* token_dev, const chatts_bf16* table, int64_t vocab_offset,
                        int64_t vocab_rows, int hidden, float* out, chatts_stream_t stream);
 
@@ -315,6 +337,9 @@ int chatts_decoder_layer_part(ChattsDecoder*, int layer, int part, int t, int po
                               const int32_t* pos0_dev, int n_splits, chatts_stream_t stream);
 int chatts_residual_add(float* x, const float* delta, int64_t n, chatts_stream_t stream);
 
+/* Token selection of chatts_decoder_decode_step(_batched): NULL (default) = greedy argmax; otherwise the sampler above
+ * with these parameters (copied).  Changing it invalidates any hipGraph captured over a decode step. */
+int chatts_decoder_set_sampling(ChattsDecoder*, const ChattsSamplingArgs* args_or_null);
 /* KV-cache slot (sequence) used by the single-sequence entry points (layer_part, prefill, decode_step). */
 int chatts_decoder_select_sequence(ChattsDecoder*, int seq);
 /* Batched decode (continuous batching): `batch` sequences advance one token each; row b of

@@ -20,7 +20,7 @@ def split_state_dict(sd):
     return ts, dec
 
 
-def generate(cfg, sd, ids, series, max_new_tokens, num_layers=None):
+def generate(cfg, sd, ids, series, max_new_tokens, num_layers=None, forced_tokens=None):
     """cfg: chatts_amd ChatTSConfig-like (uses .ts, .ts_token_start_index, .oracle_dict()).
     ids: un-expanded prompt ids; series: [N, 2*Lmax, 1] float array or None.
     Returns dict(tokens, logits (list of [V] per step), embeds [T,H], ts_features [P,H], expanded_ids)."""
@@ -34,5 +34,5 @@ def generate(cfg, sd, ids, series, max_new_tokens, num_layers=None):
     table = dec["model.embed_tokens.weight"].numpy()
     emb = protocol.merge_embeddings(full, table, feats, ts0)
     m = QwenOracle(cfg.oracle_dict(), dec, num_layers=num_layers)
-    toks, logits = m.greedy(torch.from_numpy(emb), max_new_tokens)
+    toks, logits = m.greedy(torch.from_numpy(emb), max_new_tokens, forced_tokens=forced_tokens)
     return dict(tokens=toks, logits=logits, embeds=emb, ts_features=feats, expanded_ids=full, patch_cnt=pc)

@@ -119,12 +119,14 @@ class QwenOracle:
         return h @ self.w["lm_head.weight"].T
 
     @torch.no_grad()
-    def greedy(self, prefill_embeds, max_new_tokens, eos_ids=()):
-        """Greedy decode after a prefill with embeddings -> (token ids, per-step last logits)."""
+    def greedy(self, prefill_embeds, max_new_tokens, eos_ids=(), forced_tokens=None):
+        """Greedy decode after a prefill with embeddings -> (token ids, per-step last logits).
+        forced_tokens (teacher forcing): follow this continuation instead of the argmax - the per-step logits are then
+        the ones a sampler saw along that continuation."""
         logits = self.forward_embeds(prefill_embeds)[-1]
         toks, all_logits = [], [logits]
-        for _ in range(max_new_tokens):
-            t = int(torch.argmax(logits))
+        for i in range(max_new_tokens):
+            t = int(torch.argmax(logits)) if forced_tokens is None else int(forced_tokens[i])
             toks.append(t)
             if t in eos_ids or len(toks) == max_new_tokens:
                 break

@@ -392,3 +392,55 @@ def test_fp8_weight_format_matches_oracle_on_dequantised_weights():
     toks, lg = model.generate_one(ids, inputs["timeseries"].cuda(), proc.last_lengths, 10, return_logits=True)
     assert rel_err(lg.cpu().numpy(), want["logits"][0].numpy()) < TIGHT_TOL
     assert toks == want["tokens"]
+
+
+def test_sampled_generation_is_valid_reproducible_and_graph_safe():
+    """do_sample: every drawn token is the one oracle/sampler.py's rule selects from THAT step's logits (teacher forcing
+    through the CPU decoder oracle), the hipGraph replay draws the same tokens as the eager path, the seed matters."""
+    from oracle import sampler as osamp
+    cfg, proc, inputs, model, sd = _setup("tiny-qwen2", [100, 40])
+    ids = inputs["input_ids"][0].tolist()
+    ser = inputs["timeseries"].cuda()
+    T, K, P, new = 0.8, 50, 0.95, 12
+    runs = {}
+    for use_graph in (True, False):
+        model.use_graph = use_graph
+        model.set_sampling(T, K, P, seed=21)
+        runs[use_graph] = model.generate_one(ids, ser, proc.last_lengths, new, eos_token_id=None)
+    assert runs[True] == runs[False]
+    toks = runs[True]
+    model.set_sampling(T, K, P, seed=22)
+    other = model.generate_one(ids, ser, proc.last_lengths, new, eos_token_id=None)
+    assert other != toks
+    model.set_sampling(0.0)                                    # back to greedy: the oracle's greedy tokens again
+    greedy = pipeline.generate(cfg, sd, ids, inputs["timeseries"].numpy(), 4)
+    assert model.generate_one(ids, ser, proc.last_lengths, 4, eos_token_id=None) == greedy["tokens"]
+    assert toks != greedy["tokens"] + toks[4:]
+    # teacher forcing: the oracle's logits along the SAMPLED continuation
+    want = pipeline.generate(cfg, sd, ids, inputs["timeseries"].numpy(), new, forced_tokens=toks)
+    for step, tok in enumerate(toks):
+        lg = want["logits"][step].numpy().astype(np.float64)
+        p, _ = osamp.kept_set(lg, T, K, P)
+        assert p[tok] > 0 or np.isclose(np.exp((lg[tok] - lg.max()) / T), np.exp((lg[p > 0].min() - lg.max()) / T), rtol=2e-3)
+        u = osamp.uniform24(21, 0, step) / float(1 << 24)
+        cum = np.cumsum(p) / p.sum()
+        assert cum[tok] - p[tok] / p.sum() - 2e-3 <= u <= cum[tok] + 2e-3
+
+
+def test_sampled_batch_and_llm_surface():
+    from chatts_amd import LLM, SamplingParams
+    cfg = cfgmod.preset("tiny-qwen2")
+    llm = LLM(cfg, tensor_parallel_size=1, max_model_len=512, seed=3, max_num_seqs=3)
+    rng = np.random.default_rng(5)
+    reqs = [{"prompt": chat_prompt([L]), "multi_modal_data": {"timeseries": [random_walk_series(rng, L).tolist()]}} for L in (64, 30, 100, 17)]
+    sp = SamplingParams(max_tokens=8, temperature=0.5, top_p=0.95, ignore_eos=True, seed=7)      # llm_utils.py:94 settings
+    a = [o.outputs[0].token_ids for o in llm.generate(reqs, sampling_params=sp)]
+    b = [o.outputs[0].token_ids for o in llm.generate(reqs, sampling_params=sp)]
+    assert a == b and all(len(t) == 8 for t in a)
+    g = [o.outputs[0].token_ids for o in llm.generate(reqs, sampling_params=SamplingParams(max_tokens=8, ignore_eos=True))]
+    assert g != a
+    hot = [o.outputs[0].token_ids for o in llm.generate(reqs, sampling_params=SamplingParams(max_tokens=8, temperature=1.5, ignore_eos=True, seed=7))]
+    assert hot != a
+    # temperature -> 0+ with top_k = 1 is greedy
+    k1 = [o.outputs[0].token_ids for o in llm.generate(reqs, sampling_params=SamplingParams(max_tokens=8, temperature=0.7, top_k=1, ignore_eos=True))]
+    assert k1 == g

@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 
 from chatts_amd import config as cfgmod, synth
 from chatts_amd.tp import Comm, ShardPlan
-from oracle import qwen_decoder as qd, synth as osynth
+from oracle import qwen_decoder as qd, sampler as osamp, synth as osynth
 
 
 def _free_port():
@@ -82,10 +82,15 @@ def _worker(rank, world, port, q):
         tok = comm.argmax_pair(val.reshape(1), (idx + plan.v0).reshape(1))
         # tie rule: equal maxima on both ranks -> the lowest token id wins
         tie = comm.argmax_pair(torch.tensor([1.0]), torch.tensor([100 + 7 * (world - rank)]))
+        # sampling under TP: every rank gathers the vocab-parallel logits in rank order and draws from the full vocabulary
+        # with the same (seed, sequence, step) -> the same token everywhere (here: the oracle's draw on the gathered row)
+        full = comm.all_gather_cat(logits.contiguous())
+        drawn = osamp.sample(full.numpy(), 0.5, 50, 0.95, seed=9, seq=0, step=3)
         comm.barrier()
         if rank == 0:
             ref = qd.QwenOracle(cfg.oracle_dict(), sd).forward_embeds(x)
             q.put((int(tok), int(torch.argmax(ref[-1])), float((h - _ref_hidden(cfg, sd, x)).abs().max()), int(tie)))
+            q.put((float((full - ref[-1]).abs().max()), drawn, osamp.sample(ref[-1].numpy(), 0.5, 50, 0.95, seed=9, seq=0, step=3)))
             q.put(float(np.linalg.norm((logits - ref[-1][plan.v0:plan.v0 + plan.vocab]).numpy()) /
                         np.linalg.norm(ref[-1][plan.v0:plan.v0 + plan.vocab].numpy())))
     finally:
@@ -107,7 +112,9 @@ def test_tensor_parallel_plan_and_comm_gloo_world2():
         p.join(180)
         assert p.exitcode == 0
     tok, ref_tok, hid_err, tie = q.get(timeout=10)
+    gather_err, drawn, ref_drawn = q.get(timeout=10)
     rel = q.get(timeout=10)
+    assert gather_err < 1e-4 and drawn == ref_drawn
     assert tok == ref_tok
     assert hid_err < 1e-4
     assert rel < 1e-5
