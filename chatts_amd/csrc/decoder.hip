@@ -122,14 +122,16 @@ static ChattsKvCache layer_cache(const ChattsDecoder* d, int layer, int seq) {
   return c;
 }
 
-// Prefill chunks of >= 96 rows run the projections on the LDS-DMA GEMM, whose A operand is a pair of bf16 hi / lo planes.
-static bool planes_path(const ChattsDecoder* d, int m, int k) {
-  return d->b.planes_hi && d->b.planes_lo && d->b.planes2_hi && d->b.planes2_lo && m >= 96 && k % 64 == 0;
+// Projections whose A operand is a pair of bf16 hi / lo planes: prefill chunks of >= 96 rows (LDS-DMA GEMM) and batched
+// decode with 2..16 sequences on bf16 weights (weight-streaming kernel).
+static bool planes_path(const ChattsDecoder* d, int m, int k, bool fp8 = false) {
+  if (!(d->b.planes_hi && d->b.planes_lo && d->b.planes2_hi && d->b.planes2_lo) || k % 64 != 0) return false;
+  return m >= 96 || (m >= 2 && m <= 16 && !fp8);
 }
 
 // x -> RMSNorm -> la's input: planes written by the norm kernel itself (plane path) or float32 xn.
 static int norm_into(ChattsDecoder* d, const float* norm_w, ChattsLinearArgs* la, chatts_stream_t stream) {
-  if (planes_path(d, la->m, la->k)) {
+  if (planes_path(d, la->m, la->k, la->w8 != nullptr)) {
     la->a = nullptr; la->a_hi = d->b.planes_hi; la->a_lo = d->b.planes_lo; la->ld_planes = la->k;
     return chatts_rmsnorm_planes(d->b.x, norm_w, d->b.planes_hi, d->b.planes_lo, la->k, la->m, la->k, d->cfg.rms_eps, stream);
   }
@@ -248,12 +250,12 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   ChattsLinearArgs la;
   if (part == 0) {
     const int qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim;
-    if ((rc = chatts_rmsnorm(d->b.x, lw.input_norm, d->b.xn, batch, H, c.rms_eps, stream)) != 0) return rc;
     la = ChattsLinearArgs{};
-    la.a = d->b.xn; la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = batch; la.n = qkv_n; la.k = H;
+    la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = batch; la.n = qkv_n; la.k = H;
     la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
     la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+    if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, 0);
     if ((rc = chatts_attention_decode_batched(d->b.qkv, batch, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps,
@@ -264,22 +266,29 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
     la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+    if (planes_path(d, batch, la.k, la.w8 != nullptr)) {      // the attention kernel writes float32: split it
+      if ((rc = chatts_split_bf16x2(d->b.attn, batch, la.k, la.k, d->b.planes_hi, d->b.planes_lo, la.k, stream)) != 0) return rc;
+      la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k;
+    }
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
     return chatts_linear(&la, stream);
   }
-  if ((rc = chatts_rmsnorm(d->b.x, lw.post_norm, d->b.xn, batch, H, c.rms_eps, stream)) != 0) return rc;
   la = ChattsLinearArgs{};
-  la.a = d->b.xn; la.w = lw.gate_up; la.c = d->b.act; la.m = batch; la.n = 2 * c.inter; la.k = H;
+  la.w = lw.gate_up; la.c = d->b.act; la.m = batch; la.n = 2 * c.inter; la.k = H;
   la.lda = H; la.ldw = H; la.ldc = c.inter; la.epilogue = CHATTS_EPI_SWIGLU;
   la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  if ((rc = norm_into(d, lw.post_norm, &la, stream)) != 0) return rc;
+  const bool act_planes = planes_path(d, batch, c.inter, lw.down8 != nullptr) && planes_path(d, batch, H, lw.gate_up8 != nullptr);
+  if (act_planes) { la.c = nullptr; la.c_hi = d->b.planes2_hi; la.c_lo = d->b.planes2_lo; la.ld_cplanes = c.inter; }
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
   la = ChattsLinearArgs{};
   la.a = d->b.act; la.w = lw.down; la.m = batch; la.n = H; la.k = c.inter;
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
   la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  if (act_planes) { la.a = nullptr; la.a_hi = d->b.planes2_hi; la.a_lo = d->b.planes2_lo; la.ld_planes = c.inter; }
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
   return chatts_linear(&la, stream);
@@ -304,12 +313,12 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
     if ((rc = chatts_decoder_layer_part_batched(d, l, 0, batch, pos_dev, n_splits, stream)) != 0) return rc;
     if ((rc = chatts_decoder_layer_part_batched(d, l, 1, batch, pos_dev, n_splits, stream)) != 0) return rc;
   }
-  if ((rc = chatts_rmsnorm(d->b.x, d->w.final_norm, d->b.xn, batch, c.hidden, c.rms_eps, stream)) != 0) return rc;
   ChattsLinearArgs la{};
-  la.a = d->b.xn; la.w = d->w.lm_head; la.c = logits_all; la.m = batch; la.n = (int)c.vocab_local; la.k = c.hidden;
+  la.w = d->w.lm_head; la.c = logits_all; la.m = batch; la.n = (int)c.vocab_local; la.k = c.hidden;
   la.lda = c.hidden; la.ldw = c.hidden; la.ldc = (int)c.vocab_local; la.epilogue = CHATTS_EPI_NONE;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden;
+  if ((rc = norm_into(d, d->w.final_norm, &la, stream)) != 0) return rc;
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
   if (d->sampling)
     return chatts_sample_batched(logits_all, batch, c.vocab_local, c.vocab_local, c.vocab_offset, &d->sa, token_dev,

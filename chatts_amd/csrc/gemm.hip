@@ -440,6 +440,102 @@ __global__ __launch_bounds__(kDmaThreads) void gemm_dma_kernel(GemmParams p, con
   gemm_store<FM, FN, TM, TN, false>(p, acc, m0, n0, wm, wn, lane, blockIdx.z);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-streaming kernel for 2 <= M <= 16 (batched decode: M = sequences in flight).  At this M the projection is an
+// HBM stream of W, like the M = 1 GEMV, and what decides its rate is the SHAPE of the loads, not the MFMA work:
+// fetching W in the MFMA fragment pattern (16 rows x 64 B per wave instruction - what a BK = 32 tile does, in registers
+// or through LDS) tops out near 4.0-4.5 TB/s, the same bytes as 8 rows x 128 B (whole lines) stream at 5.2-5.7 TB/s
+// (profiles/r1_probe_weight_stream_patterns.txt, DBG=1 vs DBG=3).  So: tile 16 x 128 x 64, every operand staged by
+// LDS-DMA in whole-line pieces (the same 128-byte-row, XOR-swizzled layout as gemm_dma_kernel), a ring of NSTAGE
+// 20 KB stages so that 2 workgroups per CU keep 60-80 KB of W in flight, split-K over workgroups to fill the chip
+// (52 MB of o_proj weights are only 40 N-tiles).  A comes as bf16 hi / lo planes ([M, K], M <= 16).
+constexpr int kStreamBN = 128, kStreamBK = 64, kStreamStage = 2 * 16 * 128 + kStreamBN * 128;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else static_assert(N == 0, "add the vmcnt literal");
+}
+
+template <int NSTAGE>
+__global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const uint16_t* __restrict__ a_hi,
+                                                          const uint16_t* __restrict__ a_lo, int ldp) {
+  constexpr int BN = kStreamBN, BK = kStreamBK, STAGE = kStreamStage, A_PLANE = 16 * 128;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * p.k_per_split;
+  int kend = kbeg + p.k_per_split;
+  if (kend > p.k) kend = p.k;
+  const int nk = (kend - kbeg) / BK;
+
+  // 1 KB DMA pieces (8 rows x 128 B), five per wave and stage: W pieces {wave, wave+4, wave+8, wave+12} and one of the four
+  // A pieces (plane wave >> 1, token rows 8 * (wave & 1) ..).  Every piece index this wave touches has parity wave & 1.
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lrow >> 1));
+  const uint16_t* src[5];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    int wr = n0 + (wave + 4 * h) * 8 + lrow;
+    if (wr > p.n - 1) wr = p.n - 1;
+    src[h] = p.w + (size_t)wr * p.ldw + kbeg + lchunk * 8;
+  }
+  {
+    int am = (wave & 1) * 8 + lrow;
+    if (am > p.m - 1) am = p.m - 1;
+    src[4] = ((wave >> 1) ? a_lo : a_hi) + (size_t)am * ldp + kbeg + lchunk * 8;
+  }
+  auto issue = [&](int kt) {
+    char* base = smem + (kt % NSTAGE) * STAGE;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + (size_t)kt * BK), (lptr_t)(base + 2 * A_PLANE + (wave + 4 * h) * 1024),
+                                       16, 0, 2 /* nt: streamed once */);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[4] + (size_t)kt * BK), (lptr_t)(base + (wave >> 1) * A_PLANE + (wave & 1) * 1024),
+                                     16, 0, 0);
+  };
+
+  f32x4 acc[1][2];
+  acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[0][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue(s);
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int later = nk - 1 - kt;               // stages issued after kt that may still be in flight
+    if (NSTAGE >= 4 && later >= NSTAGE - 2) wait_vmcnt<5 * (NSTAGE - 2)>();
+    else if (NSTAGE >= 5 && later == 2) wait_vmcnt<10>();
+    else if (later >= 1) wait_vmcnt<5>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
+    const char* base = smem + (kt % NSTAGE) * STAGE;
+    bf16x8_t bfrag[2][2], alo[2], ahi[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfrag[h][j] = *reinterpret_cast<const bf16x8_t*>(base + 2 * A_PLANE + lds_off128(wave * 32 + j * 16 + frow, h * 4 + fchunk));
+      alo[h] = *reinterpret_cast<const bf16x8_t*>(base + A_PLANE + lds_off128(frow, h * 4 + fchunk));
+      ahi[h] = *reinterpret_cast<const bf16x8_t*>(base + lds_off128(frow, h * 4 + fchunk));
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[h], bfrag[h][j], acc[0][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[h], bfrag[h][j], acc[0][j], 0, 0, 0);
+    }
+  }
+  gemm_store<1, 2, 16, 32, false>(p, acc, 0, n0, 0, wave, lane, blockIdx.z);
+}
+
 // x = hi + lo (to 16 mantissa bits): one thread per 8 consecutive elements.
 __global__ __launch_bounds__(256) void split_bf16x2_kernel(const float* __restrict__ x, int m, int k, int ldx,
                                                           uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int ldp) {
@@ -555,11 +651,49 @@ static void pick_dma_geometry(int m, int n, int k, int& sk) {
   pick_geometry(m < 128 ? 128 : m, n, k, bm, sk, 1, kDmaBN);
 }
 
+// Streaming kernel (2 <= M <= 16 with planes): split-K so that ~2 workgroups per CU are busy, >= 4 K-steps per split.
+static bool use_stream(const ChattsLinearArgs* a) {
+  return a->a_hi && a->a_lo && a->m >= 2 && a->m <= 16 && !a->w8 && a->k % kStreamBK == 0 &&
+         gemm_env_int("CHATTS_GEMM_STREAM", 1) != 0;
+}
+
+static int pick_stream_sk(int n, int k) {
+  const int tiles = (n + kStreamBN - 1) / kStreamBN, nk = k / kStreamBK;
+  // ~one workgroup per CU (tools/stream_sweep.py: gate_up / lm_head want no split, qkv 4, o / down ~6); each split costs a
+  // partials round trip and the epilogue launch
+  const int cus = device_cus();
+  int sk = 4 * tiles >= 3 * cus ? 1 : (cus + tiles / 2) / tiles;
+  if (sk > nk / 4) sk = nk / 4;
+  if (sk < 1) sk = 1;
+  const int force_sk = gemm_env_int("CHATTS_GEMM_SK", 0);
+  if (force_sk > 0 && force_sk <= nk) sk = force_sk;
+  return sk;
+}
+
+template <int NSTAGE>
+static int launch_stream_t(const GemmParams& p, const ChattsLinearArgs* a, int sk, hipStream_t s) {
+  constexpr int LDS = NSTAGE * kStreamStage;
+  static bool configured = false;
+  if (!configured) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NSTAGE>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "gemm_stream: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
+    configured = true;
+  }
+  dim3 grid((a->n + kStreamBN - 1) / kStreamBN, 1, sk), block(256);
+  hipLaunchKernelGGL((gemm_stream_kernel<NSTAGE>), grid, block, LDS, s, p, a->a_hi, a->a_lo, a->ld_planes);
+  return CHATTS_OK;
+}
+
 size_t gemm_workspace(int m, int n, int k) {
   int bm, sk, sk2;
   pick_geometry(m, n, k, bm, sk);
   pick_dma_geometry(m, n, k, sk2);
   if (sk2 > sk) sk = sk2;
+  if (m <= 16 && k % kStreamBK == 0) {
+    sk2 = pick_stream_sk(n, k);
+    if (sk2 > sk) sk = sk2;
+  }
   return sk > 1 ? (size_t)sk * m * n * sizeof(float) : 0;
 }
 
@@ -579,15 +713,19 @@ static int launch_dma(const GemmParams& p, const ChattsLinearArgs* a, int sk, hi
 
 int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   int bm, sk;
-  const bool dma = use_dma(a);
-  if (dma) {
+  const bool stream = use_stream(a);
+  const bool dma = !stream && use_dma(a);
+  if (stream) {
+    sk = pick_stream_sk(a->n, a->k);
+    bm = 16;
+  } else if (dma) {
     pick_dma_geometry(a->m, a->n, a->k, sk);
     bm = 128;
   } else {
     CHATTS_REQUIRE(a->a, CHATTS_E_SHAPE, "linear: a == NULL needs K %% %d == 0 (K=%d) for the plane path", kDmaBK, a->k);
     pick_geometry(a->m, a->n, a->k, bm, sk);
   }
-  const int kps = k_per_split(a->k, sk, dma ? kDmaBK : 32);
+  const int kps = k_per_split(a->k, sk, stream || dma ? kDmaBK : 32);
   sk = (a->k + kps - 1) / kps;
   GemmParams p;
   p.a = a->a; p.w = a->w; p.bias = a->bias; p.resid = a->resid;
@@ -605,7 +743,15 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   }
   const int nt_count = (a->n + 127) / 128, mt_count = (a->m + bm - 1) / bm;
   dim3 grid(8 * ((nt_count + 7) / 8) * mt_count, 1, sk), block(256);
-  if (dma) {
+  if (stream) {
+    int rc;
+    switch (gemm_env_int("CHATTS_GEMM_STREAM_STAGES", 4)) {
+      case 3: rc = launch_stream_t<3>(p, a, sk, s); break;
+      case 5: rc = launch_stream_t<5>(p, a, sk, s); break;
+      default: rc = launch_stream_t<4>(p, a, sk, s); break;
+    }
+    if (rc) return rc;
+  } else if (dma) {
     const int rc = launch_dma(p, a, sk, s);
     if (rc) return rc;
   } else if (a->w8) {

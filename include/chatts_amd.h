@@ -143,8 +143,10 @@ size_t chatts_linear_workspace(int m, int n, int k);
 /* hi = bf16(x) (RNE), lo = bf16(x - hi): the operand split of the bf16x2 GEMM, done once per activation matrix. */
 int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, chatts_bf16* lo, int ld_planes,
                         chatts_stream_t stream);
-/* Dispatch: M == 1 -> weight-streaming GEMV (exact f32 VALU products, HBM-bound);
- *           M  > 1 -> LDS-tiled MFMA GEMM, v_mfma_f32_16x16x32_bf16, bf16x2 split of A. */
+/* Dispatch: M == 1       -> weight-streaming GEMV (exact f32 VALU products, HBM-bound);
+ *           2 <= M <= 16 -> weight-streaming MFMA kernel (W rows are the MFMA A operand, read once, no LDS staging);
+ *           larger M     -> LDS-tiled MFMA GEMM (register-staged, or LDS-DMA on pre-split planes for M >= 96);
+ *           all MFMA paths: v_mfma_f32_16x16x32_bf16 with the bf16x2 split of A. */
 int chatts_linear(const ChattsLinearArgs* args, chatts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

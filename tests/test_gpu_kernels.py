@@ -318,6 +318,31 @@ def test_rmsnorm_planes_equals_split_of_rmsnorm(lib):
     assert torch.equal(hi[:, :h], want_hi) and torch.equal(lo[:, :h], want_lo)
 
 
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k", [(2, 128, 64), (3, 160, 320), (7, 5120, 5120), (16, 7168, 5120), (16, 1024, 13824),
+                                   (5, 152064 // 8, 512), (16, 96, 128)])
+@pytest.mark.parametrize("stages", [3, 4, 5])
+def test_gemm_stream_parity(lib, epi, m, n, k, stages, monkeypatch):
+    """2 <= M <= 16 on planes (batched decode): whole-line LDS-DMA streaming kernel; every epilogue, ragged N tiles,
+    splits shorter than the ring, all ring depths."""
+    monkeypatch.setenv("CHATTS_GEMM_STREAM_STAGES", str(stages))
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
+    out = _linear_planes(lib, a, w, bias, resid if epi == _lib.EPI_RESID else None, epi, with_a=False, ld=k + 64)
+    want = _ref_linear(a, w, bias, resid, epi)
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu().numpy(), want) < 2e-5
+
+
+def test_gemm_stream_rows_do_not_depend_on_the_batch(lib):
+    """Continuous batching invariant: a sequence's projection is bit-identical whichever other rows share the launch."""
+    a, w, bias, resid, _ = _rand_problem(16, 5120, 5120, seed=77, scale=2.0)
+    full = _linear_planes(lib, a, w, bias, None, _lib.EPI_NONE, with_a=False)
+    assert torch.equal(full, _linear_planes(lib, a, w, bias, None, _lib.EPI_NONE, with_a=False))
+    for rows in ([0, 1], [3, 9, 15], list(range(5))):
+        sub = _linear_planes(lib, a[rows].contiguous(), w, bias, None, _lib.EPI_NONE, with_a=False)
+        assert torch.equal(sub, full[rows])
+
+
 def test_gemm_dma_small_m_and_odd_k_fall_back(lib):
     a, w, bias, resid, _ = _rand_problem(40, 256, 512, seed=9)
     assert torch.equal(_linear_planes(lib, a, w, bias, None, _lib.EPI_NONE), _linear(lib, a, w, bias, None, _lib.EPI_NONE))
