@@ -41,7 +41,7 @@ extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) 
                    CHATTS_E_SHAPE, "linear: plane output needs both planes, M > 1 and ld_cplanes >= the output width");
   if (planes)
     CHATTS_REQUIRE(a->a_hi && a->a_lo && a->ld_planes >= a->k && a->ld_planes % 8 == 0 && ((uintptr_t)a->a_hi % 16) == 0 &&
-                       ((uintptr_t)a->a_lo % 16) == 0 && a->m > 1 && !a->w8 && !a->norm_w,
+                       ((uintptr_t)a->a_lo % 16) == 0 && a->m > 1 && !a->norm_w,
                    CHATTS_E_SHAPE, "linear: pre-split A needs both planes, ld_planes >= K and %% 8, 16-byte alignment, M > 1");
   CHATTS_REQUIRE(a->epilogue >= CHATTS_EPI_NONE && a->epilogue <= CHATTS_EPI_SWIGLU, CHATTS_E_BADARG,
                  "linear: epilogue %d", a->epilogue);
@@ -126,7 +126,8 @@ static ChattsKvCache layer_cache(const ChattsDecoder* d, int layer, int seq) {
 // decode with 2..16 sequences on bf16 weights (weight-streaming kernel).
 static bool planes_path(const ChattsDecoder* d, int m, int k, bool fp8 = false) {
   if (!(d->b.planes_hi && d->b.planes_lo && d->b.planes2_hi && d->b.planes2_lo) || k % 64 != 0) return false;
-  return m >= 96 || (m >= 2 && m <= 16 && !fp8);
+  if (m >= 2 && m <= 16) return !fp8 || k % 128 == 0;      // (the fp8 stream's K-step is one 128-byte line = 128 values)
+  return m >= 96 && !fp8;
 }
 
 // x -> RMSNorm -> la's input: planes written by the norm kernel itself (plane path) or float32 xn.

@@ -449,21 +449,32 @@ __global__ __launch_bounds__(kDmaThreads) void gemm_dma_kernel(GemmParams p, con
 // LDS-DMA in whole-line pieces (the same 128-byte-row, XOR-swizzled layout as gemm_dma_kernel), a ring of NSTAGE
 // 20 KB stages so that 2 workgroups per CU keep 60-80 KB of W in flight, split-K over workgroups to fill the chip
 // (52 MB of o_proj weights are only 40 N-tiles).  A comes as bf16 hi / lo planes ([M, K], M <= 16).
-constexpr int kStreamBN = 128, kStreamBK = 64, kStreamStage = 2 * 16 * 128 + kStreamBN * 128;
+constexpr int kStreamBN = 128;
+constexpr int stream_bk(bool w8) { return w8 ? 128 : 64; }                       // K per stage = one 128-byte line of a W row
+constexpr int stream_stage(bool w8) { return 2 * 16 * stream_bk(w8) * 2 + kStreamBN * 128; }   // A_hi | A_lo | W
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
   else static_assert(N == 0, "add the vmcnt literal");
 }
 
-template <int NSTAGE>
+// W8: W is the fp8 (e4m3fn) copy: a 128-byte line of a row holds 128 K-values, so a stage is 128 deep; the 8-byte B fragments
+// are widened (exactly) to bf16 in registers and the per-row scale is applied in the epilogue.
+template <int NSTAGE, bool W8>
 __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const uint16_t* __restrict__ a_hi,
                                                           const uint16_t* __restrict__ a_lo, int ldp) {
-  constexpr int BN = kStreamBN, BK = kStreamBK, STAGE = kStreamStage, A_PLANE = 16 * 128;
+  constexpr int BN = kStreamBN, BK = stream_bk(W8), STAGE = stream_stage(W8);
+  constexpr int A_SUB = 16 * 128;                  // one A sub-block: 16 token rows x 64 K-values (128 B)
+  constexpr int NSUB = BK / 64;                    // sub-blocks per plane and stage
+  constexpr int A_PLANE = NSUB * A_SUB, W_OFF = 2 * A_PLANE;
+  constexpr int NPIECE = 4 + NSUB;                 // DMA pieces per wave and stage
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -473,30 +484,40 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const ui
   if (kend > p.k) kend = p.k;
   const int nk = (kend - kbeg) / BK;
 
-  // 1 KB DMA pieces (8 rows x 128 B), five per wave and stage: W pieces {wave, wave+4, wave+8, wave+12} and one of the four
-  // A pieces (plane wave >> 1, token rows 8 * (wave & 1) ..).  Every piece index this wave touches has parity wave & 1.
+  // 1 KB DMA pieces (8 rows x 128 B): W pieces {wave, wave+4, wave+8, wave+12}; of the 4 * NSUB A pieces (plane, K sub-block,
+  // token-row half) this wave takes row half wave & 1 of plane wave >> 1 [bf16 W], or of both planes for K sub-block
+  // wave >> 1 [fp8 W].  Every piece index this wave touches has parity wave & 1.
   const int lrow = lane >> 3;
   const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lrow >> 1));
-  const uint16_t* src[5];
+  const char* wsrc[4];
+  const uint16_t* asrc[NSUB];
+  int adst[NSUB];
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
     int wr = n0 + (wave + 4 * h) * 8 + lrow;
     if (wr > p.n - 1) wr = p.n - 1;
-    src[h] = p.w + (size_t)wr * p.ldw + kbeg + lchunk * 8;
+    wsrc[h] = W8 ? reinterpret_cast<const char*>(p.w8) + (size_t)wr * p.ldw8 + kbeg + lchunk * 16
+                 : reinterpret_cast<const char*>(p.w + (size_t)wr * p.ldw + kbeg + lchunk * 8);
   }
   {
     int am = (wave & 1) * 8 + lrow;
     if (am > p.m - 1) am = p.m - 1;
-    src[4] = ((wave >> 1) ? a_lo : a_hi) + (size_t)am * ldp + kbeg + lchunk * 8;
+#pragma unroll
+    for (int q = 0; q < NSUB; ++q) {
+      const int plane = W8 ? q : (wave >> 1), sub = W8 ? (wave >> 1) : 0;
+      asrc[q] = (plane ? a_lo : a_hi) + (size_t)am * ldp + kbeg + sub * 64 + lchunk * 8;
+      adst[q] = plane * A_PLANE + sub * A_SUB + (wave & 1) * 1024;
+    }
   }
   auto issue = [&](int kt) {
     char* base = smem + (kt % NSTAGE) * STAGE;
 #pragma unroll
     for (int h = 0; h < 4; ++h)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + (size_t)kt * BK), (lptr_t)(base + 2 * A_PLANE + (wave + 4 * h) * 1024),
-                                       16, 0, 2 /* nt: streamed once */);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[4] + (size_t)kt * BK), (lptr_t)(base + (wave >> 1) * A_PLANE + (wave & 1) * 1024),
-                                     16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[h] + (size_t)kt * 128), (lptr_t)(base + W_OFF + (wave + 4 * h) * 1024), 16, 0,
+                                       2 /* nt: streamed once */);
+#pragma unroll
+    for (int q = 0; q < NSUB; ++q)
+      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + (size_t)kt * BK), (lptr_t)(base + adst[q]), 16, 0, 0);
   };
 
   f32x4 acc[1][2];
@@ -509,31 +530,46 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const ui
   const int frow = lane & 15, fchunk = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int later = nk - 1 - kt;               // stages issued after kt that may still be in flight
-    if (NSTAGE >= 4 && later >= NSTAGE - 2) wait_vmcnt<5 * (NSTAGE - 2)>();
-    else if (NSTAGE >= 5 && later == 2) wait_vmcnt<10>();
-    else if (later >= 1) wait_vmcnt<5>();
+    if (NSTAGE >= 4 && later >= NSTAGE - 2) wait_vmcnt<NPIECE * (NSTAGE - 2)>();
+    else if (NSTAGE >= 5 && later == 2) wait_vmcnt<2 * NPIECE>();
+    else if (later >= 1) wait_vmcnt<NPIECE>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
     const char* base = smem + (kt % NSTAGE) * STAGE;
-    bf16x8_t bfrag[2][2], alo[2], ahi[2];
+    constexpr int NH = BK / 32;                  // MFMA K-steps per stage
+    bf16x8_t bfrag[NH][2], alo[NH], ahi[NH];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        bfrag[h][j] = *reinterpret_cast<const bf16x8_t*>(base + 2 * A_PLANE + lds_off128(wave * 32 + j * 16 + frow, h * 4 + fchunk));
-      alo[h] = *reinterpret_cast<const bf16x8_t*>(base + A_PLANE + lds_off128(frow, h * 4 + fchunk));
-      ahi[h] = *reinterpret_cast<const bf16x8_t*>(base + lds_off128(frow, h * 4 + fchunk));
+      for (int j = 0; j < 2; ++j) {
+        const int r = wave * 32 + j * 16 + frow;
+        if (W8) {   // 8 fp8 = 8 bytes at byte 32 h + 8 q of the row: 16-byte chunk 2 h + (q >> 1), half q & 1
+          const u32x2 q8 = *reinterpret_cast<const u32x2*>(base + W_OFF + lds_off128(r, 2 * h + (fchunk >> 1)) + (fchunk & 1) * 8);
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          const f32x2_t f0 = __builtin_amdgcn_cvt_pk_f32_fp8(q8.x, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(q8.x, true);
+          const f32x2_t f2 = __builtin_amdgcn_cvt_pk_f32_fp8(q8.y, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(q8.y, true);
+          bf16x8_t bv;
+          bv[0] = (__bf16)f0.x; bv[1] = (__bf16)f0.y; bv[2] = (__bf16)f1.x; bv[3] = (__bf16)f1.y;
+          bv[4] = (__bf16)f2.x; bv[5] = (__bf16)f2.y; bv[6] = (__bf16)f3.x; bv[7] = (__bf16)f3.y;
+          bfrag[h][j] = bv;
+        } else {
+          bfrag[h][j] = *reinterpret_cast<const bf16x8_t*>(base + W_OFF + lds_off128(r, h * 4 + fchunk));
+        }
+      }
+      const int aoff = (h >> 1) * A_SUB + lds_off128(frow, (h & 1) * 4 + fchunk);
+      alo[h] = *reinterpret_cast<const bf16x8_t*>(base + A_PLANE + aoff);
+      ahi[h] = *reinterpret_cast<const bf16x8_t*>(base + aoff);
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[h], bfrag[h][j], acc[0][j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[h], bfrag[h][j], acc[0][j], 0, 0, 0);
     }
   }
-  gemm_store<1, 2, 16, 32, false>(p, acc, 0, n0, 0, wave, lane, blockIdx.z);
+  gemm_store<1, 2, 16, 32, W8>(p, acc, 0, n0, 0, wave, lane, blockIdx.z);
 }
 
 // x = hi + lo (to 16 mantissa bits): one thread per 8 consecutive elements.
@@ -653,12 +689,12 @@ static void pick_dma_geometry(int m, int n, int k, int& sk) {
 
 // Streaming kernel (2 <= M <= 16 with planes): split-K so that ~2 workgroups per CU are busy, >= 4 K-steps per split.
 static bool use_stream(const ChattsLinearArgs* a) {
-  return a->a_hi && a->a_lo && a->m >= 2 && a->m <= 16 && !a->w8 && a->k % kStreamBK == 0 &&
+  return a->a_hi && a->a_lo && a->m >= 2 && a->m <= 16 && a->k % stream_bk(a->w8 != nullptr) == 0 &&
          gemm_env_int("CHATTS_GEMM_STREAM", 1) != 0;
 }
 
-static int pick_stream_sk(int n, int k) {
-  const int tiles = (n + kStreamBN - 1) / kStreamBN, nk = k / kStreamBK;
+static int pick_stream_sk(int n, int k, bool w8) {
+  const int tiles = (n + kStreamBN - 1) / kStreamBN, nk = k / stream_bk(w8);
   // ~one workgroup per CU (tools/stream_sweep.py: gate_up / lm_head want no split, qkv 4, o / down ~6); each split costs a
   // partials round trip and the epilogue launch
   const int cus = device_cus();
@@ -670,18 +706,18 @@ static int pick_stream_sk(int n, int k) {
   return sk;
 }
 
-template <int NSTAGE>
+template <int NSTAGE, bool W8>
 static int launch_stream_t(const GemmParams& p, const ChattsLinearArgs* a, int sk, hipStream_t s) {
-  constexpr int LDS = NSTAGE * kStreamStage;
+  constexpr int LDS = NSTAGE * stream_stage(W8);
   static bool configured = false;
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NSTAGE>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NSTAGE, W8>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "gemm_stream: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
     configured = true;
   }
   dim3 grid((a->n + kStreamBN - 1) / kStreamBN, 1, sk), block(256);
-  hipLaunchKernelGGL((gemm_stream_kernel<NSTAGE>), grid, block, LDS, s, p, a->a_hi, a->a_lo, a->ld_planes);
+  hipLaunchKernelGGL((gemm_stream_kernel<NSTAGE, W8>), grid, block, LDS, s, p, a->a_hi, a->a_lo, a->ld_planes);
   return CHATTS_OK;
 }
 
@@ -690,8 +726,8 @@ size_t gemm_workspace(int m, int n, int k) {
   pick_geometry(m, n, k, bm, sk);
   pick_dma_geometry(m, n, k, sk2);
   if (sk2 > sk) sk = sk2;
-  if (m <= 16 && k % kStreamBK == 0) {
-    sk2 = pick_stream_sk(n, k);
+  if (m <= 16 && k % 64 == 0) {
+    sk2 = pick_stream_sk(n, k, false);         // (the fp8 variant's K-steps are twice as long: never more splits)
     if (sk2 > sk) sk = sk2;
   }
   return sk > 1 ? (size_t)sk * m * n * sizeof(float) : 0;
@@ -716,7 +752,7 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   const bool stream = use_stream(a);
   const bool dma = !stream && use_dma(a);
   if (stream) {
-    sk = pick_stream_sk(a->n, a->k);
+    sk = pick_stream_sk(a->n, a->k, a->w8 != nullptr);
     bm = 16;
   } else if (dma) {
     pick_dma_geometry(a->m, a->n, a->k, sk);
@@ -725,7 +761,7 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
     CHATTS_REQUIRE(a->a, CHATTS_E_SHAPE, "linear: a == NULL needs K %% %d == 0 (K=%d) for the plane path", kDmaBK, a->k);
     pick_geometry(a->m, a->n, a->k, bm, sk);
   }
-  const int kps = k_per_split(a->k, sk, stream || dma ? kDmaBK : 32);
+  const int kps = k_per_split(a->k, sk, stream ? stream_bk(a->w8 != nullptr) : (dma ? kDmaBK : 32));
   sk = (a->k + kps - 1) / kps;
   GemmParams p;
   p.a = a->a; p.w = a->w; p.bias = a->bias; p.resid = a->resid;
@@ -745,11 +781,11 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   dim3 grid(8 * ((nt_count + 7) / 8) * mt_count, 1, sk), block(256);
   if (stream) {
     int rc;
-    switch (gemm_env_int("CHATTS_GEMM_STREAM_STAGES", 4)) {
-      case 3: rc = launch_stream_t<3>(p, a, sk, s); break;
-      case 5: rc = launch_stream_t<5>(p, a, sk, s); break;
-      default: rc = launch_stream_t<4>(p, a, sk, s); break;
-    }
+    const int stages = gemm_env_int("CHATTS_GEMM_STREAM_STAGES", 4);
+    if (a->w8) rc = stages == 3 ? launch_stream_t<3, true>(p, a, sk, s) : launch_stream_t<4, true>(p, a, sk, s);
+    else if (stages == 3) rc = launch_stream_t<3, false>(p, a, sk, s);
+    else if (stages == 5) rc = launch_stream_t<5, false>(p, a, sk, s);
+    else rc = launch_stream_t<4, false>(p, a, sk, s);
     if (rc) return rc;
   } else if (dma) {
     const int rc = launch_dma(p, a, sk, s);

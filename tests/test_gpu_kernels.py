@@ -631,3 +631,30 @@ def test_gemm_fp8_weights_parity(lib, epi, m, n, k):
     want = _ref_linear(a, deq, bias, resid, epi)
     assert not torch.isnan(out).any()
     assert rel_err(out.cpu().numpy(), want) < 2e-5
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k", [(2, 128, 128), (5, 160, 384), (16, 5120, 5120), (16, 1024, 13824), (9, 7168, 5120)])
+@pytest.mark.parametrize("stages", [3, 4])
+def test_gemm_stream_fp8_weights_parity(lib, epi, m, n, k, stages, monkeypatch):
+    """Batched decode on the fp8 copy of W (BASELINE config 5): the streaming kernel's 128-deep stages, 8-byte fragments
+    widened in registers, row scale in the epilogue - against float64 on the dequantised matrix."""
+    from chatts_amd.modeling import quantize_fp8_rows
+    monkeypatch.setenv("CHATTS_GEMM_STREAM_STAGES", str(stages))
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
+    w[5] *= 50.0
+    q, scale, deq = quantize_fp8_rows(w)
+    hi, lo = _split_planes(lib, a)
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    out = torch.full((m, ncols), float("nan"), device=DEV)
+    wsb = int(lib.chatts_linear_workspace(m, n, k))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    la = _lib.LinearArgs(a=None, w=deq.data_ptr(), bias=bias.data_ptr(), resid=resid.data_ptr() if epi == _lib.EPI_RESID else None,
+                         c=out.data_ptr(), norm_w=None, norm_eps=0.0, m=m, n=n, k=k, lda=k, ldw=k, ldc=ncols, epilogue=epi,
+                         workspace=ws.data_ptr(), workspace_bytes=wsb, w8=q.data_ptr(), w8_scale=scale.data_ptr(), ldw8=k,
+                         a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=k)
+    _lib.check(lib.chatts_linear(la, st()))
+    torch.cuda.synchronize()
+    want = _ref_linear(a, deq, bias, resid, epi)
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu().numpy(), want) < 2e-5
