@@ -92,6 +92,49 @@ def roofline_gate_up(model, reps=2):
                 avg_us=avg_s * 1e6, bytes_per_launch=bytes_per_launch, gbs=bytes_per_launch / avg_s / 1e9)
 
 
+def prefill_mfma_gate_up(model, T, reps=1):
+    """The prefill's dominant GEMM (gate_up, M = prompt tokens, LDS-DMA kernel on bf16 planes) between two HIP events on
+    the launching stream, over every layer's weights: MFMA-issued flops = 2 passes (hi, lo) x 2 M N K."""
+    import torch
+    from chatts_amd import _lib
+    lib, cfg, plan = model.lib, model.config, model.plan
+    H, n = cfg.hidden_size, 2 * plan.inter
+    if T < 96 or H % 64:
+        return None
+    x = torch.randn((T, H), dtype=torch.float32, device=model.device)
+    hi = torch.empty((T, H), dtype=torch.bfloat16, device=model.device)
+    lo = torch.empty((T, H), dtype=torch.bfloat16, device=model.device)
+    out = torch.empty((T, plan.inter), dtype=torch.float32, device=model.device)
+    stream = torch.cuda.current_stream()
+    _lib.check(lib.chatts_split_bf16x2(x.data_ptr(), T, H, H, hi.data_ptr(), lo.data_ptr(), H, stream.cuda_stream))
+    wsb = max(int(lib.chatts_linear_workspace(T, n, H)), 16)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=model.device)
+
+    def sweep():
+        for lw in model.layers:
+            la = _lib.LinearArgs(a=None, w=lw["gate_up"].data_ptr(), bias=None, resid=None, c=out.data_ptr(), norm_w=None,
+                                 norm_eps=0.0, m=T, n=n, k=H, lda=H, ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU,
+                                 workspace=ws.data_ptr(), workspace_bytes=wsb, a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=H)
+            _lib.check(lib.chatts_linear(la, stream.cuda_stream))
+
+    sweep()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        sweep()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    launches = reps * len(model.layers)
+    avg_s = e0.elapsed_time(e1) * 1e-3 / launches
+    issued = 2 * 2.0 * T * n * H
+    return {"kernel": "gemm_dma_kernel (gate_up_proj + SwiGLU, M = prompt tokens)", "bound": "mfma", "avg_us": avg_s * 1e6,
+            "achieved": issued / avg_s / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": issued / avg_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, "useful_tflops": issued / 2 / avg_s / 1e12,
+            "launches_timed": launches,
+            "note": "MFMA-issued flops (bf16x2: two passes per product); rows padded to 128 are not counted"}
+
+
 def cpu_baseline(model, prompt_tokens, budget_s=30.0):
     """CPU float32 oracle (the reference's HF float32 path restated, see oracle/) on the host cores of THIS box.
     Bounded sample: ChatTS-14B widths with 2 and then 4 decoder layers (weights copied back from the GPU, so both
@@ -306,6 +349,10 @@ def main():
                      "avg_us": roof["avg_us"], "bytes_per_launch": roof["bytes_per_launch"],
                      "launches_timed": roof["launches"]},
     }
+    try:        # secondary evidence: MFMA utilisation of the prefill's dominant GEMM (north_star asks for it beside the HBM rate)
+        result["prefill_roofline"] = prefill_mfma_gate_up(model, T)
+    except Exception as e:
+        result["prefill_roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(model, T)
