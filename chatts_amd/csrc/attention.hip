@@ -389,25 +389,27 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
 // prefill, flash style on the exact-f32 matrix cores (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate, bitwise an
 // fmaf chain - the parity target is the float32 reference, and attention is ~3 % of prefill FLOPs, so the f32 MFMA
 // rate (155 TF) is enough).  grid (ceil(T/64), n_q), 256 threads: wave w owns query rows q0+16w .. +15 of ONE q head.
-//   Q fragment  A[i = lane&15][k = lane>>4 + 4j]: 32 floats per lane, loaded once
-//   K tile      [KT][130] f32 in LDS (row stride 130 floats: the B-fragment reads K[n = lane&15][k] are conflict-free)
+//   Q fragment  A[i = lane&15][K-slot group lane>>4 = head dims 32*(lane>>4) ..+31]: 32 floats per lane, loaded once
+//   K tile      [KT][136] f32 in LDS: B fragments are ds_read_b128 (4 MFMAs per read), conflict-free with the rotation kq & 1
 //   S = Q.K^T   KT/16 accumulators in C layout (col = lane&15 = key, row = 4*(lane>>4) + reg)
 //   softmax     online, per C-layout row: 16-lane xor shuffles for max and sum
 //   P           C layout -> wave-private LDS [16][KT+2] -> A layout (row = lane&15, k = lane>>4 + 4j)
-//   O += P.V    V tile [KT][144] f32 in LDS (stride 144: rows k and k+1 land 16 banks apart), 8 accumulators
-// Heaviest query tiles (most key tiles under the causal mask) are scheduled first.
+//   O += P.V    V tile [KT][132] f32 in LDS, 8 accumulators with permuted columns (lane n, acc db -> head dim 8n + db)
+// Heaviest query tiles (most key tiles under the causal mask) are scheduled first (pairing heavy + light tiles in one
+// workgroup was measured: slower, the chip then holds one wave per SIMD and nothing hides the per-tile overheads).
 // ---------------------------------------------------------------------------------------------------
 template <int KT>
-__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(AttnParams p) {
-  constexpr int KS = 130, VS = 144, PS = KT + 2, NB = KT / 16;
+__global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p) {
+  constexpr int KS = 136, VS = 132, PS = KT + 2, NB = KT / 16;
   __shared__ __attribute__((aligned(16))) float v_s[KT * VS];
   __shared__ __attribute__((aligned(16))) float k_s[KT * KS];
   __shared__ float p_all[4 * 16 * PS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = gridDim.x - 1 - blockIdx.x, hq = blockIdx.y;
+  const int hq = blockIdx.y;
   const int G = p.n_q / p.n_kv, hk = hq / G;
   const int heads = p.n_q + 2 * p.n_kv;
   const int T = p.t, pos0 = p.pos0_dev ? *p.pos0_dev : p.pos0;
+  const int qt = gridDim.x - 1 - blockIdx.x;                // heaviest query tiles (most key tiles) first
   const int q0 = qt * 64;
   const int arow = lane & 15, kq = lane >> 4;              // A/B fragment coordinates
   const int ccol = lane & 15, crow0 = (lane >> 4) * 4;     // C layout
@@ -418,9 +420,15 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(AttnParams p) {
   {
     int qrow = q0 + wave * 16 + arow;
     if (qrow > T - 1) qrow = T - 1;                         // padded rows compute garbage that is never stored
-    const float* qp = p.qkv + ((size_t)qrow * heads + hq) * kHeadDim + kq;
+    // K-slot assignment: the MFMA's K index is free as long as both operands agree, so lane group kq takes head dims
+    // kq*32 .. kq*32+31 (contiguous: the K fragments below are ds_read_b128, four MFMAs per read), visiting its eight
+    // 4-float chunks rotated by kq & 1 - the rotation that makes the b128 reads of the [KT][136] tile conflict-free.
+    const float* qp = p.qkv + ((size_t)qrow * heads + hq) * kHeadDim + kq * 32;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) qreg[j] = qp[4 * j];
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + 4 * ((i + (kq & 1)) & 7));
+      qreg[4 * i] = qv.x; qreg[4 * i + 1] = qv.y; qreg[4 * i + 2] = qv.z; qreg[4 * i + 3] = qv.w;
+    }
   }
   int qpos[4];
 #pragma unroll
@@ -438,29 +446,49 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(AttnParams p) {
   const float* kbase = p.kc + (size_t)hk * p.max_ctx * kHeadDim;
   const float* vbase = p.vc + (size_t)hk * p.max_ctx * kHeadDim;
 
+  // K/V tiles go global -> registers -> LDS; the loads of tile kt+1 are issued BEFORE the MFMAs of tile kt, so their L2
+  // latency hides under the tile's 128 MFMAs per wave instead of sitting between two barriers.
+  constexpr int SLOTS = KT * 32 / 256;                      // float4 slots per thread and operand
+  f32x4 kreg[SLOTS], vreg[SLOTS];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int idx = tid + i * 256, key = idx >> 5, c4 = idx & 31;
+      const int kr = kt * KT + key <= kmax ? kt * KT + key : kmax;    // clamped address; masked by key index below
+      kreg[i] = *reinterpret_cast<const f32x4*>(kbase + (size_t)kr * kHeadDim + c4 * 4);
+      vreg[i] = *reinterpret_cast<const f32x4*>(vbase + (size_t)kr * kHeadDim + c4 * 4);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int idx = tid + i * 256, key = idx >> 5, c4 = idx & 31;
+      *reinterpret_cast<f32x4*>(k_s + key * KS + c4 * 4) = kreg[i];
+      *reinterpret_cast<f32x4*>(v_s + key * VS + c4 * 4) = vreg[i];
+    }
+  };
+  load_tile(0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * KT;
     __syncthreads();                                        // the previous tile has been consumed by every wave
-    for (int idx = tid; idx < KT * 32; idx += 256) {
-      const int key = idx >> 5, c4 = idx & 31;
-      const int kr = k0 + key <= kmax ? k0 + key : kmax;    // clamped address; masked by key index below
-      const f32x4 kvv = *reinterpret_cast<const f32x4*>(kbase + (size_t)kr * kHeadDim + c4 * 4);
-      const f32x4 vvv = *reinterpret_cast<const f32x4*>(vbase + (size_t)kr * kHeadDim + c4 * 4);
-      float2* kd = reinterpret_cast<float2*>(k_s + key * KS + c4 * 4);
-      kd[0] = make_float2(kvv.x, kvv.y);
-      kd[1] = make_float2(kvv.z, kvv.w);
-      *reinterpret_cast<f32x4*>(v_s + key * VS + c4 * 4) = vvv;
-    }
+    store_tile();
     __syncthreads();
+    if (kt + 1 < nkt) load_tile(kt + 1);
 
     f32x4 s_acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) s_acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
+    for (int i = 0; i < 8; ++i) {
+      f32x4 kf[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
-        s_acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(qreg[j], k_s[(nb * 16 + arow) * KS + kq + 4 * j], s_acc[nb], 0, 0, 0);
+        kf[nb] = *reinterpret_cast<const f32x4*>(k_s + (nb * 16 + arow) * KS + kq * 32 + 4 * ((i + (kq & 1)) & 7));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          s_acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(qreg[4 * i + e], kf[nb][e], s_acc[nb], 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -494,11 +522,16 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(AttnParams p) {
     }
     __builtin_amdgcn_wave_barrier();                        // P is wave private: LDS ops of one wave stay in order
 #pragma unroll
+    // O += P.V with the output columns permuted: accumulator db of lane n holds head dim n*8 + db, so one key row gives a
+    // lane its eight V values as two ds_read_b128 (conflict-free for the [KT][132] tile) and the final store is 32 B per lane
     for (int j = 0; j < KT / 4; ++j) {
       const float pa = p_s[arow * PS + kq + 4 * j];
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(v_s + (kq + 4 * j) * VS + arow * 8);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(v_s + (kq + 4 * j) * VS + arow * 8 + 4);
 #pragma unroll
-      for (int db = 0; db < 8; ++db)
-        o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, v_s[(kq + 4 * j) * VS + db * 16 + arow], o_acc[db], 0, 0, 0);
+      for (int db = 0; db < 4; ++db) o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, v0[db], o_acc[db], 0, 0, 0);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) o_acc[4 + db] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, v1[db], o_acc[4 + db], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -506,9 +539,9 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(AttnParams p) {
     const int qrow = q0 + wave * 16 + crow0 + r;
     if (qrow < T) {
       const float inv = 1.0f / l_run[r];
-      float* dst = p.out + ((size_t)qrow * p.n_q + hq) * kHeadDim + ccol;
-#pragma unroll
-      for (int db = 0; db < 8; ++db) dst[db * 16] = o_acc[db][r] * inv;
+      float* dst = p.out + ((size_t)qrow * p.n_q + hq) * kHeadDim + ccol * 8;
+      *reinterpret_cast<f32x4*>(dst) = (f32x4){o_acc[0][r] * inv, o_acc[1][r] * inv, o_acc[2][r] * inv, o_acc[3][r] * inv};
+      *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o_acc[4][r] * inv, o_acc[5][r] * inv, o_acc[6][r] * inv, o_acc[7][r] * inv};
     }
   }
 }
@@ -568,6 +601,7 @@ extern "C" int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int 
   }
   static const bool force_rows = getenv("CHATTS_ATTN_ROWS") != nullptr;   // debugging aid: VALU kernel for every T
   if (t >= 16 && n_splits == 1 && !force_rows) {
+    // (64-key tiles were measured too: 155 us vs 148 us at T = 798 - the per-tile work is not what is slow)
     hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, dim3((t + 63) / 64, n_q), dim3(256), 0, as_stream(stream), p);
     CHATTS_CHECK_LAUNCH("attn_prefill_mfma");
     return CHATTS_OK;
