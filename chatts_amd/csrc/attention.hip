@@ -500,8 +500,7 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
         s_acc[nb][r] = s;
         mx = fmaxf(mx, s);
       }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mx = row16_max(mx);
       const float m_new = fmaxf(m_run[r], mx);              // finite from the first tile on (key 0 is always visible)
       const float alpha = expf(m_run[r] - m_new);
       float ps = 0.f;
@@ -511,8 +510,7 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
         s_acc[nb][r] = e;
         ps += e;
       }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) ps += __shfl_xor(ps, o, 64);
+      ps = row16_sum(ps);
       l_run[r] = l_run[r] * alpha + ps;
       m_run[r] = m_new;
 #pragma unroll

@@ -54,6 +54,26 @@ __device__ __forceinline__ void split_bf16x2(float x, uint16_t& hi, uint16_t& lo
   lo = f32_to_bf16_rne(x - bf16_to_f32(hi));
 }
 
+// Cross-lane moves on the VALU (DPP) instead of the LDS crossbar (__shfl_xor lowers to ds_bpermute_b32: an LDS
+// instruction and an lgkmcnt wait per step).  quad_perm covers lane ^ 1 and lane ^ 2, row_ror:4 / row_ror:8 rotate within a
+// row of 16 lanes: after the four steps every lane of the row holds the row's reduction.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float row_ror4(float v) { return dpp_mov<0x124>(v); }
+__device__ __forceinline__ float row_ror8(float v) { return dpp_mov<0x128>(v); }
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, lane_xor1(v)); v = fmaxf(v, lane_xor2(v)); v = fmaxf(v, row_ror4(v)); v = fmaxf(v, row_ror8(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {     // ((v0+v1)+(v2+v3)) per quad, then quads 0+1.. : fixed order
+  v += lane_xor1(v); v += lane_xor2(v); v += row_ror4(v); v += row_ror8(v);
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
