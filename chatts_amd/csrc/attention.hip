@@ -174,17 +174,15 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
       pr[g] = 0.f;
       if (g < G) {
         float sc = dot[g];
-        sc += __shfl_xor(sc, 1, 64);
-        sc += __shfl_xor(sc, 2, 64);            // all 4 lanes of a key now hold its score
+        sc += lane_xor1(sc);
+        sc += lane_xor2(sc);                    // all 4 lanes of a key now hold its score (DPP, no LDS round trip)
         sc = j <= pos ? sc * scale : -INFINITY;
-        float mt = sc;
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1) mt = fmaxf(mt, __shfl_xor(mt, o, 64));
+        // max / sum over the 16 keys: keys of one 16-lane row with row_ror (DPP), the four rows with v_readlane
+        const float mt = rows4_max(fmaxf(fmaxf(sc, row_ror4(sc)), row_ror8(fmaxf(sc, row_ror4(sc)))));
         const float m_new = fmaxf(m_run[g], mt);  // finite: key j0 <= pos is always valid
         const float e = expf(sc - m_new);
-        float es = e;
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1) es += __shfl_xor(es, o, 64);   // sum over the 16 keys
+        float es = e + row_ror4(e);
+        es = rows4_sum(es + row_ror8(es));
         const float alpha = expf(m_run[g] - m_new);
         l_run[g] = l_run[g] * alpha + es;
         m_run[g] = m_new;
@@ -308,8 +306,8 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
       for (int g = 0; g < kMaxGroup; ++g) {
         if (g < G) {
           float v = dot[g];
-          v += __shfl_xor(v, 1, 64);
-          v += __shfl_xor(v, 2, 64);
+          v += lane_xor1(v);
+          v += lane_xor2(v);
           if (quarter == 0) s_s[g * kTile + key_l] = j <= pos ? v * scale : -INFINITY;
         }
       }

@@ -74,16 +74,20 @@ __device__ __forceinline__ float row16_sum(float v) {     // ((v0+v1)+(v2+v3)) p
   return v;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Whole-wave reductions of a value that is already constant within quads or rows: the 16-lane rows are reduced with DPP,
+// the four row results are fetched with v_readlane (wave-uniform) and combined in a fixed order.
+__device__ __forceinline__ float readlane_bits(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+__device__ __forceinline__ float rows4_max(float v) {    // v: per-row value -> max over the 4 rows, in every lane
+  return fmaxf(fmaxf(readlane_bits(v, 0), readlane_bits(v, 16)), fmaxf(readlane_bits(v, 32), readlane_bits(v, 48)));
 }
+__device__ __forceinline__ float rows4_sum(float v) {
+  return (readlane_bits(v, 0) + readlane_bits(v, 16)) + (readlane_bits(v, 32) + readlane_bits(v, 48));
+}
+
+__device__ __forceinline__ float wave_sum(float v) { return rows4_sum(row16_sum(v)); }   // every lane gets the total
+__device__ __forceinline__ float wave_max(float v) { return rows4_max(row16_max(v)); }
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
