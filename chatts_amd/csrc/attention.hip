@@ -41,6 +41,8 @@ struct AttnParams {
   const float* sin_tab;
   float eps;
   size_t seq_stride;   // batched decode: floats between the caches of consecutive sequences (same layer)
+  uint16_t* out_hi;    // decode combine, optional: the output as bf16 hi / lo planes [T, n_q * 128] (the o_proj operand of the
+  uint16_t* out_lo;    // weight-streaming kernel) instead of float32 `out`
 };
 
 // rotate one 128-wide head held as (a = x[lane], b = x[lane+64]) by the wave; optional RMSNorm first
@@ -241,7 +243,15 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnParams p) 
       num = fmaf(ws, o[u], num);
     }
   }
-  p.out[((size_t)seq * p.n_q + hq) * kHeadDim + d] = num / den;
+  const size_t oi = ((size_t)seq * p.n_q + hq) * kHeadDim + d;
+  const float v = num / den;
+  if (p.out_hi) {
+    const __bf16 h = (__bf16)v;
+    p.out_hi[oi] = __builtin_bit_cast(uint16_t, h);
+    p.out_lo[oi] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+  } else {
+    p.out[oi] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -611,14 +621,17 @@ extern "C" int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int 
   return CHATTS_OK;
 }
 
-extern "C" int chatts_attention_decode_batched(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w,
-                                               const float* k_norm_w, float norm_eps, const float* cos_tab,
-                                               const float* sin_tab, int pos, const int32_t* pos_dev,
-                                               const ChattsKvCache* cache, size_t seq_stride, float* out, int n_splits,
-                                               void* workspace, size_t workspace_bytes, chatts_stream_t stream) {
+namespace chatts {
+// chatts_attention_decode_batched with an optional plane output (internal: the decoder's batched step feeds o_proj's
+// weight-streaming kernel directly from the combine)
+int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w,
+                                  const float* k_norm_w, float norm_eps, const float* cos_tab, const float* sin_tab, int pos,
+                                  const int32_t* pos_dev, const ChattsKvCache* cache, size_t seq_stride, float* out,
+                                  uint16_t* out_hi, uint16_t* out_lo, int n_splits, void* workspace, size_t workspace_bytes,
+                                  chatts_stream_t stream) {
   CHATTS_REQUIRE(batch >= 1 && n_q > 0 && n_kv > 0 && n_splits >= 1 && n_splits <= kMaxSlots, CHATTS_E_BADARG,
                  "attention_decode: bad sizes (batch >= 1, 1 <= n_splits <= %d)", kMaxSlots);
-  CHATTS_REQUIRE(qkv_raw && out && cos_tab && sin_tab && cache && cache->k && cache->v, CHATTS_E_BADARG,
+  CHATTS_REQUIRE(qkv_raw && (out || (out_hi && out_lo)) && cos_tab && sin_tab && cache && cache->k && cache->v, CHATTS_E_BADARG,
                  "attention_decode: null pointer");
   CHATTS_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), CHATTS_E_BADARG,
                  "attention_decode: q_norm and k_norm must both be set or both be null");
@@ -631,7 +644,7 @@ extern "C" int chatts_attention_decode_batched(const float* qkv_raw, int batch, 
   p.qkv = qkv_raw; p.kc = cache->k; p.vc = cache->v; p.out = out; p.pos0_dev = pos_dev; p.pos0 = pos;
   p.t = batch; p.n_q = n_q; p.n_kv = n_kv; p.max_ctx = cache->max_ctx; p.n_splits = n_splits;
   p.q_norm_w = q_norm_w; p.k_norm_w = k_norm_w; p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.eps = norm_eps;
-  p.seq_stride = seq_stride;
+  p.seq_stride = seq_stride; p.out_hi = out_hi; p.out_lo = out_lo;
   const int rc = bind_workspace(p, workspace, workspace_bytes);
   if (rc) return rc;
   hipLaunchKernelGGL(attn_decode_kernel, dim3(n_kv, n_splits, batch), dim3(64), 0, as_stream(stream), p);
@@ -639,6 +652,17 @@ extern "C" int chatts_attention_decode_batched(const float* qkv_raw, int batch, 
   hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(n_q, batch), dim3(128), 0, as_stream(stream), p);
   CHATTS_CHECK_LAUNCH("attn_decode_combine");
   return CHATTS_OK;
+}
+}  // namespace chatts
+
+extern "C" int chatts_attention_decode_batched(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w,
+                                               const float* k_norm_w, float norm_eps, const float* cos_tab,
+                                               const float* sin_tab, int pos, const int32_t* pos_dev,
+                                               const ChattsKvCache* cache, size_t seq_stride, float* out, int n_splits,
+                                               void* workspace, size_t workspace_bytes, chatts_stream_t stream) {
+  return chatts::attention_decode_batched_impl(qkv_raw, batch, n_q, n_kv, q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos,
+                                               pos_dev, cache, seq_stride, out, nullptr, nullptr, n_splits, workspace,
+                                               workspace_bytes, stream);
 }
 
 extern "C" int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int n_kv, const float* q_norm_w,

@@ -11,6 +11,10 @@
 namespace chatts {
 int launch_gemv(const ChattsLinearArgs* a, hipStream_t s);
 int launch_gemm(const ChattsLinearArgs* a, hipStream_t s);
+int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w, const float* k_norm_w,
+                                  float norm_eps, const float* cos_tab, const float* sin_tab, int pos, const int32_t* pos_dev,
+                                  const ChattsKvCache* cache, size_t seq_stride, float* out, uint16_t* out_hi, uint16_t* out_lo,
+                                  int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream);
 int launch_split_bf16x2(const float* x, int m, int k, int ldx, uint16_t* hi, uint16_t* lo, int ldp, hipStream_t s);
 size_t gemm_workspace(int m, int n, int k);
 }  // namespace chatts
@@ -259,18 +263,17 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, 0);
-    if ((rc = chatts_attention_decode_batched(d->b.qkv, batch, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps,
-                                              d->w.cos_tab, d->w.sin_tab, 0, pos_dev, &kc, seq_stride(d), d->b.attn,
-                                              n_splits, d->b.workspace, d->b.workspace_bytes, stream)) != 0) return rc;
+    const bool attn_planes = planes_path(d, batch, c.n_q * kHeadDim, lw.o8 != nullptr);   // the combine writes o_proj's operand format
+    if ((rc = attention_decode_batched_impl(d->b.qkv, batch, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
+                                            d->w.sin_tab, 0, pos_dev, &kc, seq_stride(d), d->b.attn,
+                                            attn_planes ? d->b.planes_hi : nullptr, attn_planes ? d->b.planes_lo : nullptr,
+                                            n_splits, d->b.workspace, d->b.workspace_bytes, stream)) != 0) return rc;
     la = ChattsLinearArgs{};
     la.a = d->b.attn; la.w = lw.o; la.m = batch; la.n = H; la.k = c.n_q * kHeadDim;
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
     la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
-    if (planes_path(d, batch, la.k, la.w8 != nullptr)) {      // the attention kernel writes float32: split it
-      if ((rc = chatts_split_bf16x2(d->b.attn, batch, la.k, la.k, d->b.planes_hi, d->b.planes_lo, la.k, stream)) != 0) return rc;
-      la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k;
-    }
+    if (attn_planes) { la.a = nullptr; la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k; }
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
     return chatts_linear(&la, stream);
