@@ -109,8 +109,9 @@ class ChatTSForCausalLM:
         return m
 
     @classmethod
-    def from_pretrained(cls, path, trust_remote_code=True, device_map=None, torch_dtype=None, **kw):
-        """HF checkpoint directory (config.json + *.safetensors with the names of SURVEY.md section 5)."""
+    def from_pretrained(cls, path, trust_remote_code=True, device_map=None, torch_dtype=None, lora_adapter=None, **kw):
+        """HF checkpoint directory (config.json + *.safetensors with the names of SURVEY.md section 5).
+        lora_adapter: a peft LoRA adapter directory merged into the weights while loading (chatts_amd/lora.py)."""
         import glob
         import os
         from safetensors import safe_open
@@ -124,7 +125,12 @@ class ChatTSForCausalLM:
             handles.append(h)
             for k in h.keys():
                 index[k] = h
-        m.load_weights((k, h.get_tensor(k)) for k, h in index.items())
+        pairs = ((k, h.get_tensor(k)) for k, h in index.items())
+        if lora_adapter is not None:
+            from . import lora
+            pairs = lora.merged(pairs, lora_adapter)
+        m.load_weights(pairs)
+        m._checkpoint_path, m._checkpoint_kw = path, dict(kw)
         return m
 
     def load_weights(self, weights):
