@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void fill_hash_kernel(void* __restrict__ dst, 
 using namespace chatts;
 
 extern "C" const char* chatts_last_error(void) { return g_err; }
-extern "C" int chatts_abi_version(void) { return 1; }
+extern "C" int chatts_abi_version(void) { return CHATTS_ABI_VERSION; }
 extern "C" int chatts_device_cus(void) { return device_cus(); }
 
 extern "C" int chatts_fill_hash(void* dst, int out_f32, uint32_t key, float base, int shift, int64_t rows,

@@ -33,7 +33,9 @@ typedef void* chatts_stream_t; /* hipStream_t */
 typedef uint16_t chatts_bf16;  /* raw bfloat16 bits */
 
 const char* chatts_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header: bumped whenever a struct grows or a signature changes
+ * (2: plane operands, sampler, decoder plane buffers). */
+#define CHATTS_ABI_VERSION 2
 int chatts_abi_version(void);
 /* Number of CUs of the current device (grid sizing), or <0. */
 int chatts_device_cus(void);
