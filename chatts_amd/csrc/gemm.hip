@@ -1,17 +1,24 @@
-// gemm.hip - prefill / TS-encoder projections:  C[M,N] = epilogue(A[M,K] . W[N,K]^T)
-// A float32 activations, W bfloat16 weights (HF nn.Linear layout, K contiguous for both operands).
+// gemm.hip - MFMA projections for M > 1:  C[M,N] = epilogue(A[M,K] . W[N,K]^T)
+// A float32 activations (or their bf16 hi / lo planes), W bfloat16 weights (HF nn.Linear layout, K contiguous for both).
 //
 // Precision scheme "bf16x2": the reference path we must match is float32 (1e-3 relative on logits,
-// identical greedy tokens).  Weights are bf16 by definition, so only A needs care: each f32 element
-// is split while it is staged into LDS,  a = hi + lo,  hi = bf16(a), lo = bf16(a - hi), and the
-// wave issues two v_mfma_f32_16x16x32_bf16 per fragment pair (hi.W, lo.W) into ONE f32 accumulator.
-// The W tile is staged and read once; products are exact (8b x 8b mantissas), accumulation is f32.
+// identical greedy tokens).  Weights are bf16 by definition, so only A needs care: a = hi + lo,
+// hi = bf16(a), lo = bf16(a - hi), and the wave issues two v_mfma_f32_16x16x32_bf16 per fragment pair
+// (lo.W, hi.W) into ONE f32 accumulator.  Products are exact (8b x 8b mantissas), accumulation is f32.
 //
-// Geometry: 256 threads = 4 waves (WM x WN), tile BM x 128, BK = 32, double-buffered LDS,
-// register-staged global loads issued one K-step ahead, one barrier per K-step.
-// LDS rows are 64 B (32 bf16); 16-byte chunk c of row r lives at chunk c ^ (((r>>3)&1)<<1), which
-// makes every ds_read_b128 fragment read conflict-free (checked exhaustively over the 4 lane groups).
-// Split-K (grid.z) fills the 256 CUs when M is small; partials go to a workspace and a second kernel
+// Three kernels share the epilogue (gemm_store: bias / GELU / residual / SwiGLU / fp8 row scale / plane output / split-K
+// partials) and therefore produce bit-identical results at equal split-K:
+//   gemm_bf16x2_kernel  register-staged, BM x 128 x 32 tiles, A split on the VALU while staging; any M, float32 A;
+//                       TS-encoder MLP, prefill chunks below 96 rows, generic callers
+//   gemm_dma_kernel     prefill (M >= 96) on pre-split planes: 128 x 256 x 64, LDS-DMA whole-line staging by 4 loader
+//                       waves, 8 compute waves
+//   gemm_stream_kernel  batched decode (2 <= M <= 16) on planes: 16 x 128 x 64 (128 for fp8 W), weight-streaming shape
+// The comments above each kernel say which measurement made it look the way it does.
+//
+// Register-staged kernel geometry: 256 threads = 4 waves (WM x WN), double-buffered LDS, global loads issued one
+// K-step ahead, one barrier per K-step.  LDS rows are 64 B (32 bf16); 16-byte chunk c of row r lives at chunk
+// c ^ (((r>>3)&1)<<1), which makes every ds_read_b128 fragment read conflict-free (checked exhaustively over the 4
+// lane groups).  Split-K (grid.z) fills the 256 CUs when M is small; partials go to a workspace and a second kernel
 // applies the epilogue.
 #include "common.h"
 
