@@ -475,13 +475,16 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
       *reinterpret_cast<f32x4*>(v_s + key * VS + c4 * 4) = vreg[i];
     }
   };
-  load_tile(0);
-  for (int kt = 0; kt < nkt; ++kt) {
+  // Key split (flash-decoding style): workgroup z takes key tiles z, z + NS, ...  T/16 x heads waves is all the parallelism one
+  // sequence has (~2 waves per SIMD at T = 798, and the causal mask makes them unequal); splitting the keys doubles it.
+  const int NS = p.n_splits, split = blockIdx.z;
+  if (split < nkt) load_tile(split);
+  for (int kt = split; kt < nkt; kt += NS) {
     const int k0 = kt * KT;
     __syncthreads();                                        // the previous tile has been consumed by every wave
     store_tile();
     __syncthreads();
-    if (kt + 1 < nkt) load_tile(kt + 1);
+    if (kt + NS < nkt) load_tile(kt + NS);
 
     f32x4 s_acc[NB];
 #pragma unroll
@@ -509,12 +512,14 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
         mx = fmaxf(mx, s);
       }
       mx = row16_max(mx);
-      const float m_new = fmaxf(m_run[r], mx);              // finite from the first tile on (key 0 is always visible)
-      const float alpha = expf(m_run[r] - m_new);
+      const float m_new = fmaxf(m_run[r], mx);
+      // a split other than 0 may start on a tile this row cannot see at all: keep m = -inf, contribute nothing
+      const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = expf(m_run[r] - m_ref);
       float ps = 0.f;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const float e = expf(s_acc[nb][r] - m_new);
+        const float e = expf(s_acc[nb][r] - m_ref);
         s_acc[nb][r] = e;
         ps += e;
       }
@@ -543,7 +548,13 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int qrow = q0 + wave * 16 + crow0 + r;
-    if (qrow < T) {
+    if (qrow < T && NS > 1) {                               // partial (unnormalised) result of this key split
+      const size_t pi = ((size_t)qrow * p.n_q + hq) * NS + split;
+      float* dst = p.part_o + pi * kHeadDim + ccol * 8;
+      *reinterpret_cast<f32x4*>(dst) = (f32x4){o_acc[0][r], o_acc[1][r], o_acc[2][r], o_acc[3][r]};
+      *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o_acc[4][r], o_acc[5][r], o_acc[6][r], o_acc[7][r]};
+      if (ccol == 0) { p.part_ml[pi * 2] = m_run[r]; p.part_ml[pi * 2 + 1] = l_run[r]; }
+    } else if (qrow < T) {
       const float inv = 1.0f / l_run[r];
       float* dst = p.out + ((size_t)qrow * p.n_q + hq) * kHeadDim + ccol * 8;
       *reinterpret_cast<f32x4*>(dst) = (f32x4){o_acc[0][r] * inv, o_acc[1][r] * inv, o_acc[2][r] * inv, o_acc[3][r] * inv};
@@ -606,10 +617,14 @@ extern "C" int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int 
     if (rc) return rc;
   }
   static const bool force_rows = getenv("CHATTS_ATTN_ROWS") != nullptr;   // debugging aid: VALU kernel for every T
-  if (t >= 16 && n_splits == 1 && !force_rows) {
+  if (t >= 16 && n_splits <= 4 && !force_rows) {
     // (64-key tiles were measured too: 155 us vs 148 us at T = 798 - the per-tile work is not what is slow)
-    hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, dim3((t + 63) / 64, n_q), dim3(256), 0, as_stream(stream), p);
+    hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, dim3((t + 63) / 64, n_q, n_splits), dim3(256), 0, as_stream(stream), p);
     CHATTS_CHECK_LAUNCH("attn_prefill_mfma");
+    if (n_splits > 1) {
+      hipLaunchKernelGGL(attn_combine_kernel, dim3(n_q, t), dim3(128), 0, as_stream(stream), p);
+      CHATTS_CHECK_LAUNCH("attn_combine");
+    }
     return CHATTS_OK;
   }
   hipLaunchKernelGGL(attn_rows_kernel, dim3(n_kv, t, n_splits), dim3(256), 0, as_stream(stream), p);

@@ -91,7 +91,9 @@ extern "C" size_t chatts_decoder_workspace(const ChattsDecoderConfig* c, int t_m
       if (w > ws) ws = w;
     }
   }
-  const size_t aw = chatts_attn_workspace(1, c->n_q, n_splits_max);
+  size_t aw = chatts_attn_workspace(1, c->n_q, n_splits_max);
+  const size_t pw = chatts_attn_workspace(t_max, c->n_q, 2);      // prefill attention with the keys split in two
+  if (pw > aw) aw = pw;
   return (ws > aw ? ws : aw) + 256;
 }
 
@@ -194,7 +196,11 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     } else {
       if ((rc = chatts_rope_kv_write(d->b.qkv, t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
                                      d->w.sin_tab, pos0, pos0_dev, &kc, stream)) != 0) return rc;
-      if ((rc = chatts_attention(d->b.qkv, t, c.n_q, c.n_kv, pos0, pos0_dev, &kc, d->b.attn, 1, d->b.workspace,
+      // long chunks: split the keys over 2 workgroups per (query tile, head) - one sequence has too few waves otherwise
+      static const int env_ks = getenv("CHATTS_ATTN_KSPLIT") ? atoi(getenv("CHATTS_ATTN_KSPLIT")) : 0;
+      int ks = env_ks >= 1 && env_ks <= 4 ? env_ks : (t >= 256 ? 2 : 1);
+      if (chatts_attn_workspace(t, c.n_q, ks) > d->b.workspace_bytes) ks = 1;
+      if ((rc = chatts_attention(d->b.qkv, t, c.n_q, c.n_kv, pos0, pos0_dev, &kc, d->b.attn, ks, d->b.workspace,
                                  d->b.workspace_bytes, stream)) != 0) return rc;
     }
     // o_proj (+ residual, or partial sum for the TP all-reduce)
