@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
   const int q0 = qt * 64;
   const int arow = lane & 15, kq = lane >> 4;              // A/B fragment coordinates
   const int ccol = lane & 15, crow0 = (lane >> 4) * 4;     // C layout
-  const float scale = 0.08838834764831845f;
+  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // d^-1/2 * log2(e): the softmax runs on exp2
   float* p_s = p_all + wave * 16 * PS;
 
   float qreg[32];
@@ -501,41 +501,66 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
         for (int nb = 0; nb < NB; ++nb)
           s_acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(qreg[4 * i + e], kf[nb][e], s_acc[nb], 0, 0, 0);
     }
+    // Online softmax in the log2 domain (scores are pre-scaled by d^-1/2 * log2 e, so every exponential is one v_exp_f32),
+    // written stage by stage over the four rows a lane holds: the DPP reductions are dependent chains with wait states,
+    // and four independent chains in flight are what hides them (measured with s_memtime: this block was 3.5k cycles per
+    // tile as a per-row loop with expf, against 2k cycles for the 64 MFMAs of Q.K^T).
+    float mx[4], ps[4], alpha[4], m_ref[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float mx = -INFINITY;
+      mx[r] = -INFINITY;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        float s = s_acc[nb][r] * scale;
-        if (k0 + nb * 16 + ccol > qpos[r]) s = -INFINITY;   // causal mask
-        s_acc[nb][r] = s;
-        mx = fmaxf(mx, s);
+        float sc = s_acc[nb][r] * scale2;
+        if (k0 + nb * 16 + ccol > qpos[r]) sc = -INFINITY;  // causal mask
+        s_acc[nb][r] = sc;
+        mx[r] = fmaxf(mx[r], sc);
       }
-      mx = row16_max(mx);
-      const float m_new = fmaxf(m_run[r], mx);
-      // a split other than 0 may start on a tile this row cannot see at all: keep m = -inf, contribute nothing
-      const float m_ref = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = expf(m_run[r] - m_ref);
-      float ps = 0.f;
+    }
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const float e = expf(s_acc[nb][r] - m_ref);
-        s_acc[nb][r] = e;
-        ps += e;
-      }
-      ps = row16_sum(ps);
-      l_run[r] = l_run[r] * alpha + ps;
+    for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], lane_xor1(mx[r]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], lane_xor2(mx[r]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], row_ror4(mx[r]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], row_ror8(mx[r]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float m_new = fmaxf(m_run[r], mx[r]);
+      // a key split other than 0 may start on a tile this row cannot see at all: keep m = -inf, contribute nothing
+      m_ref[r] = m_new == -INFINITY ? 0.f : m_new;
+      alpha[r] = __builtin_amdgcn_exp2f(m_run[r] - m_ref[r]);
       m_run[r] = m_new;
+      ps[r] = 0.f;
 #pragma unroll
-      for (int db = 0; db < 8; ++db) o_acc[db][r] *= alpha;
+      for (int nb = 0; nb < NB; ++nb) {
+        const float e = __builtin_amdgcn_exp2f(s_acc[nb][r] - m_ref[r]);
+        s_acc[nb][r] = e;
+        ps[r] += e;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps[r] += lane_xor1(ps[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps[r] += lane_xor2(ps[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps[r] += row_ror4(ps[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps[r] += row_ror8(ps[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      l_run[r] = l_run[r] * alpha[r] + ps[r];
+#pragma unroll
+      for (int db = 0; db < 8; ++db) o_acc[db][r] *= alpha[r];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) p_s[(crow0 + r) * PS + nb * 16 + ccol] = s_acc[nb][r];
     }
     __builtin_amdgcn_wave_barrier();                        // P is wave private: LDS ops of one wave stay in order
-#pragma unroll
     // O += P.V with the output columns permuted: accumulator db of lane n holds head dim n*8 + db, so one key row gives a
     // lane its eight V values as two ds_read_b128 (conflict-free for the [KT][132] tile) and the final store is 32 B per lane
-    for (int j = 0; j < KT / 4; ++j) {
+#pragma unroll
+    for (int j = 0; j < KT / 4; ++j) {                      // unrolled: the reads of step j+1 are issued under the MFMAs of step j
       const float pa = p_s[arow * PS + kq + 4 * j];
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(v_s + (kq + 4 * j) * VS + arow * 8);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(v_s + (kq + 4 * j) * VS + arow * 8 + 4);
@@ -553,7 +578,7 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
       float* dst = p.part_o + pi * kHeadDim + ccol * 8;
       *reinterpret_cast<f32x4*>(dst) = (f32x4){o_acc[0][r], o_acc[1][r], o_acc[2][r], o_acc[3][r]};
       *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o_acc[4][r], o_acc[5][r], o_acc[6][r], o_acc[7][r]};
-      if (ccol == 0) { p.part_ml[pi * 2] = m_run[r]; p.part_ml[pi * 2 + 1] = l_run[r]; }
+      if (ccol == 0) { p.part_ml[pi * 2] = m_run[r] * 0.6931471805599453f; p.part_ml[pi * 2 + 1] = l_run[r]; }   // m back to nats
     } else if (qrow < T) {
       const float inv = 1.0f / l_run[r];
       float* dst = p.out + ((size_t)qrow * p.n_q + hq) * kHeadDim + ccol * 8;
