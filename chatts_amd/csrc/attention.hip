@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
   float* kcache = p.kc + (size_t)seq * p.seq_stride;
   float* vcache = p.vc + (size_t)seq * p.seq_stride;
   const bool owner = ((pos / kDTile) % NS) == slot;
-  const float scale = 0.08838834764831845f;    // 128^-1/2
+  const float scale = 0.08838834764831845f * 1.4426950408889634f;    // 128^-1/2 * log2(e): the softmax runs on v_exp_f32 (exp2)
   const float* kbase = kcache + (size_t)hk * p.max_ctx * kHeadDim;
   const float* vbase = vcache + (size_t)hk * p.max_ctx * kHeadDim;
   const int key_l = lane >> 2, quarter = lane & 3;
@@ -182,10 +182,10 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
         // max / sum over the 16 keys: keys of one 16-lane row with row_ror (DPP), the four rows with v_readlane
         const float mt = rows4_max(fmaxf(fmaxf(sc, row_ror4(sc)), row_ror8(fmaxf(sc, row_ror4(sc)))));
         const float m_new = fmaxf(m_run[g], mt);  // finite: key j0 <= pos is always valid
-        const float e = expf(sc - m_new);
+        const float e = __builtin_amdgcn_exp2f(sc - m_new);
         float es = e + row_ror4(e);
         es = rows4_sum(es + row_ror8(es));
-        const float alpha = expf(m_run[g] - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
         l_run[g] = l_run[g] * alpha + es;
         m_run[g] = m_new;
         acc0[g] *= alpha;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
     if (g < G) {
       const size_t pi = ((size_t)seq * p.n_q + hk * G + g) * NS + slot;
       *reinterpret_cast<float2*>(p.part_o + pi * kHeadDim + lane * 2) = make_float2(acc0[g], acc1[g]);
-      if (lane == 0) { p.part_ml[pi * 2] = m_run[g]; p.part_ml[pi * 2 + 1] = l_run[g]; }
+      if (lane == 0) { p.part_ml[pi * 2] = m_run[g] * 0.6931471805599453f; p.part_ml[pi * 2 + 1] = l_run[g]; }   // m back to nats for the combine
     }
   }
 }
