@@ -20,6 +20,8 @@
 // c ^ (((r>>3)&1)<<1), which makes every ds_read_b128 fragment read conflict-free (checked exhaustively over the 4
 // lane groups).  Split-K (grid.z) fills the 256 CUs when M is small; partials go to a workspace and a second kernel
 // applies the epilogue.
+#include <type_traits>
+
 #include "common.h"
 
 namespace chatts {
@@ -358,6 +360,7 @@ __global__ __launch_bounds__(kDmaThreads) void gemm_dma_kernel(GemmParams p, con
       char* base = smem + (kt & 1) * STAGE + L * 1024;
 #pragma unroll
       for (int h = 0; h < NA; ++h) {
+        if (m0 + (L + NLOAD * h) * 8 >= p.m) continue;     // ragged last M-tile: these 8 rows lie past M, nobody reads them
         __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + (size_t)kt * BK), (lptr_t)(base + h * NLOAD * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(src[NA + h] + (size_t)kt * BK), (lptr_t)(base + A_PLANE + h * NLOAD * 1024),
                                          16, 0, 0);
@@ -367,11 +370,20 @@ __global__ __launch_bounds__(kDmaThreads) void gemm_dma_kernel(GemmParams p, con
         __builtin_amdgcn_global_load_lds((gptr_t)(src[2 * NA + h] + (size_t)kt * BK),
                                          (lptr_t)(base + 2 * A_PLANE + h * NLOAD * 1024), 16, 0, 0);
     };
-    static_assert(2 * NA + NW == 16, "vmcnt(16) below = the pieces of one stage");
+    static_assert(NA == 4 && NW == 8, "the vmcnt literals below count NW + 2 * (live A piece pairs) pieces per stage");
     issue(0);
     if (nk > 1) {
       issue(1);
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");            // stage 0 landed, stage 1 may be in flight
+      int a_live = 0;                                               // a ragged tile issues fewer than 16 pieces per stage
+#pragma unroll
+      for (int h = 0; h < NA; ++h) a_live += m0 + (L + NLOAD * h) * 8 < p.m;
+      switch (a_live) {                                             // stage 0 landed, stage 1 (NW + 2 a_live pieces) may be in flight
+        case 0: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -392,58 +404,76 @@ __global__ __launch_bounds__(kDmaThreads) void gemm_dma_kernel(GemmParams p, con
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // Ragged last M-tile (798 = 6 x 128 + 30): the 16-row fragments of this wave that lie wholly past M are not read and not
+  // multiplied - the K loop is instantiated for 1..4 live fragments - and a wave with none only keeps the barrier cadence.
+  // One in seven workgroups of the benchmark prompt is such a tile, and the kernel is MFMA-bound.
+  const int rows_left = p.m - (m0 + wm * TM);
+  const int fm_live = rows_left <= 0 ? 0 : (rows_left >= TM ? FM : (rows_left + 15) / 16);
+  if (fm_live == 0) {
+    for (int kt = 0; kt < nk; ++kt) __builtin_amdgcn_s_barrier();    // nk barriers, like the live waves
+    return;
+  }
   const int frow = lane & 15, fchunk = lane >> 4;
-  bf16x8_t bfrag[2][FN], alo[2][FM], ahi[2][FM];
-  auto read_b = [&](int kt, int h) {
-    const char* base = smem + (kt & 1) * STAGE + 2 * A_PLANE;
+  auto k_loop = [&](auto fml_c) {
+    constexpr int FML = decltype(fml_c)::value;
+    bf16x8_t bfrag[2][FN], alo[2][FML], ahi[2][FML];
+    auto read_b = [&](int kt, int h) {
+      const char* base = smem + (kt & 1) * STAGE + 2 * A_PLANE;
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
-      bfrag[h][j] = *reinterpret_cast<const bf16x8_t*>(base + lds_off128(wn * TN + j * 16 + frow, h * 4 + fchunk));
-  };
-  auto read_a = [&](int kt, int h, int plane, bf16x8_t (&dst)[FM]) {
-    const char* base = smem + (kt & 1) * STAGE + plane * A_PLANE;
+      for (int j = 0; j < FN; ++j)
+        bfrag[h][j] = *reinterpret_cast<const bf16x8_t*>(base + lds_off128(wn * TN + j * 16 + frow, h * 4 + fchunk));
+    };
+    auto read_a = [&](int kt, int h, int plane, bf16x8_t (&dst)[FML]) {
+      const char* base = smem + (kt & 1) * STAGE + plane * A_PLANE;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
-      dst[i] = *reinterpret_cast<const bf16x8_t*>(base + lds_off128(wm * TM + i * 16 + frow, h * 4 + fchunk));
-  };
-  auto sweep = [&](const bf16x8_t (&af)[FM], const bf16x8_t (&bf)[FN]) {
+      for (int i = 0; i < FML; ++i)
+        dst[i] = *reinterpret_cast<const bf16x8_t*>(base + lds_off128(wm * TM + i * 16 + frow, h * 4 + fchunk));
+    };
+    auto sweep = [&](const bf16x8_t (&af)[FML], const bf16x8_t (&bf)[FN]) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+      for (int i = 0; i < FML; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-  };
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
 
-  __builtin_amdgcn_s_barrier();                // stage 0 published
-  read_b(0, 0);
-  read_a(0, 0, 1, alo[0]);
-  read_a(0, 0, 0, ahi[0]);
-  // (the last K-step is peeled: with the `more` test inside the loop the register allocator stops accumulating in place
-  // and spills fragments)
-  auto step = [&](int kt, bool more) {
-    __builtin_amdgcn_sched_barrier(0);
-    sweep(alo[0], bfrag[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    read_b(kt, 1);
-    read_a(kt, 1, 1, alo[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    sweep(ahi[0], bfrag[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    read_a(kt, 1, 0, ahi[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    sweep(alo[1], bfrag[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of slot kt has returned
-      __builtin_amdgcn_s_barrier();
-      read_b(kt + 1, 0);
-      read_a(kt + 1, 0, 1, alo[0]);
-      read_a(kt + 1, 0, 0, ahi[0]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    sweep(ahi[1], bfrag[1]);
+    __builtin_amdgcn_s_barrier();                // stage 0 published
+    read_b(0, 0);
+    read_a(0, 0, 1, alo[0]);
+    read_a(0, 0, 0, ahi[0]);
+    // (the last K-step is peeled: with the `more` test inside the loop the register allocator stops accumulating in place
+    // and spills fragments)
+    auto step = [&](int kt, bool more) {
+      __builtin_amdgcn_sched_barrier(0);
+      sweep(alo[0], bfrag[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(kt, 1);
+      read_a(kt, 1, 1, alo[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      sweep(ahi[0], bfrag[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(kt, 1, 0, ahi[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      sweep(alo[1], bfrag[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of slot kt has returned
+        __builtin_amdgcn_s_barrier();
+        read_b(kt + 1, 0);
+        read_a(kt + 1, 0, 1, alo[0]);
+        read_a(kt + 1, 0, 0, ahi[0]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      sweep(ahi[1], bfrag[1]);
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) step(kt, true);
+    step(nk - 1, false);
   };
-  for (int kt = 0; kt + 1 < nk; ++kt) step(kt, true);
-  step(nk - 1, false);
+  switch (fm_live) {
+    case 1: k_loop(std::integral_constant<int, 1>{}); break;
+    case 2: k_loop(std::integral_constant<int, 2>{}); break;
+    case 3: k_loop(std::integral_constant<int, 3>{}); break;
+    default: k_loop(std::integral_constant<int, 4>{}); break;
+  }
   gemm_store<FM, FN, TM, TN, false>(p, acc, m0, n0, wm, wn, lane, blockIdx.z);
 }
 
