@@ -35,7 +35,8 @@ class LinearArgs(C.Structure):
                 ("lda", c_int), ("ldw", c_int), ("ldc", c_int), ("epilogue", c_int), ("workspace", c_void_p),
                 ("workspace_bytes", c_size_t), ("w8", c_void_p), ("w8_scale", c_void_p), ("ldw8", c_int),
                 ("a_hi", c_void_p), ("a_lo", c_void_p), ("ld_planes", c_int),
-                ("c_hi", c_void_p), ("c_lo", c_void_p), ("ld_cplanes", c_int)]
+                ("c_hi", c_void_p), ("c_lo", c_void_p), ("ld_cplanes", c_int),
+                ("post_norm_w", c_void_p), ("post_norm_eps", c_float), ("post_hi", c_void_p), ("post_lo", c_void_p), ("ld_post", c_int)]
 
 
 class KvCache(C.Structure):

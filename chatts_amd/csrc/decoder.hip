@@ -27,6 +27,10 @@ struct ChattsDecoder {
   std::vector<ChattsLayerWeights> layers;
   ChattsDecoderBuffers b;
   int cur_seq = 0;          // sequence (KV-cache slot) the single-sequence entry points operate on
+  bool chain = false;       // set by the entry points that run the layers back to back themselves (chatts_decoder_prefill,
+                            // decode_step_batched): only then may a projection write the NEXT projection's normed operand
+  bool normed = false;      // planes 0 already hold RMSNorm(x) for the projection that comes next (written by the previous
+                            // projection's fused epilogue): norm_into only binds them
   bool sampling = false;    // token selection of the decode steps: greedy argmax, or the sampler with `sa`
   ChattsSamplingArgs sa{};
 };
@@ -62,6 +66,10 @@ extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) 
   if (a->w8)
     CHATTS_REQUIRE(a->w8_scale && a->ldw8 >= a->k && a->ldw8 % 16 == 0 && ((uintptr_t)a->w8 % 16) == 0 && a->k % 16 == 0,
                    CHATTS_E_SHAPE, "linear: fp8 weights need a scale, ldw8 >= K, 16-byte alignment");
+  if (a->post_norm_w)
+    CHATTS_REQUIRE(a->m > 1 && a->c && a->post_hi && a->post_lo && a->ld_post >= a->n && a->ld_post % 4 == 0 && a->n % 4 == 0 &&
+                       (a->epilogue == CHATTS_EPI_NONE || a->epilogue == CHATTS_EPI_RESID) && !cplanes,
+                   CHATTS_E_BADARG, "linear: post-norm planes need M > 1, float32 c, EPI_NONE / EPI_RESID, both planes, ld_post >= N");
   if (a->m == 1 && a->epilogue != CHATTS_EPI_GELU) return launch_gemv(a, as_stream(stream));
   CHATTS_REQUIRE(a->norm_w == nullptr, CHATTS_E_BADARG, "linear: fused RMSNorm is only available for M == 1");
   return launch_gemm(a, as_stream(stream));
@@ -140,10 +148,23 @@ static bool planes_path(const ChattsDecoder* d, int m, int k, bool fp8 = false) 
 static int norm_into(ChattsDecoder* d, const float* norm_w, ChattsLinearArgs* la, chatts_stream_t stream) {
   if (planes_path(d, la->m, la->k, la->w8 != nullptr)) {
     la->a = nullptr; la->a_hi = d->b.planes_hi; la->a_lo = d->b.planes_lo; la->ld_planes = la->k;
+    if (d->normed) { d->normed = false; return CHATTS_OK; }
     return chatts_rmsnorm_planes(d->b.x, norm_w, d->b.planes_hi, d->b.planes_lo, la->k, la->m, la->k, d->cfg.rms_eps, stream);
   }
+  d->normed = false;
   la->a = d->b.xn;
   return chatts_rmsnorm(d->b.x, norm_w, d->b.xn, la->m, la->k, d->cfg.rms_eps, stream);
+}
+
+// The residual-updating projection (o_proj / down_proj, tp_world == 1) also produces the NEXT projection's operand:
+// RMSNorm(x) with `next_norm_w` as planes 0, when that projection will take the plane path for the same M.
+static void request_post_norm(ChattsDecoder* d, ChattsLinearArgs* la, const float* next_norm_w, bool next_fp8) {
+  if (!d->chain || d->cfg.tp_world > 1 || !next_norm_w || la->epilogue != CHATTS_EPI_RESID) return;
+  if (la->m < 64) return;     // the fused epilogue runs one workgroup per row: at batched-decode M it leaves the chip idle (measured slower)
+  if (!planes_path(d, la->m, la->n, next_fp8)) return;
+  la->post_norm_w = next_norm_w; la->post_norm_eps = d->cfg.rms_eps;
+  la->post_hi = d->b.planes_hi; la->post_lo = d->b.planes_lo; la->ld_post = la->n;
+  d->normed = true;
 }
 
 extern "C" int chatts_decoder_set_sampling(ChattsDecoder* d, const ChattsSamplingArgs* sa) {
@@ -216,6 +237,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     }
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
+    request_post_norm(d, &la, lw.post_norm, false);
     return chatts_linear(&la, stream);
   }
   // part 1: RMSNorm -> gate_up + SwiGLU -> down (+ residual / partial)
@@ -240,6 +262,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   if (act_planes) { la.a = nullptr; la.a_hi = d->b.planes2_hi; la.a_lo = d->b.planes2_lo; la.ld_planes = c.inter; }
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
+  request_post_norm(d, &la, layer + 1 < c.n_layers ? d->layers[layer + 1].input_norm : nullptr, false);
   return chatts_linear(&la, stream);
 }
 
@@ -282,6 +305,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     if (attn_planes) { la.a = nullptr; la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k; }
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
+    request_post_norm(d, &la, lw.post_norm, lw.gate_up8 != nullptr);
     return chatts_linear(&la, stream);
   }
   la = ChattsLinearArgs{};
@@ -301,6 +325,8 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   if (act_planes) { la.a = nullptr; la.a_hi = d->b.planes2_hi; la.a_lo = d->b.planes2_lo; la.ld_planes = c.inter; }
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
+  request_post_norm(d, &la, layer + 1 < c.n_layers ? d->layers[layer + 1].input_norm : d->w.final_norm,
+                    (layer + 1 < c.n_layers ? d->layers[layer + 1].qkv8 : d->w.lm_head8) != nullptr);
   return chatts_linear(&la, stream);
 }
 
@@ -319,16 +345,21 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
   // use x between two steps) and ENDS with the per-sequence argmax
   if ((rc = chatts_embed_token_batched(token_dev, batch, d->w.embed, c.vocab_offset, c.vocab_local, c.hidden, d->b.x,
                                        stream)) != 0) return rc;
-  for (int l = 0; l < c.n_layers; ++l) {
-    if ((rc = chatts_decoder_layer_part_batched(d, l, 0, batch, pos_dev, n_splits, stream)) != 0) return rc;
-    if ((rc = chatts_decoder_layer_part_batched(d, l, 1, batch, pos_dev, n_splits, stream)) != 0) return rc;
+  d->chain = true;               // layers run back to back: a projection may write the next one's normed operand
+  d->normed = false;
+  for (int l = 0; l < c.n_layers && rc == CHATTS_OK; ++l) {
+    rc = chatts_decoder_layer_part_batched(d, l, 0, batch, pos_dev, n_splits, stream);
+    if (rc == CHATTS_OK) rc = chatts_decoder_layer_part_batched(d, l, 1, batch, pos_dev, n_splits, stream);
   }
   ChattsLinearArgs la{};
   la.w = d->w.lm_head; la.c = logits_all; la.m = batch; la.n = (int)c.vocab_local; la.k = c.hidden;
   la.lda = c.hidden; la.ldw = c.hidden; la.ldc = (int)c.vocab_local; la.epilogue = CHATTS_EPI_NONE;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden;
-  if ((rc = norm_into(d, d->w.final_norm, &la, stream)) != 0) return rc;
+  if (rc == CHATTS_OK) rc = norm_into(d, d->w.final_norm, &la, stream);
+  d->chain = false;
+  d->normed = false;
+  if (rc) return rc;
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
   if (d->sampling)
     return chatts_sample_batched(logits_all, batch, c.vocab_local, c.vocab_local, c.vocab_offset, &d->sa, token_dev,
@@ -340,12 +371,16 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
 extern "C" int chatts_decoder_prefill(ChattsDecoder* d, int t, int pos0, chatts_stream_t stream) {
   CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_prefill: null decoder");
   CHATTS_REQUIRE(d->cfg.tp_world == 1, CHATTS_E_BADARG, "decoder_prefill: TP>1 must drive chatts_decoder_layer_part");
-  for (int l = 0; l < d->cfg.n_layers; ++l) {
-    int rc;
-    if ((rc = chatts_decoder_layer_part(d, l, 0, t, pos0, nullptr, 1, stream)) != 0) return rc;
-    if ((rc = chatts_decoder_layer_part(d, l, 1, t, pos0, nullptr, 1, stream)) != 0) return rc;
+  d->chain = true;
+  d->normed = false;
+  int rc = CHATTS_OK;
+  for (int l = 0; l < d->cfg.n_layers && rc == CHATTS_OK; ++l) {
+    rc = chatts_decoder_layer_part(d, l, 0, t, pos0, nullptr, 1, stream);
+    if (rc == CHATTS_OK) rc = chatts_decoder_layer_part(d, l, 1, t, pos0, nullptr, 1, stream);
   }
-  return CHATTS_OK;
+  d->chain = false;
+  d->normed = false;
+  return rc;
 }
 
 extern "C" int chatts_decoder_logits(ChattsDecoder* d, int row, chatts_stream_t stream) {

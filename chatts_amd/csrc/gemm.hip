@@ -671,6 +671,57 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   else c[(size_t)row * ldc + col] = v;
 }
 
+// Split-K epilogue fused with the RMSNorm that consumes its result: one workgroup per output row sums the partials
+// (fixed order), applies bias / residual, writes the row, and - the row's sum of squares being at hand - writes
+// norm_w * (row * rsqrt(mean(row^2) + eps)) as bf16 hi / lo planes, the next projection's operand.  Replaces the
+// element-wise epilogue launch and the rmsnorm_planes launch behind it (same arithmetic, same order: bit-identical).
+__global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* __restrict__ ws, int sk, int m, int n,
+                                                                  const float* __restrict__ bias, const float* __restrict__ resid,
+                                                                  float* __restrict__ c, int ldc, int epilogue,
+                                                                  const float* __restrict__ scale, const float* __restrict__ norm_w,
+                                                                  float eps, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                                  int ldp) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const size_t plane = (size_t)m * n;
+  float ss = 0.f;
+  for (int col = threadIdx.x * 4; col < n; col += 1024) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < sk; ++s) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(ws + s * plane + (size_t)row * n + col);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (scale) { const f32x4 t = *reinterpret_cast<const f32x4*>(scale + col); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+    if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + col); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (epilogue == CHATTS_EPI_RESID) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(resid + (size_t)row * ldc + col);
+      v.x = t.x + v.x; v.y = t.y + v.y; v.z = t.z + v.z; v.w = t.w + v.w;
+    }
+    *reinterpret_cast<f32x4*>(c + (size_t)row * ldc + col) = v;
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;        // same accumulation pattern as rmsnorm_kernel
+  }
+  ss = block_sum<4>(ss, red);
+  const float rstd = rsqrtf(ss / (float)n + eps);
+  for (int col = threadIdx.x * 4; col < n; col += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(c + (size_t)row * ldc + col);    // this thread's own stores
+    const f32x4 g = *reinterpret_cast<const f32x4*>(norm_w + col);
+    const float o[4] = {g.x * (v.x * rstd), g.y * (v.y * rstd), g.z * (v.z * rstd), g.w * (v.w * rstd)};
+    {
+#pragma clang fp contract(off)   // lo must be the split of the ROUNDED product, as in rmsnorm_kernel<true>
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      bf16x4_t hv, lv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const __bf16 h = (__bf16)o[j];
+        hv[j] = h;
+        lv[j] = (__bf16)(o[j] - (float)h);
+      }
+      *reinterpret_cast<bf16x4_t*>(hi + (size_t)row * ldp + col) = hv;
+      *reinterpret_cast<bf16x4_t*>(lo + (size_t)row * ldp + col) = lv;
+    }
+  }
+}
+
 static int gemm_env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -843,6 +894,14 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
     }
   }
   CHATTS_CHECK_LAUNCH("gemm_bf16x2");
+  const bool post_norm = a->post_norm_w != nullptr;
+  if (sk > 1 && post_norm) {        // epilogue + the consumer's RMSNorm in one row-wise launch
+    hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(a->m), dim3(256), 0, s, reinterpret_cast<const float*>(a->workspace), sk,
+                       a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue, a->w8 ? a->w8_scale : nullptr, a->post_norm_w,
+                       a->post_norm_eps, a->post_hi, a->post_lo, a->ld_post);
+    CHATTS_CHECK_LAUNCH("splitk_epilogue_norm");
+    return CHATTS_OK;
+  }
   if (sk > 1) {
     const int ncols = a->epilogue == CHATTS_EPI_SWIGLU ? a->n / 2 : a->n;
     const size_t total = (size_t)a->m * ncols;
@@ -851,6 +910,9 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
                        a->ldc, a->epilogue, a->w8 ? a->w8_scale : nullptr, a->c_hi, a->c_lo, a->ld_cplanes);
     CHATTS_CHECK_LAUNCH("splitk_epilogue");
   }
+  if (post_norm)                  // no split-K epilogue to fuse into: the contract still holds, as its own launch
+    return chatts_rmsnorm_planes(a->c, a->post_norm_w, a->post_hi, a->post_lo, a->ld_post, a->m, a->n, a->post_norm_eps,
+                                 reinterpret_cast<chatts_stream_t>(s));
   return CHATTS_OK;
 }
 

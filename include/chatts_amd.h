@@ -34,8 +34,8 @@ typedef uint16_t chatts_bf16;  /* raw bfloat16 bits */
 
 const char* chatts_last_error(void);
 /* ABI version of this header: bumped whenever a struct grows or a signature changes
- * (2: plane operands, sampler, decoder plane buffers). */
-#define CHATTS_ABI_VERSION 2
+ * (2: plane operands, sampler, decoder plane buffers; 3: post-norm planes of chatts_linear). */
+#define CHATTS_ABI_VERSION 3
 int chatts_abi_version(void);
 /* Number of CUs of the current device (grid sizing), or <0. */
 int chatts_device_cus(void);
@@ -140,6 +140,14 @@ typedef struct ChattsLinearArgs {
   chatts_bf16* c_hi;
   chatts_bf16* c_lo;
   int ld_cplanes;
+  /* optional (M > 1, EPI_NONE / EPI_RESID, float32 c): additionally write RMSNorm(c) - rows of width N, weight
+   * post_norm_w, chatts_rmsnorm_planes arithmetic - as bf16 hi / lo planes [M, ld_post]: the operand of the projection that
+   * follows a residual update.  Fused into the split-K epilogue when there is one, otherwise an extra launch. */
+  const float* post_norm_w;
+  float post_norm_eps;
+  chatts_bf16* post_hi;
+  chatts_bf16* post_lo;
+  int ld_post;
 } ChattsLinearArgs;
 size_t chatts_linear_workspace(int m, int n, int k);
 /* hi = bf16(x) (RNE), lo = bf16(x - hi): the operand split of the bf16x2 GEMM, done once per activation matrix. */

@@ -658,3 +658,37 @@ def test_gemm_stream_fp8_weights_parity(lib, epi, m, n, k, stages, monkeypatch):
     want = _ref_linear(a, deq, bias, resid, epi)
     assert not torch.isnan(out).any()
     assert rel_err(out.cpu().numpy(), want) < 2e-5
+
+
+@pytest.mark.parametrize("m,n,k", [(16, 5120, 5120), (300, 5120, 1536), (16, 5120, 64), (7, 256, 512)])
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID])
+def test_linear_post_norm_planes_equal_separate_rmsnorm(lib, m, n, k, epi):
+    """ChattsLinearArgs.post_norm_*: the projection also writes RMSNorm(c) as planes (fused into the split-K epilogue when
+    there is one) - bit-identical to chatts_linear followed by chatts_rmsnorm_planes, c itself unchanged."""
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=2.0)
+    g = torch.Generator().manual_seed(3)
+    nw = (1 + 0.1 * torch.randn(n, generator=g)).to(DEV)
+    hi, lo = _split_planes(lib, a)
+    wsb = int(lib.chatts_linear_workspace(m, n, k))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+
+    def run(fused):
+        out = torch.full((m, n), float("nan"), device=DEV)
+        r = resid.clone() if epi == _lib.EPI_RESID else None
+        phi = torch.full((m, n + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+        plo = torch.full((m, n + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+        la = _lib.LinearArgs(a=a.data_ptr(), w=w.data_ptr(), bias=bias.data_ptr(), resid=_lib.ptr(r), c=out.data_ptr(), norm_w=None,
+                             norm_eps=0.0, m=m, n=n, k=k, lda=k, ldw=k, ldc=n, epilogue=epi, workspace=ws.data_ptr(),
+                             workspace_bytes=wsb, a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=k)
+        if fused:
+            la.post_norm_w, la.post_norm_eps, la.post_hi, la.post_lo, la.ld_post = nw.data_ptr(), 1e-6, phi.data_ptr(), plo.data_ptr(), n + 8
+        _lib.check(lib.chatts_linear(la, st()))
+        if not fused:
+            _lib.check(lib.chatts_rmsnorm_planes(out.data_ptr(), nw.data_ptr(), phi.data_ptr(), plo.data_ptr(), n + 8, m, n, 1e-6, st()))
+        torch.cuda.synchronize()
+        return out, phi, plo
+
+    o1, h1, l1 = run(False)
+    o2, h2, l2 = run(True)
+    assert torch.equal(o1, o2) and torch.equal(h1[:, :n], h2[:, :n]) and torch.equal(l1[:, :n], l2[:, :n])
+    assert not torch.isnan(h2[:, :n].float()).any() and torch.isnan(h2[:, n:].float()).all()
