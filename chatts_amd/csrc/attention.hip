@@ -581,9 +581,25 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
       if (ccol == 0) { p.part_ml[pi * 2] = m_run[r] * 0.6931471805599453f; p.part_ml[pi * 2 + 1] = l_run[r]; }   // m back to nats
     } else if (qrow < T) {
       const float inv = 1.0f / l_run[r];
-      float* dst = p.out + ((size_t)qrow * p.n_q + hq) * kHeadDim + ccol * 8;
-      *reinterpret_cast<f32x4*>(dst) = (f32x4){o_acc[0][r] * inv, o_acc[1][r] * inv, o_acc[2][r] * inv, o_acc[3][r] * inv};
-      *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o_acc[4][r] * inv, o_acc[5][r] * inv, o_acc[6][r] * inv, o_acc[7][r] * inv};
+      const size_t oi = ((size_t)qrow * p.n_q + hq) * kHeadDim + ccol * 8;
+      if (p.out_hi) {
+        typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+        bf16x8v hv, lv;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+#pragma clang fp contract(off)   // lo = split of the ROUNDED product, as chatts_split_bf16x2 of the float32 output would give
+          const float v = o_acc[db][r] * inv;
+          const __bf16 h = (__bf16)v;
+          hv[db] = h;
+          lv[db] = (__bf16)(v - (float)h);
+        }
+        *reinterpret_cast<bf16x8v*>(p.out_hi + oi) = hv;
+        *reinterpret_cast<bf16x8v*>(p.out_lo + oi) = lv;
+      } else {
+        float* dst = p.out + oi;
+        *reinterpret_cast<f32x4*>(dst) = (f32x4){o_acc[0][r] * inv, o_acc[1][r] * inv, o_acc[2][r] * inv, o_acc[3][r] * inv};
+        *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o_acc[4][r] * inv, o_acc[5][r] * inv, o_acc[6][r] * inv, o_acc[7][r] * inv};
+      }
     }
   }
 }
@@ -602,7 +618,15 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(AttnParams p) {
     num = fmaf(w, p.part_o[(base + s) * kHeadDim + d], num);
     den = fmaf(w, p.part_ml[(base + s) * 2 + 1], den);
   }
-  p.out[((size_t)row * p.n_q + hq) * kHeadDim + d] = num / den;
+  const size_t oi = ((size_t)row * p.n_q + hq) * kHeadDim + d;
+  const float v = num / den;
+  if (p.out_hi) {                                 // the o_proj operand format, written where the value is made
+    const __bf16 h = (__bf16)v;
+    p.out_hi[oi] = __builtin_bit_cast(uint16_t, h);
+    p.out_lo[oi] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+  } else {
+    p.out[oi] = v;
+  }
 }
 
 }  // namespace chatts
@@ -623,13 +647,28 @@ static int bind_workspace(AttnParams& p, void* workspace, size_t workspace_bytes
   return CHATTS_OK;
 }
 
+namespace chatts {
+int attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev, const ChattsKvCache* cache, float* out,
+                   uint16_t* out_hi, uint16_t* out_lo, int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream);
+}  // namespace chatts
+
 extern "C" int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev,
                                 const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
                                 size_t workspace_bytes, chatts_stream_t stream) {
+  return chatts::attention_impl(qkv, t, n_q, n_kv, pos0, pos0_dev, cache, out, nullptr, nullptr, n_splits, workspace,
+                                workspace_bytes, stream);
+}
+
+// chatts_attention with an optional plane output (internal: the decoder's prefill feeds o_proj's LDS-DMA GEMM directly).
+// Planes are written by the MFMA kernel / its combine only (t >= 16, n_splits <= 4): the caller checks that.
+int chatts::attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev,
+                           const ChattsKvCache* cache, float* out, uint16_t* out_hi, uint16_t* out_lo, int n_splits,
+                           void* workspace, size_t workspace_bytes, chatts_stream_t stream) {
   CHATTS_REQUIRE(t >= 0 && n_q > 0 && n_kv > 0 && n_splits >= 1 && n_splits <= kMaxSlots, CHATTS_E_BADARG,
                  "attention: bad sizes");
   if (t == 0) return CHATTS_OK;
-  CHATTS_REQUIRE(qkv && out && cache && cache->k && cache->v, CHATTS_E_BADARG, "attention: null pointer");
+  CHATTS_REQUIRE(qkv && (out || (out_hi && out_lo)) && cache && cache->k && cache->v, CHATTS_E_BADARG, "attention: null pointer");
+  CHATTS_REQUIRE(!out_hi || (t >= 16 && n_splits <= 4), CHATTS_E_BADARG, "attention: plane output needs the MFMA path");
   CHATTS_REQUIRE(n_q % n_kv == 0 && n_q / n_kv <= kMaxGroup, CHATTS_E_SHAPE,
                  "attention: GQA group %d/%d unsupported (max %d)", n_q, n_kv, kMaxGroup);
   if (!pos0_dev)
@@ -637,12 +676,13 @@ extern "C" int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int 
   AttnParams p{};
   p.qkv = qkv; p.kc = cache->k; p.vc = cache->v; p.out = out; p.pos0_dev = pos0_dev; p.pos0 = pos0;
   p.t = t; p.n_q = n_q; p.n_kv = n_kv; p.max_ctx = cache->max_ctx; p.n_splits = n_splits;
+  p.out_hi = out_hi; p.out_lo = out_lo;
   if (n_splits > 1) {
     const int rc = bind_workspace(p, workspace, workspace_bytes);
     if (rc) return rc;
   }
   static const bool force_rows = getenv("CHATTS_ATTN_ROWS") != nullptr;   // debugging aid: VALU kernel for every T
-  if (t >= 16 && n_splits <= 4 && !force_rows) {
+  if (t >= 16 && n_splits <= 4 && (!force_rows || out_hi)) {
     // (64-key tiles were measured too: 155 us vs 148 us at T = 798 - the per-tile work is not what is slow)
     hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, dim3((t + 63) / 64, n_q, n_splits), dim3(256), 0, as_stream(stream), p);
     CHATTS_CHECK_LAUNCH("attn_prefill_mfma");

@@ -15,6 +15,8 @@ int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int 
                                   float norm_eps, const float* cos_tab, const float* sin_tab, int pos, const int32_t* pos_dev,
                                   const ChattsKvCache* cache, size_t seq_stride, float* out, uint16_t* out_hi, uint16_t* out_lo,
                                   int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream);
+int attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev, const ChattsKvCache* cache, float* out,
+                   uint16_t* out_hi, uint16_t* out_lo, int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream);
 int launch_split_bf16x2(const float* x, int m, int k, int ldx, uint16_t* hi, uint16_t* lo, int ldp, hipStream_t s);
 size_t gemm_workspace(int m, int n, int k);
 }  // namespace chatts
@@ -210,6 +212,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     }
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, d->cur_seq);
+    bool attn_out_planes = false;
     if (t == 1) {   // decode: RoPE + cache write fused into the attention kernel
       if ((rc = chatts_attention_decode_fused(d->b.qkv, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
                                               d->w.sin_tab, pos0, pos0_dev, &kc, d->b.attn, n_splits, d->b.workspace,
@@ -221,8 +224,12 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
       static const int env_ks = getenv("CHATTS_ATTN_KSPLIT") ? atoi(getenv("CHATTS_ATTN_KSPLIT")) : 0;
       int ks = env_ks >= 1 && env_ks <= 4 ? env_ks : (t >= 256 ? 2 : 1);
       if (chatts_attn_workspace(t, c.n_q, ks) > d->b.workspace_bytes) ks = 1;
-      if ((rc = chatts_attention(d->b.qkv, t, c.n_q, c.n_kv, pos0, pos0_dev, &kc, d->b.attn, ks, d->b.workspace,
-                                 d->b.workspace_bytes, stream)) != 0) return rc;
+      // ... and, on the plane path, let the attention kernel (or its combine) write o_proj's operand format itself
+      const bool out_planes = t >= 16 && planes_path(d, t, c.n_q * kHeadDim) && !getenv("CHATTS_ATTN_ROWS");
+      if ((rc = attention_impl(d->b.qkv, t, c.n_q, c.n_kv, pos0, pos0_dev, &kc, d->b.attn, out_planes ? d->b.planes_hi : nullptr,
+                               out_planes ? d->b.planes_lo : nullptr, ks, d->b.workspace, d->b.workspace_bytes, stream)) != 0)
+        return rc;
+      attn_out_planes = out_planes;
     }
     // o_proj (+ residual, or partial sum for the TP all-reduce)
     la = ChattsLinearArgs{};
@@ -231,7 +238,9 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if (t == 1) {
       la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k;
-    } else if (planes_path(d, t, la.k)) {      // the attention kernel writes float32: split it
+    } else if (attn_out_planes) {              // written by the attention kernel
+      la.a = nullptr; la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k;
+    } else if (planes_path(d, t, la.k)) {      // the VALU attention kernel writes float32: split it
       if ((rc = chatts_split_bf16x2(d->b.attn, t, la.k, la.k, d->b.planes_hi, d->b.planes_lo, la.k, stream)) != 0) return rc;
       la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k;
     }
