@@ -629,6 +629,45 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(AttnParams p) {
   }
 }
 
+// Combine of the key-split MFMA prefill path (n_splits <= 4): one workgroup per query row, every thread merges float4s of
+// the row's n_q x 128 outputs (the (head, row)-per-workgroup kernel above costs 16 us at T = 798 just in launch count).
+__global__ __launch_bounds__(256) void attn_combine_rows_kernel(AttnParams p) {
+  const int row = blockIdx.x, NS = p.n_splits;
+  const int per_row = p.n_q * (kHeadDim / 4);
+  for (int q = threadIdx.x; q < per_row; q += 256) {
+    const int hq = q / (kHeadDim / 4), d4 = (q % (kHeadDim / 4)) * 4;
+    const size_t base = ((size_t)row * p.n_q + hq) * NS;
+    float M = -INFINITY;
+    for (int s = 0; s < NS; ++s) M = fmaxf(M, p.part_ml[(base + s) * 2]);
+    f32x4 num = {0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+    for (int s = 0; s < NS; ++s) {
+      const float m = p.part_ml[(base + s) * 2];
+      if (m == -INFINITY) continue;
+      const float w = expf(m - M);
+      const f32x4 o = *reinterpret_cast<const f32x4*>(p.part_o + (base + s) * kHeadDim + d4);
+      num.x = fmaf(w, o.x, num.x); num.y = fmaf(w, o.y, num.y); num.z = fmaf(w, o.z, num.z); num.w = fmaf(w, o.w, num.w);
+      den = fmaf(w, p.part_ml[(base + s) * 2 + 1], den);
+    }
+    const size_t oi = ((size_t)row * p.n_q + hq) * kHeadDim + d4;
+    const float v[4] = {num.x / den, num.y / den, num.z / den, num.w / den};
+    if (p.out_hi) {
+      typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+      bf16x4v hv, lv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        hv[j] = h;
+        lv[j] = (__bf16)(v[j] - (float)h);
+      }
+      *reinterpret_cast<bf16x4v*>(p.out_hi + oi) = hv;
+      *reinterpret_cast<bf16x4v*>(p.out_lo + oi) = lv;
+    } else {
+      *reinterpret_cast<f32x4*>(p.out + oi) = (f32x4){v[0], v[1], v[2], v[3]};
+    }
+  }
+}
+
 }  // namespace chatts
 
 using namespace chatts;
@@ -687,8 +726,8 @@ int chatts::attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0,
     hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, dim3((t + 63) / 64, n_q, n_splits), dim3(256), 0, as_stream(stream), p);
     CHATTS_CHECK_LAUNCH("attn_prefill_mfma");
     if (n_splits > 1) {
-      hipLaunchKernelGGL(attn_combine_kernel, dim3(n_q, t), dim3(128), 0, as_stream(stream), p);
-      CHATTS_CHECK_LAUNCH("attn_combine");
+      hipLaunchKernelGGL(attn_combine_rows_kernel, dim3(t), dim3(256), 0, as_stream(stream), p);
+      CHATTS_CHECK_LAUNCH("attn_combine_rows");
     }
     return CHATTS_OK;
   }
