@@ -526,12 +526,19 @@ class ChatTSForCausalLM:
     def select_sequence(self, slot):
         _lib.check(self.lib.chatts_decoder_select_sequence(self._decoder, int(slot)))
 
+    def _n_splits_batched(self):
+        """16-key slots per sequence of the batched decode attention: with many sequences in flight the grid is full anyway and
+        fewer, longer slots save partials traffic (B = 16: 64 -> 8 slots, 7.10 -> 6.91 ms per step)."""
+        if self.max_batch <= 4:
+            return self.n_splits
+        return max(1, min(self.n_splits, max(8, 128 // self.max_batch)))
+
     def _batched_step_eager(self):
         B = self.buf
         _lib.check(self.lib.chatts_decoder_decode_step_batched(
             self._decoder, self.max_batch, _lib.ptr(B["pos_all"]), _lib.ptr(B["step_all"]), _lib.ptr(B["token_all"]),
             _lib.ptr(B["token_logit_all"]), _lib.ptr(B["out_tokens_all"]), B["out_tokens_all"].shape[1],
-            _lib.ptr(B["logits_all"]), self.n_splits, _lib.stream_ptr()))
+            _lib.ptr(B["logits_all"]), self._n_splits_batched(), _lib.stream_ptr()))
 
     def batched_step(self):
         """One greedy token for EVERY cache slot (idle slots compute harmlessly; their position saturates)."""
