@@ -122,6 +122,7 @@ SIGNATURES = {
     "chatts_decoder_workspace": (c_size_t, [C.POINTER(DecoderConfig), c_int, c_int]),
     "chatts_decoder_layer_part": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "chatts_residual_add": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "chatts_decoder_layer_part_add": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "chatts_decoder_prefill": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "chatts_decoder_logits": (c_int, [c_void_p, c_int, c_void_p]),
     "chatts_decoder_decode_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

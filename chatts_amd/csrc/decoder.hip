@@ -275,6 +275,17 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   return chatts_linear(&la, stream);
 }
 
+extern "C" int chatts_decoder_layer_part_add(ChattsDecoder* d, int add_delta, int layer, int part, int t, int pos0,
+                                             const int32_t* pos0_dev, int n_splits, chatts_stream_t stream) {
+  CHATTS_REQUIRE(d && t >= 1 && t <= d->b.t_max, CHATTS_E_BADARG, "decoder_layer_part_add: bad arguments");
+  if (add_delta) {
+    CHATTS_REQUIRE(d->b.delta, CHATTS_E_BADARG, "decoder_layer_part_add: no delta buffer");
+    const int rc = chatts_residual_add(d->b.x, d->b.delta, (int64_t)t * d->cfg.hidden, stream);
+    if (rc) return rc;
+  }
+  return chatts_decoder_layer_part(d, layer, part, t, pos0, pos0_dev, n_splits, stream);
+}
+
 // Batched decode: `batch` sequences advance one token each.  Row b of x / qkv / attn /
 // act belongs to sequence b (cache slot b, position pos_dev[b]).  The projections run as M = batch GEMMs (bf16x2
 // MFMA, weights streamed once for the whole batch); attention runs per sequence on its own cache.

@@ -395,12 +395,17 @@ class ChatTSForCausalLM:
             return
         H = self.config.hidden_size
         delta = self.buf["delta"][:T]
+        tp = self.plan.world > 1
+        pending = 0                      # TP: the all-reduced delta of the previous part is added by the next C call
         for l in range(self.config.num_hidden_layers):
             for part in (0, 1):
-                _lib.check(lib.chatts_decoder_layer_part(self._decoder, l, part, T, pos0, _lib.ptr(pos_dev), n_splits, st))
-                if self.plan.world > 1:
+                _lib.check(lib.chatts_decoder_layer_part_add(self._decoder, pending, l, part, T, pos0, _lib.ptr(pos_dev),
+                                                             n_splits, st))
+                if tp:
                     self.comm.all_reduce(delta)
-                    _lib.check(lib.chatts_residual_add(_lib.ptr(self.buf["x"]), _lib.ptr(delta), T * H, st))
+                    pending = 1
+        if pending:
+            _lib.check(lib.chatts_residual_add(_lib.ptr(self.buf["x"]), _lib.ptr(delta), T * H, st))
 
     def reset(self):
         self.buf["pos"].zero_()

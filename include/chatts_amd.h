@@ -348,6 +348,10 @@ size_t chatts_decoder_workspace(const ChattsDecoderConfig*, int t_max, int n_spl
 int chatts_decoder_layer_part(ChattsDecoder*, int layer, int part, int t, int pos0,
                               const int32_t* pos0_dev, int n_splits, chatts_stream_t stream);
 int chatts_residual_add(float* x, const float* delta, int64_t n, chatts_stream_t stream);
+/* The same layer part preceded by x[0:t] += delta[0:t] (buffers.delta = the all-reduced partial sum of the PREVIOUS part):
+ * one host call per exchange point instead of two.  add_delta == 0: identical to chatts_decoder_layer_part. */
+int chatts_decoder_layer_part_add(ChattsDecoder*, int add_delta, int layer, int part, int t, int pos0,
+                                  const int32_t* pos0_dev, int n_splits, chatts_stream_t stream);
 
 /* Token selection of chatts_decoder_decode_step(_batched): NULL (default) = greedy argmax; otherwise the sampler above
  * with these parameters (copied).  Changing it invalidates any hipGraph captured over a decode step. */
