@@ -225,6 +225,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ttft-runs", type=int, default=5)
+    ap.add_argument("--max-ctx", type=int, default=2048, help="KV-cache length (longer prompts, e.g. --series 30, need more)")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = BASELINE.json config 5 weight format (NOT the headline: reported as a separate workload)")
     args = ap.parse_args()
@@ -261,7 +262,7 @@ def main():
     cfg = cfgmod.preset(args.model, **over)
     proc, prompt, series, lengths = build_inputs(cfg, args.series, args.length)
     t0 = time.time()
-    max_ctx = 2048
+    max_ctx = args.max_ctx
     model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, device=device, comm=comm, max_ctx=max_ctx,
                                              max_prefill_tokens=1024, use_graph=not args.no_graph,
                                              weight_format=args.weights)
