@@ -213,6 +213,32 @@ def cpu_baseline(model, prompt_tokens, budget_s=30.0):
                 ttft_s_extrapolated=pre_s, wall_s=time.time() - t_start)
 
 
+def parity_check(args, toks):
+    """Compare the tokens this run generated with the committed FULL-DEPTH oracle run of the same workload
+    (tools/parity_full_depth.py -> profiles/r2_parity_<model>_full.json: CPU float32 oracle, all layers, same prompt, seed 0)."""
+    tag = {"chatts-14b": "14b", "chatts-8b": "8b"}.get(args.model)
+    path = os.path.join(ROOT, "profiles", f"r2_parity_{tag}_full.json")
+    if tag is None or args.layers is not None or args.weights != "bf16" or not os.path.exists(path):
+        return False, {"reason": "no committed full-depth oracle run for this workload"}
+    with open(path) as f:
+        ref = json.load(f)
+    if (ref.get("series"), ref.get("length")) != (args.series, args.length):
+        return False, {"reason": f"oracle run is for {ref.get('series')}x{ref.get('length')}"}
+    want = ref["tokens_oracle"]
+    n = min(len(want), len(toks))
+    ok = n > 0 and toks[:n] == want[:n]
+    return ok, {"source": os.path.relpath(path, ROOT), "tokens_compared": n, "tokens_match": ok,
+                "first_token_logits_rel_err_recorded": ref.get("first_token_logits_rel_err"),
+                "max_step_logits_rel_err_recorded": max(ref.get("step_logits_rel_err", [0.0])), "tolerance": ref.get("tolerance", 1e-3)}
+
+
+def workload_name(args, world):
+    names = {"chatts-14b": "ChatTS-14B", "chatts-8b": "ChatTS-8B"}
+    if args.model not in names or args.layers is not None:
+        return f"DEBUG {args.model} layers={args.layers}"
+    return (f"{names[args.model]} {args.weights} weights, {args.series} series x {args.length} steps, greedy decode, TP={world}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,13 +354,12 @@ def main():
         pmc = None
     step_bytes = model.weight_bytes_local()
     result = {
-        "metric": "generated tokens/sec (greedy, batch 1) + p50 TTFT, ChatTS-14B, 8x256-step TS prompt, TP=N",
+        "metric": f"generated tokens/sec (greedy, batch 1) + p50 TTFT, {'ChatTS-8B' if args.model == 'chatts-8b' else 'ChatTS-14B'}, "
+                  f"{args.series}x{args.length}-step TS prompt, TP=N",
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "bf16" if args.weights == "bf16" else "fp8-e4m3 weights (pow2 row scales), f32 math", "data": "synthetic",
-        "config": {"workload": f"ChatTS-14B {args.weights} weights, {args.series} series x {args.length} steps, greedy decode, "
-                               f"TP={world}" if args.model == "chatts-14b" and args.layers is None else
-                               f"DEBUG {args.model} layers={args.layers}",
+        "config": {"workload": workload_name(args, world),
                    "model": args.model, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
                    "parallelism": f"tp{world}", "batch": 1, "decode_graph": bool(model.use_graph and world == 1),
                    "precision": "bf16 weights; f32 activations, KV cache and accumulation (bf16x2 MFMA split in "
@@ -350,6 +375,7 @@ def main():
                      "avg_us": roof["avg_us"], "bytes_per_launch": roof["bytes_per_launch"],
                      "launches_timed": roof["launches"]},
     }
+    result["parity_checked"], result["parity"] = parity_check(args, toks)
     try:        # secondary evidence: MFMA utilisation of the prefill's dominant GEMM (north_star asks for it beside the HBM rate)
         result["prefill_roofline"] = prefill_mfma_gate_up(model, T)
     except Exception as e:

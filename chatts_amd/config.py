@@ -41,16 +41,18 @@ class ChatTSConfig:
         self.tie_word_embeddings = bool(kw.pop("tie_word_embeddings", False))
         self.attention_bias = bool(kw.pop("attention_bias", self.model_type == "qwen2"))
         self.qk_norm = bool(kw.pop("qk_norm", self.model_type == "qwen3"))
+        raw_ts = kw.pop("ts", {}) or {}
         ts = dict(_DEFAULT_TS)
-        ts.update(kw.pop("ts", {}) or {})
-        if "max_length" in ts and "max_sequence_length" not in (kw.get("ts") or {}):
-            ts["max_sequence_length"] = ts["max_length"]           # chatts_vllm.py:245 accepts either key
+        ts.update(raw_ts)
+        if "max_length" in raw_ts and "max_sequence_length" not in raw_ts:
+            ts["max_sequence_length"] = raw_ts["max_length"]       # chatts_vllm.py:245 accepts either key, prefers this one
         if ts.get("hidden_size") is None:
             ts["hidden_size"] = self.hidden_size
         self.ts = ts
         self.ts_token_start_index = kw.pop("ts_token_start_index", TS_START_ID)
         self.ts_token_end_index = kw.pop("ts_token_end_index", self.ts_token_start_index + 1)
-        self.eos_token_id = kw.pop("eos_token_id", [IM_END_ID, EOS_ID])
+        eos = kw.pop("eos_token_id", [IM_END_ID, EOS_ID])           # Qwen configs store a scalar or a list
+        self.eos_token_id = [] if eos is None else ([int(e) for e in eos] if isinstance(eos, (list, tuple)) else [int(eos)])
         self.pad_token_id = kw.pop("pad_token_id", EOS_ID)
         self.torch_dtype = kw.pop("torch_dtype", "bfloat16")
         self.name = kw.pop("name", "custom")

@@ -315,7 +315,7 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   else if (a->n > 6000) nw_auto = 16;                  // qkv
   else nw_auto = 4;                                    // o_proj
   int nw = env_int("CHATTS_GEMV_NW", nw_auto);
-  if (nw != 8 && nw != 16) nw = 4;
+  if (nw < 1 || nw > 16) nw = 4;
   int occ = (int)((150 * 1024) / lds);          // workgroups per CU that fit in LDS
   const int wave_cap = 32 / nw;                  // 32 waves per CU
   if (occ > wave_cap) occ = wave_cap;
@@ -326,8 +326,15 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   p.tasks = (units + upt - 1) / upt;
   int blocks = (p.tasks + nw - 1) / nw;
   if (blocks > cus * occ) blocks = cus * occ;
+  blocks = env_int("CHATTS_GEMV_BLOCKS", blocks);
   if (blocks < 1) blocks = 1;
   const int threads = nw * 64;
+  // CHATTS_GEMV_LDSPAD = p: declare 1/p of a CU's LDS, so that exactly p workgroups fit per CU and a grid of
+  // cus * p workgroups is necessarily spread evenly (every CU streams the same number of bytes)
+  size_t lds_launch = lds;
+  const int pad = env_int("CHATTS_GEMV_LDSPAD", 0);
+  if (pad >= 1 && (size_t)(160 * 1024 / pad) / 16 * 16 > lds) lds_launch = (size_t)(160 * 1024 / pad) / 16 * 16;
+  if (lds_launch > 64 * 1024 && lds <= 64 * 1024) lds_launch = 64 * 1024;      // default dynamic-LDS cap (still 2 per CU)
   if (a->w8 != nullptr) {                       // fp8 weights: 2 rows x 2 chunks of 1024 elements in flight
     const int nchunks8 = (a->k + 1023) / 1024;
     const size_t lds8 = (size_t)nchunks8 * 1024 * 4 + 64 * 4;
@@ -343,10 +350,10 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
     CHATTS_CHECK_LAUNCH("gemv8_ldsx");
     return CHATTS_OK;
   }
-  if (rows == 4 && unr == 2) launch_ldsx<4, 2>(p, a->epilogue, norm, blocks, threads, lds, s);
-  else if (rows == 4) launch_ldsx<4, 4>(p, a->epilogue, norm, blocks, threads, lds, s);
-  else if (unr == 2) launch_ldsx<2, 2>(p, a->epilogue, norm, blocks, threads, lds, s);
-  else launch_ldsx<2, 4>(p, a->epilogue, norm, blocks, threads, lds, s);
+  if (rows == 4 && unr == 2) launch_ldsx<4, 2>(p, a->epilogue, norm, blocks, threads, lds_launch, s);
+  else if (rows == 4) launch_ldsx<4, 4>(p, a->epilogue, norm, blocks, threads, lds_launch, s);
+  else if (unr == 2) launch_ldsx<2, 2>(p, a->epilogue, norm, blocks, threads, lds_launch, s);
+  else launch_ldsx<2, 4>(p, a->epilogue, norm, blocks, threads, lds_launch, s);
   CHATTS_CHECK_LAUNCH("gemv_ldsx");
   return CHATTS_OK;
 }

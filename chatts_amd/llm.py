@@ -31,6 +31,21 @@ class RequestOutput:
         self.prompt, self.prompt_token_ids, self.outputs = prompt, prompt_token_ids, outputs
 
 
+def _load_checkpoint_tokenizer(path):
+    """The HF tokenizer stored in a checkpoint directory (demo/demo_vllm.py builds prompts with it).  A directory written
+    by ChatTSConfig.save_pretrained for the synthetic-weight tests marks itself with `synthetic_tokenizer` in config.json."""
+    import json
+    with open(os.path.join(path, "config.json")) as f:
+        if json.load(f).get("synthetic_tokenizer"):
+            return None
+    has_files = any(os.path.exists(os.path.join(path, f)) for f in ("tokenizer.json", "vocab.json", "tokenizer.model"))
+    if not has_files:
+        raise ValueError(f"{path} holds no tokenizer files (tokenizer.json / vocab.json): pass tokenizer=... explicitly; "
+                         "the synthetic stand-in tokenizer would feed meaningless ids to real weights")
+    from transformers import AutoTokenizer
+    return AutoTokenizer.from_pretrained(path, trust_remote_code=False)
+
+
 class LLM:
     def __init__(self, model, tensor_parallel_size=1, max_model_len=6000, limit_mm_per_prompt=None,
                  trust_remote_code=True, gpu_memory_utilization=None, seed=0, tokenizer=None, comm=None,
@@ -54,6 +69,8 @@ class LLM:
             self.model = ChatTSForCausalLM.from_synthetic(preset(model), seed=seed, **mk)
         elif isinstance(model, str) and os.path.isdir(model):
             self.model = ChatTSForCausalLM.from_pretrained(model, **mk)
+            if tokenizer is None:           # real weights need the checkpoint's own tokenizer, never the synthetic stand-in
+                tokenizer = _load_checkpoint_tokenizer(model)
         else:
             raise ValueError(f"model must be a checkpoint directory, a ChatTSConfig or one of {sorted(PRESETS)}")
         self.config = self.model.config
@@ -82,7 +99,8 @@ class LLM:
             ser = torch.from_numpy(self.processor.pad_stack(encs)) if encs else None
             reqs.append((ids, ser, lens))
             metas.append((req["prompt"], ids))
-        eos = None if sp.ignore_eos else (list(self.config.eos_token_id) + sp.stop_token_ids)
+        e = self.config.eos_token_id
+        eos = None if sp.ignore_eos else ((list(e) if isinstance(e, (list, tuple)) else [e]) + sp.stop_token_ids)
         toks_all = self.model.generate_batch(reqs, sp.max_tokens, eos)      # sequential when max_num_seqs == 1
         tok = self.processor.tokenizer
         return [RequestOutput(p, ids, [CompletionOutput(tok.decode(t, skip_special_tokens=True), t)])

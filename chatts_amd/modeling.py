@@ -356,10 +356,15 @@ class ChatTSForCausalLM:
         if out is None:
             out = torch.empty((t, H), dtype=torch.float32, device=self.device)
         scan = self.buf["scan"] if t + 1 <= self.buf["scan"].numel() else torch.empty(t + 1, dtype=torch.int32, device=self.device)
+        if ids_host is None:
+            self.buf["status"].zero_()
         _lib.check(self.lib.chatts_embed_merge(
             _lib.ptr(ids_dev), _lib.ptr(ids_host) if ids_host is not None else None, t, _lib.ptr(self._tensors["embed"]),
             self.config.vocab_size, H, _lib.ptr(rows) if n_rows else None, n_rows, self.config.ts_token_start_index,
             _lib.ptr(out), _lib.ptr(scan), _lib.ptr(self.buf["status"]), _lib.stream_ptr()))
+        if ids_host is None and int(self.buf["status"].item()) & 1:
+            # device-resident ids: the count check ran on the GPU (one D2H sync, as vLLM's merge_multimodal_embeddings does)
+            raise ValueError(f"Attempted to assign {n_rows} multimodal tokens to a different number of <ts> placeholders")
         return out
 
     def forward(self, input_ids=None, positions=None, intermediate_tensors=None, inputs_embeds=None, **kw):
@@ -573,7 +578,7 @@ class ChatTSForCausalLM:
             self._graph_batched = g
         self._graph_batched.replay()
 
-    def _admit(self, slot, ids, series, lengths):
+    def _admit(self, slot, ids, series, lengths, max_new_tokens=1):
         """Prefill one request into cache slot `slot` and produce its first token (out_tokens_all[slot, 0])."""
         cfg, B = self.config, self.buf
         ps = cfg.ts["patch_size"]
@@ -586,8 +591,8 @@ class ChatTSForCausalLM:
             mm = self.get_multimodal_embeddings(timeseries=series, valid_lengths=lengths)
         full = self.expand_input_ids(list(ids), counts)
         T = len(full)
-        if T + 1 > self.max_ctx:
-            raise ValueError(f"prompt ({T}) exceeds max_ctx={self.max_ctx}")
+        if T + max_new_tokens > self.max_ctx:       # same bound as generate_one: a sequence must never outgrow its cache
+            raise ValueError(f"prompt ({T}) + max_new_tokens ({max_new_tokens}) exceeds max_ctx={self.max_ctx}")
         emb = self.get_input_embeddings(torch.tensor(full, dtype=torch.int64), mm)
         self.select_sequence(slot)
         last = self.prefill(emb, 0)
@@ -645,7 +650,7 @@ class ChatTSForCausalLM:
                 if slots[s] is None and waiting:
                     r = waiting.pop()
                     ids, series, lengths = requests[r]
-                    self._admit(s, ids, series, lengths)
+                    self._admit(s, ids, series, lengths, max_new_tokens)
                     slots[s], produced[s] = r, 1
             if all(r is None or produced[s] >= max_new_tokens for s, r in enumerate(slots)):
                 harvest()

@@ -64,6 +64,9 @@ class TimeSeriesEmbedding:
         self._tsw = None
         t = tensor.to(self.device)
         if name == "position_embedding.weight":
+            if t.dim() != 2 or t.shape[0] != self.max_sequence_length + 1:      # row max_sequence_length is the padding_idx row
+                raise ValueError(f"position_embedding.weight has {tuple(t.shape)} rows, config ts.max_sequence_length="
+                                 f"{self.max_sequence_length} needs {self.max_sequence_length + 1}")
             self.position_embedding = t.float().contiguous()
             return
         l, kind = int(name.split(".")[1]) // 2, name.split(".")[2]
@@ -129,6 +132,8 @@ class TimeSeriesEmbedding:
         vl_host = [int(v) for v in valid_lengths]
         if len(vl_host) != n:
             raise ValueError("valid_lengths does not match the number of series")
+        if any(v < 0 or v > lmax for v in vl_host):
+            raise ValueError(f"valid_lengths {vl_host} exceed the padded series length {lmax}")
         if any(v > self.max_sequence_length for v in vl_host) and self.mode == 1:
             raise IndexError("index out of range in self")     # nn.Embedding lookup, chatts_vllm.py:165
         ps = self.patch_size

@@ -105,14 +105,17 @@ class QwenOracle:
         return x
 
     @torch.no_grad()
-    def forward_embeds(self, x, return_hidden=False):
-        """x [T,H] appended at positions ctx..ctx+T-1 -> logits [T,V] (or final-norm hidden)."""
+    def forward_embeds(self, x, return_hidden=False, last_only=False):
+        """x [T,H] appended at positions ctx..ctx+T-1 -> logits [T,V] (or final-norm hidden).
+        last_only: final norm + lm_head on the last row only -> logits [1,V] (what compute_logits needs after a prefill)."""
         T = x.shape[0]
         positions = torch.arange(self.ctx, self.ctx + T)
         x = x.float()
         for l in range(self.L):
             x = self.layer(l, x, positions)
         self.ctx += T
+        if last_only:
+            x = x[-1:]
         h = rms_norm(x, self.w["model.norm.weight"], self.c["rms_norm_eps"])
         if return_hidden:
             return h
@@ -123,7 +126,7 @@ class QwenOracle:
         """Greedy decode after a prefill with embeddings -> (token ids, per-step last logits).
         forced_tokens (teacher forcing): follow this continuation instead of the argmax - the per-step logits are then
         the ones a sampler saw along that continuation."""
-        logits = self.forward_embeds(prefill_embeds)[-1]
+        logits = self.forward_embeds(prefill_embeds, last_only=True)[-1]
         toks, all_logits = [], [logits]
         for i in range(max_new_tokens):
             t = int(torch.argmax(logits)) if forced_tokens is None else int(forced_tokens[i])

@@ -181,10 +181,18 @@ def test_gemv_parity(lib, epi, norm, n, k):
     assert not torch.isnan(out).any()
 
 
-@pytest.mark.parametrize("geom", [1, 2])       # 1 = x in LDS (one wave per row group), 2 = x in registers (K split)
-@pytest.mark.parametrize("k", [256, 1600, 3072, 5120, 8192, 10240, 13824])   # chunks per wave: 1,1,2,3,4,5->7,7
+# launch geometries the kernel really reads (gemv.hip launch_gemv): rows per wave, chunks in flight, waves per workgroup
+# (any 1..16, incl. the non-power-of-two counts of the balanced layouts), grid size, LDS padding
+GEMV_GEOMS = [dict(ROWS=2, UNR=2, NW=4), dict(ROWS=4, UNR=2, NW=8), dict(ROWS=2, UNR=4, NW=16), dict(ROWS=4, UNR=4, NW=4),
+              dict(ROWS=2, UNR=2, NW=7, BLOCKS=512, LDSPAD=2), dict(ROWS=2, UNR=2, NW=9, BLOCKS=768, LDSPAD=3),
+              dict(ROWS=2, UNR=4, NW=5, BLOCKS=3), dict(ROWS=4, UNR=2, NW=11, BLOCKS=256, LDSPAD=1)]
+
+
+@pytest.mark.parametrize("geom", range(len(GEMV_GEOMS)))
+@pytest.mark.parametrize("k", [256, 1600, 3072, 5120, 8192, 10240, 13824])   # chunks per wave: 1,4,6,10,16,20,27
 def test_gemv_all_geometries(lib, geom, k, monkeypatch):
-    monkeypatch.setenv("CHATTS_GEMV_GEOM", str(geom))
+    for key, v in GEMV_GEOMS[geom].items():
+        monkeypatch.setenv("CHATTS_GEMV_" + key, str(v))
     for epi in (_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU):
         for n in (1504, 96):
             a, w, bias, resid, nw = _rand_problem(1, n, k, seed=geom * 10 + k)

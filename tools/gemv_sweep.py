@@ -56,18 +56,28 @@ def bench(name, env, reps=3):
     return best, n * k * 2 / best / 1e3   # us, GB/s
 
 
+BALANCED = {   # (ROWS, NW, workgroups per CU): waves per CU divide the tasks per CU exactly -> every wave gets the same work
+    "qkv": [(2, 7, 2), (2, 7, 1), (2, 14, 1), (4, 7, 1)],
+    "o": [(2, 5, 2), (2, 10, 1), (2, 5, 1), (4, 5, 1)],
+    "gate_up": [(2, 9, 3), (2, 9, 2), (2, 9, 1), (2, 6, 3), (4, 9, 3), (4, 9, 1)],
+    "down": [(2, 5, 2), (2, 10, 1), (2, 5, 1), (4, 5, 1)],
+    "lm_head": [(2, 9, 3), (2, 11, 3), (2, 9, 1), (2, 11, 1), (4, 11, 3)],
+}
+
+
 def main():
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
-    configs = [{"CHATTS_GEMV_GEOM": 2}]
-    for occ in (3, 4, 6):
-        configs.append({"CHATTS_GEMV_GEOM": 2, "CHATTS_GEMV_OCC": occ})
-    for rows, unr, nw in itertools.product((2, 4), (2, 4), (4, 8, 16)):
-        configs.append({"CHATTS_GEMV_GEOM": 1, "CHATTS_GEMV_ROWS": rows, "CHATTS_GEMV_UNR": unr, "CHATTS_GEMV_NW": nw})
-    if not quick:
-        for rows, unr, nw, occ in itertools.product((2, 4), (2, 4), (4, 8), (1, 2, 3)):
-            configs.append({"CHATTS_GEMV_GEOM": 1, "CHATTS_GEMV_ROWS": rows, "CHATTS_GEMV_UNR": unr,
-                            "CHATTS_GEMV_NW": nw, "CHATTS_GEMV_OCC": occ})
+    cus = int(lib.chatts_device_cus())
     for name in SHAPES:
+        configs = [{}]                                    # the shipped auto geometry
+        for rows, nw, per_cu in BALANCED[name]:
+            for unr in (2, 4):
+                for pad in (0, per_cu):
+                    configs.append({"CHATTS_GEMV_ROWS": rows, "CHATTS_GEMV_UNR": unr, "CHATTS_GEMV_NW": nw,
+                                    "CHATTS_GEMV_BLOCKS": cus * per_cu, "CHATTS_GEMV_OCC": per_cu, "CHATTS_GEMV_LDSPAD": pad})
+        if not quick:
+            for rows, unr, nw in itertools.product((2, 4), (2, 4), (4, 8, 16)):
+                configs.append({"CHATTS_GEMV_ROWS": rows, "CHATTS_GEMV_UNR": unr, "CHATTS_GEMV_NW": nw})
         res = []
         for env in configs:
             try:
@@ -78,8 +88,8 @@ def main():
             res.append((us, gbs, env))
         res.sort(key=lambda r: r[0])
         print(f"== {name} N={SHAPES[name][0]} K={SHAPES[name][1]}")
-        for us, gbs, env in res[:6] + res[-2:]:
-            print(f"   {us:8.2f} us {gbs:7.0f} GB/s  " + " ".join(f"{k.replace('CHATTS_GEMV_', '')}={v}" for k, v in env.items()))
+        for us, gbs, env in res[:10] + res[-2:]:
+            print(f"   {us:8.2f} us {gbs:7.0f} GB/s  " + (" ".join(f"{k.replace('CHATTS_GEMV_', '')}={v}" for k, v in env.items()) or "auto"))
         sys.stdout.flush()
 
 
