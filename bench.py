@@ -361,7 +361,8 @@ def main():
         "dtype": "bf16" if args.weights == "bf16" else "fp8-e4m3 weights (pow2 row scales), f32 math", "data": "synthetic",
         "config": {"workload": workload_name(args, world),
                    "model": args.model, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
-                   "parallelism": f"tp{world}", "batch": 1, "decode_graph": bool(model.use_graph and world == 1),
+                   "parallelism": f"tp{world}", "batch": 1, "decode_graph": model.graph_capturable(),
+                   "tp_exchange": None if world == 1 else ("p2p one-shot kernels (csrc/tp.hip)" if model._tp is not None else "rccl, host-driven"),
                    "precision": "bf16 weights; f32 activations, KV cache and accumulation (bf16x2 MFMA split in "
                                 "prefill, exact f32 FMA in decode)",
                    "first_tokens": toks[:8]},

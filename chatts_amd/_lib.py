@@ -59,7 +59,7 @@ class SamplingArgs(C.Structure):
 class DecoderConfig(C.Structure):
     _fields_ = [("hidden", c_int), ("n_layers", c_int), ("n_q", c_int), ("n_kv", c_int), ("head_dim", c_int),
                 ("inter", c_int), ("vocab_local", c_int64), ("vocab_offset", c_int64), ("rms_eps", c_float),
-                ("max_ctx", c_int), ("max_pos", c_int), ("tp_world", c_int)]
+                ("max_ctx", c_int), ("max_pos", c_int), ("tp_world", c_int), ("embed_rows", c_int64), ("embed_offset", c_int64)]
 
 
 class DecoderWeights(C.Structure):
@@ -72,7 +72,8 @@ class DecoderBuffers(C.Structure):
     _fields_ = [("kv_k", c_void_p), ("kv_v", c_void_p), ("x", c_void_p), ("xn", c_void_p), ("qkv", c_void_p),
                 ("attn", c_void_p), ("act", c_void_p), ("delta", c_void_p), ("logits", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("t_max", c_int), ("max_batch", c_int),
-                ("planes_hi", c_void_p), ("planes_lo", c_void_p), ("planes2_hi", c_void_p), ("planes2_lo", c_void_p)]
+                ("planes_hi", c_void_p), ("planes_lo", c_void_p), ("planes2_hi", c_void_p), ("planes2_lo", c_void_p),
+                ("tp_pair_logit", c_void_p), ("tp_pair_token", c_void_p), ("logits_full", c_void_p)]
 
 
 # name -> (restype, argtypes); this table IS the list of symbols include/chatts_amd.h declares
@@ -127,7 +128,27 @@ SIGNATURES = {
     "chatts_decoder_logits": (c_int, [c_void_p, c_int, c_void_p]),
     "chatts_decoder_decode_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                            c_void_p]),
+    "chatts_decoder_set_tp": (c_int, [c_void_p, c_void_p]),
+    "chatts_decoder_select_tokens": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                             c_void_p, c_int, C.POINTER(SamplingArgs), c_void_p]),
+    # tensor-parallel exchange (tp.hip)
+    "chatts_tp_buffer_bytes": (c_size_t, [c_int, c_int64]),
+    "chatts_tp_buffer_alloc": (c_int, [c_size_t, C.POINTER(c_void_p), c_void_p]),
+    "chatts_tp_buffer_free": (c_int, [c_void_p]),
+    "chatts_tp_init": (c_void_p, [c_int, c_int, c_void_p, c_void_p, c_size_t, c_int64]),
+    "chatts_tp_init_local": (c_void_p, [c_int, c_int, C.POINTER(c_void_p), c_size_t, c_int64]),
+    "chatts_tp_destroy": (None, [c_void_p]),
+    "chatts_tp_rank": (c_int, [c_void_p]),
+    "chatts_tp_world": (c_int, [c_void_p]),
+    "chatts_tp_max_elems": (c_int64, [c_void_p]),
+    "chatts_tp_status": (c_int, [c_void_p]),
+    "chatts_tp_reset": (c_int, [c_void_p, c_void_p]),
+    "chatts_allreduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "chatts_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "chatts_tp_argmax": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                 c_int, c_void_p]),
 }
+TP_HANDLE_BYTES = 64
 
 
 class ChattsError(RuntimeError):

@@ -35,7 +35,11 @@ struct ChattsDecoder {
                             // projection's fused epilogue): norm_into only binds them
   bool sampling = false;    // token selection of the decode steps: greedy argmax, or the sampler with `sa`
   ChattsSamplingArgs sa{};
+  ChattsTpComm* tp = nullptr;   // tensor-parallel exchange (borrowed); required by the whole-step entry points when tp_world > 1
 };
+
+static int64_t embed_rows(const ChattsDecoder* d) { return d->cfg.embed_rows > 0 ? d->cfg.embed_rows : d->cfg.vocab_local; }
+static int64_t embed_offset(const ChattsDecoder* d) { return d->cfg.embed_rows > 0 ? d->cfg.embed_offset : d->cfg.vocab_offset; }
 
 extern "C" size_t chatts_linear_workspace(int m, int n, int k) { return gemm_workspace(m, n, k); }
 
@@ -177,6 +181,56 @@ extern "C" int chatts_decoder_set_sampling(ChattsDecoder* d, const ChattsSamplin
   d->sampling = sa != nullptr;
   if (sa) d->sa = *sa;
   return CHATTS_OK;
+}
+
+extern "C" int chatts_decoder_set_tp(ChattsDecoder* d, ChattsTpComm* comm) {
+  CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_set_tp: null decoder");
+  if (comm) {
+    CHATTS_REQUIRE(chatts_tp_world(comm) == d->cfg.tp_world, CHATTS_E_BADARG, "decoder_set_tp: comm of %d ranks, decoder built for %d",
+                   chatts_tp_world(comm), d->cfg.tp_world);
+    const int mb = d->b.max_batch > 0 ? d->b.max_batch : 1;
+    CHATTS_REQUIRE(chatts_tp_max_elems(comm) >= (int64_t)mb * d->cfg.hidden, CHATTS_E_SHAPE,
+                   "decoder_set_tp: exchange buffer holds %lld elements, a step needs %lld", (long long)chatts_tp_max_elems(comm),
+                   (long long)mb * d->cfg.hidden);
+    CHATTS_REQUIRE(d->b.tp_pair_logit && d->b.tp_pair_token && d->b.delta, CHATTS_E_BADARG,
+                   "decoder_set_tp: buffers.delta / tp_pair_logit / tp_pair_token are required");
+  }
+  d->tp = comm;
+  return CHATTS_OK;
+}
+
+// Greedy / sampled token for `batch` logits rows of this rank, agreed across the TP ranks (see the header).
+extern "C" int chatts_decoder_select_tokens(ChattsDecoder* d, const float* logits, int batch, int64_t logits_stride, int64_t* token,
+                                            float* token_logit, int64_t* out_tokens, int64_t out_stride, int32_t* step_dev,
+                                            int32_t* pos_dev, int pos_limit, const ChattsSamplingArgs* override_sa,
+                                            chatts_stream_t stream) {
+  CHATTS_REQUIRE(d && logits && token && batch >= 1, CHATTS_E_BADARG, "decoder_select_tokens: bad arguments");
+  const ChattsDecoderConfig& c = d->cfg;
+  const ChattsSamplingArgs* sa = override_sa ? override_sa : (d->sampling ? &d->sa : nullptr);
+  if (c.tp_world <= 1) {
+    if (sa)
+      return chatts_sample_batched(logits, batch, logits_stride, c.vocab_local, c.vocab_offset, sa, token, token_logit, out_tokens,
+                                   out_stride, step_dev, pos_dev, pos_limit, stream);
+    return chatts_argmax_batched(logits, batch, logits_stride, c.vocab_local, c.vocab_offset, token, token_logit, out_tokens, out_stride,
+                                 step_dev, pos_dev, pos_limit, stream);
+  }
+  CHATTS_REQUIRE(d->tp, CHATTS_E_BADARG, "decoder_select_tokens: tp_world = %d but no exchange attached (chatts_decoder_set_tp)", c.tp_world);
+  const int mb = d->b.max_batch > 0 ? d->b.max_batch : 1;
+  CHATTS_REQUIRE(batch <= mb, CHATTS_E_SHAPE, "decoder_select_tokens: batch %d exceeds max_batch %d", batch, mb);
+  int rc;
+  if (!sa) {      // one (max logit, global id) pair per rank and sequence instead of the [V / W] logits
+    if ((rc = chatts_argmax_batched(logits, batch, logits_stride, c.vocab_local, c.vocab_offset, d->b.tp_pair_token, d->b.tp_pair_logit,
+                                    nullptr, 0, nullptr, nullptr, 0, stream)) != 0) return rc;
+    return chatts_tp_argmax(d->tp, batch, d->b.tp_pair_logit, d->b.tp_pair_token, token, token_logit, out_tokens, out_stride, step_dev,
+                            pos_dev, pos_limit, stream);
+  }
+  // sampling: every rank draws from the gathered full-vocabulary logits with the same counter-hash variate -> the same token
+  CHATTS_REQUIRE(d->b.logits_full, CHATTS_E_BADARG, "decoder_select_tokens: sampling under tensor parallelism needs buffers.logits_full");
+  CHATTS_REQUIRE(logits_stride == c.vocab_local || batch == 1, CHATTS_E_SHAPE, "decoder_select_tokens: logits rows must be contiguous");
+  if ((rc = chatts_allgather(d->tp, logits, d->b.logits_full, batch, c.vocab_local, stream)) != 0) return rc;
+  const int64_t vfull = c.vocab_local * c.tp_world;
+  return chatts_sample_batched(d->b.logits_full, batch, vfull, vfull, 0, sa, token, token_logit, out_tokens, out_stride, step_dev,
+                               pos_dev, pos_limit, stream);
 }
 
 extern "C" int chatts_decoder_select_sequence(ChattsDecoder* d, int seq) {
@@ -358,18 +412,23 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
                                                   int64_t out_stride, float* logits_all, int n_splits,
                                                   chatts_stream_t stream) {
   CHATTS_REQUIRE(d && pos_dev && step_dev && token_dev && logits_all, CHATTS_E_BADARG, "decode_step_batched: null argument");
-  CHATTS_REQUIRE(d->cfg.tp_world == 1, CHATTS_E_BADARG, "decode_step_batched: TP>1 must drive chatts_decoder_layer_part_batched");
+  const bool tp = d->cfg.tp_world > 1;
+  CHATTS_REQUIRE(!tp || d->tp, CHATTS_E_BADARG, "decode_step_batched: tp_world = %d but no exchange attached (chatts_decoder_set_tp)",
+                 d->cfg.tp_world);
   int rc;
   const ChattsDecoderConfig& c = d->cfg;
   // the step STARTS by loading the input embeddings from the current tokens (so a prefill of another request may
   // use x between two steps) and ENDS with the per-sequence argmax
-  if ((rc = chatts_embed_token_batched(token_dev, batch, d->w.embed, c.vocab_offset, c.vocab_local, c.hidden, d->b.x,
+  if ((rc = chatts_embed_token_batched(token_dev, batch, d->w.embed, embed_offset(d), embed_rows(d), c.hidden, d->b.x,
                                        stream)) != 0) return rc;
   d->chain = true;               // layers run back to back: a projection may write the next one's normed operand
   d->normed = false;
+  const int64_t nx = (int64_t)batch * c.hidden;
   for (int l = 0; l < c.n_layers && rc == CHATTS_OK; ++l) {
     rc = chatts_decoder_layer_part_batched(d, l, 0, batch, pos_dev, n_splits, stream);
+    if (tp && rc == CHATTS_OK) rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, nx, stream);     // x += sum of the partial o_proj
     if (rc == CHATTS_OK) rc = chatts_decoder_layer_part_batched(d, l, 1, batch, pos_dev, n_splits, stream);
+    if (tp && rc == CHATTS_OK) rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, nx, stream);     // ... and down_proj
   }
   ChattsLinearArgs la{};
   la.w = d->w.lm_head; la.c = logits_all; la.m = batch; la.n = (int)c.vocab_local; la.k = c.hidden;
@@ -381,11 +440,8 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
   d->normed = false;
   if (rc) return rc;
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
-  if (d->sampling)
-    return chatts_sample_batched(logits_all, batch, c.vocab_local, c.vocab_local, c.vocab_offset, &d->sa, token_dev,
-                                 token_logit_dev, out_tokens, out_stride, step_dev, pos_dev, c.max_ctx - 1, stream);
-  return chatts_argmax_batched(logits_all, batch, c.vocab_local, c.vocab_local, c.vocab_offset, token_dev, token_logit_dev,
-                               out_tokens, out_stride, step_dev, pos_dev, c.max_ctx - 1, stream);
+  return chatts_decoder_select_tokens(d, logits_all, batch, c.vocab_local, token_dev, token_logit_dev, out_tokens, out_stride, step_dev,
+                                      pos_dev, c.max_ctx - 1, nullptr, stream);
 }
 
 extern "C" int chatts_decoder_prefill(ChattsDecoder* d, int t, int pos0, chatts_stream_t stream) {
@@ -418,19 +474,18 @@ extern "C" int chatts_decoder_decode_step(ChattsDecoder* d, int32_t* pos_dev, in
                                           float* token_logit_dev, int64_t* out_tokens, int n_splits,
                                           chatts_stream_t stream) {
   CHATTS_REQUIRE(d && pos_dev && step_dev && token_dev, CHATTS_E_BADARG, "decode_step: null argument");
-  CHATTS_REQUIRE(d->cfg.tp_world == 1, CHATTS_E_BADARG, "decode_step: TP>1 must drive chatts_decoder_layer_part");
+  const bool tp = d->cfg.tp_world > 1;
+  CHATTS_REQUIRE(!tp || d->tp, CHATTS_E_BADARG, "decode_step: tp_world = %d but no exchange attached (chatts_decoder_set_tp)", d->cfg.tp_world);
   int rc;
+  const int H = d->cfg.hidden;
   for (int l = 0; l < d->cfg.n_layers; ++l) {
     if ((rc = chatts_decoder_layer_part(d, l, 0, 1, 0, pos_dev, n_splits, stream)) != 0) return rc;
+    if (tp && (rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, H, stream)) != 0) return rc;    // x += sum of the partial o_proj
     if ((rc = chatts_decoder_layer_part(d, l, 1, 1, 0, pos_dev, n_splits, stream)) != 0) return rc;
+    if (tp && (rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, H, stream)) != 0) return rc;    // ... and down_proj
   }
   if ((rc = chatts_decoder_logits(d, 0, stream)) != 0) return rc;
-  if (d->sampling)
-    rc = chatts_sample_batched(d->b.logits, 1, d->cfg.vocab_local, d->cfg.vocab_local, d->cfg.vocab_offset, &d->sa, token_dev,
-                               token_logit_dev, out_tokens, 0, step_dev, pos_dev, 0, stream);
-  else
-    rc = chatts_argmax(d->b.logits, d->cfg.vocab_local, d->cfg.vocab_offset, token_dev, token_logit_dev, out_tokens, step_dev,
-                       pos_dev, stream);
-  if (rc) return rc;
-  return chatts_embed_token(token_dev, d->w.embed, d->cfg.vocab_offset, d->cfg.vocab_local, d->cfg.hidden, d->b.x, stream);
+  if ((rc = chatts_decoder_select_tokens(d, d->b.logits, 1, d->cfg.vocab_local, token_dev, token_logit_dev, out_tokens, 0, step_dev,
+                                         pos_dev, 0, nullptr, stream)) != 0) return rc;
+  return chatts_embed_token(token_dev, d->w.embed, embed_offset(d), embed_rows(d), d->cfg.hidden, d->b.x, stream);
 }

@@ -314,6 +314,17 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   else if (a->n >= 16384) { nw_auto = 8; occ_auto = 2; }    // gate_up
   else if (a->n > 6000) nw_auto = 16;                  // qkv
   else nw_auto = 4;                                    // o_proj
+  // Balanced layout (profiles/r2_gemv_sweep_balanced.txt): when the CUs divide the row-group tasks, one workgroup per CU whose
+  // wave count divides the tasks per CU gives every wave the same number of tasks (no ragged last round): o_proj 11.5 ->
+  // 11.2 us, gate_up 44.5 -> 44.1, down_proj 24.9 -> 24.5; lm_head (297 tasks per CU) keeps the 2-workgroup layout.
+  const int tasks_r2 = (units + (swiglu ? 0 : 1)) / (swiglu ? 1 : 2);
+  int balanced_nw = 0;
+  if (units < 65536 && tasks_r2 % cus == 0) {
+    const int per_cu = tasks_r2 / cus;
+    for (int w = 16; w >= 5 && !balanced_nw; --w)
+      if (per_cu % w == 0) balanced_nw = w;
+  }
+  if (balanced_nw) { nw_auto = balanced_nw; occ_auto = 1; }
   int nw = env_int("CHATTS_GEMV_NW", nw_auto);
   if (nw < 1 || nw > 16) nw = 4;
   int occ = (int)((150 * 1024) / lds);          // workgroups per CU that fit in LDS

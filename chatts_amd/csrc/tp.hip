@@ -1,0 +1,330 @@
+// tp.hip - tensor-parallel exchange for the decoder: one-shot peer-to-peer collectives over xGMI.
+//
+// The reference gets tensor parallelism from vLLM (tensor_parallel_size=k: NetManAIOps/ChatTS demo/demo_vllm.py:30,
+// chatts/utils/llm_utils.py:154), i.e. NCCL all-reduces after o_proj and down_proj.  A decode step exchanges 96 vectors of
+// H float32 (20 KB at batch 1): pure latency.  RCCL's ring / tree launch costs ~25 us per call and cannot be captured
+// together with our kernels into one hipGraph, so the small exchanges are hand-written here (RCCL keeps the prefill-sized
+// messages, chatts_amd/tp.py):
+//
+//   * every rank owns ONE exchange buffer (fine-grained device memory, exported with hipIpcGetMemHandle); every rank maps
+//     all peers' buffers (hipIpcOpenMemHandle) -> a table of W device pointers.  xGMI is point to point: a rank PUSHES
+//     its vector to all W-1 peers in parallel over its W-1 links (posted writes, no read round trip);
+//   * the payload travels as 8-byte {tag, value} granules written by ONE system-scope store each: the data is its own
+//     flag (the low-latency protocol: no fence, no separate flag round trip).  The receiver polls its LOCAL buffer until
+//     the tag equals the call's epoch, then adds the W vectors in RANK ORDER - every rank computes bit-identical sums,
+//     so the replicated residual stream never diverges between ranks;
+//   * the epoch is a device-resident call counter bumped by the last workgroup of every collective, never a kernel
+//     argument: a captured decode step replays with fresh epochs.  Slots alternate by epoch parity; a rank can run at
+//     most one collective ahead of the slowest peer (it needs that peer's contribution to finish), so two slots suffice;
+//   * every spin is bounded (~2 s of the 100 MHz wall clock); a timeout sets a status word instead of hanging the GPU.
+#include <string.h>
+
+#include <new>
+
+#include "common.h"
+
+namespace chatts {
+
+constexpr int kMaxWorld = 8;
+constexpr uint64_t kSpinTicks = 200000000ull;      // wall_clock64 runs at 100 MHz: 2 s
+
+struct TpParams {
+  uint64_t* peer[kMaxWorld];   // peer[p]: rank p's exchange buffer as mapped in this process (peer[rank] = local)
+  uint32_t* ctr;               // device words: [0] completed-call counter (epoch - 1), [1] arrivals, [2] status
+  int rank, world;
+  int64_t max_elems;           // granules per (slot, source rank)
+};
+
+__device__ __forceinline__ uint64_t* slot_ptr(const TpParams& p, int owner, uint32_t epoch, int src) {
+  return p.peer[owner] + ((int64_t)(epoch & 1u) * p.world + src) * p.max_elems;
+}
+__device__ __forceinline__ void put(uint64_t* g, uint32_t epoch, uint32_t bits) {
+  __hip_atomic_store(g, ((uint64_t)epoch << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// poll one granule of the LOCAL buffer until its tag is `epoch`; false on timeout
+__device__ __forceinline__ bool take(uint64_t* g, uint32_t epoch, uint32_t& bits, uint32_t* status) {
+  uint64_t v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((uint32_t)(v >> 32) != epoch) {
+    const uint64_t t0 = wall_clock64();
+    do {
+      __builtin_amdgcn_s_sleep(1);
+      v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((uint32_t)(v >> 32) == epoch) break;
+      if (wall_clock64() - t0 > kSpinTicks) { atomicOr(status, 1u); bits = 0; return false; }
+    } while (true);
+  }
+  bits = (uint32_t)v;
+  return true;
+}
+// the last workgroup to finish publishes the new call count (every workgroup has read ctr[0] before it arrives)
+__device__ __forceinline__ void finish_call(const TpParams& p, uint32_t epoch) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t old = atomicAdd(&p.ctr[1], 1u);
+    if (old == gridDim.x - 1) { p.ctr[1] = 0; __hip_atomic_store(&p.ctr[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  }
+}
+
+// out[i] = (resid ? resid[i] : 0) + sum_r in_r[i], r = 0..W-1 in rank order.  out may alias resid (x += all-reduced delta).
+__global__ __launch_bounds__(1024) void tp_allreduce_kernel(TpParams p, const float* __restrict__ in, const float* resid,
+                                                           float* out, int64_t n) {
+  const uint32_t epoch = p.ctr[0] + 1u;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = i0; i < n; i += stride) {
+    const uint32_t bits = __float_as_uint(in[i]);
+    for (int k = 0; k < p.world; ++k) {                     // start with myself, then ring order: spreads the links
+      const int q = (p.rank + k) % p.world;
+      put(slot_ptr(p, q, epoch, p.rank) + i, epoch, bits);
+    }
+  }
+  for (int64_t i = i0; i < n; i += stride) {
+    float sum = 0.f;
+    bool ok = true;
+    for (int src = 0; src < p.world && ok; ++src) {
+      uint32_t bits;
+      ok = take(slot_ptr(p, p.rank, epoch, src) + i, epoch, bits, &p.ctr[2]);
+      sum = src == 0 ? __uint_as_float(bits) : sum + __uint_as_float(bits);
+    }
+    out[i] = resid ? resid[i] + sum : sum;
+  }
+  finish_call(p, epoch);
+}
+
+// in_r: [rows, row_len] of every rank -> out [rows, W * row_len]: row b = concatenation of the ranks' rows b in rank order
+// (vocab-parallel logits -> full vocabulary, one row per sequence)
+__global__ __launch_bounds__(1024) void tp_allgather_kernel(TpParams p, const float* __restrict__ in, float* out, int64_t rows,
+                                                           int64_t row_len) {
+  const uint32_t epoch = p.ctr[0] + 1u;
+  const int64_t n_local = rows * row_len;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = i0; i < n_local; i += stride) {
+    const uint32_t bits = __float_as_uint(in[i]);
+    for (int k = 0; k < p.world; ++k) {
+      const int q = (p.rank + k) % p.world;
+      put(slot_ptr(p, q, epoch, p.rank) + i, epoch, bits);
+    }
+  }
+  bool ok = true;
+  for (int src = 0; src < p.world && ok; ++src)
+    for (int64_t i = i0; i < n_local && ok; i += stride) {
+      uint32_t bits;
+      ok = take(slot_ptr(p, p.rank, epoch, src) + i, epoch, bits, &p.ctr[2]);
+      const int64_t b = i / row_len, v = i - b * row_len;
+      out[(b * p.world + src) * row_len + v] = __uint_as_float(bits);
+    }
+  finish_call(p, epoch);
+}
+
+// Greedy token under a vocab-parallel lm_head: every rank contributes its local (max logit, global token id) per sequence;
+// all ranks select the same winner (largest logit, ties -> lowest token id = torch.argmax over the full vocabulary) and
+// apply the side effects of chatts_argmax_batched (token, logit, out_tokens[step], ++step, ++pos).  One wave per sequence
+// (blockIdx.x = sequence b); lane l < W talks to rank l.
+__global__ __launch_bounds__(64) void tp_argmax_kernel(TpParams p, const float* __restrict__ logit, const int64_t* __restrict__ token_in,
+                                                      int64_t* token, float* token_logit, int64_t* out_tokens, int64_t out_stride,
+                                                      int32_t* step_dev, int32_t* pos_dev, int pos_limit) {
+  const uint32_t epoch = p.ctr[0] + 1u;
+  const int lane = threadIdx.x, b = blockIdx.x;
+  if (lane < p.world) {
+    uint64_t* g = slot_ptr(p, lane, epoch, p.rank) + 2 * b;
+    put(g, epoch, __float_as_uint(logit[b]));
+    put(g + 1, epoch, (uint32_t)token_in[b]);
+  }
+  float best = -INFINITY;
+  uint32_t best_tok = 0xffffffffu;
+  if (lane < p.world) {
+    uint64_t* g = slot_ptr(p, p.rank, epoch, lane) + 2 * b;
+    uint32_t lb = 0, tb = 0;
+    if (take(g, epoch, lb, &p.ctr[2]) && take(g + 1, epoch, tb, &p.ctr[2])) { best = __uint_as_float(lb); best_tok = tb; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const uint32_t ot = __shfl_xor(best_tok, o, 64);
+    if (ob > best || (ob == best && ot < best_tok)) { best = ob; best_tok = ot; }
+  }
+  if (lane == 0) {
+    token[b] = (int64_t)best_tok;
+    if (token_logit) token_logit[b] = best;
+    if (out_tokens && step_dev) out_tokens[(int64_t)b * out_stride + step_dev[b]] = (int64_t)best_tok;
+    if (step_dev) step_dev[b] += 1;
+    if (pos_dev) { const int np = pos_dev[b] + 1; pos_dev[b] = (pos_limit > 0 && np > pos_limit) ? pos_limit : np; }
+  }
+  finish_call(p, epoch);
+}
+
+__global__ void tp_reset_kernel(uint64_t* buf, int64_t granules, uint32_t* ctr) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < granules; i += stride) buf[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 4) ctr[threadIdx.x] = 0;
+}
+
+}  // namespace chatts
+
+using namespace chatts;
+
+struct ChattsTpComm {
+  TpParams p{};
+  void* opened[kMaxWorld] = {};      // IPC mappings to close
+  bool ipc = false;
+  size_t bytes = 0;
+};
+
+extern "C" size_t chatts_tp_buffer_bytes(int world, int64_t max_elems) {
+  if (world < 1 || world > kMaxWorld || max_elems < 1) return 0;
+  const int64_t per = (max_elems + 1) / 2 * 2;
+  return (size_t)2 * world * per * sizeof(uint64_t) + 256;        // + the counter words at the end
+}
+
+extern "C" int chatts_tp_buffer_alloc(size_t bytes, void** dev_ptr, uint8_t* handle /* [CHATTS_TP_HANDLE_BYTES] */) {
+  CHATTS_REQUIRE(dev_ptr && bytes >= 512, CHATTS_E_BADARG, "tp_buffer_alloc: bad arguments");
+  void* ptr = nullptr;
+  // fine-grained (uncached) device memory: remote stores and local polls must not sit in a non-coherent L2
+  hipError_t e = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocFinegrained); }
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&ptr, bytes); }
+  CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "tp_buffer_alloc: %s", hipGetErrorString(e));
+  e = hipMemset(ptr, 0, bytes);
+  CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "tp_buffer_alloc: memset: %s", hipGetErrorString(e));
+  if (handle) {
+    static_assert(sizeof(hipIpcMemHandle_t) <= CHATTS_TP_HANDLE_BYTES, "IPC handle does not fit");
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, ptr);
+    if (e != hipSuccess) {
+      (void)hipFree(ptr);
+      set_error("tp_buffer_alloc: hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)", hipGetErrorString(e));
+      return CHATTS_E_LAUNCH;
+    }
+    memset(handle, 0, CHATTS_TP_HANDLE_BYTES);
+    memcpy(handle, &h, sizeof(h));
+  }
+  *dev_ptr = ptr;
+  return CHATTS_OK;
+}
+
+extern "C" int chatts_tp_buffer_free(void* dev_ptr) {
+  if (dev_ptr && hipFree(dev_ptr) != hipSuccess) { (void)hipGetLastError(); return CHATTS_E_LAUNCH; }
+  return CHATTS_OK;
+}
+
+static ChattsTpComm* tp_make(int rank, int world, int64_t max_elems, size_t bytes) {
+  if (rank < 0 || world < 1 || world > kMaxWorld || rank >= world || max_elems < 2) {
+    set_error("tp_init: bad rank %d / world %d / max_elems %lld", rank, world, (long long)max_elems);
+    return nullptr;
+  }
+  if (bytes < chatts_tp_buffer_bytes(world, max_elems)) {
+    set_error("tp_init: exchange buffer of %zu bytes < %zu", bytes, chatts_tp_buffer_bytes(world, max_elems));
+    return nullptr;
+  }
+  ChattsTpComm* c = new (std::nothrow) ChattsTpComm();
+  if (!c) { set_error("tp_init: out of host memory"); return nullptr; }
+  c->p.rank = rank; c->p.world = world; c->p.max_elems = (max_elems + 1) / 2 * 2; c->bytes = bytes;
+  return c;
+}
+
+static void tp_bind_local(ChattsTpComm* c, void* local) {
+  c->p.peer[c->p.rank] = reinterpret_cast<uint64_t*>(local);
+  c->p.ctr = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(local) + (size_t)2 * c->p.world * c->p.max_elems * sizeof(uint64_t));
+}
+
+extern "C" ChattsTpComm* chatts_tp_init(int rank, int world, void* local_buf, const uint8_t* handles, size_t bytes, int64_t max_elems) {
+  ChattsTpComm* c = tp_make(rank, world, max_elems, bytes);
+  if (!c) return nullptr;
+  if (!local_buf || (world > 1 && !handles)) { set_error("tp_init: null buffer / handles"); delete c; return nullptr; }
+  tp_bind_local(c, local_buf);
+  c->ipc = true;
+  for (int r = 0; r < world; ++r) {
+    if (r == rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + (size_t)r * CHATTS_TP_HANDLE_BYTES, sizeof(h));
+    void* ptr = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      set_error("tp_init: hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+      (void)hipGetLastError();
+      chatts_tp_destroy(c);
+      return nullptr;
+    }
+    c->opened[r] = ptr;
+    c->p.peer[r] = reinterpret_cast<uint64_t*>(ptr);
+  }
+  return c;
+}
+
+extern "C" ChattsTpComm* chatts_tp_init_local(int rank, int world, void* const* bufs, size_t bytes, int64_t max_elems) {
+  ChattsTpComm* c = tp_make(rank, world, max_elems, bytes);
+  if (!c) return nullptr;
+  if (!bufs) { set_error("tp_init_local: null buffer table"); delete c; return nullptr; }
+  for (int r = 0; r < world; ++r) {
+    if (!bufs[r]) { set_error("tp_init_local: null buffer of rank %d", r); delete c; return nullptr; }
+    c->p.peer[r] = reinterpret_cast<uint64_t*>(bufs[r]);
+  }
+  tp_bind_local(c, bufs[rank]);
+  return c;
+}
+
+extern "C" void chatts_tp_destroy(ChattsTpComm* c) {
+  if (!c) return;
+  if (c->ipc)
+    for (int r = 0; r < kMaxWorld; ++r)
+      if (c->opened[r] && hipIpcCloseMemHandle(c->opened[r]) != hipSuccess) (void)hipGetLastError();
+  delete c;
+}
+
+extern "C" int chatts_tp_rank(const ChattsTpComm* c) { return c ? c->p.rank : -1; }
+extern "C" int chatts_tp_world(const ChattsTpComm* c) { return c ? c->p.world : -1; }
+extern "C" int64_t chatts_tp_max_elems(const ChattsTpComm* c) { return c ? c->p.max_elems : 0; }
+// diagnostic, NOT for the hot path: blocks until the device is idle on the null stream's terms (hipMemcpy)
+extern "C" int chatts_tp_status(ChattsTpComm* c) {
+  CHATTS_REQUIRE(c, CHATTS_E_BADARG, "tp_status: null comm");
+  uint32_t v = 0;
+  const hipError_t e = hipMemcpy(&v, c->p.ctr + 2, sizeof(v), hipMemcpyDeviceToHost);
+  CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "tp_status: %s", hipGetErrorString(e));
+  return (int)(v & 0x7fffffffu);
+}
+
+extern "C" int chatts_tp_reset(ChattsTpComm* c, chatts_stream_t stream) {
+  CHATTS_REQUIRE(c, CHATTS_E_BADARG, "tp_reset: null comm");
+  const int64_t granules = (int64_t)2 * c->p.world * c->p.max_elems;
+  hipLaunchKernelGGL(tp_reset_kernel, dim3(256), dim3(256), 0, as_stream(stream), c->p.peer[c->p.rank], granules, c->p.ctr);
+  CHATTS_CHECK_LAUNCH("tp_reset");
+  return CHATTS_OK;
+}
+
+static int tp_blocks(int64_t n) {      // one 1024-thread workgroup up to 8 k elements (latency), then 4 per thread
+  if (n <= 8192) return 1;
+  const int64_t b = (n + 4095) / 4096;
+  return (int)(b > 64 ? 64 : b);
+}
+
+extern "C" int chatts_allreduce(ChattsTpComm* c, const float* in, float* out, const float* resid, int64_t n, chatts_stream_t stream) {
+  CHATTS_REQUIRE(c && in && out, CHATTS_E_BADARG, "allreduce: null argument");
+  CHATTS_REQUIRE(n >= 0 && n <= c->p.max_elems, CHATTS_E_SHAPE, "allreduce: %lld elements exceed the exchange buffer (%lld)",
+                 (long long)n, (long long)c->p.max_elems);
+  if (n == 0) return CHATTS_OK;
+  hipLaunchKernelGGL(tp_allreduce_kernel, dim3(tp_blocks(n)), dim3(1024), 0, as_stream(stream), c->p, in, resid, out, n);
+  CHATTS_CHECK_LAUNCH("tp_allreduce");
+  return CHATTS_OK;
+}
+
+extern "C" int chatts_allgather(ChattsTpComm* c, const float* in, float* out, int64_t rows, int64_t row_len, chatts_stream_t stream) {
+  CHATTS_REQUIRE(c && in && out, CHATTS_E_BADARG, "allgather: null argument");
+  CHATTS_REQUIRE(rows >= 0 && row_len >= 0 && rows * row_len <= c->p.max_elems, CHATTS_E_SHAPE,
+                 "allgather: %lld x %lld elements exceed the exchange buffer (%lld)", (long long)rows, (long long)row_len,
+                 (long long)c->p.max_elems);
+  if (rows * row_len == 0) return CHATTS_OK;
+  hipLaunchKernelGGL(tp_allgather_kernel, dim3(tp_blocks(rows * row_len)), dim3(1024), 0, as_stream(stream), c->p, in, out, rows, row_len);
+  CHATTS_CHECK_LAUNCH("tp_allgather");
+  return CHATTS_OK;
+}
+
+extern "C" int chatts_tp_argmax(ChattsTpComm* c, int batch, const float* local_logit, const int64_t* local_token, int64_t* token,
+                                float* token_logit, int64_t* out_tokens, int64_t out_stride, int32_t* step_dev, int32_t* pos_dev,
+                                int pos_limit, chatts_stream_t stream) {
+  CHATTS_REQUIRE(c && local_logit && local_token && token, CHATTS_E_BADARG, "tp_argmax: null argument");
+  CHATTS_REQUIRE(batch >= 1 && 2 * (int64_t)batch <= c->p.max_elems, CHATTS_E_SHAPE, "tp_argmax: batch %d", batch);
+  hipLaunchKernelGGL(tp_argmax_kernel, dim3(batch), dim3(64), 0, as_stream(stream), c->p, local_logit, local_token, token, token_logit,
+                     out_tokens, out_stride, step_dev, pos_dev, pos_limit);
+  CHATTS_CHECK_LAUNCH("tp_argmax");
+  return CHATTS_OK;
+}

@@ -62,7 +62,7 @@ class LLM:
                              f"one per GPU (torchrun); this process group has {comm.world}")
         # max_num_seqs (vLLM's name): cache slots decoded together (continuous batching); 1 = one request at a time
         mk = dict(comm=comm, max_ctx=max_model_len, max_prefill_tokens=min(2048, max_model_len),
-                  max_batch=max(1, int(max_num_seqs)) if tensor_parallel_size == 1 else 1)
+                  max_batch=max(1, int(max_num_seqs)))
         if isinstance(model, ChatTSConfig):
             self.model = ChatTSForCausalLM.from_synthetic(model, seed=seed, **mk)
         elif isinstance(model, str) and model in PRESETS:

@@ -60,7 +60,7 @@ class ChatTSForCausalLM:
     packed_modules_mapping = packed_modules_mapping
 
     def __init__(self, config, device="cuda", comm=None, max_ctx=2048, max_prefill_tokens=2048, use_graph=True,
-                 max_batch=1, weight_format="bf16"):
+                 max_batch=1, weight_format="bf16", use_p2p=True):
         if not torch.cuda.is_available():
             raise RuntimeError("chatts_amd needs a ROCm GPU: there is no CPU fallback for the model")
         self.lib = _lib.load()
@@ -75,6 +75,8 @@ class ChatTSForCausalLM:
         self.max_batch = int(max_batch)          # KV-cache slots for batched decode (continuous batching)
         self.t_max = int(max(min(max_prefill_tokens, max_ctx), self.max_batch))
         self.use_graph = use_graph
+        self.use_p2p = use_p2p                   # TP: decode-sized exchanges through csrc/tp.hip instead of RCCL (chatts_amd/tp.py)
+        self._tp = None                          # P2PExchange of this rank once attached
         self.ts_encoder = TimeSeriesEmbedding(config.ts, device=self.device)
         self._tensors = {}            # keeps every device tensor alive (the C side borrows pointers)
         self._decoder = None
@@ -215,7 +217,8 @@ class ChatTSForCausalLM:
         self.n_splits = max(1, min(64, (self.max_ctx + 15) // 16))
         dc = _lib.DecoderConfig(hidden=H, n_layers=cfg.num_hidden_layers, n_q=plan.nq, n_kv=plan.nkv, head_dim=d,
                                 inter=plan.inter, vocab_local=plan.vocab, vocab_offset=plan.v0,
-                                rms_eps=cfg.rms_norm_eps, max_ctx=self.max_ctx, max_pos=max_pos, tp_world=plan.world)
+                                rms_eps=cfg.rms_norm_eps, max_ctx=self.max_ctx, max_pos=max_pos, tp_world=plan.world,
+                                embed_rows=cfg.vocab_size, embed_offset=0)       # the embedding table is replicated
         ws_bytes = int(lib.chatts_decoder_workspace(C.byref(dc), self.t_max, self.n_splits))
         ws_bytes = max(ws_bytes, int(lib.chatts_linear_workspace(self.t_max, plan.vocab, H)))
         for m in range(2, self.max_batch + 1):     # batched lm_head
@@ -242,6 +245,10 @@ class ChatTSForCausalLM:
             "logits_all": torch.zeros((MB, plan.vocab), **f32) if MB > 1 else None,
             "scan": torch.zeros(self.t_max + 8, dtype=torch.int32, device=dev),
             "status": torch.zeros(1, dtype=torch.int32, device=dev),
+            # tensor parallel: scratch of the token agreement (chatts_decoder_select_tokens)
+            "tp_pair_logit": torch.zeros(MB, **f32) if plan.world > 1 else None,
+            "tp_pair_token": torch.zeros(MB, dtype=torch.int64, device=dev) if plan.world > 1 else None,
+            "logits_full": torch.zeros((MB, plan.vocab * plan.world), **f32) if plan.world > 1 else None,
         }
         # single-sequence views (slot 0): the batch-1 fast path and its hipGraph use these
         B["pos"], B["step"], B["token"], B["token_logit"] = B["pos_all"][:1], B["step_all"][:1], B["token_all"][:1], B["token_logit_all"][:1]
@@ -268,11 +275,26 @@ class ChatTSForCausalLM:
                                  workspace=_lib.ptr(B["ws"]), workspace_bytes=ws_bytes, t_max=self.t_max,
                                  max_batch=self.max_batch, planes_hi=_lib.ptr(B["planes"][0]),
                                  planes_lo=_lib.ptr(B["planes"][1]), planes2_hi=_lib.ptr(B["planes"][2]),
-                                 planes2_lo=_lib.ptr(B["planes"][3]))
+                                 planes2_lo=_lib.ptr(B["planes"][3]), tp_pair_logit=_lib.ptr(B["tp_pair_logit"]),
+                                 tp_pair_token=_lib.ptr(B["tp_pair_token"]), logits_full=_lib.ptr(B["logits_full"]))
         h = lib.chatts_decoder_create(C.byref(dc), C.byref(dw), C.byref(db))
         if not h:
             raise _lib.ChattsError(-1, lib.chatts_last_error().decode())
         self._decoder = C.c_void_p(h)
+        self._graph = None
+        self._graph_batched = None
+        if plan.world > 1 and self.use_p2p and getattr(self.comm, "dist", None) is not None and self._tp is None:
+            from .tp import P2PExchange
+            self.attach_exchange(P2PExchange.create(self.comm, self.exchange_elems()))
+
+    def exchange_elems(self):
+        """float32 elements per rank the largest in-step collective moves: [max_batch, H] partial sums, or the logits gather."""
+        return max(self.max_batch * self.config.hidden_size, self.max_batch * self.plan.vocab, 2 * self.max_batch)
+
+    def attach_exchange(self, exchange):
+        """Bind this rank's P2PExchange (chatts_amd/tp.py): the whole TP decode step then runs behind one C call / one hipGraph."""
+        _lib.check(self.lib.chatts_decoder_set_tp(self._decoder, exchange.handle if exchange is not None else None))
+        self._tp = exchange
         self._graph = None
         self._graph_batched = None
 
@@ -280,6 +302,8 @@ class ChatTSForCausalLM:
         try:
             if self._decoder:
                 self.lib.chatts_decoder_destroy(self._decoder)
+            if self._tp is not None:
+                self._tp.close()
         except Exception:
             pass
 
@@ -401,13 +425,16 @@ class ChatTSForCausalLM:
         H = self.config.hidden_size
         delta = self.buf["delta"][:T]
         tp = self.plan.world > 1
+        p2p = tp and self._tp is not None and T <= 16 and T * H <= self._tp.max_elems
         pending = 0                      # TP: the all-reduced delta of the previous part is added by the next C call
         for l in range(self.config.num_hidden_layers):
             for part in (0, 1):
                 _lib.check(lib.chatts_decoder_layer_part_add(self._decoder, pending, l, part, T, pos0, _lib.ptr(pos_dev),
                                                              n_splits, st))
-                if tp:
-                    self.comm.all_reduce(delta)
+                if tp and p2p:
+                    self._tp.all_reduce(delta, out=self.buf["x"][:T], resid=self.buf["x"][:T])      # x += sum of the partials
+                elif tp:
+                    self.comm.all_reduce(delta)         # RCCL for prefill-sized messages
                     pending = 1
         if pending:
             _lib.check(lib.chatts_residual_add(_lib.ptr(self.buf["x"]), _lib.ptr(delta), T * H, st))
@@ -449,28 +476,24 @@ class ChatTSForCausalLM:
         self._graph_batched = None
 
     def _select_token(self):
-        """logits of this rank -> next token in B['token'] (appended to out_tokens, step bumped) on every rank."""
+        """logits of this rank -> next token in B['token'] (appended to out_tokens, step bumped) on every rank: greedy or the
+        configured sampler, agreed across TP ranks by chatts_decoder_select_tokens ((max, idx) pairs / gathered logits)."""
         lib, st, B = self.lib, _lib.stream_ptr(), self.buf
-        sa = getattr(self, "_sampling", None)
-        if self.plan.world == 1:
-            if sa is None:
-                _lib.check(lib.chatts_argmax(_lib.ptr(B["logits"]), self.plan.vocab, self.plan.v0, _lib.ptr(B["token"]),
-                                             _lib.ptr(B["token_logit"]), _lib.ptr(B["out_tokens"]), _lib.ptr(B["step"]),
-                                             None, st))
-            else:
-                _lib.check(lib.chatts_sample_batched(_lib.ptr(B["logits"]), 1, self.plan.vocab, self.plan.vocab, self.plan.v0,
-                                                     C.byref(sa), _lib.ptr(B["token"]), _lib.ptr(B["token_logit"]),
-                                                     _lib.ptr(B["out_tokens"]), 0, _lib.ptr(B["step"]), None, 0, st))
+        if self.plan.world == 1 or self._tp is not None:
+            _lib.check(lib.chatts_decoder_select_tokens(self._decoder, _lib.ptr(B["logits"]), 1, self.plan.vocab, _lib.ptr(B["token"]),
+                                                        _lib.ptr(B["token_logit"]), _lib.ptr(B["out_tokens"]), 0,
+                                                        _lib.ptr(B["step"]), None, 0, None, st))
             return
-        if sa is None:      # TP greedy: one (logit, index) pair per rank instead of the [V / W] logits
+        # TP without the peer-to-peer exchange (use_p2p=False): host-driven RCCL gathers
+        sa = getattr(self, "_sampling", None)
+        if sa is None:      # greedy: one (logit, index) pair per rank instead of the [V / W] logits
             _lib.check(lib.chatts_argmax(_lib.ptr(B["logits"]), self.plan.vocab, self.plan.v0, _lib.ptr(B["token"]),
                                          _lib.ptr(B["token_logit"]), None, None, None, st))
             B["token"].copy_(self.comm.argmax_pair(B["token_logit"], B["token"]))
             B["out_tokens"].index_copy_(0, B["step"].to(torch.int64), B["token"])
             B["step"] += 1
             return
-        # TP sampling: every rank draws from the gathered full-vocabulary logits with the same seed -> the same token
-        full = self.comm.all_gather_cat(B["logits"])
+        full = self.comm.all_gather_cat(B["logits"])     # every rank draws from the full logits with the same seed
         _lib.check(lib.chatts_sample_batched(_lib.ptr(full), 1, full.numel(), full.numel(), 0, C.byref(sa),
                                              _lib.ptr(B["token"]), _lib.ptr(B["token_logit"]), _lib.ptr(B["out_tokens"]), 0,
                                              _lib.ptr(B["step"]), None, 0, st))
@@ -489,7 +512,7 @@ class ChatTSForCausalLM:
 
     def _decode_step_eager(self):
         lib, st, B = self.lib, _lib.stream_ptr(), self.buf
-        if self.plan.world == 1:
+        if self.plan.world == 1 or self._tp is not None:         # one C call enqueues the whole (TP) step
             _lib.check(lib.chatts_decoder_decode_step(self._decoder, _lib.ptr(B["pos"]), _lib.ptr(B["step"]),
                                                       _lib.ptr(B["token"]), _lib.ptr(B["token_logit"]),
                                                       _lib.ptr(B["out_tokens"]), self.n_splits, st))
@@ -501,27 +524,33 @@ class ChatTSForCausalLM:
         self._load_token_embedding()
 
     def decode_step(self):
-        """One greedy token.  TP=1: a hipGraph of the whole step (captured on first use) is replayed."""
-        if self.use_graph and self.plan.world == 1:
+        """One token.  A hipGraph of the whole step (captured on first use) is replayed - under tensor parallelism too, when the
+        peer-to-peer exchange is attached (its collectives are ordinary kernels with device-resident epochs)."""
+        if self.graph_capturable():
             if self._graph is None:
                 self._capture()
             self._graph.replay()
         else:
             self._decode_step_eager()
 
-    def _capture(self):
+    def graph_capturable(self):
+        return bool(self.use_graph and (self.plan.world == 1 or self._tp is not None))
+
+    def _capture(self, warm=True):
+        """Capture one decode step.  warm: run one eager step first (populates every lazy host-side cache; under tensor
+        parallelism all ranks do, so it really exchanges) and restore the state; capturing itself executes nothing."""
         B = self.buf
         saved = {k: B[k].clone() for k in ("pos", "step", "token", "token_logit", "x", "out_tokens")}
-        kv = None
         torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):      # warm-up on a side stream (populates every lazy host-side cache)
-            self._decode_step_eager()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        for k, v in saved.items():
-            B[k].copy_(v)
+        if warm:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._decode_step_eager()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for k, v in saved.items():
+                B[k].copy_(v)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._decode_step_eager()
@@ -552,8 +581,8 @@ class ChatTSForCausalLM:
 
     def batched_step(self):
         """One greedy token for EVERY cache slot (idle slots compute harmlessly; their position saturates)."""
-        if self.plan.world != 1:
-            raise NotImplementedError("batched decode is implemented for tensor_parallel_size=1")
+        if self.plan.world != 1 and self._tp is None:
+            raise NotImplementedError("batched decode under tensor parallelism needs the peer-to-peer exchange (use_p2p=True)")
         if not self.use_graph:
             return self._batched_step_eager()
         if self._graph_batched is None:
@@ -601,18 +630,14 @@ class ChatTSForCausalLM:
         B["pos_all"][slot] = T
         B["step_all"][slot] = 0
         sa = getattr(self, "_sampling", None)
-        if sa is None:
-            _lib.check(self.lib.chatts_argmax_batched(
-                _lib.ptr(B["logits"]), 1, self.plan.vocab, self.plan.vocab, self.plan.v0,
-                B["token_all"][slot:].data_ptr(), B["token_logit_all"][slot:].data_ptr(), B["out_tokens_all"][slot].data_ptr(),
-                B["out_tokens_all"].shape[1], B["step_all"][slot:].data_ptr(), None, 0, st))
-        else:   # the batched steps draw with (seed, slot, step); this single-row call would see slot 0: fold the slot into the seed
+        sa1 = None
+        if sa is not None:   # the batched steps draw with (seed, slot, step); this single-row call would see slot 0: fold the slot into the seed
             sa1 = _lib.SamplingArgs(temperature=sa.temperature, top_k=sa.top_k, top_p=sa.top_p,
                                     seed=(sa.seed ^ (0x51ED27 * (slot + 1))) & 0xFFFFFFFF, n_kept=None, kept_mass=None)
-            _lib.check(self.lib.chatts_sample_batched(
-                _lib.ptr(B["logits"]), 1, self.plan.vocab, self.plan.vocab, self.plan.v0, C.byref(sa1),
-                B["token_all"][slot:].data_ptr(), B["token_logit_all"][slot:].data_ptr(), B["out_tokens_all"][slot].data_ptr(),
-                B["out_tokens_all"].shape[1], B["step_all"][slot:].data_ptr(), None, 0, st))
+        _lib.check(self.lib.chatts_decoder_select_tokens(
+            self._decoder, _lib.ptr(B["logits"]), 1, self.plan.vocab, B["token_all"][slot:].data_ptr(),
+            B["token_logit_all"][slot:].data_ptr(), B["out_tokens_all"][slot].data_ptr(), B["out_tokens_all"].shape[1],
+            B["step_all"][slot:].data_ptr(), None, 0, None if sa1 is None else C.byref(sa1), st))
         self.select_sequence(0)
         return T
 
@@ -761,7 +786,7 @@ class ChatTSForCausalLM:
             cursor += n_ts
             reqs.append((seq, ser, lens))
         budget = max_new_tokens if max_length is None else max(1, max_length - max(len(r[0]) for r in reqs))
-        if self.max_batch > 1 and len(reqs) > 1 and streamer is None and self.plan.world == 1:
+        if self.max_batch > 1 and len(reqs) > 1 and streamer is None and (self.plan.world == 1 or self._tp is not None):
             outs = self.generate_batch(reqs, budget, eos_token_id)          # continuous batching over the cache slots
         else:
             outs = []

@@ -9,7 +9,15 @@ lm_head vocab-parallel.  Here:
     instead of gathering [V/W] logits
   * the TS encoder, the token embedding and all norms are replicated (213 MB + 1.5 GB: cheaper than a collective)
 The exchange is a float32 sum all-reduce; there is no other data-path collective.
+
+Two transports:
+  * decode-sized messages ([B, H] float32, 96 per token): `P2PExchange` - the one-shot peer-to-peer kernels of
+    csrc/tp.hip (chatts_allreduce / chatts_tp_argmax / chatts_allgather) over IPC-mapped exchange buffers; the whole
+    TP decode step is enqueued by ONE C call and captured into ONE hipGraph;
+  * prefill-sized messages ([T, H]): RCCL through torch.distributed (`Comm.all_reduce`) between the two halves of a layer.
 """
+import ctypes as C
+
 import torch
 
 
@@ -74,3 +82,84 @@ class Comm:
 class LocalComm(Comm):
     def __init__(self):
         self.rank, self.world, self.group, self.dist = 0, 1, None, None
+
+
+class P2PExchange:
+    """One rank's end of the peer-to-peer exchange (csrc/tp.hip).  Owns the exchange buffer; `handle` is the C ChattsTpComm*."""
+
+    def __init__(self, lib, handle, buf_ptr, owns_buffer=True):
+        self.lib, self.handle, self.buf_ptr, self.owns_buffer = lib, C.c_void_p(handle), buf_ptr, owns_buffer
+        self.rank, self.world = lib.chatts_tp_rank(self.handle), lib.chatts_tp_world(self.handle)
+        self.max_elems = int(lib.chatts_tp_max_elems(self.handle))
+
+    @classmethod
+    def create(cls, comm, max_elems):
+        """Collective over `comm` (a torch.distributed-backed Comm): allocate + export this rank's buffer, exchange the IPC
+        handles out of band (all_gather_object), map every peer.  HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment."""
+        from . import _lib
+        lib = _lib.load()
+        nbytes = int(lib.chatts_tp_buffer_bytes(comm.world, int(max_elems)))
+        ptr = C.c_void_p()
+        hbuf = (C.c_uint8 * _lib.TP_HANDLE_BYTES)()
+        _lib.check(lib.chatts_tp_buffer_alloc(nbytes, C.byref(ptr), hbuf))
+        mine = bytes(hbuf)
+        allh = [None] * comm.world
+        comm.dist.all_gather_object(allh, mine, group=comm.group)
+        table = (C.c_uint8 * (_lib.TP_HANDLE_BYTES * comm.world)).from_buffer_copy(b"".join(allh))
+        h = lib.chatts_tp_init(comm.rank, comm.world, ptr, table, nbytes, int(max_elems))
+        if not h:
+            lib.chatts_tp_buffer_free(ptr)
+            raise _lib.ChattsError(-1, lib.chatts_last_error().decode())
+        comm.barrier()                           # every rank has mapped every buffer before anyone pushes
+        return cls(lib, h, ptr)
+
+    @classmethod
+    def create_local_group(cls, world, max_elems):
+        """`world` exchanges living in THIS process on the current device (single-GPU emulation of TP: every 'rank' runs on
+        its own stream; peers are plain device pointers, no IPC)."""
+        from . import _lib
+        lib = _lib.load()
+        nbytes = int(lib.chatts_tp_buffer_bytes(world, int(max_elems)))
+        ptrs = []
+        for _ in range(world):
+            ptr = C.c_void_p()
+            _lib.check(lib.chatts_tp_buffer_alloc(nbytes, C.byref(ptr), None))
+            ptrs.append(ptr)
+        arr = (C.c_void_p * world)(*[p.value for p in ptrs])
+        out = []
+        for r in range(world):
+            h = lib.chatts_tp_init_local(r, world, arr, nbytes, int(max_elems))
+            if not h:
+                raise _lib.ChattsError(-1, lib.chatts_last_error().decode())
+            out.append(cls(lib, h, ptrs[r]))
+        return out
+
+    def status(self):
+        """0 = healthy; bit 0 = a peer's contribution timed out.  Synchronising diagnostic (hipMemcpy of one word)."""
+        rc = int(self.lib.chatts_tp_status(self.handle))
+        if rc < 0:
+            from . import _lib
+            _lib.check(rc)
+        return rc
+
+    def all_reduce(self, inp, out=None, resid=None):
+        from . import _lib
+        out = inp if out is None else out
+        _lib.check(self.lib.chatts_allreduce(self.handle, inp.data_ptr(), out.data_ptr(), _lib.ptr(resid), inp.numel(),
+                                             _lib.stream_ptr()))
+        return out
+
+    def all_gather(self, inp, rows=1):
+        from . import _lib
+        row_len = inp.numel() // rows
+        out = torch.empty((rows, self.world * row_len), dtype=torch.float32, device=inp.device)
+        _lib.check(self.lib.chatts_allgather(self.handle, inp.data_ptr(), out.data_ptr(), rows, row_len, _lib.stream_ptr()))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.lib.chatts_tp_destroy(self.handle)
+            self.handle = None
+        if self.buf_ptr and self.owns_buffer:
+            self.lib.chatts_tp_buffer_free(self.buf_ptr)
+            self.buf_ptr = None

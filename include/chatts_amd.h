@@ -9,8 +9,8 @@
  * Each function cites the reference interface (file:line under NetManAIOps/ChatTS) it replaces.
  * Number formats: activations / residual stream / KV cache / logits are float32; weights are
  * bfloat16 (uint16_t bit patterns) streamed from HBM; every weight x activation product is formed
- * either exactly on the f32 VALU (decode, M<=4) or by two bf16 MFMA passes over a hi/lo split of the
- * f32 activation ("bf16x2", prefill) - see DESIGN.md section 3 for why (1e-3 logit tolerance).
+ * either exactly on the f32 VALU (decode, M == 1) or by two bf16 MFMA passes over a hi/lo split of the
+ * f32 activation ("bf16x2": batched decode M = 2..16, prefill, TS MLP) - see DESIGN.md section 3 for why (1e-3 logit tolerance).
  */
 #ifndef CHATTS_AMD_H
 #define CHATTS_AMD_H
@@ -34,8 +34,9 @@ typedef uint16_t chatts_bf16;  /* raw bfloat16 bits */
 
 const char* chatts_last_error(void);
 /* ABI version of this header: bumped whenever a struct grows or a signature changes
- * (2: plane operands, sampler, decoder plane buffers; 3: post-norm planes of chatts_linear). */
-#define CHATTS_ABI_VERSION 3
+ * (2: plane operands, sampler, decoder plane buffers; 3: post-norm planes of chatts_linear;
+ *  4: tensor-parallel exchange chatts_tp_* / chatts_allreduce, decoder embed_rows + TP buffers, chatts_decoder_select_tokens). */
+#define CHATTS_ABI_VERSION 4
 int chatts_abi_version(void);
 /* Number of CUs of the current device (grid sizing), or <0. */
 int chatts_device_cus(void);
@@ -153,9 +154,11 @@ size_t chatts_linear_workspace(int m, int n, int k);
 /* hi = bf16(x) (RNE), lo = bf16(x - hi): the operand split of the bf16x2 GEMM, done once per activation matrix. */
 int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, chatts_bf16* lo, int ld_planes,
                         chatts_stream_t stream);
-/* Dispatch: M == 1       -> weight-streaming GEMV (exact f32 VALU products, HBM-bound);
- *           2 <= M <= 16 -> weight-streaming MFMA kernel (W rows are the MFMA A operand, read once, no LDS staging);
- *           larger M     -> LDS-tiled MFMA GEMM (register-staged, or LDS-DMA on pre-split planes for M >= 96);
+/* Dispatch: M == 1       -> weight-streaming GEMV (gemv_ldsx_kernel: exact f32 VALU products, x staged in LDS, HBM-bound);
+ *           2 <= M <= 16 -> with pre-split planes: gemm_stream_kernel (W and the A planes staged by whole-line LDS-DMA through a
+ *                           4-deep ring, split-K over workgroups); with float32 A: the register-staged gemm_bf16x2_kernel;
+ *           larger M     -> gemm_dma_kernel (LDS-DMA, loader + compute waves) on pre-split planes for M >= 96 and K % 64 == 0,
+ *                           otherwise gemm_bf16x2_kernel (register-staged LDS tiles);
  *           all MFMA paths: v_mfma_f32_16x16x32_bf16 with the bf16x2 split of A. */
 int chatts_linear(const ChattsLinearArgs* args, chatts_stream_t stream);
 
@@ -241,7 +244,6 @@ int chatts_argmax_batched(const float* logits, int batch, int64_t logits_stride,
 int chatts_embed_token_batched(const int64_t* token_dev, int batch, const chatts_bf16* table, int64_t vocab_offset,
                                int64_t vocab_rows, int hidden, float* out /* [batch, hidden] */, chatts_stream_t stream);
 
-/* x[h] = float(table[*token, h]) : next-step input embedding, token id read on the device. */
 /* ---------------------------------------------------------------------------------------------
  * Sampling (temperature / top-k / top-p): what the reference's evaluation drivers ask of vLLM / HF -
  * SamplingParams(temperature=0.2) (chatts/utils/inference_tsmllm_vllm.py:43-46), temperature=0.5 + top_p=0.95
@@ -264,8 +266,52 @@ int chatts_sample_batched(const float* logits, int batch, int64_t logits_stride,
                           const ChattsSamplingArgs* args, int64_t* token, float* token_logit, int64_t* out_tokens,
                           int64_t out_stride, int32_t* step_dev, int32_t* pos_dev, int pos_limit, chatts_stream_t stream);
 
+/* x[h] = float(table[*token - vocab_offset, h]) : next-step input embedding, token id read on the device. */
 int chatts_embed_token(const int64_t* token_dev, const chatts_bf16* table, int64_t vocab_offset,
                        int64_t vocab_rows, int hidden, float* out, chatts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tensor-parallel exchange (one process per GPU).  Replaces what the reference gets from vLLM's
+ * tensor_parallel_size=k (demo/demo_vllm.py:30, chatts/utils/llm_utils.py:154): the NCCL all-reduce after o_proj and
+ * down_proj, and the logits gather / greedy-token agreement of a vocab-parallel lm_head.  The decode-sized messages
+ * (H float32 per sequence, 96 per token) are pure latency, so they are one-shot peer-to-peer kernels over IPC-mapped
+ * exchange buffers (8-byte {epoch tag, value} granules pushed over every xGMI link in parallel; sums in rank order, hence
+ * bit-identical on all ranks; epochs live on the device, so the collectives are hipGraph-capturable); prefill-sized
+ * all-reduces stay with RCCL (torch.distributed) in the host loop.  Bootstrap: every rank allocates a buffer and exports
+ * a handle, the host exchanges the W handles (any out-of-band channel: torch.distributed all_gather_object), then
+ * chatts_tp_init maps the peers.  The ONLY entry points that allocate device memory are the two buffer calls below:
+ * IPC-exportable fine-grained memory cannot come from the caller's caching allocator.
+ * ------------------------------------------------------------------------------------------- */
+#define CHATTS_TP_HANDLE_BYTES 64
+#define CHATTS_TP_MAX_WORLD 8
+typedef struct ChattsTpComm ChattsTpComm;     /* opaque; host memory only */
+/* bytes of one rank's exchange buffer for collectives of up to max_elems float32 per rank */
+size_t chatts_tp_buffer_bytes(int world, int64_t max_elems);
+/* hipExtMallocWithFlags(uncached) + zero fill + (handle != NULL) hipIpcGetMemHandle into handle[CHATTS_TP_HANDLE_BYTES] */
+int chatts_tp_buffer_alloc(size_t bytes, void** dev_ptr, uint8_t* handle);
+int chatts_tp_buffer_free(void* dev_ptr);
+/* handles: [world][CHATTS_TP_HANDLE_BYTES] in rank order (entry `rank` is ignored); maps every peer buffer (hipIpcOpenMemHandle). */
+ChattsTpComm* chatts_tp_init(int rank, int world, void* local_buf, const uint8_t* handles, size_t bytes, int64_t max_elems);
+/* the same for ranks that live in ONE process (bufs[r] = rank r's buffer, plain device pointers): single-GPU emulation, tests */
+ChattsTpComm* chatts_tp_init_local(int rank, int world, void* const* bufs, size_t bytes, int64_t max_elems);
+void chatts_tp_destroy(ChattsTpComm*);
+int chatts_tp_rank(const ChattsTpComm*);
+int chatts_tp_world(const ChattsTpComm*);
+int64_t chatts_tp_max_elems(const ChattsTpComm*);
+/* diagnostic (synchronises: one hipMemcpy): >= 0 status bits - bit 0 = a peer's contribution did not arrive within ~2 s,
+ * the results since then are garbage; call chatts_tp_reset on every rank before re-using the comm */
+int chatts_tp_status(ChattsTpComm*);
+/* zero the local buffer and the call counter (all ranks, then a host barrier, before re-using a comm after an error) */
+int chatts_tp_reset(ChattsTpComm*, chatts_stream_t stream);
+/* out[i] = (resid ? resid[i] : 0) + sum over ranks of in[i], ranks added in rank order; n <= max_elems; out may alias resid */
+int chatts_allreduce(ChattsTpComm*, const float* in, float* out, const float* resid, int64_t n, chatts_stream_t stream);
+/* in [rows, row_len] per rank -> out [rows, world * row_len] (row b = the ranks' rows b concatenated in rank order) */
+int chatts_allgather(ChattsTpComm*, const float* in, float* out, int64_t rows, int64_t row_len, chatts_stream_t stream);
+/* per sequence b < batch: the global greedy token from every rank's local (max logit, global token id); ties -> lowest id;
+ * side effects of chatts_argmax_batched on every rank */
+int chatts_tp_argmax(ChattsTpComm*, int batch, const float* local_logit, const int64_t* local_token, int64_t* token,
+                     float* token_logit, int64_t* out_tokens, int64_t out_stride, int32_t* step_dev, int32_t* pos_dev,
+                     int pos_limit, chatts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole decoder (TP rank-local).  Replaces Qwen2TSForCausalLM.forward / compute_logits
@@ -298,6 +344,8 @@ typedef struct ChattsDecoderConfig {
   float rms_eps;
   int max_ctx, max_pos;
   int tp_world;                                       /* > 1: o/down outputs are partial sums   */
+  int64_t embed_rows, embed_offset;                   /* rows of `embed` this rank holds and the id of row 0; 0 rows = the lm_head
+                                                         slice (vocab_local, vocab_offset).  Replicated table: (vocab, 0)          */
 } ChattsDecoderConfig;
 
 typedef struct ChattsDecoderWeights {
@@ -332,6 +380,11 @@ typedef struct ChattsDecoderBuffers {
   chatts_bf16* planes_lo;
   chatts_bf16* planes2_hi;
   chatts_bf16* planes2_lo;
+  /* tensor parallel only: scratch of the token agreement - local (max logit, token) per sequence, and (sampling) the
+   * gathered full-vocabulary logits [max(max_batch,1), tp_world * vocab_local] */
+  float* tp_pair_logit;    /* [max(max_batch,1)] */
+  int64_t* tp_pair_token;  /* [max(max_batch,1)] */
+  float* logits_full;      /* or NULL: sampling under TP is then refused */
 } ChattsDecoderBuffers;
 
 typedef struct ChattsDecoder ChattsDecoder;  /* opaque; host memory only */
@@ -352,6 +405,19 @@ int chatts_residual_add(float* x, const float* delta, int64_t n, chatts_stream_t
  * one host call per exchange point instead of two.  add_delta == 0: identical to chatts_decoder_layer_part. */
 int chatts_decoder_layer_part_add(ChattsDecoder*, int add_delta, int layer, int part, int t, int pos0,
                                   const int32_t* pos0_dev, int n_splits, chatts_stream_t stream);
+
+/* Attach the tensor-parallel exchange (tp_world > 1): chatts_decoder_decode_step(_batched) then run whole TP steps on the
+ * stream - partial o_proj / down_proj sums are all-reduced into the residual stream by chatts_allreduce, tokens are agreed on
+ * by chatts_tp_argmax (greedy) or by sampling from the chatts_allgather-ed logits with the shared seed - and stay
+ * graph-capturable.  The comm must outlive the decoder; NULL detaches. */
+int chatts_decoder_set_tp(ChattsDecoder*, ChattsTpComm*);
+/* Token selection for `batch` rows of this rank's logits [batch, logits_stride] (greedy, or the sampler configured with
+ * chatts_decoder_set_sampling / `override`), agreed across the TP ranks when a comm is attached.  Side effects as
+ * chatts_argmax_batched. */
+int chatts_decoder_select_tokens(ChattsDecoder*, const float* logits, int batch, int64_t logits_stride, int64_t* token,
+                                 float* token_logit, int64_t* out_tokens, int64_t out_stride, int32_t* step_dev,
+                                 int32_t* pos_dev, int pos_limit, const ChattsSamplingArgs* override_or_null,
+                                 chatts_stream_t stream);
 
 /* Token selection of chatts_decoder_decode_step(_batched): NULL (default) = greedy argmax; otherwise the sampler above
  * with these parameters (copied).  Changing it invalidates any hipGraph captured over a decode step. */

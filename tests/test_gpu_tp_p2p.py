@@ -1,0 +1,190 @@
+"""GPU: the peer-to-peer tensor-parallel exchange (csrc/tp.hip: chatts_allreduce / chatts_allgather / chatts_tp_argmax) and
+the whole-step TP decode behind it, on ONE GPU: the W 'ranks' live in this process (chatts_tp_init_local: plain device
+pointers instead of IPC mappings), each on its own stream, and really rendezvous inside the kernels.  The cross-PROCESS
+form (hipIpc handles, one process per rank) is exercised by tools/jobs/tp2_single_device.sh on the GPU box.
+Reference behaviour: vLLM tensor_parallel_size=k (NetManAIOps/ChatTS demo/demo_vllm.py:30) = sum all-reduce after
+o_proj / down_proj + a vocab-parallel lm_head; the oracle is the unsharded float32 decoder."""
+import numpy as np
+import pytest
+import torch
+
+from chatts_amd import _lib, config as cfgmod, synth
+from chatts_amd.modeling import ChatTSForCausalLM
+from chatts_amd.processing import ChatTSProcessor
+from chatts_amd.tp import LocalComm, P2PExchange
+from oracle import pipeline, synth as osynth
+from tests.util import chat_prompt, random_walk_series, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeComm(LocalComm):
+    def __init__(self, rank, world):
+        self.rank, self.world, self.group, self.dist = rank, world, None, None
+
+
+def _on_streams(world, fn):
+    """run fn(rank) for every rank on its own stream (the kernels of different ranks must be co-resident: they wait for
+    each other), then join."""
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    cur = torch.cuda.current_stream()
+    for s in streams:
+        s.wait_stream(cur)
+    for r in range(world):
+        with torch.cuda.stream(streams[r]):
+            fn(r)
+    for s in streams:
+        cur.wait_stream(s)
+    return streams
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_allreduce_allgather_argmax_local_group(world):
+    exs = P2PExchange.create_local_group(world, 40000)
+    try:
+        g = torch.Generator().manual_seed(world)
+        for it, n in enumerate([5120, 5120, 640, 8192, 20000, 1, 37777, 5120]):     # odd / even epochs, 1 and many workgroups
+            ins = [(torch.randn(n, generator=g) * (r + 1)).cuda() for r in range(world)]
+            resid = torch.randn(n, generator=g).cuda()
+            outs = [torch.empty(n, device="cuda") for _ in range(world)]
+            torch.cuda.synchronize()
+            _on_streams(world, lambda r: exs[r].all_reduce(ins[r], out=outs[r], resid=resid if it % 2 else None))
+            torch.cuda.synchronize()
+            want = ins[0].clone()
+            for r in range(1, world):
+                want = want + ins[r]                     # rank order, float32: the kernel's order
+            if it % 2:
+                want = resid + want
+            for r in range(world):
+                assert torch.equal(outs[r], want), (it, n, r)      # bit-identical on every rank
+        # in place (x += sum of deltas), as the decode step uses it
+        x = [torch.ones(5120, device="cuda") * 3 for _ in range(world)]
+        d = [torch.full((5120,), float(r + 1), device="cuda") for r in range(world)]
+        _on_streams(world, lambda r: exs[r].all_reduce(d[r], out=x[r], resid=x[r]))
+        torch.cuda.synchronize()
+        assert all(torch.equal(x[r], torch.full((5120,), 3.0 + world * (world + 1) / 2, device="cuda")) for r in range(world))
+        # all-gather of [rows, row_len] slices
+        rows, row_len = 3, 1000
+        parts = [torch.randn((rows, row_len), generator=g).cuda() for _ in range(world)]
+        got = [None] * world
+
+        def gather(r):
+            got[r] = exs[r].all_gather(parts[r], rows=rows)
+        _on_streams(world, gather)
+        torch.cuda.synchronize()
+        want = torch.cat(parts, dim=1)
+        assert all(torch.equal(got[r], want) for r in range(world))
+        # greedy-token agreement: ties resolve to the lowest token id; side effects on every rank
+        lib = _lib.load()
+        logit = [torch.tensor([1.5, -2.0], device="cuda"), torch.tensor([7.25, -2.0], device="cuda")] + \
+                [torch.tensor([7.25, -3.0], device="cuda") for _ in range(world - 2)]
+        tok_in = [torch.tensor([11 + 100 * r, 5 + r], dtype=torch.int64, device="cuda") for r in range(world)]
+        tok = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(world)]
+        tl = [torch.zeros(2, device="cuda") for _ in range(world)]
+        outt = [torch.zeros((2, 8), dtype=torch.int64, device="cuda") for _ in range(world)]
+        step = [torch.tensor([2, 0], dtype=torch.int32, device="cuda") for _ in range(world)]
+        pos = [torch.tensor([9, 30], dtype=torch.int32, device="cuda") for _ in range(world)]
+
+        def agree(r):
+            _lib.check(lib.chatts_tp_argmax(exs[r].handle, 2, logit[r].data_ptr(), tok_in[r].data_ptr(), tok[r].data_ptr(),
+                                            tl[r].data_ptr(), outt[r].data_ptr(), 8, step[r].data_ptr(), pos[r].data_ptr(), 30,
+                                            _lib.stream_ptr()))
+        _on_streams(world, agree)
+        torch.cuda.synchronize()
+        for r in range(world):
+            assert tok[r].tolist() == [111, 5]            # 7.25 first held by rank 1 (id 111); the -2.0 tie -> lowest id 5
+            assert tl[r].tolist() == [7.25, -2.0]
+            assert outt[r][0, 2].item() == 111 and outt[r][1, 0].item() == 5
+            assert step[r].tolist() == [3, 1] and pos[r].tolist() == [10, 30]      # pos saturates at the limit
+            assert exs[r].status() == 0
+    finally:
+        for e in exs:
+            e.close()
+
+
+def test_exchange_timeout_sets_status_instead_of_hanging():
+    """A rank whose peer never shows up gives up after ~2 s and raises the status bit (the box must never hang)."""
+    exs = P2PExchange.create_local_group(2, 1024)
+    try:
+        x = torch.ones(256, device="cuda")
+        exs[0].all_reduce(x, out=torch.empty_like(x))          # rank 1 never calls
+        assert exs[0].status() & 1
+    finally:
+        for e in exs:
+            e.close()
+
+
+def _shards(cfg, world, seed, **kw):
+    ms = [ChatTSForCausalLM.from_synthetic(cfg, seed=seed, comm=FakeComm(r, world), **kw) for r in range(world)]
+    exs = P2PExchange.create_local_group(world, ms[0].exchange_elems())
+    for m, e in zip(ms, exs):
+        m.attach_exchange(e)
+    return ms
+
+
+def _emulated_prefill(ms, emb, T):
+    """prefill of all shards with the partial sums added on the host side of the test (prefill-sized all-reduces are RCCL's
+    job in a real run; this test is about the decode exchange)."""
+    lib, st = ms[0].lib, _lib.stream_ptr()
+    for m in ms:
+        m.reset()
+        m.buf["x"][:T].copy_(emb)
+    for l in range(ms[0].config.num_hidden_layers):
+        for part in (0, 1):
+            for m in ms:
+                _lib.check(lib.chatts_decoder_layer_part(m._decoder, l, part, T, 0, None, 1, st))
+            total = ms[0].buf["delta"][:T].clone()
+            for m in ms[1:]:
+                total += m.buf["delta"][:T]
+            for m in ms:
+                m.buf["x"][:T] += total
+    for m in ms:
+        m.buf["pos"].fill_(T)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_tp2_decode_step_through_the_exchange_matches_oracle(use_graph):
+    """TP=2 decode: both rank-local models run chatts_decoder_decode_step (layer halves + chatts_allreduce + vocab-parallel
+    logits + chatts_tp_argmax + embedding) concurrently on two streams - eager and as two replayed hipGraphs - and produce
+    the oracle's greedy tokens; both ranks hold bit-identical residual streams."""
+    cfg = cfgmod.preset("tiny-qwen3")                  # 8 q heads / 2 kv heads -> TP=2
+    world, seed, new = 2, 9, 8
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(3)
+    lengths = [64, 33]
+    series = [random_walk_series(rng, L) for L in lengths]
+    inputs = proc(text=[chat_prompt(lengths)], timeseries=series, padding=True, return_tensors="pt")
+    ids = inputs["input_ids"][0].tolist()
+    sd = osynth.state_dict(synth.all_specs(cfg), seed)
+    want = pipeline.generate(cfg, sd, ids, inputs["timeseries"].numpy(), new)
+    ms = _shards(cfg, world, seed, max_ctx=256, max_prefill_tokens=256, use_graph=use_graph)
+    try:
+        mm = ms[0].get_multimodal_embeddings(timeseries=inputs["timeseries"].cuda(), valid_lengths=proc.last_lengths)
+        full = ms[0].expand_input_ids(ids, [(L + 15) // 16 for L in lengths])
+        emb = ms[0].get_input_embeddings(torch.tensor(full), mm)
+        T = len(full)
+        _emulated_prefill(ms, emb, T)
+        torch.cuda.synchronize()
+        _on_streams(world, lambda r: ms[r]._first_token(T))          # vocab-parallel logits + (max, idx) agreement
+        torch.cuda.synchronize()
+        lg = torch.cat([m.buf["logits"] for m in ms]).cpu().numpy()
+        assert rel_err(lg, want["logits"][0].numpy()) < 1e-3
+        assert ms[0].graph_capturable() == use_graph
+        steps = new - 1
+        if use_graph:      # one eager step on both ranks (warms every host-side cache), then capture each rank's step: capturing
+            _on_streams(world, lambda r: ms[r]._decode_step_eager())     # executes nothing, so it needs no partner
+            torch.cuda.synchronize()
+            for m in ms:
+                m._capture(warm=False)
+            steps -= 1
+        for _ in range(steps):
+            _on_streams(world, lambda r: ms[r].decode_step())
+        torch.cuda.synchronize()
+        for m in ms:
+            assert m.buf["out_tokens"][:new].tolist() == want["tokens"]
+            assert m._tp.status() == 0
+        assert torch.equal(ms[0].buf["x"][:1], ms[1].buf["x"][:1])       # replicated state never diverges
+    finally:
+        for m in ms:
+            m._tp.close()
+            m._tp = None
