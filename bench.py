@@ -135,6 +135,41 @@ def prefill_mfma_gate_up(model, T, reps=1):
             "note": "MFMA-issued flops (bf16x2: two passes per product); rows padded to 128 are not counted"}
 
 
+def ts_encoder_roofline(model, ser, lengths, reps=20):
+    """TS encoder (chatts_ts_encode: patchify + 5-layer MLP) between two HIP events on the launching stream, inputs resident.
+    Bound: HBM on the MLP weights for P <= ~1k patches (212.6 MB at H = 5120), MFMA above.
+    Algorithmic bytes per call = bf16 weights + f32 biases + touched position rows + series + f32 output."""
+    import torch
+    enc = model.ts_encoder
+    out = model.get_multimodal_embeddings(timeseries=ser, valid_lengths=lengths)
+    P = sum(o.shape[0] for o in out)
+    H = enc.hidden_size
+    stream = torch.cuda.current_stream()
+    enc.replay_last()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        enc.replay_last()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    avg_s = e0.elapsed_time(e1) * 1e-3 / reps
+    w_bytes = sum(enc.layer_in_features(l) * H * 2 + H * 4 for l in range(enc.num_layers))
+    pos_rows = min(max(lengths) + 1, enc.max_sequence_length + 1) * enc.embedding_dim * 4 if enc.mode == 1 else 0
+    byts = w_bytes + pos_rows + 8 * sum(lengths) + 4 * P * H
+    flops = 2.0 * P * sum(enc.layer_in_features(l) * H for l in range(enc.num_layers))
+    hbm_floor_us, mfma_floor_us = byts / HBM_PEAK_GBS / 1e3, 2 * flops / MFMA_BF16_PEAK_TFLOPS / 1e6     # bf16x2: two MFMA passes
+    bound = "hbm" if hbm_floor_us >= mfma_floor_us else "mfma"
+    res = {"kernel": "chatts_ts_encode (ts_patchify + 5 x gemm_{stream,dma}_kernel on bf16 planes, GELU fused)", "patches": P,
+           "bound": bound, "avg_us": avg_s * 1e6, "bytes_per_call": byts, "flops_per_call": flops, "calls_timed": reps}
+    if bound == "hbm":
+        res.update(achieved=byts / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=byts / avg_s / 1e9 / HBM_PEAK_GBS)
+    else:
+        res.update(achieved=2 * flops / avg_s / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                   frac=2 * flops / avg_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, note="MFMA-issued flops (bf16x2)")
+    return res
+
+
 def cpu_baseline(model, prompt_tokens, budget_s=30.0):
     """CPU float32 oracle (the reference's HF float32 path restated, see oracle/) on the host cores of THIS box.
     Bounded sample: ChatTS-14B widths with 2 and then 4 decoder layers (weights copied back from the GPU, so both
@@ -377,6 +412,10 @@ def main():
                      "launches_timed": roof["launches"]},
     }
     result["parity_checked"], result["parity"] = parity_check(args, toks)
+    try:        # north_star: "rocprof HBM GB/s on the TS-encoder" - the encoder's own roofline line, at the workload's shape
+        result["ts_encoder_roofline"] = ts_encoder_roofline(model, ser, lengths)
+    except Exception as e:
+        result["ts_encoder_roofline"] = {"error": f"{type(e).__name__}: {e}"}
     try:        # secondary evidence: MFMA utilisation of the prefill's dominant GEMM (north_star asks for it beside the HBM rate)
         result["prefill_roofline"] = prefill_mfma_gate_up(model, T)
     except Exception as e:

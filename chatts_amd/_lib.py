@@ -20,7 +20,7 @@ class PatchifyArgs(C.Structure):
     _fields_ = [("series", c_void_p), ("row_off", c_void_p), ("valid_len", c_void_p), ("pos_table", c_void_p),
                 ("out", c_void_p), ("n_series", c_int), ("lmax", c_int), ("patch_size", c_int), ("mode", c_int),
                 ("emb_dim", c_int), ("max_seq_len", c_int), ("max_valid_len", c_int), ("total_patches", c_int),
-                ("ld_out", c_int)]
+                ("ld_out", c_int), ("out_hi", c_void_p), ("out_lo", c_void_p)]
 
 
 class TsWeights(C.Structure):

@@ -42,7 +42,19 @@ __global__ __launch_bounds__(256) void ts_patchify_kernel(ChattsPatchifyArgs a) 
   const int pp = p - a.row_off[s];          // patch index inside the series
   const int ps = a.patch_size;
   const float2* row = reinterpret_cast<const float2*>(a.series) + (size_t)s * a.lmax;
-  float* out = a.out + (size_t)p * a.ld_out;
+  // the row goes out as float32, or (out_hi / out_lo set) directly as the bf16 hi / lo planes of that float32 value - the
+  // operand format of the first MLP GEMM (same split as chatts_split_bf16x2: hi = bf16(v), lo = bf16(v - hi))
+  const size_t obase = (size_t)p * a.ld_out;
+  auto put = [&](int col, float v) {
+    if (a.out_hi) {
+      uint16_t h, l;
+      split_bf16x2(v, h, l);
+      a.out_hi[obase + col] = h;
+      a.out_lo[obase + col] = l;
+    } else {
+      a.out[obase + col] = v;
+    }
+  };
   const int t0 = pp * ps;
   const float last = row[vl - 1].x;          // last VALID value (chatts_vllm.py:122); vl >= 1 here
   int feat;
@@ -50,31 +62,31 @@ __global__ __launch_bounds__(256) void ts_patchify_kernel(ChattsPatchifyArgs a) 
     feat = ps + ps * a.emb_dim;
     if (lane < ps) {
       const int t = t0 + lane;
-      out[lane] = t < vl ? row[t].x : last;
+      put(lane, t < vl ? row[t].x : last);
     }
     // out[ps + j*emb + e] = pos_table[idx_j][e], idx_j = t0+j if valid else padding_idx (= max_seq_len)
     for (int q = lane; q < ps * a.emb_dim; q += 64) {
       const int j = q / a.emb_dim, e = q - j * a.emb_dim;
       const int t = t0 + j;
       const int idx = t < vl ? t : a.max_seq_len;
-      out[ps + q] = a.pos_table[(size_t)idx * a.emb_dim + e];
+      put(ps + q, a.pos_table[(size_t)idx * a.emb_dim + e]);
     }
   } else if (a.mode == 2) {
     feat = 2 * ps;
     if (lane < ps) {
       const int t = t0 + lane;
       const int den = a.max_valid_len - 1 > 1 ? a.max_valid_len - 1 : 1;   // max(1, max_vl-1), :147
-      out[2 * lane] = t < vl ? row[t].x : last;
-      out[2 * lane + 1] = t < vl ? (float)t / (float)den : -1.0f;
+      put(2 * lane, t < vl ? row[t].x : last);
+      put(2 * lane + 1, t < vl ? (float)t / (float)den : -1.0f);
     }
   } else {
     feat = ps;
     if (lane < ps) {
       const int t = t0 + lane;
-      out[lane] = t < vl ? row[t].x : last;
+      put(lane, t < vl ? row[t].x : last);
     }
   }
-  for (int q = feat + lane; q < a.ld_out; q += 64) out[q] = 0.f;   // K padding for the MFMA GEMM
+  for (int q = feat + lane; q < a.ld_out; q += 64) put(q, 0.f);   // K padding for the MFMA GEMM
 }
 
 }  // namespace chatts
@@ -99,7 +111,8 @@ extern "C" int chatts_ts_patchify(const ChattsPatchifyArgs* a, chatts_stream_t s
   CHATTS_REQUIRE(a != nullptr, CHATTS_E_BADARG, "ts_patchify: null args");
   CHATTS_REQUIRE(a->total_patches >= 0 && a->n_series >= 0, CHATTS_E_BADARG, "ts_patchify: negative size");
   if (a->total_patches == 0) return CHATTS_OK;
-  CHATTS_REQUIRE(a->series && a->row_off && a->valid_len && a->out, CHATTS_E_BADARG, "ts_patchify: null pointer");
+  CHATTS_REQUIRE(a->series && a->row_off && a->valid_len && (a->out || (a->out_hi && a->out_lo)), CHATTS_E_BADARG,
+                 "ts_patchify: null pointer");
   CHATTS_REQUIRE(a->patch_size > 0 && a->patch_size <= 64, CHATTS_E_SHAPE, "ts_patchify: patch_size %d not in 1..64",
                  a->patch_size);
   CHATTS_REQUIRE(a->mode >= 0 && a->mode <= 2, CHATTS_E_BADARG, "ts_patchify: mode %d", a->mode);
@@ -128,20 +141,37 @@ extern "C" int chatts_ts_encode(const float* series, const int32_t* row_off, con
   pa.n_series = n_series; pa.lmax = lmax; pa.patch_size = w->patch_size; pa.mode = w->mode; pa.emb_dim = w->emb_dim;
   pa.max_seq_len = w->max_seq_len; pa.max_valid_len = max_valid_len; pa.total_patches = total_patches;
   pa.ld_out = w->in_features_pad;
+  // Plane path (P > 1 and every K a multiple of 64): each activation matrix lives as bf16 hi / lo planes inside the caller's
+  // float32 scratch of the same byte size (4 B per element = 2 + 2) - patchify writes the planes of layer 0's operand, every
+  // GELU epilogue writes the planes of the next layer's, and the GEMMs stage all operands with whole-line LDS-DMA
+  // (gemm_stream_kernel for P <= 16: the 213 MB of MLP weights are streamed once; gemm_dma_kernel above).  The values are
+  // the splits of exactly the float32 numbers the float32 path would hold, so both paths give the same result.
+  const int P = total_patches, H = w->hidden;
+  const bool planes = P > 1 && w->in_features_pad % 64 == 0 && H % 64 == 0 && getenv("CHATTS_TS_F32_PATH") == nullptr;
+  auto hi_of = [&](float* buf) { return reinterpret_cast<chatts_bf16*>(buf); };
+  auto lo_of = [&](float* buf, int k) { return reinterpret_cast<chatts_bf16*>(buf) + (size_t)P * k; };
+  if (planes) { pa.out = nullptr; pa.out_hi = hi_of(feat); pa.out_lo = lo_of(feat, w->in_features_pad); }
   int rc = chatts_ts_patchify(&pa, stream);
   if (rc) return rc;
-  const float* cur = feat;
+  float* cur = feat;
   int k = w->in_features_pad;
   for (int l = 0; l < w->num_layers; ++l) {
     const bool last = l == w->num_layers - 1;
     float* dst = last ? out : ((l & 1) ? h1 : h0);
     ChattsLinearArgs la{};
-    la.a = cur; la.w = w->w[l]; la.bias = w->b[l]; la.c = dst; la.m = total_patches; la.n = w->hidden; la.k = k;
-    la.lda = k; la.ldw = k; la.ldc = w->hidden; la.epilogue = last ? CHATTS_EPI_NONE : CHATTS_EPI_GELU;
+    la.w = w->w[l]; la.bias = w->b[l]; la.m = P; la.n = H; la.k = k;
+    la.lda = k; la.ldw = k; la.ldc = H; la.epilogue = last ? CHATTS_EPI_NONE : CHATTS_EPI_GELU;
     la.workspace = workspace; la.workspace_bytes = workspace_bytes;
+    if (planes) {
+      la.a_hi = hi_of(cur); la.a_lo = lo_of(cur, k); la.ld_planes = k;
+      if (last) la.c = dst;
+      else { la.c_hi = hi_of(dst); la.c_lo = lo_of(dst, H); la.ld_cplanes = H; }
+    } else {
+      la.a = cur; la.c = dst;
+    }
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     cur = dst;
-    k = w->hidden;
+    k = H;
   }
   return CHATTS_OK;
 }

@@ -16,8 +16,9 @@ import torch
 from . import _lib
 
 
-def _pad32(k):
-    return (k + 31) // 32 * 32
+def _pad64(k):
+    """K of the first Linear, zero padded: whole 128-byte bf16 lines, the K-step of the LDS-DMA GEMM kernels."""
+    return (k + 63) // 64 * 64
 
 
 class TimeSeriesEmbedding:
@@ -38,7 +39,7 @@ class TimeSeriesEmbedding:
             self.mode, self.in_features = 2, 2 * self.patch_size
         else:
             self.mode, self.in_features = 0, self.patch_size
-        self.k0 = _pad32(self.in_features)           # K of the first Linear, zero padded for the MFMA GEMM
+        self.k0 = _pad64(self.in_features)           # K of the first Linear, zero padded for the MFMA GEMM
         if self.hidden_size % 32:
             raise ValueError("ts hidden_size must be a multiple of 32")
         self.device = torch.device(device)
@@ -169,11 +170,19 @@ class TimeSeriesEmbedding:
             self._tsw = tw
         B = self._bufs
         out = torch.empty((P, self.hidden_size), dtype=torch.float32, device=dev)
-        import ctypes as C
-        _lib.check(lib.chatts_ts_encode(_lib.ptr(x), _lib.ptr(row_off_dev), _lib.ptr(vl_dev), n, lmax,
-                                        max(vl_host) if vl_host else 0, P, C.byref(self._tsw), _lib.ptr(B["feat"]),
-                                        _lib.ptr(B["h0"]), _lib.ptr(B["h1"]), _lib.ptr(out), _lib.ptr(B["ws"]),
-                                        B["ws_bytes"], _lib.stream_ptr()))
+        self._last = (x, row_off_dev, vl_dev, n, lmax, max(vl_host) if vl_host else 0, P, out)
+        self.replay_last()
         return out, pc_dev
+
+    def replay_last(self):
+        """Enqueue the kernels of the most recent forward() again (same device inputs and buffers): what bench.py times
+        between HIP events for the encoder's roofline line - no host-side staging in the timed region."""
+        import ctypes as C
+        lib, B = _lib.load(), self._bufs
+        x, row_off_dev, vl_dev, n, lmax, maxvl, P, out = self._last
+        _lib.check(lib.chatts_ts_encode(_lib.ptr(x), _lib.ptr(row_off_dev), _lib.ptr(vl_dev), n, lmax, maxvl, P,
+                                        C.byref(self._tsw), _lib.ptr(B["feat"]), _lib.ptr(B["h0"]), _lib.ptr(B["h1"]),
+                                        _lib.ptr(out), _lib.ptr(B["ws"]), B["ws_bytes"], _lib.stream_ptr()))
+        return out
 
     __call__ = forward

@@ -76,6 +76,10 @@ typedef struct ChattsPatchifyArgs {
   int max_valid_len;       /* mode 2 only: max_i valid_len (chatts_vllm.py:146)                      */
   int total_patches;       /* P = row_off[N], known on the host                                      */
   int ld_out;              /* >= feature count, multiple of 32 (K padding for the MFMA GEMM)         */
+  /* optional: write the rows as bf16 hi / lo planes [P, ld_out] (hi = bf16(v), lo = bf16(v - hi): the operand format of
+   * chatts_linear's plane path) instead of float32 `out`, which may then be NULL */
+  chatts_bf16* out_hi;
+  chatts_bf16* out_lo;
 } ChattsPatchifyArgs;
 /* Builds the MLP input rows: values of patch p of series i, tail padded with the LAST VALID value
  * (:121-125), followed by the position-embedding rows of indices 16p..16p+15 with padding_idx =
@@ -85,10 +89,11 @@ int chatts_ts_patchify(const ChattsPatchifyArgs* args, chatts_stream_t stream);
 /* Whole encoder in one call = _parse_and_validate_ts_input + TimeSeriesEmbedding.forward (chatts_vllm.py:493-536,
  * 93-193) after the host computed the row offsets: patchify into feat [P, in_features_pad], then the MLP
  * (Linear + exact-erf GELU) x (n-1) + Linear through the ping-pong buffers h0/h1 [P, hidden] into out [P, hidden].
- * workspace >= max_l chatts_linear_workspace(P, hidden, K_l).  Declared after ChattsLinearArgs users below. */
+ * feat / h0 / h1 are SCRATCH (float32-sized; with P > 1 and in_features_pad, hidden multiples of 64 they hold bf16 hi / lo
+ * planes and every GEMM runs on the LDS-DMA plane kernels).  workspace >= max_l chatts_linear_workspace(P, hidden, K_l). */
 typedef struct ChattsTsWeights {
   int patch_size, num_layers, hidden, mode, emb_dim, max_seq_len;
-  int in_features_pad;         /* K of layer 0, padded to a multiple of 32 (288 for 16 + 16*16) */
+  int in_features_pad;         /* K of layer 0, zero padded to a multiple of 32 (64 for the plane path: 320 for 16 + 16*16) */
   const float* pos_table;      /* mode 1 */
   const chatts_bf16* w[8];     /* [hidden, K_l] bf16 */
   const float* b[8];           /* [hidden] */

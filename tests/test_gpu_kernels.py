@@ -109,6 +109,52 @@ def test_ts_encoder_vs_reference_golden(lib, golden, name):
         assert rel_err(feats.cpu().numpy(), g["features"]) < 2e-2
 
 
+@pytest.mark.parametrize("hidden,lengths", [(1024, [17]), (1024, [256]), (1024, [100, 256, 1]), (1024, [256] * 8),
+                                            (5120, [256] * 8), (4096, [1024, 64, 1000] * 6)])
+def test_ts_encoder_plane_path_equals_float32_path(lib, monkeypatch, hidden, lengths):
+    """chatts_ts_encode: P > 1 runs on bf16 hi / lo planes (patchify writes them, every GELU epilogue writes the next
+    operand, LDS-DMA GEMM kernels: stream kernel for P <= 16, DMA kernel above); CHATTS_TS_F32_PATH=1 keeps the float32
+    register-staged path.  Same products, different tilings -> equal to float32 summation noise; the patchify planes are
+    exactly the split of the float32 rows."""
+    from chatts_amd.ts_encoder import TimeSeriesEmbedding
+    cfg = dict(patch_size=16, num_layers=5, hidden_size=hidden, num_features=2, max_sequence_length=2048,
+               use_position_embedding=True, embedding_dim=16)
+    enc = TimeSeriesEmbedding(cfg, device=DEV)
+    enc.load_synthetic([s for s in synth.ts_encoder_specs(type("C", (), {"ts": cfg})())], 3)
+    rng = np.random.default_rng(len(lengths) + hidden)
+    lmax = max(lengths)
+    x = np.zeros((len(lengths), 2 * lmax, 1), dtype=np.float32)
+    for i, L in enumerate(lengths):
+        x[i, 0:2 * L:2, 0] = rng.standard_normal(L)
+        x[i, 1:2 * L:2, 0] = 1.0
+    xd = torch.from_numpy(x).to(DEV)
+    a, _ = enc(xd, valid_lengths=lengths)
+    monkeypatch.setenv("CHATTS_TS_F32_PATH", "1")
+    b, _ = enc(xd, valid_lengths=lengths)
+    torch.cuda.synchronize()
+    assert a.shape == b.shape == (sum((L + 15) // 16 for L in lengths), hidden)
+    assert torch.isfinite(a).all()
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 5e-6
+    # patchify alone: planes == split of the float32 rows
+    pcs = [(v + 15) // 16 for v in lengths]
+    off = torch.tensor(np.concatenate([[0], np.cumsum(pcs)]).astype(np.int32), device=DEV)
+    vl = torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    P = int(sum(pcs))
+    f32 = torch.empty((P, enc.k0), dtype=torch.float32, device=DEV)
+    hi = torch.empty((P, enc.k0), dtype=torch.bfloat16, device=DEV)
+    lo = torch.empty((P, enc.k0), dtype=torch.bfloat16, device=DEV)
+    for planes in (False, True):
+        pa = _lib.PatchifyArgs(series=xd.data_ptr(), row_off=off.data_ptr(), valid_len=vl.data_ptr(),
+                               pos_table=enc.position_embedding.data_ptr(), out=None if planes else f32.data_ptr(),
+                               n_series=len(lengths), lmax=lmax, patch_size=16, mode=1, emb_dim=16, max_seq_len=2048,
+                               max_valid_len=lmax, total_patches=P, ld_out=enc.k0, out_hi=hi.data_ptr() if planes else None,
+                               out_lo=lo.data_ptr() if planes else None)
+        _lib.check(lib.chatts_ts_patchify(pa, st()))
+    torch.cuda.synchronize()
+    want_hi = f32.to(torch.bfloat16)
+    assert torch.equal(hi, want_hi) and torch.equal(lo, (f32 - want_hi.float()).to(torch.bfloat16))
+
+
 def test_ts_encoder_empty_and_errors(lib):
     from chatts_amd.ts_encoder import TimeSeriesEmbedding
     cfg = dict(patch_size=16, num_layers=2, hidden_size=64, num_features=2, max_sequence_length=64,
