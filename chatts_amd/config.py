@@ -19,11 +19,35 @@ _DEFAULT_TS = dict(patch_size=16, num_layers=5, hidden_size=None, num_features=2
                    use_position_embedding=True, use_position_idx=False, embedding_dim=16)
 
 
+# The trust_remote_code entry points save_pretrained() drops next to config.json: transformers copies them into its module
+# cache and imports them, so they only re-export the installed package (which must be importable: PYTHONPATH / pip -e).
+REMOTE_CODE = {
+    "configuration_chatts_amd.py": (
+        '"""AutoConfig entry point of the MI355X-native ChatTS engine (chatts_amd)."""\n'
+        "from transformers import PretrainedConfig\n\n\n"
+        "class ChatTSAmdConfig(PretrainedConfig):\n"
+        '    model_type = "chatts_amd"\n\n'
+        "    def __init__(self, ts=None, **kw):\n"
+        "        self.ts = ts or {}            # model.config.ts['patch_size'] stays readable (inference_tsmllm_deepspeed.py:86)\n"
+        "        super().__init__(**kw)\n"),
+    "modeling_chatts_amd.py": (
+        '"""AutoModelForCausalLM entry point: the hand-written HIP engine behind the reference\'s HF surface."""\n'
+        "from chatts_amd.modeling import ChatTSForCausalLM  # noqa: F401\n"),
+    "processing_chatts_amd.py": (
+        '"""AutoProcessor entry point: sp encoding + <ts><ts/> splicing on the host (chatts_amd.processing)."""\n'
+        "from chatts_amd.processing import ChatTSProcessor  # noqa: F401\n"),
+}
+
+
 class ChatTSConfig:
     model_type_default = "qwen2"
 
     def __init__(self, **kw):
+        kw.pop("auto_map", None); kw.pop("architectures", None)
+        decoder_type = kw.pop("decoder_type", None)               # written by save_pretrained next to model_type "chatts_amd"
         self.model_type = kw.pop("model_type", "qwen2")           # "qwen2" (bias, no qk-norm) | "qwen3"
+        if self.model_type == "chatts_amd":
+            self.model_type = decoder_type or "qwen2"
         if self.model_type in ("chatts", "qwen2_ts"):
             self.model_type = "qwen2"
         if self.model_type == "qwen3_ts":
@@ -73,10 +97,29 @@ class ChatTSConfig:
         with open(os.path.join(path, "config.json")) as f:
             return cls.from_dict(json.load(f))
 
-    def save_pretrained(self, path):
+    def save_pretrained(self, path, remote_code=True):
+        """config.json (+ the trust_remote_code entry points).  With remote_code the directory also gets three one-line modules
+        and an `auto_map`, so that the reference's UNMODIFIED loading cell (README.md:88-90)
+            AutoModelForCausalLM.from_pretrained(path, trust_remote_code=True, device_map=0, torch_dtype='float16')
+            AutoProcessor.from_pretrained(path, trust_remote_code=True, tokenizer=tokenizer)
+        resolves to this engine (the published checkpoints point their auto_map at the HF-hub PyTorch implementation)."""
         os.makedirs(path, exist_ok=True)
+        d = self.to_dict()
+        if remote_code:
+            d["model_type"] = "chatts_amd"
+            d["decoder_type"] = self.model_type
+            d["architectures"] = ["ChatTSForCausalLM"]
+            d["auto_map"] = {"AutoConfig": "configuration_chatts_amd.ChatTSAmdConfig",
+                             "AutoModelForCausalLM": "modeling_chatts_amd.ChatTSForCausalLM",
+                             "AutoProcessor": "processing_chatts_amd.ChatTSProcessor"}
+            for name, body in REMOTE_CODE.items():
+                with open(os.path.join(path, name), "w") as f:
+                    f.write(body)
+            with open(os.path.join(path, "processor_config.json"), "w") as f:
+                json.dump({"processor_class": "ChatTSProcessor",
+                           "auto_map": {"AutoProcessor": "processing_chatts_amd.ChatTSProcessor"}}, f, indent=1)
         with open(os.path.join(path, "config.json"), "w") as f:
-            json.dump(self.to_dict(), f, indent=1)
+            json.dump(d, f, indent=1)
 
     def oracle_dict(self):
         """The keys oracle/qwen_decoder.py reads."""

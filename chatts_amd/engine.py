@@ -1,0 +1,206 @@
+"""Request-level engine: incremental continuous batching over the model's KV-cache slots.
+
+The role vLLM's LLMEngine / AsyncLLMEngine plays for the reference (NetManAIOps/ChatTS demo/demo_vllm.py:49-63 offline,
+scripts/start_vllm_server.sh + chatts/utils/vllm_stream_qa.py:41-52 streaming): requests arrive at any time, are admitted
+into free cache slots between decode steps, advance together in one batched step, and hand their new tokens back as
+they are produced.  One engine owns one model (= one GPU, or one TP rank group); it is driven by a single thread
+(`EngineThread`) because the HIP stream, the captured graphs and the slot state are not re-entrant.
+
+Sampling parameters are baked into the captured decode step, so the requests decoded together share one sampling
+configuration: a request with a different one waits until the running batch has drained.
+"""
+import queue
+import threading
+import time
+from collections import deque
+
+import numpy as np
+
+
+class Request:
+    def __init__(self, rid, prompt, timeseries, max_tokens, sampling_key, eos, on_tokens):
+        self.rid, self.prompt, self.timeseries, self.max_tokens = rid, prompt, timeseries, int(max_tokens)
+        self.sampling_key, self.eos, self.on_tokens = sampling_key, set(eos or ()), on_tokens
+        self.tokens, self.sent, self.finished, self.finish_reason = [], 0, False, None
+        self.prompt_tokens = 0
+        self.t_arrival, self.t_first = time.perf_counter(), None
+        self.error = None
+
+
+class Engine:
+    """add_request() / step() like vLLM's LLMEngine.  `on_tokens(request, new_token_ids, finished)` is called from step()."""
+
+    def __init__(self, model, processor, sync_every=4):
+        self.model, self.processor = model, processor
+        self.sync_every = max(1, int(sync_every))       # decode steps between device->host token reads
+        self.waiting = deque()
+        self.nslots = max(1, model.max_batch)
+        self.slots = [None] * self.nslots
+        self.produced = [0] * self.nslots
+        self.active_key = None
+        self._since_sync = 0
+        self._rid = 0
+
+    # ---- requests ---------------------------------------------------------------------------------
+    def add_request(self, prompt, timeseries=None, max_tokens=64, temperature=0.0, top_p=1.0, top_k=0, seed=0,
+                    stop_token_ids=None, ignore_eos=False, on_tokens=None):
+        e = self.model.config.eos_token_id
+        eos = [] if ignore_eos else (list(e) if isinstance(e, (list, tuple)) else [e])
+        eos += list(stop_token_ids or [])
+        key = None if not temperature else (float(temperature), int(top_k or 0), float(top_p), int(seed))
+        self._rid += 1
+        r = Request(self._rid, prompt, list(timeseries or []), max_tokens, key, eos, on_tokens)
+        self.waiting.append(r)
+        return r
+
+    def has_work(self):
+        return bool(self.waiting) or any(s is not None for s in self.slots)
+
+    def _encode(self, r):
+        import torch
+        text, encs, lens = self.processor.splice(r.prompt, [np.asarray(s, dtype=np.float64) for s in r.timeseries])
+        ids = self.processor.tokenizer.encode(text)
+        ser = torch.from_numpy(self.processor.pad_stack(encs)) if encs else None
+        return ids, ser, lens
+
+    def _apply_sampling(self, key):
+        if key is None:
+            self.model.set_sampling(0.0)
+        else:
+            self.model.set_sampling(key[0], key[1], key[2], key[3])
+        self.active_key = key
+
+    def _emit(self, r, finished, reason=None):
+        new = r.tokens[r.sent:]
+        r.sent = len(r.tokens)
+        if finished:
+            r.finished, r.finish_reason = True, reason
+        if r.on_tokens is not None and (new or finished):
+            r.on_tokens(r, new, finished)
+
+    # ---- one scheduler iteration ---------------------------------------------------------------------
+    def step(self):
+        """Admit what fits, advance every running sequence by one token, deliver finished / newly read tokens.
+        Returns the requests that finished in this call."""
+        m = self.model
+        done = []
+        running = any(s is not None for s in self.slots)
+        if not running and self.waiting and self.waiting[0].sampling_key != self.active_key:
+            self._apply_sampling(self.waiting[0].sampling_key)
+        # admission: free slots take waiting requests that share the running batch's sampling configuration
+        for s in range(self.nslots):
+            if self.slots[s] is not None or not self.waiting:
+                continue
+            r = next((q for q in self.waiting if q.sampling_key == self.active_key), None)
+            if r is None:
+                break
+            self.waiting.remove(r)
+            try:
+                ids, ser, lens = self._encode(r)
+                r.prompt_tokens = len(ids)
+                if self.nslots == 1:
+                    m._prefill_request(ids, ser, lens, r.max_tokens)
+                else:
+                    m._admit(s, ids, ser, lens, r.max_tokens)
+            except Exception as e:          # a bad request must not take the engine down
+                r.error = e
+                self._emit(r, True, "error")
+                done.append(r)
+                continue
+            self.slots[s], self.produced[s] = r, 1
+            self._since_sync = self.sync_every          # read the first token right away (time to first token)
+        live = [s for s in range(self.nslots) if self.slots[s] is not None]
+        if not live:
+            return done
+        if self._since_sync >= self.sync_every or any(self.produced[s] >= self.slots[s].max_tokens for s in live):
+            done += self._harvest()
+            live = [s for s in range(self.nslots) if self.slots[s] is not None]
+            if not live:
+                return done
+        if self.nslots == 1:
+            m.decode_step()
+        else:
+            m.batched_step()
+        for s in live:
+            if self.produced[s] < self.slots[s].max_tokens:
+                self.produced[s] += 1
+        self._since_sync += 1
+        return done
+
+    def _harvest(self):
+        """One device->host read of every slot's tokens; deliver the new ones; retire finished sequences."""
+        m, B = self.model, self.model.buf
+        done = []
+        self._since_sync = 0
+        toks_all = B["out_tokens_all"].cpu() if self.nslots > 1 else B["out_tokens"][None].cpu()
+        for s in range(self.nslots):
+            r = self.slots[s]
+            if r is None:
+                continue
+            toks = toks_all[s, :self.produced[s]].tolist()
+            cut = next((i + 1 for i, t in enumerate(toks) if t in r.eos), None) if r.eos else None
+            if r.t_first is None:
+                r.t_first = time.perf_counter()
+            if cut is not None:
+                r.tokens = toks[:cut]
+                self._retire(s, "stop", done)
+            elif self.produced[s] >= r.max_tokens:
+                r.tokens = toks[:r.max_tokens]
+                self._retire(s, "length", done)
+            else:
+                r.tokens = toks
+                self._emit(r, False)
+        return done
+
+    def _retire(self, s, reason, done):
+        r = self.slots[s]
+        self.slots[s] = None
+        if self.nslots > 1:
+            self.model.buf["pos_all"][s] = 0          # an idle slot attends over one key, not over its stale context
+        self._emit(r, True, reason)
+        done.append(r)
+
+    def run_until_done(self):
+        out = []
+        while self.has_work():
+            out += self.step()
+        return out
+
+
+class EngineThread:
+    """Owns an Engine on one thread; other threads (the HTTP server's event loop) submit requests through a queue and get
+    their tokens through the per-request callback."""
+
+    def __init__(self, engine, device=None):
+        self.engine, self.device = engine, device
+        self.inbox = queue.Queue()
+        self._stop = threading.Event()
+        self.thread = threading.Thread(target=self._run, name="chatts-engine", daemon=True)
+        self.thread.start()
+
+    def submit(self, **kw):
+        """-> a threading.Event set once the request object exists (kw['holder'] receives it)."""
+        self.inbox.put(kw)
+
+    def _run(self):
+        if self.device is not None:
+            import torch
+            torch.cuda.set_device(self.device)
+        while not self._stop.is_set():
+            try:
+                block = not self.engine.has_work()
+                while True:
+                    kw = self.inbox.get(timeout=0.05) if block else self.inbox.get_nowait()
+                    holder = kw.pop("holder", None)
+                    r = self.engine.add_request(**kw)
+                    if holder is not None:
+                        holder.append(r)
+                    block = False
+            except queue.Empty:
+                pass
+            if self.engine.has_work():
+                self.engine.step()
+
+    def close(self):
+        self._stop.set()
+        self.thread.join(timeout=5)

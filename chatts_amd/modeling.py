@@ -111,13 +111,29 @@ class ChatTSForCausalLM:
         return m
 
     @classmethod
-    def from_pretrained(cls, path, trust_remote_code=True, device_map=None, torch_dtype=None, lora_adapter=None, **kw):
+    def register_for_auto_class(cls, auto_class="AutoModelForCausalLM"):
+        """transformers calls this on a class resolved through config.json's auto_map (trust_remote_code); nothing to register."""
+
+    @classmethod
+    def from_pretrained(cls, path, *model_args, trust_remote_code=True, device_map=None, torch_dtype=None, dtype=None,
+                        lora_adapter=None, config=None, **kw):
         """HF checkpoint directory (config.json + *.safetensors with the names of SURVEY.md section 5).
+        Also the target of ``AutoModelForCausalLM.from_pretrained(path, trust_remote_code=True, device_map=..., torch_dtype=...)``
+        (README.md:88) through the auto_map ChatTSConfig.save_pretrained writes: transformers' own keywords are accepted and
+        ignored (`config` is re-read from config.json; activations are float32 whatever torch_dtype says).
         lora_adapter: a peft LoRA adapter directory merged into the weights while loading (chatts_amd/lora.py)."""
         import glob
         import os
         from safetensors import safe_open
         cfg = ChatTSConfig.from_pretrained(path)
+        for hf_only in ("cache_dir", "force_download", "local_files_only", "token", "revision", "use_safetensors", "subfolder",
+                        "low_cpu_mem_usage", "attn_implementation", "code_revision", "_from_auto", "adapter_kwargs", "use_auth_token",
+                        "proxies", "resume_download", "_commit_hash", "_from_pipeline", "quantization_config", "weights_only"):
+            kw.pop(hf_only, None)
+        if isinstance(device_map, int):
+            device_map = f"cuda:{device_map}"
+        if isinstance(device_map, dict):
+            device_map = "cuda"
         if device_map not in (None, "auto") and "device" not in kw:
             kw["device"] = device_map if isinstance(device_map, str) else "cuda"
         m = cls(cfg, **kw)
@@ -715,10 +731,56 @@ class ChatTSForCausalLM:
     def generate_one(self, ids, series=None, lengths=None, max_new_tokens=64, eos_token_id=None, sync_every=16,
                      return_logits=False):
         """ids: un-expanded prompt ids (host list); series: [n, 2*Lmax, 1] tensor of this prompt's series."""
+        self._prefill_request(ids, series, lengths, max_new_tokens)
+        logits0 = self.buf["logits"].clone() if return_logits else None
+        eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple, set)) else
+                  ([] if eos_token_id is None else [eos_token_id]))
+        produced = 1
+        toks = None
+        while produced < max_new_tokens:
+            self.decode_step()
+            produced += 1
+            if eos and (produced % sync_every == 0):
+                toks = self.buf["out_tokens"][:produced].tolist()
+                if any(t in eos for t in toks):
+                    break
+        toks = self.buf["out_tokens"][:produced].tolist()
+        if self._tp is not None and self._tp.status():
+            raise RuntimeError("tensor-parallel exchange timed out (a peer rank did not reach the collective): tokens are invalid")
+        if eos:
+            for i, t in enumerate(toks):
+                if t in eos:
+                    toks = toks[:i + 1]
+                    break
+        return (toks, logits0) if return_logits else toks
+
+    @torch.no_grad()
+    def generate_stream(self, ids, series=None, lengths=None, max_new_tokens=64, eos_token_id=None, chunk=1):
+        """Generator over the new tokens of ONE request: yields a list of token ids every `chunk` decode steps (chunk=1: token by
+        token, what an SSE stream / HF TextStreamer consumes; each yield costs one device->host read of the tokens so far).
+        Stops after an EOS token (which is yielded) or max_new_tokens.  Same kernels and tokens as generate_one."""
+        eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple, set)) else ([] if eos_token_id is None else [eos_token_id]))
+        self._prefill_request(ids, series, lengths, max_new_tokens)
+        produced, sent = 1, 0
+        while True:
+            if produced - sent >= chunk or produced >= max_new_tokens:
+                toks = self.buf["out_tokens"][sent:produced].tolist()
+                hit = next((i for i, t in enumerate(toks) if t in eos), None)
+                if hit is not None:
+                    yield toks[:hit + 1]
+                    return
+                yield toks
+                sent = produced
+            if produced >= max_new_tokens:
+                return
+            self.decode_step()
+            produced += 1
+
+    def _prefill_request(self, ids, series, lengths, max_new_tokens):
+        """TS encode + merge + prefill + first token of one request on the single-sequence path -> prompt length T."""
         cfg = self.config
         ps = cfg.ts["patch_size"]
-        mm = None
-        counts = []
+        mm, counts = None, []
         if series is not None and series.shape[0] > 0:
             series = series.to(self.device, dtype=torch.float32)
             if lengths is None:
@@ -734,25 +796,7 @@ class ChatTSForCausalLM:
         last = self.prefill(emb, 0)
         self.buf["pos"].fill_(T)
         self._first_token(last)
-        logits0 = self.buf["logits"].clone() if return_logits else None
-        eos = set(eos_token_id if isinstance(eos_token_id, (list, tuple, set)) else
-                  ([] if eos_token_id is None else [eos_token_id]))
-        produced = 1
-        toks = None
-        while produced < max_new_tokens:
-            self.decode_step()
-            produced += 1
-            if eos and (produced % sync_every == 0):
-                toks = self.buf["out_tokens"][:produced].tolist()
-                if any(t in eos for t in toks):
-                    break
-        toks = self.buf["out_tokens"][:produced].tolist()
-        if eos:
-            for i, t in enumerate(toks):
-                if t in eos:
-                    toks = toks[:i + 1]
-                    break
-        return (toks, logits0) if return_logits else toks
+        return T
 
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, timeseries=None, max_new_tokens=64, max_length=None,
@@ -790,10 +834,17 @@ class ChatTSForCausalLM:
             outs = self.generate_batch(reqs, budget, eos_token_id)          # continuous batching over the cache slots
         else:
             outs = []
+            if streamer is not None:          # HF generate(): the prompt goes to the streamer first, then every token as it is made
+                streamer.put(ids)
             for seq, ser, lens in reqs:
-                toks = self.generate_one(seq, ser, lens, budget, eos_token_id)
-                if streamer is not None:
-                    streamer.put(torch.tensor(toks))
+                if streamer is None:
+                    toks = self.generate_one(seq, ser, lens, budget, eos_token_id)
+                else:
+                    toks = []
+                    for new in self.generate_stream(seq, ser, lens, budget, eos_token_id, chunk=1):
+                        for t in new:
+                            streamer.put(torch.tensor([t]))
+                        toks += new
                 outs.append(toks)
         rows = [ids[b].tolist() + outs[b] for b in range(ids.shape[0])]
         if streamer is not None:

@@ -76,11 +76,17 @@ class ChatTSProcessor:
         self.prefix_format = prefix_format
 
     @classmethod
-    def from_pretrained(cls, path_or_config, tokenizer=None, trust_remote_code=True, **kw):
+    def register_for_auto_class(cls, auto_class="AutoProcessor"):
+        """called by transformers on a class resolved through auto_map; nothing to register"""
+
+    @classmethod
+    def from_pretrained(cls, path_or_config, tokenizer=None, trust_remote_code=True, prefix_format="hf", **kw):
+        """``AutoProcessor.from_pretrained(path, trust_remote_code=True, tokenizer=tokenizer)`` (README.md:90) lands here through
+        the auto_map; transformers' own keywords (cache_dir, revision, ...) are accepted and ignored."""
         from .config import ChatTSConfig
         from .tokenizer import SyntheticTokenizer
         cfg = path_or_config if isinstance(path_or_config, ChatTSConfig) else ChatTSConfig.from_pretrained(path_or_config)
-        return cls(tokenizer or SyntheticTokenizer.for_config(cfg), cfg, **kw)
+        return cls(tokenizer or SyntheticTokenizer.for_config(cfg), cfg, prefix_format=prefix_format)
 
     # ---- series handling ----------------------------------------------------------------------
     @staticmethod
