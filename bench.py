@@ -53,7 +53,7 @@ def median(xs):
     return s[len(s) // 2]
 
 
-def roofline_gate_up(model, reps=2):
+def roofline_gate_up(model, reps=2, m=1):
     """Dominant kernel: gemv_kernel<.., SWIGLU, NORM> on gate_up (2*I_local x H bf16 per launch).  Launch it once
     per layer over every layer's own weights (13.6 GB at TP=1: no cache reuse) between two HIP events recorded on
     the launching stream; achieved = algorithmic bytes per launch / average launch duration."""
@@ -62,16 +62,30 @@ def roofline_gate_up(model, reps=2):
     lib, cfg, plan = model.lib, model.config, model.plan
     H = cfg.hidden_size
     n = 2 * plan.inter
-    out = torch.empty(plan.inter, dtype=torch.float32, device=model.device)
-    x = torch.randn(H, dtype=torch.float32, device=model.device)
+    out = torch.empty((m, plan.inter), dtype=torch.float32, device=model.device)
+    x = torch.randn((m, H), dtype=torch.float32, device=model.device)
     stream = torch.cuda.current_stream()
+    if m > 1:        # batched decode: the weight-streaming MFMA kernel on bf16 hi / lo planes (what the B-wide step launches)
+        hi, lo = torch.empty((m, H), dtype=torch.bfloat16, device=model.device), torch.empty((m, H), dtype=torch.bfloat16, device=model.device)
+        chi = torch.empty((m, plan.inter), dtype=torch.bfloat16, device=model.device)
+        clo = torch.empty((m, plan.inter), dtype=torch.bfloat16, device=model.device)
+        _lib.check(lib.chatts_split_bf16x2(x.data_ptr(), m, H, H, hi.data_ptr(), lo.data_ptr(), H, stream.cuda_stream))
+        wsb = max(int(lib.chatts_linear_workspace(m, n, H)), 16)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=model.device)
 
     def sweep():
         for lw in model.layers:
-            la = _lib.LinearArgs(a=x.data_ptr(), w=lw["gate_up"].data_ptr(), bias=None, resid=None, c=out.data_ptr(),
-                                 norm_w=lw["post_norm"].data_ptr(), norm_eps=cfg.rms_norm_eps, m=1, n=n, k=H, lda=H,
-                                 ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU, workspace=None, workspace_bytes=0,
-                                 w8=_lib.ptr(lw.get("gate_up8")), w8_scale=_lib.ptr(lw.get("gate_up8_scale")), ldw8=H)
+            if m == 1:
+                la = _lib.LinearArgs(a=x.data_ptr(), w=lw["gate_up"].data_ptr(), bias=None, resid=None, c=out.data_ptr(),
+                                     norm_w=lw["post_norm"].data_ptr(), norm_eps=cfg.rms_norm_eps, m=1, n=n, k=H, lda=H,
+                                     ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU, workspace=None, workspace_bytes=0,
+                                     w8=_lib.ptr(lw.get("gate_up8")), w8_scale=_lib.ptr(lw.get("gate_up8_scale")), ldw8=H)
+            else:
+                la = _lib.LinearArgs(a=None, w=lw["gate_up"].data_ptr(), bias=None, resid=None, c=None, norm_w=None, norm_eps=0.0,
+                                     m=m, n=n, k=H, lda=H, ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU, workspace=ws.data_ptr(),
+                                     workspace_bytes=wsb, w8=_lib.ptr(lw.get("gate_up8")), w8_scale=_lib.ptr(lw.get("gate_up8_scale")),
+                                     ldw8=H, a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=H, c_hi=chi.data_ptr(),
+                                     c_lo=clo.data_ptr(), ld_cplanes=plan.inter)
             _lib.check(lib.chatts_linear(la, stream.cuda_stream))
 
     sweep()
@@ -86,7 +100,10 @@ def roofline_gate_up(model, reps=2):
     avg_s = e0.elapsed_time(e1) * 1e-3 / launches
     # algorithmic bytes per launch: bf16 weights + f32 x in + norm weights + f32 out (SURVEY.md 8d per-unit figure)
     fp8 = "gate_up8" in model.layers[0]
-    bytes_per_launch = n * H * (1 if fp8 else 2) + (n * 4 if fp8 else 0) + H * 4 + H * 4 + plan.inter * 4
+    bytes_per_launch = n * H * (1 if fp8 else 2) + (n * 4 if fp8 else 0) + m * (H * 4 + H * 4 + plan.inter * 4)
+    if m > 1:
+        return dict(kernel=f"gemm_stream_kernel<4,{'fp8' if fp8 else 'bf16'}> (gate_up_proj + SwiGLU, M = {m} sequences, bf16 planes in/out)",
+                    launches=launches, avg_us=avg_s * 1e6, bytes_per_launch=bytes_per_launch, gbs=bytes_per_launch / avg_s / 1e9)
     return dict(kernel=("gemv8_ldsx_kernel" if fp8 else "gemv_ldsx_kernel") +
                 "<2,2,SWIGLU,NORM> (gate_up_proj + fused RMSNorm + SwiGLU)", launches=launches,
                 avg_us=avg_s * 1e6, bytes_per_launch=bytes_per_launch, gbs=bytes_per_launch / avg_s / 1e9)
@@ -170,82 +187,58 @@ def ts_encoder_roofline(model, ser, lengths, reps=20):
     return res
 
 
-def cpu_baseline(model, prompt_tokens, budget_s=30.0):
-    """CPU float32 oracle (the reference's HF float32 path restated, see oracle/) on the host cores of THIS box.
-    Bounded sample: ChatTS-14B widths with 2 and then 4 decoder layers (weights copied back from the GPU, so both
-    arms hold identical values), prefill of the real prompt length + 4 decode tokens each; per-layer and fixed
-    (lm_head) costs are fitted from the two depths and extrapolated to 48 layers."""
+def cpu_baseline(model, prompt_tokens, depth=8):
+    """The reference's own decoder dependency - stock `transformers` Qwen2ForCausalLM / Qwen3ForCausalLM, float32, eager
+    attention (oracle/hf_reference.py) - timed on the host cores of THIS box.  Bounded sample: the model's real widths at
+    `depth` layers (weights copied back from the GPU, so both arms hold identical values), prefill of the real prompt length +
+    4 decode tokens, then the same with the first depth/2 layers only; per-layer and fixed (embedding, lm_head) costs are
+    fitted from the two depths and extrapolated to the full depth."""
     import torch
-    from oracle.qwen_decoder import QwenOracle
+    from oracle import from_device, hf_reference
     cfg = model.config
     ncores_box = os.cpu_count() or 1
-    d, nq, nkv, I = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size
     t_start = time.time()
-    sd = {"model.embed_tokens.weight": model._tensors["embed"][:4096].float().cpu(),       # only ids < 4096 are fed
-          "lm_head.weight": model._tensors["lm_head"].float().cpu(),
-          "model.norm.weight": model._tensors["final_norm"].cpu()}
-    depth = 4
+    sd = from_device.head_tensors(model)
+    depth = min(depth, cfg.num_hidden_layers)
     for l in range(depth):
-        lw, p = model.layers[l], f"model.layers.{l}."
-        qkv = lw["qkv"].float().cpu()
-        sd[p + "self_attn.q_proj.weight"] = qkv[:nq * d]
-        sd[p + "self_attn.k_proj.weight"] = qkv[nq * d:(nq + nkv) * d]
-        sd[p + "self_attn.v_proj.weight"] = qkv[(nq + nkv) * d:]
-        if "qkv_bias" in lw:
-            b = lw["qkv_bias"].cpu()
-            sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"] = \
-                b[:nq * d], b[nq * d:(nq + nkv) * d], b[(nq + nkv) * d:]
-        if "q_norm" in lw:
-            sd[p + "self_attn.q_norm.weight"], sd[p + "self_attn.k_norm.weight"] = lw["q_norm"].cpu(), lw["k_norm"].cpu()
-        sd[p + "self_attn.o_proj.weight"] = lw["o"].float().cpu()
-        gu = lw["gate_up"].float().cpu().view(I // 16, 2, 16, -1)
-        sd[p + "mlp.gate_proj.weight"] = gu[:, 0].reshape(I, -1).contiguous()
-        sd[p + "mlp.up_proj.weight"] = gu[:, 1].reshape(I, -1).contiguous()
-        sd[p + "mlp.down_proj.weight"] = lw["down"].float().cpu()
-        sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = lw["input_norm"].cpu(), lw["post_norm"].cpu()
+        sd.update(from_device.layer_tensors(model, l))
+    m = hf_reference.build(cfg, sd, num_layers=depth)
     g = torch.Generator().manual_seed(0)
     emb = torch.randn((prompt_tokens, cfg.hidden_size), generator=g) * 0.02
     # thread count: all host cores is the default, but torch's intra-op pool collapses on many-core boxes for the
-    # small decode GEMVs; pick the fastest of a few counts on a 2-layer decode probe and REPORT the count used.
+    # memory-bound decode GEMVs; pick the fastest of a few counts on a decode probe and REPORT the count used.
     best = None
     for nt in sorted({ncores_box, min(ncores_box, 64), min(ncores_box, 32), min(ncores_box, 16)}, reverse=True):
         torch.set_num_threads(nt)
-        o = QwenOracle(cfg.oracle_dict(), sd, num_layers=2)
-        o.forward_embeds(emb[:8], return_hidden=True)
-        t0 = time.time()
-        for _ in range(2):
-            o.forward_embeds(emb[:1], return_hidden=True)
-        dt = (time.time() - t0) / 2
+        _, _, _, td = hf_reference.prefill_and_decode(m, emb[:8], 3, embed_table_rows=4096)
+        dt = median(td[1:])
         if best is None or dt < best[0]:
             best = (dt, nt)
     ncores = best[1]
     torch.set_num_threads(ncores)
     res = {}
-    for L in (2, depth):
-        o = QwenOracle(cfg.oracle_dict(), sd, num_layers=L)
-        t0 = time.time()
-        logits = o.forward_embeds(emb, return_hidden=True)[-1] @ sd["lm_head.weight"].T   # last row only
-        t_prefill = time.time() - t0
-        times = []
-        for _ in range(4):
-            tok = int(torch.argmax(logits)) % 4096
-            t0 = time.time()
-            logits = o.forward_embeds(o.embed([tok]))[-1]
-            times.append(time.time() - t0)
-        res[L] = (t_prefill, median(times))
-    per_layer_dec = (res[depth][1] - res[2][1]) / (depth - 2)
-    fixed_dec = res[2][1] - 2 * per_layer_dec
-    per_layer_pre = (res[depth][0] - res[2][0]) / (depth - 2)
-    fixed_pre = res[2][0] - 2 * per_layer_pre
+    layers_all = m.model.layers
+    for L in (depth, depth // 2):
+        m.model.layers = layers_all[:L]
+        _, _, t_pre, td = hf_reference.prefill_and_decode(m, emb, 4, embed_table_rows=4096)
+        res[L] = (t_pre, median(td))
+    m.model.layers = layers_all
+    half = depth // 2
+    per_layer_dec = (res[depth][1] - res[half][1]) / (depth - half)
+    fixed_dec = res[depth][1] - depth * per_layer_dec
+    per_layer_pre = (res[depth][0] - res[half][0]) / (depth - half)
+    fixed_pre = res[depth][0] - depth * per_layer_pre
     Lfull = cfg.num_hidden_layers
     dec_s = fixed_dec + Lfull * per_layer_dec
     pre_s = fixed_pre + Lfull * per_layer_pre
-    return dict(value=1.0 / dec_s, unit="tokens/s", cores=ncores, kind="port",
-                host_cores=ncores_box,
-                sample=(f"CPU float32 oracle on {ncores} of {ncores_box} host threads (fastest of a probe), ChatTS-14B widths, depths 2 and {depth} of {Lfull} layers measured "
-                        f"(prefill {prompt_tokens} tok + 4 decode tok each), linearly extrapolated to {Lfull} layers; "
-                        f"decode {per_layer_dec * 1e3:.1f} ms/layer + {fixed_dec * 1e3:.0f} ms lm_head"),
-                ttft_s_extrapolated=pre_s, wall_s=time.time() - t_start)
+    import transformers
+    return dict(value=1.0 / dec_s, unit="tokens/s", cores=ncores, kind="reference", host_cores=ncores_box,
+                sample=(f"stock transformers {transformers.__version__} {type(m).__name__} (the reference's decoder dependency), float32, eager "
+                        f"attention, on {ncores} of {ncores_box} host threads (fastest of a decode probe); {cfg.name} widths, depths {depth} and {half} "
+                        f"of {Lfull} layers measured (prefill {prompt_tokens} tok + 4 decode tok each), linearly extrapolated to {Lfull} "
+                        f"layers; decode {per_layer_dec * 1e3:.1f} ms/layer + {fixed_dec * 1e3:.0f} ms embedding + lm_head"),
+                ttft_s_extrapolated=pre_s, measured={"depth": depth, "prefill_s": res[depth][0], "decode_s_per_token": res[depth][1]},
+                wall_s=time.time() - t_start)
 
 
 def parity_check(args, toks):
@@ -274,6 +267,84 @@ def workload_name(args, world):
     return (f"{names[args.model]} {args.weights} weights, {args.series} series x {args.length} steps, greedy decode, TP={world}")
 
 
+def bench_batched(args, model, cfg, comm, world, device):
+    """BASELINE.json config 5 shape on this many GPUs: `--batch` different prompts (each `--series` x `--length`) are admitted
+    into the cache slots (TTFT = per-request processor + TS encode + merge + prefill + first token, p50 over the requests),
+    then decode TOGETHER: a step = one B-wide decode step (one hipGraph: M = B weight-streaming GEMMs, per-sequence
+    attention, per-sequence token selection); value = B * steps / max-over-ranks time."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from chatts_amd.processing import ChatTSProcessor
+    B = args.batch
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(1234)
+    lengths = [args.length] * args.series
+    body = f"I have {args.series} time series. " + " ".join(f"TS{i} is of length {L}: <ts><ts/>;" for i, L in enumerate(lengths)) + \
+        " Please analyze the local changes in these time series first and then conclude if these time series show local changes near the same time?"
+    prompt = "<|im_start|>system\nYou are a helpful assistant.<|im_end|><|im_start|>user\n" + body + "<|im_end|><|im_start|>assistant\n"
+    reqs = [[50 + 2 * np.cumsum(rng.standard_normal(L)) for L in lengths] for _ in range(B)]
+    budget = 1 + args.warmup + args.steps
+    Bf = model.buf
+    Bf["pos_all"].zero_(); Bf["step_all"].zero_(); Bf["token_all"].zero_()
+    ttfts, T = [], None
+    comm.barrier()
+    torch.cuda.synchronize()
+    t_admit0 = time.perf_counter()
+    for slot, series in enumerate(reqs):
+        t0 = time.perf_counter()
+        inputs = proc(text=[prompt], timeseries=series, padding=True, return_tensors="pt")
+        ids = inputs["input_ids"][0].tolist()
+        T = model._admit(slot, ids, inputs["timeseries"], proc.last_lengths, budget)
+        torch.cuda.synchronize()
+        ttfts.append((time.perf_counter() - t0) * 1e3)
+    admit_ms = (time.perf_counter() - t_admit0) * 1e3
+    for _ in range(args.warmup):
+        model.batched_step()
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.batched_step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    toks = Bf["out_tokens_all"][:, :budget].tolist()
+    roof = roofline_gate_up(model, m=B)
+    step_bytes = model.weight_bytes_local()
+    names = {"chatts-14b": "ChatTS-14B", "chatts-8b": "ChatTS-8B"}
+    label = (f"{names.get(args.model, args.model)} {args.weights} weights, {args.series} series x {args.length} steps, batch {B} continuous "
+             f"prompts, TP={world}") if args.layers is None and args.model in names else f"DEBUG {args.model} layers={args.layers}"
+    return {
+        "metric": f"generated tokens/sec (aggregate over {B} sequences decoding together) + p50 TTFT, {names.get(args.model, args.model)}, "
+                  f"{args.series}x{args.length}-step TS prompts, TP=N",
+        "value": B * args.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16" if args.weights == "bf16" else "fp8-e4m3 weights (pow2 row scales, exactly representable in bf16), bf16x2 MFMA / f32 accumulate",
+        "data": "synthetic",
+        "config": {"workload": label, "model": args.model, "batch": B, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
+                   "parallelism": f"tp{world}", "decode_graph": model.graph_capturable(),
+                   "tp_exchange": None if world == 1 else ("p2p one-shot kernels (csrc/tp.hip)" if model._tp is not None else "rccl, host-driven"),
+                   "weights_note": None if args.weights == "bf16" else
+                   "fp8 copies are streamed by the decode GEMMs and widened to bf16 while staged (no v_mfma fp8 issue: the 1e-3 "
+                   "logit bar needs f32-exact products of the f32 activations); prefill keeps the bf16 copy",
+                   "first_tokens_seq0": toks[0][:8]},
+        "ttft_ms_p50": median(ttfts), "batch_admit_ms_total": admit_ms, "per_sequence_tokens_per_s": args.steps / dt,
+        "decode_hbm_gbs_per_gpu": step_bytes / (dt / args.steps) / 1e9,
+        "decode_hbm_frac_of_8TBs": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": roof["kernel"], "avg_us": roof["avg_us"], "bytes_per_launch": roof["bytes_per_launch"],
+                     "launches_timed": roof["launches"]},
+        "parity_checked": False,
+        "parity": {"reason": "no full-depth oracle run is committed for this workload; per-slot oracle parity of the batched path is "
+                             "tests/test_gpu_e2e.py::test_continuous_batching_matches_oracle"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,6 +358,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ttft-runs", type=int, default=5)
     ap.add_argument("--max-ctx", type=int, default=2048, help="KV-cache length (longer prompts, e.g. --series 30, need more)")
+    ap.add_argument("--batch", type=int, default=1, help="> 1: continuous-batching workload (BASELINE.json config 5): B prompts decode "
+                    "together; a step = one B-wide decode step; value = aggregate tokens/s")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = BASELINE.json config 5 weight format (NOT the headline: reported as a separate workload)")
     args = ap.parse_args()
@@ -326,10 +399,17 @@ def main():
     max_ctx = args.max_ctx
     model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, device=device, comm=comm, max_ctx=max_ctx,
                                              max_prefill_tokens=1024, use_graph=not args.no_graph,
-                                             weight_format=args.weights)
+                                             weight_format=args.weights, max_batch=max(1, args.batch))
     torch.cuda.synchronize()
     log(f"[bench] {args.model} TP={world} materialised in {time.time() - t0:.1f}s, "
         f"{model.weight_bytes_local() / 1e9:.2f} GB decoder weights on this rank")
+    if args.batch > 1:
+        result = bench_batched(args, model, cfg, comm, world, device)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # ---- TTFT: processor -> H2D -> TS encoder -> merge -> prefill -> first token (p50) ---------------------
     ttfts, enc_ms = [], []

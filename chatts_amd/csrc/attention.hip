@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
   const int lane = threadIdx.x;
   const int G = p.n_q / p.n_kv;
   const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;     // batched decode: one position per sequence
+  if (pos < 0) return;                         // parked slot of a batched step: no cache write, no attention (its row is ignored)
   const int ntiles = pos / kDTile + 1;
   if (slot >= ntiles) return;                  // the combine only reads slots < min(ntiles, NS)
   const float* qkv = p.qkv + (size_t)seq * (p.n_q + 2 * p.n_kv) * kHeadDim;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnParams p) {
   const int hq = blockIdx.x, seq = blockIdx.y, d = threadIdx.x, lane = threadIdx.x & 63;
   const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;
-  const int ntiles = pos / kDTile + 1;
+  const int ntiles = pos < 0 ? 0 : pos / kDTile + 1;         // parked slot: no partials exist, the row is written as zeros
   const int ns = ntiles < p.n_splits ? ntiles : p.n_splits;
   const size_t base = ((size_t)seq * p.n_q + hq) * p.n_splits;
   float m = -INFINITY, l = 0.f;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnParams p) 
     }
   }
   const size_t oi = ((size_t)seq * p.n_q + hq) * kHeadDim + d;
-  const float v = num / den;
+  const float v = ns > 0 ? num / den : 0.f;
   if (p.out_hi) {
     const __bf16 h = (__bf16)v;
     p.out_hi[oi] = __builtin_bit_cast(uint16_t, h);

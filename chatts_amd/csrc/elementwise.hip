@@ -214,7 +214,8 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     if (token_logit) *token_logit = best;
     if (out_tokens && step_dev && (out_stride == 0 || *step_dev < out_stride)) out_tokens[*step_dev] = tok;
     if (step_dev) *step_dev += 1;
-    if (pos_dev && (pos_limit <= 0 || *pos_dev < pos_limit)) *pos_dev += 1;     // idle batch slots saturate, never overflow
+    // a parked slot (pos < 0: inactive sequence of a batched step) stays parked; live ones saturate, never overflow
+    if (pos_dev && *pos_dev >= 0 && (pos_limit <= 0 || *pos_dev < pos_limit)) *pos_dev += 1;
   }
 }
 

@@ -771,6 +771,19 @@ static bool use_dma(const ChattsLinearArgs* a) {
 
 // DMA geometry: 128 x 256 tiles, one 8-wave workgroup per CU.
 static void pick_dma_geometry(int m, int n, int k, int& sk) {
+  // Few tiles (the TS-encoder MLP: P <= 128 patches x 5120 columns = 20 tiles): split K as far as ONE round of workgroups
+  // allows - the grid is padded to 8 * ceil(tiles / 8) per split, and one workgroup more than the CUs costs a whole second
+  // round (profiles/r2_ts_gemm_sweep.txt, P = 128: 10 splits 33.7 us, 12 splits 47.7 us, 1 split 133 us; K = 320: 2 splits
+  // 16.4 us, 1 split 28.0 us).
+  const int tiles = ((m + 127) / 128) * ((n + kDmaBN - 1) / kDmaBN), gx = 8 * ((tiles + 7) / 8), cus = device_cus();
+  if (2 * gx <= cus && gemm_env_int("CHATTS_GEMM_SK", 0) == 0) {
+    sk = cus / gx;
+    const int nk = k / kDmaBK;
+    if (sk > nk / 2) sk = nk / 2;          // >= 2 K-steps per split
+    if (sk > 16) sk = 16;
+    if (sk < 1) sk = 1;
+    return;
+  }
   int bm;
   pick_geometry(m < 128 ? 128 : m, n, k, bm, sk, 1, kDmaBN);
 }

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
       if (p.token_logit) p.token_logit[seq] = chosen_logit;
       if (p.out_tokens && p.step && (p.out_stride == 0 || step < p.out_stride)) p.out_tokens[(size_t)seq * p.out_stride + step] = tok;
       if (p.step) p.step[seq] = step + 1;
-      if (p.pos && (p.pos_limit <= 0 || p.pos[seq] < p.pos_limit)) p.pos[seq] += 1;
+      if (p.pos && p.pos[seq] >= 0 && (p.pos_limit <= 0 || p.pos[seq] < p.pos_limit)) p.pos[seq] += 1;   // parked slots (pos < 0) stay parked
       if (p.n_kept) p.n_kept[seq] = kept;
       if (p.kept_mass) p.kept_mass[seq] = zq ? (float)((double)total / (double)zq) : 0.f;
     }

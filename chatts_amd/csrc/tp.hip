@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void tp_argmax_kernel(TpParams p, const float* 
     if (token_logit) token_logit[b] = best;
     if (out_tokens && step_dev) out_tokens[(int64_t)b * out_stride + step_dev[b]] = (int64_t)best_tok;
     if (step_dev) step_dev[b] += 1;
-    if (pos_dev) { const int np = pos_dev[b] + 1; pos_dev[b] = (pos_limit > 0 && np > pos_limit) ? pos_limit : np; }
+    if (pos_dev && pos_dev[b] >= 0) { const int np = pos_dev[b] + 1; pos_dev[b] = (pos_limit > 0 && np > pos_limit) ? pos_limit : np; }   // parked slots (pos < 0) stay parked
   }
   finish_call(p, epoch);
 }

@@ -40,6 +40,8 @@ class Engine:
         self.active_key = None
         self._since_sync = 0
         self._rid = 0
+        if self.nslots > 1:
+            model.buf["pos_all"].fill_(-1)            # every slot starts parked
 
     # ---- requests ---------------------------------------------------------------------------------
     def add_request(self, prompt, timeseries=None, max_tokens=64, temperature=0.0, top_p=1.0, top_k=0, seed=0,
@@ -88,16 +90,17 @@ class Engine:
         if not running and self.waiting and self.waiting[0].sampling_key != self.active_key:
             self._apply_sampling(self.waiting[0].sampling_key)
         # admission: free slots take waiting requests that share the running batch's sampling configuration
-        for s in range(self.nslots):
-            if self.slots[s] is not None or not self.waiting:
-                continue
+        while self.waiting and any(v is None for v in self.slots):
             r = next((q for q in self.waiting if q.sampling_key == self.active_key), None)
             if r is None:
                 break
             self.waiting.remove(r)
+            s = 0
             try:
                 ids, ser, lens = self._encode(r)
                 r.prompt_tokens = len(ids)
+                free = [i for i, v in enumerate(self.slots) if v is None]
+                s = m.pick_slot(free, m._request_idents(ids, ser, lens))      # the slot whose resident prefix matches best
                 if self.nslots == 1:
                     m._prefill_request(ids, ser, lens, r.max_tokens)
                 else:
@@ -156,7 +159,8 @@ class Engine:
         r = self.slots[s]
         self.slots[s] = None
         if self.nslots > 1:
-            self.model.buf["pos_all"][s] = 0          # an idle slot attends over one key, not over its stale context
+            self.model.buf["pos_all"][s] = -1         # parked: the batched step neither attends nor writes this slot's cache
+        self.model.note_generated(s, r.tokens)
         self._emit(r, True, reason)
         done.append(r)
 

@@ -60,7 +60,7 @@ class ChatTSForCausalLM:
     packed_modules_mapping = packed_modules_mapping
 
     def __init__(self, config, device="cuda", comm=None, max_ctx=2048, max_prefill_tokens=2048, use_graph=True,
-                 max_batch=1, weight_format="bf16", use_p2p=True):
+                 max_batch=1, weight_format="bf16", use_p2p=True, enable_prefix_caching=True):
         if not torch.cuda.is_available():
             raise RuntimeError("chatts_amd needs a ROCm GPU: there is no CPU fallback for the model")
         self.lib = _lib.load()
@@ -77,6 +77,11 @@ class ChatTSForCausalLM:
         self.use_graph = use_graph
         self.use_p2p = use_p2p                   # TP: decode-sized exchanges through csrc/tp.hip instead of RCCL (chatts_amd/tp.py)
         self._tp = None                          # P2PExchange of this rank once attached
+        # prefix reuse (vLLM's enable_prefix_caching; demo/demo_vllm.py:55 submits 100 identical prompts, multi-turn chats
+        # re-send their history): per cache slot, the identity of every token whose K/V rows are resident
+        self.enable_prefix_caching = bool(enable_prefix_caching)
+        self._slot_idents = [[] for _ in range(max(1, int(max_batch)))]
+        self.prefix_stats = {"requests": 0, "hits": 0, "tokens_reused": 0, "tokens_prefilled": 0}
         self.ts_encoder = TimeSeriesEmbedding(config.ts, device=self.device)
         self._tensors = {}            # keeps every device tensor alive (the C side borrows pointers)
         self._decoder = None
@@ -623,6 +628,94 @@ class ChatTSForCausalLM:
             self._graph_batched = g
         self._graph_batched.replay()
 
+    # ---- prefix reuse ---------------------------------------------------------------------------------
+    @staticmethod
+    def _token_idents(full, series, lengths, counts, ts0):
+        """Identity of every token of an EXPANDED prompt: the id for text tokens; for a <ts> placeholder the digest of its
+        series' (value, mask) row + the patch index - two placeholder rows hold the same embedding iff those agree."""
+        import hashlib
+        digests = []
+        if series is not None and len(counts):
+            host = series.detach().cpu().numpy() if hasattr(series, "detach") else np.asarray(series)
+            for i, L in enumerate(lengths):
+                digests.append(hashlib.blake2b(np.ascontiguousarray(host[i].reshape(-1)[:2 * int(L)]).tobytes(), digest_size=8).digest())
+        out, k, j = [], -1, 0
+        owner = []                                   # series index of every placeholder, in order
+        for i, c in enumerate(counts):
+            owner += [(i, p) for p in range(int(c))]
+        for t in full:
+            if t == ts0:
+                i, pidx = owner[j]
+                j += 1
+                out.append((digests[i], pidx))
+            else:
+                out.append(t)
+        return out
+
+    def _request_idents(self, ids, series, lengths):
+        """token identities of a request before it is admitted (slot choice): host-side only, no device work"""
+        if not self.enable_prefix_caching:
+            return None
+        ps = self.config.ts["patch_size"]
+        if series is not None and series.shape[0] > 0 and lengths is None:
+            return None
+        counts = [(int(v) + ps - 1) // ps for v in (lengths or [])]
+        try:
+            full = self.expand_input_ids(list(ids), counts)
+        except ValueError:
+            return None
+        return self._token_idents(full, series, lengths, counts, self.config.ts_token_start_index)
+
+    def _reuse_prefix(self, slot, idents, T):
+        """Longest prefix of `idents` already resident in some slot's cache -> copy those K/V rows into `slot` (nothing to copy
+        when it is the slot itself) and return how many leading tokens need no prefill (at most T - 1: the last prompt
+        position is always recomputed, it yields the logits)."""
+        self.prefix_stats["requests"] += 1
+        if not self.enable_prefix_caching:
+            return 0
+        best, src = 0, -1
+        for s, have in enumerate(self._slot_idents):
+            n = 0
+            for a, b in zip(idents, have):
+                if a != b:
+                    break
+                n += 1
+            if n > best or (n == best and s == slot and n > 0):
+                best, src = n, s
+        n = min(best, T - 1)
+        if n < 16:                                   # not worth a copy + a ragged prefill start
+            return 0
+        if src != slot:
+            B = self.buf
+            B["kv_k"][slot, :, :, :n].copy_(B["kv_k"][src, :, :, :n])
+            B["kv_v"][slot, :, :, :n].copy_(B["kv_v"][src, :, :, :n])
+        self.prefix_stats["hits"] += 1
+        self.prefix_stats["tokens_reused"] += n
+        return n
+
+    def note_generated(self, slot, tokens):
+        """After a request finished: its generated tokens (all but the last, which was never fed back) also have K/V rows in
+        the slot - a follow-up turn that re-sends prompt + answer reuses them."""
+        if self.enable_prefix_caching and tokens:
+            self._slot_idents[slot] = self._slot_idents[slot] + [int(t) for t in tokens[:-1]]
+
+    def pick_slot(self, free_slots, idents=None):
+        """Which free cache slot a new request should take: the one whose resident prefix matches best (zero copy), else the
+        one whose resident tokens are least worth keeping (fewest)."""
+        if not self.enable_prefix_caching or idents is None:
+            return free_slots[0]
+        def match(s):
+            n = 0
+            for a, b in zip(idents, self._slot_idents[s]):
+                if a != b:
+                    break
+                n += 1
+            return n
+        best = max(free_slots, key=match)
+        if match(best) >= 16:
+            return best
+        return min(free_slots, key=lambda s: len(self._slot_idents[s]))
+
     def _admit(self, slot, ids, series, lengths, max_new_tokens=1):
         """Prefill one request into cache slot `slot` and produce its first token (out_tokens_all[slot, 0])."""
         cfg, B = self.config, self.buf
@@ -639,8 +732,12 @@ class ChatTSForCausalLM:
         if T + max_new_tokens > self.max_ctx:       # same bound as generate_one: a sequence must never outgrow its cache
             raise ValueError(f"prompt ({T}) + max_new_tokens ({max_new_tokens}) exceeds max_ctx={self.max_ctx}")
         emb = self.get_input_embeddings(torch.tensor(full, dtype=torch.int64), mm)
+        idents = self._token_idents(full, series, lengths, counts, cfg.ts_token_start_index)
+        n0 = self._reuse_prefix(slot, idents, T)
+        self._slot_idents[slot] = idents
+        self.prefix_stats["tokens_prefilled"] += T - n0
         self.select_sequence(slot)
-        last = self.prefill(emb, 0)
+        last = self.prefill(emb[n0:], n0)
         st = _lib.stream_ptr()
         _lib.check(self.lib.chatts_decoder_logits(self._decoder, last - 1, st))
         B["pos_all"][slot] = T
@@ -671,7 +768,7 @@ class ChatTSForCausalLM:
         waiting = list(range(len(requests)))[::-1]
         slots = [None] * self.max_batch              # request index per slot
         produced = [0] * self.max_batch
-        B["pos_all"].zero_(); B["step_all"].zero_(); B["token_all"].zero_()
+        B["pos_all"].fill_(-1); B["step_all"].zero_(); B["token_all"].zero_()
         steps_since_sync = 0
 
         def harvest(final=False):
@@ -684,15 +781,16 @@ class ChatTSForCausalLM:
                 if cut is not None or produced[s] >= max_new_tokens or final:
                     results[r] = toks[:cut] if cut is not None else toks[:max_new_tokens]
                     slots[s] = None
-                    B["pos_all"][s] = 0          # an idle slot attends over one key, not over its stale context
+                    B["pos_all"][s] = -1         # parked: the batched step neither attends nor writes this slot's cache
+                    self.note_generated(s, results[r])
 
         while waiting or any(r is not None for r in slots):
-            for s in range(self.max_batch):
-                if slots[s] is None and waiting:
-                    r = waiting.pop()
-                    ids, series, lengths = requests[r]
-                    self._admit(s, ids, series, lengths, max_new_tokens)
-                    slots[s], produced[s] = r, 1
+            while waiting and any(v is None for v in slots):
+                r = waiting.pop()
+                ids, series, lengths = requests[r]
+                s = self.pick_slot([i for i, v in enumerate(slots) if v is None], self._request_idents(ids, series, lengths))
+                self._admit(s, ids, series, lengths, max_new_tokens)
+                slots[s], produced[s] = r, 1
             if all(r is None or produced[s] >= max_new_tokens for s, r in enumerate(slots)):
                 harvest()
                 continue
@@ -752,6 +850,7 @@ class ChatTSForCausalLM:
                 if t in eos:
                     toks = toks[:i + 1]
                     break
+        self.note_generated(0, toks)
         return (toks, logits0) if return_logits else toks
 
     @torch.no_grad()
@@ -792,8 +891,12 @@ class ChatTSForCausalLM:
         if T + max_new_tokens > self.max_ctx:
             raise ValueError(f"prompt ({T}) + max_new_tokens ({max_new_tokens}) exceeds max_ctx={self.max_ctx}")
         emb = self.get_input_embeddings(torch.tensor(full, dtype=torch.int64), mm)
+        idents = self._token_idents(full, series, lengths, counts, cfg.ts_token_start_index)
+        n0 = self._reuse_prefix(0, idents, T)
+        self._slot_idents[0] = idents
+        self.prefix_stats["tokens_prefilled"] += T - n0
         self.reset()
-        last = self.prefill(emb, 0)
+        last = self.prefill(emb[n0:], n0)
         self.buf["pos"].fill_(T)
         self._first_token(last)
         return T

@@ -444,3 +444,51 @@ def test_sampled_batch_and_llm_surface():
     # temperature -> 0+ with top_k = 1 is greedy
     k1 = [o.outputs[0].token_ids for o in llm.generate(reqs, sampling_params=SamplingParams(max_tokens=8, temperature=0.7, top_k=1, ignore_eos=True))]
     assert k1 == g
+
+
+def test_prefix_reuse_matches_oracle():
+    """enable_prefix_caching (vLLM's name; demo/demo_vllm.py:55 submits one prompt 100 times, multi-turn chats re-send their
+    history): K/V rows of the longest resident prefix are copied / kept instead of recomputed.  Tokens must stay the oracle's;
+    the statistics prove the reuse happened."""
+    cfg = cfgmod.preset("tiny-qwen2")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    sd = osynth.state_dict(synth.all_specs(cfg), 5)
+    rng = np.random.default_rng(9)
+    lengths = [64, 40]
+    series = [random_walk_series(rng, L) for L in lengths]
+    inp = proc(text=[chat_prompt(lengths)], timeseries=series, return_tensors="pt")
+    ids = inp["input_ids"][0].tolist()
+    want = pipeline.generate(cfg, sd, ids, inp["timeseries"].numpy(), 8)["tokens"]
+    T = len(pipeline.generate(cfg, sd, ids, inp["timeseries"].numpy(), 1)["expanded_ids"])
+    # (1) single-sequence path: the same request again re-prefills ONE token
+    m = ChatTSForCausalLM.from_synthetic(cfg, seed=5, max_ctx=512, max_prefill_tokens=256)
+    assert m.generate_one(ids, inp["timeseries"], list(lengths), 8) == want and m.prefix_stats["hits"] == 0
+    assert m.generate_one(ids, inp["timeseries"], list(lengths), 8) == want
+    assert m.prefix_stats["hits"] == 1 and m.prefix_stats["tokens_reused"] == T - 1
+    # (2) a follow-up turn = prompt + answer + new text: the generated tokens' rows are reused too
+    ids2 = ids + want + proc.tokenizer.encode("<|im_end|><|im_start|>user\nAnd the second one?<|im_end|><|im_start|>assistant\n")
+    want2 = pipeline.generate(cfg, sd, ids2, inp["timeseries"].numpy(), 6)["tokens"]
+    before = m.prefix_stats["tokens_reused"]
+    assert m.generate_one(ids2, inp["timeseries"], list(lengths), 6) == want2
+    assert m.prefix_stats["tokens_reused"] - before == T + len(want) - 1
+    # (3) same text, another first series: only the tokens before the first placeholder can be shared
+    series3 = [random_walk_series(rng, 64), series[1]]
+    inp3 = proc(text=[chat_prompt(lengths)], timeseries=series3, return_tensors="pt")
+    want3 = pipeline.generate(cfg, sd, inp3["input_ids"][0].tolist(), inp3["timeseries"].numpy(), 6)["tokens"]
+    before = m.prefix_stats["tokens_reused"]
+    assert m.generate_one(inp3["input_ids"][0].tolist(), inp3["timeseries"], list(lengths), 6) == want3
+    # (the spliced statistics text "[offset=...|" of the new series differs before the placeholder is reached)
+    ea = pipeline.generate(cfg, sd, ids2, inp["timeseries"].numpy(), 1)["expanded_ids"].tolist()       # what slot 0 holds now
+    e3 = pipeline.generate(cfg, sd, inp3["input_ids"][0].tolist(), inp3["timeseries"].numpy(), 1)["expanded_ids"].tolist()
+    lcp = next(i for i, (a, b) in enumerate(zip(ea, e3)) if a != b)
+    assert lcp < e3.index(cfg.ts_token_start_index)
+    assert m.prefix_stats["tokens_reused"] - before == (lcp if lcp >= 16 else 0)
+    # (4) continuous batching: 5 copies of one request through 3 slots -> every later admission copies / keeps the rows
+    mb = ChatTSForCausalLM.from_synthetic(cfg, seed=5, max_ctx=512, max_prefill_tokens=256, max_batch=3)
+    outs = mb.generate_batch([(ids, inp["timeseries"], list(lengths))] * 5, max_new_tokens=8, eos_token_id=None, sync_every=3)
+    assert outs == [want] * 5
+    assert mb.prefix_stats["hits"] == 4 and mb.prefix_stats["tokens_prefilled"] == T + 4
+    # ... and switched off, everything is prefilled
+    off = ChatTSForCausalLM.from_synthetic(cfg, seed=5, max_ctx=512, max_prefill_tokens=256, enable_prefix_caching=False)
+    assert off.generate_one(ids, inp["timeseries"], list(lengths), 8) == want == off.generate_one(ids, inp["timeseries"], list(lengths), 8)
+    assert off.prefix_stats["hits"] == 0

@@ -36,3 +36,46 @@ def test_uniform24_stream():
     # pinned values of the stream (the HIP kernel is checked against the oracle, the oracle against these constants)
     assert [sampler.uniform24(1234, 0, s) for s in range(3)] == [16190760, 11032913, 8685192]
     assert sampler.uniform24(1234, 3, 17) == 12540707
+
+
+def test_kept_set_is_pinned_by_the_transformers_warpers():
+    """Third-party pin: the reference's HF drivers sample through transformers' logits warpers
+    (model.generate(..., temperature=0.2), chatts/utils/inference_tsmllm_deepspeed.py:95-100; transformers is the
+    requirements.txt:7 dependency and IS installed here).  TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper
+    (generate()'s order) must keep exactly the token set oracle/sampler.kept_set keeps, with the same renormalised
+    probabilities, on real decoder logits (the committed reference-generated fixture) and on random ones."""
+    import os
+
+    import torch
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "qwen2_tiny.npz"), allow_pickle=False)
+    rows = [np.asarray(g[k], dtype=np.float64).reshape(-1, np.asarray(g[k]).shape[-1])[-1] for k in g.files if "logits" in k]
+    assert rows, g.files
+    rng = np.random.default_rng(0)
+    rows += [rng.standard_normal(4096) * s for s in (1.0, 3.0, 6.0)]
+    checked = 0
+    for logits in rows:
+        for T, K, P in [(1.0, 50, 1.0), (0.2, 0, 0.95), (0.5, 0, 0.95), (0.8, 50, 0.95), (1.5, 20, 0.5), (1.0, 0, 0.3), (0.7, 1, 1.0),
+                        (1.0, 5, 0.999)]:
+            s = torch.from_numpy(logits)[None].double()
+            ids = torch.zeros((1, 1), dtype=torch.long)
+            s = TemperatureLogitsWarper(T)(ids, s)
+            if K:
+                s = TopKLogitsWarper(K)(ids, s)
+            if P < 1.0:
+                s = TopPLogitsWarper(P)(ids, s)
+            hf_keep = torch.isfinite(s[0]).numpy()
+            hf_p = torch.softmax(s[0], -1).numpy()
+            p, _ = sampler.kept_set(logits, T, K, P)
+            ours = p > 0
+            if not np.array_equal(ours, hf_keep):
+                # the only admissible difference: a token sitting on the top-p boundary to within rounding of the cumulative sum
+                diff = np.flatnonzero(ours != hf_keep)
+                e = np.exp((logits - logits.max()) / T)
+                srt = np.sort(e[ours | hf_keep])[::-1]
+                cum = np.cumsum(srt) / e[(np.sort(logits)[-K] <= logits) if K else np.ones_like(ours)].sum()
+                assert len(diff) == 1 and np.min(np.abs(cum - P)) < 1e-9, (T, K, P, diff)
+                continue
+            assert np.allclose(p / p.sum(), hf_p, rtol=1e-9, atol=1e-15)
+            checked += 1
+    assert checked >= 8 * (len(rows) - 1)
