@@ -178,18 +178,53 @@ class EngineThread:
     def __init__(self, engine, device=None):
         self.engine, self.device = engine, device
         self.inbox = queue.Queue()
+        self.error = None
         self._stop = threading.Event()
         self.thread = threading.Thread(target=self._run, name="chatts-engine", daemon=True)
         self.thread.start()
 
     def submit(self, **kw):
-        """-> a threading.Event set once the request object exists (kw['holder'] receives it)."""
+        """Queue a request for the engine thread (kw: Engine.add_request arguments + `holder`, a list that receives the Request)."""
+        if self.error is not None or not self.thread.is_alive():
+            raise RuntimeError(f"engine thread is not running: {self.error}")
         self.inbox.put(kw)
 
     def _run(self):
-        if self.device is not None:
-            import torch
-            torch.cuda.set_device(self.device)
+        try:
+            self._loop()
+        except BaseException as e:           # the engine must never die silently: every waiting / later request is failed
+            self.error = e
+            import traceback
+            traceback.print_exc()
+            self._fail_all(e)
+
+    def _fail_all(self, e):
+        eng = self.engine
+        pending = list(eng.waiting) + [r for r in eng.slots if r is not None]
+        eng.waiting.clear()
+        eng.slots = [None] * eng.nslots
+        while True:
+            try:
+                kw = self.inbox.get_nowait()
+            except queue.Empty:
+                break
+            holder = kw.pop("holder", None)
+            r = eng.add_request(**kw)
+            eng.waiting.clear()
+            pending.append(r)
+            if holder is not None:
+                holder.append(r)
+        for r in pending:
+            r.error = RuntimeError(f"engine thread died: {type(e).__name__}: {e}")
+            if r.on_tokens is not None:
+                r.finished = True
+                r.on_tokens(r, [], True)
+
+    def _loop(self):
+        import torch
+        idx = getattr(self.device, "index", self.device) if self.device is not None else None
+        if isinstance(idx, int):
+            torch.cuda.set_device(idx)
         while not self._stop.is_set():
             try:
                 block = not self.engine.has_work()

@@ -1,0 +1,100 @@
+"""GPTQ-Int4 checkpoints (the published ``ChatTS-14B-GPTQ-Int4``; NetManAIOps/ChatTS README.md:52,262-263; the reference hands
+``quant_config`` to vLLM's GPTQ linear layers, chatts/vllm/chatts_vllm.py:475,481 - kernels NOT IN REFERENCE).
+
+AutoGPTQ tensor layout of one ``nn.Linear(K -> N)`` (bits = 4, 8 values per int32, little end first):
+    qweight int32 [K / 8, N]        q[k, n]  = (qweight[k // 8, n] >> 4 * (k % 8)) & 15
+    qzeros  int32 [K / g, N / 8]    z0[j, n] = (qzeros[j, n // 8] >> 4 * (n % 8)) & 15
+    scales  fp16  [K / g, N]
+    g_idx   int32 [K]               group of input channel k (k // g unless the checkpoint was quantised with desc_act)
+    W[n, k] = scales[g_idx[k], n] * (q[k, n] - (z0[g_idx[k], n] + 1))       ("gptq" format; "gptq_v2" stores z without the -1)
+
+What the engine holds: the dequantised matrix rounded to bf16 - the weight format of every kernel - so prefill (bf16 MFMA),
+decode and the oracle all see the same numbers, exactly as with the fp8 copies.  `pack_rows` additionally
+keeps the 4-bit codes in the row-major layout the weight-streaming decode GEMV wants (K contiguous per output row).
+"""
+import numpy as np
+import torch
+
+SUFFIXES = ("qweight", "qzeros", "scales", "g_idx")
+
+
+def unpack_int4(packed, axis):
+    """int32 tensor holding 8 4-bit values per word along `axis` -> uint8 tensor, that axis 8x longer."""
+    p = packed.to(torch.int32)
+    shifts = torch.arange(0, 32, 4, dtype=torch.int32, device=p.device)
+    if axis == 0:       # [R, C] -> [R * 8, C]
+        v = (p[:, None, :] >> shifts[None, :, None]) & 15
+        return v.reshape(p.shape[0] * 8, p.shape[1]).to(torch.uint8)
+    v = (p[:, :, None] >> shifts[None, None, :]) & 15
+    return v.reshape(p.shape[0], p.shape[1] * 8).to(torch.uint8)
+
+
+def dequantize(qweight, qzeros, scales, g_idx=None, group_size=128, v2=False):
+    """-> float32 [N, K] (the nn.Linear.weight layout), every element EXACT in float32 (fp16 scale x small integer)."""
+    q = unpack_int4(qweight, 0).to(torch.int32)                # [K, N]
+    K, N = q.shape
+    z = unpack_int4(qzeros, 1).to(torch.int32)[:, :N]           # [G, N]
+    if not v2:
+        z = z + 1
+    if g_idx is None:
+        g_idx = torch.arange(K, device=q.device) // group_size
+    g = g_idx.to(torch.long)
+    w = scales.float()[g] * (q - z[g]).float()                  # [K, N]
+    return w.t().contiguous()
+
+
+def is_gptq_config(cfg_extra):
+    qc = (cfg_extra or {}).get("quantization_config") or {}
+    return qc.get("quant_method") == "gptq"
+
+
+def dequantized_pairs(pairs, quant_cfg):
+    """(name, tensor) stream of a GPTQ checkpoint -> stream where every quantised Linear appears as `<module>.weight` (bf16);
+    other tensors pass through.  Also yields nothing for the consumed qweight / qzeros / scales / g_idx entries."""
+    if int(quant_cfg.get("bits", 4)) != 4:
+        raise ValueError(f"GPTQ bits={quant_cfg.get('bits')} is not supported (4-bit checkpoints only)")
+    gs = int(quant_cfg.get("group_size", 128))
+    v2 = quant_cfg.get("checkpoint_format", "gptq") == "gptq_v2"
+    pending = {}
+    for name, t in pairs:
+        base, _, suffix = name.rpartition(".")
+        if suffix not in SUFFIXES:
+            yield name, t
+            continue
+        d = pending.setdefault(base, {})
+        d[suffix] = t
+        need = ("qweight", "qzeros", "scales") + (("g_idx",) if quant_cfg.get("desc_act") else ())
+        if all(k in d for k in need) and ("g_idx" in d or not _expects_g_idx(pending, base)):
+            w = dequantize(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), gs if gs > 0 else d["qweight"].shape[0] * 8, v2)
+            pending.pop(base)
+            yield base + ".weight", w.to(torch.bfloat16)
+    # checkpoints always store g_idx; modules still pending only miss it because of iteration order -> flush them
+    for base, d in list(pending.items()):
+        if all(k in d for k in ("qweight", "qzeros", "scales")):
+            w = dequantize(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), gs if gs > 0 else d["qweight"].shape[0] * 8, v2)
+            yield base + ".weight", w.to(torch.bfloat16)
+        else:
+            raise ValueError(f"incomplete GPTQ module {base}: has {sorted(d)}")
+
+
+def _expects_g_idx(pending, base):
+    """g_idx may arrive after the other three tensors: wait for it unless the stream is exhausted (handled by the flush)."""
+    return True
+
+
+def quantize_rows(w, group_size=128):
+    """TEST / tooling helper (round-to-nearest, asymmetric 4-bit - NOT the GPTQ solver): float [N, K] -> AutoGPTQ tensors."""
+    N, K = w.shape
+    assert K % group_size == 0 and K % 8 == 0 and N % 8 == 0
+    wt = w.float().t().contiguous().view(K // group_size, group_size, N)          # [G, g, N]
+    lo, hi = wt.amin(1), wt.amax(1)
+    scale = ((hi - lo) / 15.0).clamp_min(1e-8).to(torch.float16)
+    zero = torch.clamp(torch.round(-lo / scale.float()), 0, 15).to(torch.int32)    # [G, N]
+    q = torch.clamp(torch.round(wt / scale.float()[:, None, :]) + zero[:, None, :], 0, 15).to(torch.int32).view(K, N)
+    shifts = torch.arange(0, 32, 4, dtype=torch.int64)
+    qweight = (q.view(K // 8, 8, N).to(torch.int64) << shifts[None, :, None]).sum(1)
+    z0 = (zero - 1) & 15                                                             # stored minus one ("gptq" format)
+    qzeros = (z0.view(-1, N // 8, 8).to(torch.int64) << shifts[None, None, :]).sum(2)
+    to_i32 = lambda v: torch.from_numpy((v.numpy() & 0xFFFFFFFF).astype(np.uint32).view(np.int32).copy())
+    g_idx = (torch.arange(K) // group_size).to(torch.int32)
+    return {"qweight": to_i32(qweight), "qzeros": to_i32(qzeros), "scales": scale, "g_idx": g_idx}

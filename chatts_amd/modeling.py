@@ -149,6 +149,9 @@ class ChatTSForCausalLM:
             for k in h.keys():
                 index[k] = h
         pairs = ((k, h.get_tensor(k)) for k, h in index.items())
+        from . import gptq
+        if gptq.is_gptq_config(cfg.extra):          # ChatTS-14B-GPTQ-Int4: unpack qweight / qzeros / scales / g_idx to bf16 weights
+            pairs = gptq.dequantized_pairs(pairs, cfg.extra["quantization_config"])
         if lora_adapter is not None:
             from . import lora
             pairs = lora.merged(pairs, lora_adapter)

@@ -121,6 +121,16 @@ def create_app(engine_thread, tokenizer, served_model_name="chatts", limit_times
         engine_thread.submit(prompt=prompt, timeseries=series, on_tokens=on_tokens, holder=holder, **sp)
         return holder, q
 
+    async def next_event(q):
+        """next (new_tokens, finished, request) of a request; a dead engine thread surfaces as an error instead of a hang"""
+        while True:
+            try:
+                return await asyncio.wait_for(q.get(), timeout=5.0)
+            except asyncio.TimeoutError:
+                err = getattr(engine_thread, "error", None)
+                if err is not None:
+                    raise RuntimeError(f"engine thread died: {err}")
+
     @app.get("/health")
     async def health():
         return {"status": "ok"}
@@ -151,7 +161,10 @@ def create_app(engine_thread, tokenizer, served_model_name="chatts", limit_times
         rid = ("chatcmpl-" if chat else "cmpl-") + uuid.uuid4().hex[:24]
         model_name = body.get("model") or served_model_name
         obj = "chat.completion" if chat else "text_completion"
-        holder, q = await run(prompt, series, sp, loop)
+        try:
+            holder, q = await run(prompt, series, sp, loop)
+        except RuntimeError as e:
+            return error(500, str(e), "server_error")
         dec = IncrementalDecoder(tokenizer)
 
         def chunk(delta_text, finish=None, first=False):
@@ -168,7 +181,11 @@ def create_app(engine_thread, tokenizer, served_model_name="chatts", limit_times
             async def gen():
                 first = True
                 while True:
-                    new, finished, r = await q.get()
+                    try:
+                        new, finished, r = await next_event(q)
+                    except RuntimeError as e:
+                        yield "data: " + json.dumps({"error": {"message": str(e), "type": "server_error"}}) + "\n\n"
+                        break
                     if r.error is not None:
                         yield "data: " + json.dumps({"error": {"message": str(r.error), "type": "invalid_request_error"}}) + "\n\n"
                         break
@@ -182,7 +199,10 @@ def create_app(engine_thread, tokenizer, served_model_name="chatts", limit_times
                 yield "data: [DONE]\n\n"
             return StreamingResponse(gen(), media_type="text/event-stream")
         while True:
-            new, finished, r = await q.get()
+            try:
+                new, finished, r = await next_event(q)
+            except RuntimeError as e:
+                return error(500, str(e), "server_error")
             if r.error is not None:
                 return error(400, str(r.error))
             dec.push(new, final=finished)

@@ -142,3 +142,34 @@ def test_synth_key_and_spec_names():
     blk = osynth.bf16_bits(osynth.tensor_key(1, "t"), 0.0, 13, 8, 100, row0=5, col0=17, full_cols=512)
     full = osynth.bf16_bits(osynth.tensor_key(1, "t"), 0.0, 13, 64, 512)
     assert np.array_equal(blk, full[5:13, 17:117])
+
+
+def test_auto_map_drop_in(tmp_path, monkeypatch):
+    """The reference's UNMODIFIED loading cell (README.md:88-90) - AutoModelForCausalLM / AutoProcessor with trust_remote_code -
+    resolves to this engine through the auto_map ChatTSConfig.save_pretrained writes (stock transformers does the resolving).
+    No GPU here, so the model constructor is expected to refuse with chatts_amd's own 'no CPU fallback' error."""
+    from transformers import AutoConfig, AutoModelForCausalLM, AutoProcessor
+    monkeypatch.setenv("PYTHONPATH", ROOT)
+    cfg = cfgmod.preset("tiny-qwen3")
+    d = str(tmp_path / "ckpt")
+    cfg.save_pretrained(d)
+    back = cfgmod.ChatTSConfig.from_pretrained(d)
+    assert back.model_type == "qwen3" and back.qk_norm and back.ts["patch_size"] == 16 and back.eos_token_id == cfg.eos_token_id
+    ac = AutoConfig.from_pretrained(d, trust_remote_code=True)
+    assert type(ac).__name__ == "ChatTSAmdConfig" and ac.ts["patch_size"] == 16          # model.config.ts['patch_size'] stays readable
+    proc = AutoProcessor.from_pretrained(d, trust_remote_code=True, tokenizer=SyntheticTokenizer.for_config(cfg))
+    assert isinstance(proc, ChatTSProcessor)
+    out = proc(text=["a <ts><ts/> b"], timeseries=[np.arange(20.0)], return_tensors="pt")
+    assert out["timeseries"].shape == (1, 40, 1)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="chatts_amd needs a ROCm GPU"):
+            AutoModelForCausalLM.from_pretrained(d, trust_remote_code=True, device_map=0, dtype="float16")
+
+
+def test_config_ts_key_aliases_and_scalar_eos():
+    """ADVICE r1: ts.max_sequence_length wins over ts.max_length when both are present (chatts_vllm.py:68,76,245 reads both);
+    a scalar eos_token_id (common in Qwen configs) is normalised to a list."""
+    c = cfgmod.ChatTSConfig(ts={"max_length": 4096, "max_sequence_length": 8192}, eos_token_id=151645)
+    assert c.ts["max_sequence_length"] == 8192 and c.eos_token_id == [151645]
+    c = cfgmod.ChatTSConfig(ts={"max_length": 4096})
+    assert c.ts["max_sequence_length"] == 4096
