@@ -66,27 +66,68 @@ __device__ __forceinline__ void finish_call(const TpParams& p, uint32_t epoch) {
 }
 
 // out[i] = (resid ? resid[i] : 0) + sum_r in_r[i], r = 0..W-1 in rank order.  out may alias resid (x += all-reduced delta).
+// E elements per thread.  The exchange is pure latency, so nothing is serialised: a thread first pushes its E values to all W
+// ranks (E * W independent stores), then keeps ALL of its E * W polls in flight at once and re-issues only the granules that
+// have not arrived (tools/tp_exchange_bench.py: a one-at-a-time poll loop cost 15 us for 5120 values, this form ~1/2 of that).
+template <int E>
 __global__ __launch_bounds__(1024) void tp_allreduce_kernel(TpParams p, const float* __restrict__ in, const float* resid,
                                                            float* out, int64_t n) {
   const uint32_t epoch = p.ctr[0] + 1u;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (int64_t i = i0; i < n; i += stride) {
-    const uint32_t bits = __float_as_uint(in[i]);
-    for (int k = 0; k < p.world; ++k) {                     // start with myself, then ring order: spreads the links
-      const int q = (p.rank + k) % p.world;
-      put(slot_ptr(p, q, epoch, p.rank) + i, epoch, bits);
+  for (int64_t base = i0; base < n; base += stride * E) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int64_t i = base + (int64_t)e * stride;
+      if (i < n) {
+        const uint32_t bits = __float_as_uint(in[i]);
+        for (int k = 0; k < p.world; ++k) {                   // start with myself, then ring order: spreads the links
+          const int q = (p.rank + k) % p.world;
+          put(slot_ptr(p, q, epoch, p.rank) + i, epoch, bits);
+        }
+      }
     }
-  }
-  for (int64_t i = i0; i < n; i += stride) {
-    float sum = 0.f;
-    bool ok = true;
-    for (int src = 0; src < p.world && ok; ++src) {
-      uint32_t bits;
-      ok = take(slot_ptr(p, p.rank, epoch, src) + i, epoch, bits, &p.ctr[2]);
-      sum = src == 0 ? __uint_as_float(bits) : sum + __uint_as_float(bits);
+    uint32_t val[E][kMaxWorld];
+    uint32_t pending = 0;                                     // bit e * 8 + src
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (base + (int64_t)e * stride < n)
+        for (int src = 0; src < p.world; ++src) pending |= 1u << (e * kMaxWorld + src);
+    uint64_t t0 = 0;
+    while (pending) {
+      uint64_t g[E][kMaxWorld];
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int src = 0; src < kMaxWorld; ++src)
+          if (pending & (1u << (e * kMaxWorld + src)))
+            g[e][src] = __hip_atomic_load(slot_ptr(p, p.rank, epoch, src) + base + (int64_t)e * stride, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int src = 0; src < kMaxWorld; ++src)
+          if ((pending & (1u << (e * kMaxWorld + src))) && (uint32_t)(g[e][src] >> 32) == epoch) {
+            val[e][src] = (uint32_t)g[e][src];
+            pending &= ~(1u << (e * kMaxWorld + src));
+          }
+      if (pending) {
+        if (t0 == 0) t0 = wall_clock64();
+        else if (wall_clock64() - t0 > kSpinTicks) { atomicOr(&p.ctr[2], 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
     }
-    out[i] = resid ? resid[i] + sum : sum;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int64_t i = base + (int64_t)e * stride;
+      if (i < n) {
+        float sum = 0.f;
+#pragma unroll
+        for (int src = 0; src < kMaxWorld; ++src)
+          if (src < p.world) sum = src == 0 ? __uint_as_float(val[e][0]) : sum + __uint_as_float(val[e][src]);
+        out[i] = resid ? resid[i] + sum : sum;
+      }
+    }
   }
   finish_call(p, epoch);
 }
@@ -291,7 +332,7 @@ extern "C" int chatts_tp_reset(ChattsTpComm* c, chatts_stream_t stream) {
   return CHATTS_OK;
 }
 
-static int tp_blocks(int64_t n) {      // one 1024-thread workgroup up to 8 k elements (latency), then 4 per thread
+static int tp_blocks(int64_t n) {      // gather / argmax: one 1024-thread workgroup up to 8 k elements, then 4 per thread
   if (n <= 8192) return 1;
   const int64_t b = (n + 4095) / 4096;
   return (int)(b > 64 ? 64 : b);
@@ -302,7 +343,12 @@ extern "C" int chatts_allreduce(ChattsTpComm* c, const float* in, float* out, co
   CHATTS_REQUIRE(n >= 0 && n <= c->p.max_elems, CHATTS_E_SHAPE, "allreduce: %lld elements exceed the exchange buffer (%lld)",
                  (long long)n, (long long)c->p.max_elems);
   if (n == 0) return CHATTS_OK;
-  hipLaunchKernelGGL(tp_allreduce_kernel, dim3(tp_blocks(n)), dim3(1024), 0, as_stream(stream), c->p, in, resid, out, n);
+  if (n <= 16384) {           // decode-sized: one value per thread, every poll of the vector in flight at once
+    hipLaunchKernelGGL(tp_allreduce_kernel<1>, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, as_stream(stream), c->p, in, resid, out, n);
+  } else {
+    const int64_t b = (n + 4095) / 4096;
+    hipLaunchKernelGGL(tp_allreduce_kernel<4>, dim3((unsigned)(b > 128 ? 128 : b)), dim3(1024), 0, as_stream(stream), c->p, in, resid, out, n);
+  }
   CHATTS_CHECK_LAUNCH("tp_allreduce");
   return CHATTS_OK;
 }

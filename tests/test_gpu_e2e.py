@@ -304,7 +304,8 @@ def test_full_size_14b_properties():
     series = [random_walk_series(rng, L) for L in lengths]
     inputs = proc(text=[chat_prompt(lengths)], timeseries=series, padding=True, return_tensors="pt")
     ids = inputs["input_ids"][0].tolist()
-    model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, max_ctx=1024, max_prefill_tokens=1024)
+    # (prefix reuse off: the repeated request must re-run the SAME prefill for the bit-for-bit comparisons below)
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, max_ctx=1024, max_prefill_tokens=1024, enable_prefix_caching=False)
     ser = inputs["timeseries"].cuda()
     model.use_graph = True
     t1, l1 = model.generate_one(ids, ser, proc.last_lengths, 6, return_logits=True)
