@@ -216,6 +216,187 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// decode, "parts" form (the batch-1 decode step): grid (n_kv, n_parts, batch), 16 waves per workgroup.  Wave w of part b is
+// tile slot b * 16 + w of n_parts * 16 slots (slot s walks tiles s, s + n_slots, ...) and does exactly what attn_decode_kernel
+// does; the 16 (m, l, o) partials of a workgroup are then merged through LDS, so that a head leaves ONE unnormalised partial
+// per part - at most 8 per head instead of up to 64.  That makes the final merge cheap enough to live in the prologue of the
+// o_proj GEMV (gemv.hip: x is built from the parts while it is staged), and the decode step loses the separate combine
+// launch (4.9 us + a kernel boundary per layer).  m stays in the log2 domain end to end.
+// Partials: part_o [batch, n_q, n_parts, 128], part_ml [batch, n_q, n_parts, 2]; parts whose first tile is beyond the context
+// are not written - the consumer derives the number of live parts from the position.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPartWaves = 16;
+
+__global__ __launch_bounds__(1024) void attn_decode_parts_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  const int hk = blockIdx.x, part = blockIdx.y, nparts = gridDim.y, seq = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int G = p.n_q / p.n_kv;
+  float* q_s = psm;                                   // [G][128]
+  float* knew_s = q_s + G * kHeadDim;                 // [128]
+  float* vnew_s = knew_s + kHeadDim;                  // [128]
+  float* ml_s = vnew_s + kHeadDim;                    // [16][G][2]
+  float* o_s = ml_s + kPartWaves * G * 2;             // [16][G][128]
+  const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;
+  if (pos < 0) return;                                // parked slot (workgroup-uniform)
+  const int ntiles = pos / kDTile + 1;
+  if (part * kPartWaves >= ntiles) return;            // no key in this part (workgroup-uniform)
+  const int nslots = nparts * kPartWaves, slot = part * kPartWaves + wave;
+  const bool active = slot < ntiles;
+  const float* qkv = p.qkv + (size_t)seq * (p.n_q + 2 * p.n_kv) * kHeadDim;
+  float* kcache = p.kc + (size_t)seq * p.seq_stride;
+  float* vcache = p.vc + (size_t)seq * p.seq_stride;
+  const bool owner = active && ((pos / kDTile) % nslots) == slot;
+  const float scale = 0.08838834764831845f * 1.4426950408889634f;    // 128^-1/2 * log2(e)
+  const float* kbase = kcache + (size_t)hk * p.max_ctx * kHeadDim;
+  const float* vbase = vcache + (size_t)hk * p.max_ctx * kHeadDim;
+  const int key_l = lane >> 2, quarter = lane & 3;
+
+  f32x4 kv[8];
+  float2 vv[kDTile];
+  auto load_tile = [&](int tile) {
+    const int j0 = tile * kDTile;
+    const int j = j0 + key_l;
+    const int jc = j <= pos ? j : pos;
+    const float* kr = kbase + (size_t)jc * kHeadDim + quarter * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
+#pragma unroll
+    for (int u = 0; u < kDTile; ++u) {
+      const int ju = j0 + u <= pos ? j0 + u : pos;
+      vv[u] = *reinterpret_cast<const float2*>(vbase + (size_t)ju * kHeadDim + lane * 2);
+    }
+  };
+  if (active) load_tile(slot);
+  {
+    const float c = p.cos_tab[(size_t)pos * 64 + lane], s = p.sin_tab[(size_t)pos * 64 + lane];
+    if (wave < G) {                                   // wave g prepares query head g for the whole workgroup
+      const float* src = qkv + (size_t)(hk * G + wave) * kHeadDim;
+      float a = src[lane], b = src[lane + 64];
+      norm_rope(a, b, p.q_norm_w, p.eps, c, s, lane);
+      q_s[wave * kHeadDim + lane] = a;
+      q_s[wave * kHeadDim + lane + 64] = b;
+    }
+    if (owner) {                                      // the new K/V row: to the cache and to LDS (only this wave reads it)
+      const float* ks = qkv + (size_t)(p.n_q + hk) * kHeadDim;
+      float a = ks[lane], b = ks[lane + 64];
+      norm_rope(a, b, p.k_norm_w, p.eps, c, s, lane);
+      knew_s[lane] = a;
+      knew_s[lane + 64] = b;
+      float* kd = kcache + ((size_t)hk * p.max_ctx + pos) * kHeadDim;
+      kd[lane] = a;
+      kd[lane + 64] = b;
+      const float* vs = qkv + (size_t)(p.n_q + p.n_kv + hk) * kHeadDim;
+      const float va = vs[lane], vb = vs[lane + 64];
+      vnew_s[lane] = va;
+      vnew_s[lane + 64] = vb;
+      float* vd = vcache + ((size_t)hk * p.max_ctx + pos) * kHeadDim;
+      vd[lane] = va;
+      vd[lane + 64] = vb;
+    }
+  }
+  __syncthreads();
+
+  float m_run[kMaxGroup], l_run[kMaxGroup], acc0[kMaxGroup], acc1[kMaxGroup];
+#pragma unroll
+  for (int g = 0; g < kMaxGroup; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.f; acc0[g] = 0.f; acc1[g] = 0.f; }
+  if (active) {
+    for (int tile = slot; tile < ntiles; tile += nslots) {
+      if (tile != slot) load_tile(tile);
+      const int j0 = tile * kDTile;
+      const int j = j0 + key_l;
+      const int jc = j <= pos ? j : pos;
+      if (owner && jc == pos) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(knew_s + quarter * 4 + i * 16);
+      }
+      if (owner) {
+        const float2 vn = *reinterpret_cast<const float2*>(vnew_s + lane * 2);
+#pragma unroll
+        for (int u = 0; u < kDTile; ++u)
+          if (j0 + u >= pos) vv[u] = vn;
+      }
+      float dot[kMaxGroup];
+#pragma unroll
+      for (int g = 0; g < kMaxGroup; ++g) dot[g] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) {
+          if (g < G) {
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(q_s + g * kHeadDim + quarter * 4 + i * 16);
+            dot[g] = fmaf(kv[i].x, qv.x, dot[g]);
+            dot[g] = fmaf(kv[i].y, qv.y, dot[g]);
+            dot[g] = fmaf(kv[i].z, qv.z, dot[g]);
+            dot[g] = fmaf(kv[i].w, qv.w, dot[g]);
+          }
+        }
+      }
+      float pr[kMaxGroup];
+#pragma unroll
+      for (int g = 0; g < kMaxGroup; ++g) {
+        pr[g] = 0.f;
+        if (g < G) {
+          float sc = dot[g];
+          sc += lane_xor1(sc);
+          sc += lane_xor2(sc);
+          sc = j <= pos ? sc * scale : -INFINITY;
+          const float mt = rows4_max(fmaxf(fmaxf(sc, row_ror4(sc)), row_ror8(fmaxf(sc, row_ror4(sc)))));
+          const float m_new = fmaxf(m_run[g], mt);
+          const float e = __builtin_amdgcn_exp2f(sc - m_new);
+          float es = e + row_ror4(e);
+          es = rows4_sum(es + row_ror8(es));
+          const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
+          l_run[g] = l_run[g] * alpha + es;
+          m_run[g] = m_new;
+          acc0[g] *= alpha;
+          acc1[g] *= alpha;
+          pr[g] = e;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kDTile; ++u) {
+#pragma unroll
+        for (int g = 0; g < kMaxGroup; ++g) {
+          if (g < G) {
+            const float pu = readlane_f(pr[g], u * 4);
+            acc0[g] = fmaf(pu, vv[u].x, acc0[g]);
+            acc1[g] = fmaf(pu, vv[u].y, acc1[g]);
+          }
+        }
+      }
+    }
+  }
+  // the workgroup's 16 partials -> LDS (inactive waves contribute m = -inf, l = 0, o = 0)
+#pragma unroll
+  for (int g = 0; g < kMaxGroup; ++g) {
+    if (g < G) {
+      *reinterpret_cast<float2*>(o_s + ((size_t)wave * G + g) * kHeadDim + lane * 2) = make_float2(acc0[g], acc1[g]);
+      if (lane == 0) { ml_s[(wave * G + g) * 2] = m_run[g]; ml_s[(wave * G + g) * 2 + 1] = l_run[g]; }
+    }
+  }
+  __syncthreads();
+  if (wave < G) {                                     // wave g merges head g (fixed slot order)
+    const int g = wave;
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < kPartWaves; ++s) M = fmaxf(M, ml_s[(s * G + g) * 2]);
+    float den = 0.f, n0 = 0.f, n1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < kPartWaves; ++s) {
+      const float w = __builtin_amdgcn_exp2f(ml_s[(s * G + g) * 2] - M);       // 0 for empty slots (m = -inf; M is finite)
+      den = fmaf(w, ml_s[(s * G + g) * 2 + 1], den);
+      const float2 o = *reinterpret_cast<const float2*>(o_s + ((size_t)s * G + g) * kHeadDim + lane * 2);
+      n0 = fmaf(w, o.x, n0);
+      n1 = fmaf(w, o.y, n1);
+    }
+    const size_t pi = ((size_t)seq * p.n_q + hk * G + g) * nparts + part;
+    *reinterpret_cast<float2*>(p.part_o + pi * kHeadDim + lane * 2) = make_float2(n0, n1);
+    if (lane == 0) { p.part_ml[pi * 2] = M; p.part_ml[pi * 2 + 1] = den; }
+  }
+}
+
 // out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots).  One workgroup
 // (2 waves) per head; lane s of each wave holds (m_s, l_s), weights are broadcast by shuffle, and 16 independent
 // o_s[d] loads are in flight per thread: no LDS, no barrier.
@@ -792,4 +973,42 @@ extern "C" int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int 
                                              size_t workspace_bytes, chatts_stream_t stream) {
   return chatts_attention_decode_batched(qkv_raw, 1, n_q, n_kv, q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos, pos_dev,
                                          cache, 0, out, n_splits, workspace, workspace_bytes, stream);
+}
+
+// Decode attention in "parts" form (see attn_decode_parts_kernel): leaves n_parts (<= 8) unnormalised partials per head in the
+// workspace - part_o [batch, n_q, n_parts, 128] then part_ml [batch, n_q, n_parts, 2], m in the log2 domain - for a consumer
+// that merges them while staging its input (chatts_linear with ChattsLinearArgs.attn_parts: the o_proj GEMV).
+extern "C" int chatts_attention_decode_parts(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w,
+                                             const float* k_norm_w, float norm_eps, const float* cos_tab, const float* sin_tab,
+                                             int pos, const int32_t* pos_dev, const ChattsKvCache* cache, size_t seq_stride,
+                                             int n_parts, void* workspace, size_t workspace_bytes, chatts_stream_t stream) {
+  CHATTS_REQUIRE(batch >= 1 && n_q > 0 && n_kv > 0 && n_parts >= 1 && n_parts <= 8, CHATTS_E_BADARG,
+                 "attention_decode_parts: bad sizes (batch >= 1, 1 <= n_parts <= 8)");
+  CHATTS_REQUIRE(qkv_raw && cos_tab && sin_tab && cache && cache->k && cache->v, CHATTS_E_BADARG, "attention_decode_parts: null pointer");
+  CHATTS_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), CHATTS_E_BADARG,
+                 "attention_decode_parts: q_norm and k_norm must both be set or both be null");
+  CHATTS_REQUIRE(n_q % n_kv == 0 && n_q / n_kv <= kMaxGroup, CHATTS_E_SHAPE, "attention: GQA group %d/%d unsupported (max %d)", n_q, n_kv,
+                 kMaxGroup);
+  CHATTS_REQUIRE(batch == 1 || pos_dev, CHATTS_E_BADARG, "attention_decode_parts: batch > 1 needs per-sequence positions on the device");
+  if (!pos_dev) CHATTS_REQUIRE(pos >= 0 && pos < cache->max_ctx, CHATTS_E_SHAPE, "attention_decode_parts: position exceeds the cache");
+  AttnParams p{};
+  p.qkv = qkv_raw; p.kc = cache->k; p.vc = cache->v; p.pos0_dev = pos_dev; p.pos0 = pos;
+  p.t = batch; p.n_q = n_q; p.n_kv = n_kv; p.max_ctx = cache->max_ctx; p.n_splits = n_parts;
+  p.q_norm_w = q_norm_w; p.k_norm_w = k_norm_w; p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.eps = norm_eps; p.seq_stride = seq_stride;
+  const int rc = bind_workspace(p, workspace, workspace_bytes);
+  if (rc) return rc;
+  const int G = n_q / n_kv;
+  const size_t lds = ((size_t)G * kHeadDim + 2 * kHeadDim + (size_t)kPartWaves * G * 2 + (size_t)kPartWaves * G * kHeadDim) * sizeof(float);
+  if (lds > 64 * 1024) {
+    static bool configured = false;
+    if (!configured) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_parts_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "attn_decode_parts: cannot reserve LDS: %s", hipGetErrorString(e));
+      configured = true;
+    }
+  }
+  hipLaunchKernelGGL(attn_decode_parts_kernel, dim3(n_kv, n_parts, batch), dim3(kPartWaves * 64), lds, as_stream(stream), p);
+  CHATTS_CHECK_LAUNCH("attn_decode_parts");
+  return CHATTS_OK;
 }

@@ -32,7 +32,37 @@ struct GemvParams {
   const uint8_t* w8;      // fp8 (OCP e4m3fn) weights [N, ldw8] or NULL
   const float* w8_scale;  // per-row power-of-two scale: w = scale[row] * float(w8)
   int ldw8;
+  // optional: x is not read from memory but merged from the decode attention's per-part partials while it is staged
+  // (attention.hip attn_decode_parts_kernel): x[h * 128 + d] = sum_p 2^(m_p - M) o_p[d] / sum_p 2^(m_p - M) l_p
+  const float* apo;       // part_o  [heads, aparts, 128]
+  const float* aml;       // part_ml [heads, aparts, 2]   (m in the log2 domain, l)
+  const int32_t* apos_dev;
+  int apos, aparts;
 };
+
+// four consecutive elements k4..k4+3 of the attention output (same head: 128 % 4 == 0) from the live parts
+__device__ __forceinline__ f32x4 attn_parts_x4(const GemvParams& p, int k4, int nact) {
+  const int h = k4 >> 7, d = k4 & 127;
+  const float* ml = p.aml + (size_t)h * p.aparts * 2;
+  float M = -INFINITY;
+  for (int q = 0; q < nact; ++q) M = fmaxf(M, ml[2 * q]);
+  float den = 0.f;
+  f32x4 num = {0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < nact; ++q) {
+    const float w = __builtin_amdgcn_exp2f(ml[2 * q] - M);
+    den = fmaf(w, ml[2 * q + 1], den);
+    const f32x4 o = *reinterpret_cast<const f32x4*>(p.apo + ((size_t)h * p.aparts + q) * kHeadDim + d);
+    num.x = fmaf(w, o.x, num.x); num.y = fmaf(w, o.y, num.y); num.z = fmaf(w, o.z, num.z); num.w = fmaf(w, o.w, num.w);
+  }
+  const float inv = 1.0f / den;
+  return (f32x4){num.x * inv, num.y * inv, num.z * inv, num.w * inv};
+}
+__device__ __forceinline__ int attn_parts_live(const GemvParams& p) {
+  const int pos = p.apos_dev ? p.apos_dev[0] : p.apos;
+  const int ntiles = pos / 16 + 1;
+  const int nact = (ntiles + 15) / 16;            // parts of 16 tile slots each (attention.hip kPartWaves)
+  return nact < p.aparts ? nact : p.aparts;
+}
 
 __device__ __forceinline__ float dot8(const u32x4 wv, const f32x4 xa, const f32x4 xb, float acc) {
   acc = fmaf(bf16_lo(wv.x), xa.x, acc);
@@ -112,13 +142,18 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(GemvParams p) {
     for (int i = 0; i < nw; ++i) t += red[i];
     rstd = rsqrtf(t / (float)K + p.eps);
   }
+  const int nact = (!NORM && p.apo) ? attn_parts_live(p) : 0;
   for (int k4 = tid * 4; k4 < nchunks * 512; k4 += nthreads * 4) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (k4 < K) {
-      v = *reinterpret_cast<const f32x4*>(p.x + k4);
-      if (NORM) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
-        v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
+      if (!NORM && p.apo) {
+        v = attn_parts_x4(p, k4, nact);
+      } else {
+        v = *reinterpret_cast<const f32x4*>(p.x + k4);
+        if (NORM) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
+          v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
+        }
       }
     }
     const int chunk = k4 >> 9, within = k4 & 511;
@@ -209,13 +244,18 @@ __global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
     for (int i = 0; i < nw; ++i) t += red[i];
     rstd = rsqrtf(t / (float)K + p.eps);
   }
+  const int nact = (!NORM && p.apo) ? attn_parts_live(p) : 0;
   for (int k4 = tid * 4; k4 < nchunks * 1024; k4 += nthreads * 4) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (k4 < K) {
-      v = *reinterpret_cast<const f32x4*>(p.x + k4);
-      if (NORM) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
-        v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
+      if (!NORM && p.apo) {
+        v = attn_parts_x4(p, k4, nact);
+      } else {
+        v = *reinterpret_cast<const f32x4*>(p.x + k4);
+        if (NORM) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
+          v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
+        }
       }
     }
     const int chunk = k4 >> 10, within = k4 & 1023;
@@ -294,6 +334,10 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   p.w = a->w; p.x = a->a; p.bias = a->bias; p.resid = a->resid; p.out = a->c;
   p.norm_w = a->norm_w; p.eps = a->norm_eps; p.n = a->n; p.k = a->k; p.ldw = a->ldw;
   p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8;
+  p.apo = a->attn_part_o; p.aml = a->attn_part_ml; p.apos_dev = a->attn_pos_dev; p.apos = a->attn_pos; p.aparts = a->attn_parts;
+  if (p.apo)
+    CHATTS_REQUIRE(p.aml && a->attn_parts >= 1 && a->attn_parts <= 8 && a->k % kHeadDim == 0 && !a->norm_w, CHATTS_E_BADARG,
+                   "gemv: attention parts need part_ml, 1..8 parts, K a multiple of 128 and no fused RMSNorm");
   const bool norm = a->norm_w != nullptr;
   const int cus = device_cus();
   const int swiglu = a->epilogue == CHATTS_EPI_SWIGLU;
