@@ -79,7 +79,9 @@ def roofline_gate_up(model, reps=2, m=1):
                 la = _lib.LinearArgs(a=x.data_ptr(), w=lw["gate_up"].data_ptr(), bias=None, resid=None, c=out.data_ptr(),
                                      norm_w=lw["post_norm"].data_ptr(), norm_eps=cfg.rms_norm_eps, m=1, n=n, k=H, lda=H,
                                      ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU, workspace=None, workspace_bytes=0,
-                                     w8=_lib.ptr(lw.get("gate_up8")), w8_scale=_lib.ptr(lw.get("gate_up8_scale")), ldw8=H)
+                                     w8=_lib.ptr(lw.get("gate_up8")), w8_scale=_lib.ptr(lw.get("gate_up8_scale")), ldw8=H,
+                                     w4=_lib.ptr(lw.get("gate_up4")), w4_sz=_lib.ptr(lw.get("gate_up4_sz")), ldw4=H // 2,
+                                     w4_group=model.int4_group)
             else:
                 la = _lib.LinearArgs(a=None, w=lw["gate_up"].data_ptr(), bias=None, resid=None, c=None, norm_w=None, norm_eps=0.0,
                                      m=m, n=n, k=H, lda=H, ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU, workspace=ws.data_ptr(),
@@ -100,11 +102,14 @@ def roofline_gate_up(model, reps=2, m=1):
     avg_s = e0.elapsed_time(e1) * 1e-3 / launches
     # algorithmic bytes per launch: bf16 weights + f32 x in + norm weights + f32 out (SURVEY.md 8d per-unit figure)
     fp8 = "gate_up8" in model.layers[0]
+    int4 = m == 1 and "gate_up4" in model.layers[0]
     bytes_per_launch = n * H * (1 if fp8 else 2) + (n * 4 if fp8 else 0) + m * (H * 4 + H * 4 + plan.inter * 4)
+    if int4:
+        bytes_per_launch = n * H // 2 + n * (H // model.int4_group) * 8 + H * 4 + H * 4 + plan.inter * 4
     if m > 1:
         return dict(kernel=f"gemm_stream_kernel<4,{'fp8' if fp8 else 'bf16'}> (gate_up_proj + SwiGLU, M = {m} sequences, bf16 planes in/out)",
                     launches=launches, avg_us=avg_s * 1e6, bytes_per_launch=bytes_per_launch, gbs=bytes_per_launch / avg_s / 1e9)
-    return dict(kernel=("gemv8_ldsx_kernel" if fp8 else "gemv_ldsx_kernel") +
+    return dict(kernel=("gemv4_ldsx_kernel" if int4 else "gemv8_ldsx_kernel" if fp8 else "gemv_ldsx_kernel") +
                 "<2,2,SWIGLU,NORM> (gate_up_proj + fused RMSNorm + SwiGLU)", launches=launches,
                 avg_us=avg_s * 1e6, bytes_per_launch=bytes_per_launch, gbs=bytes_per_launch / avg_s / 1e9)
 
@@ -360,8 +365,8 @@ def main():
     ap.add_argument("--max-ctx", type=int, default=2048, help="KV-cache length (longer prompts, e.g. --series 30, need more)")
     ap.add_argument("--batch", type=int, default=1, help="> 1: continuous-batching workload (BASELINE.json config 5): B prompts decode "
                     "together; a step = one B-wide decode step; value = aggregate tokens/s")
-    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
-                    help="fp8 = BASELINE.json config 5 weight format (NOT the headline: reported as a separate workload)")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "int4"],
+                    help="fp8 = BASELINE.json config 5 weight format, int4 = the GPTQ-Int4 checkpoint's (NOT the headline: separate workloads)")
     args = ap.parse_args()
 
     import torch
@@ -473,7 +478,8 @@ def main():
                   f"{args.series}x{args.length}-step TS prompt, TP=N",
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16" if args.weights == "bf16" else "fp8-e4m3 weights (pow2 row scales), f32 math", "data": "synthetic",
+        "dtype": {"bf16": "bf16", "fp8": "fp8-e4m3 weights (pow2 row scales), f32 math",
+                  "int4": "int4 codes + fp16 group scales (round-to-nearest, groups of 128) = a bf16 matrix, f32 math"}[args.weights], "data": "synthetic",
         "config": {"workload": workload_name(args, world),
                    "model": args.model, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
                    "parallelism": f"tp{world}", "batch": 1, "decode_graph": model.graph_capturable(),

@@ -37,6 +37,7 @@ class LinearArgs(C.Structure):
                 ("a_hi", c_void_p), ("a_lo", c_void_p), ("ld_planes", c_int),
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("ld_cplanes", c_int),
                 ("post_norm_w", c_void_p), ("post_norm_eps", c_float), ("post_hi", c_void_p), ("post_lo", c_void_p), ("ld_post", c_int),
+                ("w4", c_void_p), ("w4_sz", c_void_p), ("ldw4", c_int), ("w4_group", c_int),
                 ("attn_part_o", c_void_p), ("attn_part_ml", c_void_p), ("attn_pos_dev", c_void_p), ("attn_pos", c_int),
                 ("attn_parts", c_int)]
 
@@ -50,7 +51,9 @@ class LayerWeights(C.Structure):
                 ("k_norm", c_void_p), ("o", c_void_p), ("post_norm", c_void_p), ("gate_up", c_void_p),
                 ("down", c_void_p), ("qkv8", c_void_p), ("qkv8_scale", c_void_p), ("o8", c_void_p),
                 ("o8_scale", c_void_p), ("gate_up8", c_void_p), ("gate_up8_scale", c_void_p), ("down8", c_void_p),
-                ("down8_scale", c_void_p)]
+                ("down8_scale", c_void_p),
+                ("qkv4", c_void_p), ("qkv4_sz", c_void_p), ("o4", c_void_p), ("o4_sz", c_void_p), ("gate_up4", c_void_p),
+                ("gate_up4_sz", c_void_p), ("down4", c_void_p), ("down4_sz", c_void_p), ("w4_group", c_int)]
 
 
 class SamplingArgs(C.Structure):
@@ -85,6 +88,7 @@ SIGNATURES = {
     "chatts_device_cus": (c_int, []),
     "chatts_fill_hash": (c_int, [c_void_p, c_int, c_uint32, c_float, c_int, c_int64, c_int64, c_int64, c_int64,
                                  c_int64, c_int64, c_void_p]),
+    "chatts_ts_normalise": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "chatts_ts_patch_cnt": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "chatts_ts_patchify": (c_int, [C.POINTER(PatchifyArgs), c_void_p]),
     "chatts_ts_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(TsWeights), c_void_p,

@@ -74,6 +74,10 @@ extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) 
   if (a->w8)
     CHATTS_REQUIRE(a->w8_scale && a->ldw8 >= a->k && a->ldw8 % 16 == 0 && ((uintptr_t)a->w8 % 16) == 0 && a->k % 16 == 0,
                    CHATTS_E_SHAPE, "linear: fp8 weights need a scale, ldw8 >= K, 16-byte alignment");
+  if (a->w4)
+    CHATTS_REQUIRE(a->w4_sz && a->w4_group >= 16 && a->w4_group % 16 == 0 && a->k % a->w4_group == 0 && a->ldw4 >= a->k / 2 &&
+                       a->ldw4 % 8 == 0 && ((uintptr_t)a->w4 % 8) == 0 && ((uintptr_t)a->w4_sz % 8) == 0,
+                   CHATTS_E_SHAPE, "linear: 4-bit weights need w4_sz, a group size that is a multiple of 16 and divides K, ldw4 >= K/2 and %% 8");
   if (a->post_norm_w)
     CHATTS_REQUIRE(a->m > 1 && a->c && a->post_hi && a->post_lo && a->ld_post >= a->n && a->ld_post % 4 == 0 && a->n % 4 == 0 &&
                        (a->epilogue == CHATTS_EPI_NONE || a->epilogue == CHATTS_EPI_RESID) && !cplanes,
@@ -263,6 +267,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     if (t == 1) {
       la.a = d->b.x; la.norm_w = lw.input_norm; la.norm_eps = c.rms_eps;
       la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H;
+      la.w4 = lw.qkv4; la.w4_sz = lw.qkv4_sz; la.ldw4 = H / 2; la.w4_group = lw.w4_group;
     } else {
       if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
     }
@@ -311,6 +316,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if (t == 1) {
       la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k;
+      la.w4 = lw.o4; la.w4_sz = lw.o4_sz; la.ldw4 = la.k / 2; la.w4_group = lw.w4_group;
       if (attn_parts >= 1) {                   // x = merge of the attention parts, done in the GEMV's staging prologue
         float* po = reinterpret_cast<float*>(d->b.workspace);
         la.a = nullptr; la.attn_part_o = po; la.attn_part_ml = po + (size_t)c.n_q * attn_parts * kHeadDim;
@@ -335,6 +341,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   if (t == 1) {
     la.a = d->b.x; la.norm_w = lw.post_norm; la.norm_eps = c.rms_eps;
     la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H;
+    la.w4 = lw.gate_up4; la.w4_sz = lw.gate_up4_sz; la.ldw4 = H / 2; la.w4_group = lw.w4_group;
   } else {
     if ((rc = norm_into(d, lw.post_norm, &la, stream)) != 0) return rc;
   }
@@ -345,7 +352,10 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   la.a = d->b.act; la.w = lw.down; la.m = t; la.n = H; la.k = c.inter;
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
-  if (t == 1) { la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter; }
+  if (t == 1) {
+    la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter;
+    la.w4 = lw.down4; la.w4_sz = lw.down4_sz; la.ldw4 = c.inter / 2; la.w4_group = lw.w4_group;
+  }
   if (act_planes) { la.a = nullptr; la.a_hi = d->b.planes2_hi; la.a_lo = d->b.planes2_lo; la.ld_planes = c.inter; }
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }

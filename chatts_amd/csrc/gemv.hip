@@ -32,6 +32,11 @@ struct GemvParams {
   const uint8_t* w8;      // fp8 (OCP e4m3fn) weights [N, ldw8] or NULL
   const float* w8_scale;  // per-row power-of-two scale: w = scale[row] * float(w8)
   int ldw8;
+  // optional 4-bit copy of W (GPTQ codes, row-major: byte j of a row = codes 2j | 2j+1 << 4) with one (scale, scale * zero) pair
+  // per `w4_group` weights of a row: w = bf16_rne(q * scale - scale_zero) - exactly the bf16 matrix the other kernels stream
+  const uint8_t* w4;
+  const float* w4_sz;     // [N, K / w4_group, 2]
+  int ldw4, w4_group;
   // optional: x is not read from memory but merged from the decode attention's per-part partials while it is staged
   // (attention.hip attn_decode_parts_kernel): x[h * 128 + d] = sum_p 2^(m_p - M) o_p[d] / sum_p 2^(m_p - M) l_p
   const float* apo;       // part_o  [heads, aparts, 128]
@@ -303,6 +308,135 @@ __global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 4-bit weights (GPTQ-Int4 checkpoints: ChatTS-14B-GPTQ-Int4, NetManAIOps/ChatTS README.md:52,262-263).  Same geometry as the
+// fp8 kernel - a lane's load is 8 bytes = 16 codes, a chunk is 1024 elements, x staged as [chunk][quarter][lane] float4 -
+// with a (scale, scale * zero) pair per group of `w4_group` (a multiple of 16) weights.  The engine's weights are DEFINED as
+// bf16_rne(scale * (q - zero)) (chatts_amd/gptq.py: the prefill GEMM streams that bf16 matrix), so the kernel rebuilds exactly
+// that value: q * scale - scale * zero is exact in float32 (fp16 scale x 5-bit integer), one v_cvt_pk_bf16_f32 per pair rounds
+// it, and the widened result meets x in the same exact-product float32 FMA as everywhere else.  ~5 VALU ops per weight at
+// 0.5 B per weight: the VALU and HBM are about equally loaded.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float dot16_int4(const u32x2 wv, const float sc, const float nsz, const f32x4 x0, const f32x4 x1,
+                                             const f32x4 x2, const f32x4 x3, float acc) {
+  // codes of a dword: element 2b = low nibble of byte b, element 2b+1 = high nibble
+  auto eight = [&](uint32_t d, const f32x4 xa, const f32x4 xb, float a) {
+    const uint32_t lo = d & 0x0f0f0f0fu, hi = (d >> 4) & 0x0f0f0f0fu;      // bytes = codes of the even / odd elements
+    float q[8];
+    q[0] = (float)(lo & 0xffu); q[1] = (float)(hi & 0xffu);
+    q[2] = (float)((lo >> 8) & 0xffu); q[3] = (float)((hi >> 8) & 0xffu);
+    q[4] = (float)((lo >> 16) & 0xffu); q[5] = (float)((hi >> 16) & 0xffu);
+    q[6] = (float)(lo >> 24); q[7] = (float)(hi >> 24);
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      f32x2 v = {fmaf(q[j], sc, nsz), fmaf(q[j + 1], sc, nsz)};
+      const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);             // round to nearest even: the bf16 weight
+      const uint32_t bits = __builtin_bit_cast(uint32_t, b);
+      w[j] = __uint_as_float(bits << 16);
+      w[j + 1] = __uint_as_float(bits & 0xffff0000u);
+    }
+    a = fmaf(w[0], xa.x, a); a = fmaf(w[1], xa.y, a); a = fmaf(w[2], xa.z, a); a = fmaf(w[3], xa.w, a);
+    a = fmaf(w[4], xb.x, a); a = fmaf(w[5], xb.y, a); a = fmaf(w[6], xb.z, a); a = fmaf(w[7], xb.w, a);
+    return a;
+  };
+  acc = eight(wv.x, x0, x1, acc);
+  acc = eight(wv.y, x2, x3, acc);
+  return acc;
+}
+
+template <int ROWS, int UNR, int EPI, bool NORM>
+__global__ __launch_bounds__(1024) void gemv4_ldsx_kernel(GemvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* xs4 = reinterpret_cast<f32x4*>(smem);            // permuted x: [chunk][quarter][lane] float4
+  const int K = p.k;
+  const int nchunks = (K + 1023) >> 10;
+  float* red = reinterpret_cast<float*>(smem) + (size_t)nchunks * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthreads = blockDim.x, nw = nthreads >> 6;
+
+  float rstd = 1.f;
+  if (NORM) {
+    float ss = 0.f;
+    for (int k4 = tid * 4; k4 < K; k4 += nthreads * 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + k4);
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    rstd = rsqrtf(t / (float)K + p.eps);
+  }
+  const int nact = (!NORM && p.apo) ? attn_parts_live(p) : 0;
+  for (int k4 = tid * 4; k4 < nchunks * 1024; k4 += nthreads * 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k4 < K) {
+      if (!NORM && p.apo) {
+        v = attn_parts_x4(p, k4, nact);
+      } else {
+        v = *reinterpret_cast<const f32x4*>(p.x + k4);
+        if (NORM) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
+          v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
+        }
+      }
+    }
+    const int chunk = k4 >> 10, within = k4 & 1023;
+    xs4[chunk * 256 + ((within >> 2) & 3) * 64 + (within >> 4)] = v;
+  }
+  __syncthreads();
+
+  const int ngroups = K / p.w4_group;
+  for (int task = blockIdx.x * nw + wave; task < p.tasks; task += gridDim.x * nw) {
+    const uint8_t* wrow[ROWS];
+    const float2* szrow[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      int row = task_row<ROWS, EPI>(task, r);
+      if (row >= p.n) row = 0;
+      wrow[r] = p.w4 + (size_t)row * p.ldw4 + lane * 8;
+      szrow[r] = reinterpret_cast<const float2*>(p.w4_sz) + (size_t)row * ngroups;
+    }
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+    for (int c = 0; c < nchunks; c += UNR) {
+      u32x2 wv[UNR][ROWS];
+      float2 sz[UNR][ROWS];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int k0 = ((c + u) << 10) + lane * 16;
+        const bool ok = c + u < nchunks && k0 < K;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          wv[u][r] = (u32x2){0u, 0u};
+          sz[u][r] = make_float2(0.f, 0.f);
+          if (ok) {
+            wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wrow[r] + ((c + u) << 9)));
+            sz[u][r] = szrow[r][k0 / p.w4_group];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (c + u < nchunks) {
+          const f32x4* xb = xs4 + (c + u) * 256 + lane;
+          const f32x4 x0 = xb[0], x1 = xb[64], x2 = xb[128], x3 = xb[192];
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) acc[r] = dot16_int4(wv[u][r], sz[u][r].x, -sz[u][r].y, x0, x1, x2, x3, acc[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
+    gemv_epilogue<ROWS, EPI>(p, task, lane, acc);
+  }
+}
+
 // ---- dispatch ------------------------------------------------------------------------------------
 template <int ROWS, int UNR, int EPI>
 static void launch_ldsx_norm(const GemvParams& p, bool norm, int blocks, int threads, size_t lds, hipStream_t s) {
@@ -316,6 +450,12 @@ static void launch_ldsx(const GemvParams& p, int epi, bool norm, int blocks, int
     case CHATTS_EPI_SWIGLU: launch_ldsx_norm<ROWS, UNR, CHATTS_EPI_SWIGLU>(p, norm, blocks, threads, lds, s); break;
     default: launch_ldsx_norm<ROWS, UNR, CHATTS_EPI_NONE>(p, norm, blocks, threads, lds, s); break;
   }
+}
+
+template <int EPI>
+static void launch4_norm(const GemvParams& p, bool norm, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (norm) hipLaunchKernelGGL((gemv4_ldsx_kernel<2, 4, EPI, true>), dim3(blocks), dim3(threads), lds, s, p);
+  else hipLaunchKernelGGL((gemv4_ldsx_kernel<2, 4, EPI, false>), dim3(blocks), dim3(threads), lds, s, p);
 }
 
 template <int EPI>
@@ -334,6 +474,7 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   p.w = a->w; p.x = a->a; p.bias = a->bias; p.resid = a->resid; p.out = a->c;
   p.norm_w = a->norm_w; p.eps = a->norm_eps; p.n = a->n; p.k = a->k; p.ldw = a->ldw;
   p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8;
+  p.w4 = a->w4; p.w4_sz = a->w4_sz; p.ldw4 = a->ldw4; p.w4_group = a->w4_group;
   p.apo = a->attn_part_o; p.aml = a->attn_part_ml; p.apos_dev = a->attn_pos_dev; p.apos = a->attn_pos; p.aparts = a->attn_parts;
   if (p.apo)
     CHATTS_REQUIRE(p.aml && a->attn_parts >= 1 && a->attn_parts <= 8 && a->k % kHeadDim == 0 && !a->norm_w, CHATTS_E_BADARG,
@@ -390,6 +531,21 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   const int pad = env_int("CHATTS_GEMV_LDSPAD", 0);
   if (pad >= 1 && (size_t)(160 * 1024 / pad) / 16 * 16 > lds) lds_launch = (size_t)(160 * 1024 / pad) / 16 * 16;
   if (lds_launch > 64 * 1024 && lds <= 64 * 1024) lds_launch = 64 * 1024;      // default dynamic-LDS cap (still 2 per CU)
+  if (a->w4 != nullptr) {                       // 4-bit codes: 2 rows x 4 chunks of 1024 elements (8-byte loads) in flight
+    const int nchunks4 = (a->k + 1023) / 1024;
+    const size_t lds4 = (size_t)nchunks4 * 1024 * 4 + 64 * 4;
+    p.tasks = (units + (swiglu ? 1 : 2) - 1) / (swiglu ? 1 : 2);
+    int blocks4 = (p.tasks + nw - 1) / nw;
+    if (blocks4 > cus * occ) blocks4 = cus * occ;
+    if (blocks4 < 1) blocks4 = 1;
+    switch (a->epilogue) {
+      case CHATTS_EPI_RESID: launch4_norm<CHATTS_EPI_RESID>(p, norm, blocks4, threads, lds4, s); break;
+      case CHATTS_EPI_SWIGLU: launch4_norm<CHATTS_EPI_SWIGLU>(p, norm, blocks4, threads, lds4, s); break;
+      default: launch4_norm<CHATTS_EPI_NONE>(p, norm, blocks4, threads, lds4, s); break;
+    }
+    CHATTS_CHECK_LAUNCH("gemv4_ldsx");
+    return CHATTS_OK;
+  }
   if (a->w8 != nullptr) {                       // fp8 weights: 2 rows x 2 chunks of 1024 elements in flight
     const int nchunks8 = (a->k + 1023) / 1024;
     const size_t lds8 = (size_t)nchunks8 * 1024 * 4 + 64 * 4;

@@ -89,9 +89,74 @@ __global__ __launch_bounds__(256) void ts_patchify_kernel(ChattsPatchifyArgs a) 
   for (int q = feat + lane; q < a.ld_out; q += 64) put(q, 0.f);   // K padding for the MFMA GEMM
 }
 
+// Value-preserved normalisation on the device (sp_encoding, chatts/utils/encoding_utils.py:23-37), one workgroup per series:
+// mean, centred values, scale = max|x - mean| / 3 when some |x - mean| >= 3, and the (value, 1.0)-interleaved float32 rows
+// of the padded encoder input - plus the statistics the prompt prefix prints.  Everything is float64 like the reference's
+// numpy; the sum runs in a FIXED order (256 strided partial sums, then a binary tree), so it is reproducible, but it is not
+// numpy's order: the mean can differ from np.mean in the last bit (max / min / ends are exact).
+__global__ __launch_bounds__(256) void ts_normalise_kernel(const double* __restrict__ raw, const int32_t* __restrict__ len, int lmax,
+                                                          float* __restrict__ enc, double* __restrict__ stats) {
+  __shared__ double red[256];
+  __shared__ double bc[2];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int L = len[s];
+  const double* x = raw + (size_t)s * lmax;
+  float2* out = reinterpret_cast<float2*>(enc) + (size_t)s * lmax;
+  double* st = stats + (size_t)s * 6;          // mean, factor, max, min, left, right
+  if (L <= 0) {
+    for (int t = tid; t < lmax; t += 256) out[t] = make_float2(0.f, 0.f);
+    if (tid < 6) st[tid] = tid == 1 ? 1.0 : 0.0;
+    return;
+  }
+  auto tree = [&](double v, int op) {            // op 0 sum, 1 max, 2 min; every thread returns the result
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) {
+        const double a = red[tid], b = red[tid + o];
+        red[tid] = op == 0 ? a + b : (op == 1 ? (a > b ? a : b) : (a < b ? a : b));
+      }
+      __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+  };
+  double sum = 0.0, mx = -INFINITY, mn = INFINITY;
+  for (int t = tid; t < L; t += 256) { const double v = x[t]; sum += v; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+  const double mean = tree(sum, 0) / (double)L;
+  mx = tree(mx, 1);
+  mn = tree(mn, 2);
+  double dev = 0.0;
+  for (int t = tid; t < L; t += 256) { const double d = fabs(x[t] - mean); dev = d > dev ? d : dev; }
+  dev = tree(dev, 1);
+  const double factor = dev >= 3.0 ? dev / 3.0 : 1.0;
+  for (int t = tid; t < lmax; t += 256) {
+    if (t < L) {
+      double v = x[t] - mean;
+      if (dev >= 3.0) v = v / factor;            // the reference divides in place (scaled /= factor), float64
+      out[t] = make_float2((float)v, 1.0f);
+    } else {
+      out[t] = make_float2(0.f, 0.f);            // zero padding: mask 0 (encoding_utils.py:78-84)
+    }
+  }
+  if (tid == 0) { st[0] = mean; st[1] = factor; st[2] = mx; st[3] = mn; st[4] = x[0]; st[5] = x[L - 1]; }
+  (void)bc;
+}
+
 }  // namespace chatts
 
 using namespace chatts;
+
+extern "C" int chatts_ts_normalise(const double* raw, const int32_t* lengths, int n_series, int lmax, float* enc, double* stats,
+                                   chatts_stream_t stream) {
+  CHATTS_REQUIRE(n_series >= 0 && lmax >= 0, CHATTS_E_BADARG, "ts_normalise: bad sizes n=%d lmax=%d", n_series, lmax);
+  if (n_series == 0 || lmax == 0) return CHATTS_OK;
+  CHATTS_REQUIRE(raw && lengths && enc && stats, CHATTS_E_BADARG, "ts_normalise: null pointer");
+  hipLaunchKernelGGL(ts_normalise_kernel, dim3(n_series), dim3(256), 0, as_stream(stream), raw, lengths, lmax, enc, stats);
+  CHATTS_CHECK_LAUNCH("ts_normalise");
+  return CHATTS_OK;
+}
 
 extern "C" int chatts_ts_patch_cnt(const float* series, int n_series, int lmax, int patch_size,
                                    int32_t* valid_len, int64_t* patch_cnt, chatts_stream_t stream) {

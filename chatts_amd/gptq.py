@@ -29,6 +29,18 @@ def unpack_int4(packed, axis):
     return v.reshape(p.shape[0], p.shape[1] * 8).to(torch.uint8)
 
 
+def codes(qweight, qzeros, scales, g_idx=None, group_size=128, v2=False):
+    """-> (codes uint8 [N, K], scale f32 [N, G], zero f32 [N, G]) in the nn.Linear orientation, or None when the checkpoint's
+    channel -> group map is not the sequential k // group_size (act-order): then only the dequantised bf16 matrix is used."""
+    K = qweight.shape[0] * 8
+    if g_idx is not None and not torch.equal(g_idx.to(torch.long).cpu(), torch.arange(K) // group_size):
+        return None
+    q = unpack_int4(qweight, 0).t().contiguous()                               # [N, K]
+    N = q.shape[0]
+    z = unpack_int4(qzeros, 1)[:, :N].to(torch.float32) + (0.0 if v2 else 1.0)  # [G, N]
+    return q, scales.float().t().contiguous(), z.t().contiguous()
+
+
 def dequantize(qweight, qzeros, scales, g_idx=None, group_size=128, v2=False):
     """-> float32 [N, K] (the nn.Linear.weight layout), every element EXACT in float32 (fp16 scale x small integer)."""
     q = unpack_int4(qweight, 0).to(torch.int32)                # [K, N]
@@ -65,9 +77,13 @@ def dequantized_pairs(pairs, quant_cfg):
         d[suffix] = t
         need = ("qweight", "qzeros", "scales") + (("g_idx",) if quant_cfg.get("desc_act") else ())
         if all(k in d for k in need) and ("g_idx" in d or not _expects_g_idx(pending, base)):
-            w = dequantize(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), gs if gs > 0 else d["qweight"].shape[0] * 8, v2)
+            g = gs if gs > 0 else d["qweight"].shape[0] * 8
+            w = dequantize(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), g, v2)
+            cz = codes(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), g, v2) if g % 16 == 0 else None
             pending.pop(base)
             yield base + ".weight", w.to(torch.bfloat16)
+            if cz is not None:
+                yield base + ".gptq_codes", cz          # consumed by ChatTSForCausalLM.load_weights (int4 decode GEMV)
     # checkpoints always store g_idx; modules still pending only miss it because of iteration order -> flush them
     for base, d in list(pending.items()):
         if all(k in d for k in ("qweight", "qzeros", "scales")):

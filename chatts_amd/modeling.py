@@ -48,6 +48,28 @@ def quantize_fp8_rows(w):
     return q.view(torch.uint8).contiguous(), scale.contiguous(), deq.contiguous()
 
 
+def quantize_int4_rows(w, group_size=128):
+    """[N,K] bf16 -> (codes uint8 [N,K] in 0..15, scale f32 [N,G] (fp16-representable, like GPTQ's), zero f32 [N,G], deq bf16 [N,K]).
+    Round-to-nearest asymmetric 4-bit per group of `group_size` weights of a row (NOT the GPTQ solver: that runs offline and its
+    checkpoints are loaded as they are, chatts_amd/gptq.py).  deq = bf16_rne(scale * (code - zero)) REPLACES the bf16 weight, so
+    every kernel and the oracle see one matrix; the int4 decode GEMV rebuilds exactly these values from the codes."""
+    N, K = w.shape
+    assert K % group_size == 0 and group_size % 16 == 0
+    wf = w.float().view(N, K // group_size, group_size)
+    lo, hi = wf.amin(2), wf.amax(2)
+    scale = ((hi - lo) / 15.0).clamp_min(1e-8).to(torch.float16).float()
+    zero = torch.clamp(torch.round(-lo / scale), 0, 15)
+    q = torch.clamp(torch.round(wf / scale[:, :, None]) + zero[:, :, None], 0, 15)
+    deq = (q * scale[:, :, None] - (scale * zero)[:, :, None]).to(torch.bfloat16).view(N, K)
+    return q.to(torch.uint8).view(N, K).contiguous(), scale.contiguous(), zero.contiguous(), deq.contiguous()
+
+
+def pack_int4(codes, scale, zero):
+    """codes uint8 [N,K] -> (row-major nibbles uint8 [N,K/2]: byte j = code 2j | code 2j+1 << 4;  (scale, scale*zero) f32 [N,G,2])."""
+    packed = (codes[:, 0::2] | (codes[:, 1::2] << 4)).contiguous()
+    return packed, torch.stack([scale, scale * zero], dim=-1).contiguous()
+
+
 def rope_tables(cfg, max_pos, device):
     """float32 cos/sin [max_pos, d/2], computed like Qwen2RotaryEmbedding (inv_freq = theta^(-2i/d), f32)."""
     d = cfg.head_dim
@@ -69,9 +91,13 @@ class ChatTSForCausalLM:
         self.comm = comm or LocalComm()
         self.plan = ShardPlan(config, self.comm.rank, self.comm.world)
         self.max_ctx = int(max_ctx)
-        if weight_format not in ("bf16", "fp8"):
-            raise ValueError("weight_format must be 'bf16' or 'fp8'")
-        self.weight_format = weight_format       # "fp8": decode GEMVs stream an e4m3 copy (BASELINE.json config 5)
+        if weight_format not in ("bf16", "fp8", "int4"):
+            raise ValueError("weight_format must be 'bf16', 'fp8' or 'int4'")
+        # "fp8": decode GEMVs stream an e4m3 copy (BASELINE.json config 5); "int4": they stream 4-bit codes + group scales (what a
+        # GPTQ-Int4 checkpoint brings along; a bf16 checkpoint is quantised round-to-nearest at load)
+        self.weight_format = weight_format
+        self.int4_group = 128
+        self._gptq_codes = {}                    # HF module name -> (codes, scale, zero) of a GPTQ checkpoint, consumed by _load_with
         self.max_batch = int(max_batch)          # KV-cache slots for batched decode (continuous batching)
         self.t_max = int(max(min(max_prefill_tokens, max_ctx), self.max_batch))
         self.use_graph = use_graph
@@ -164,6 +190,9 @@ class ChatTSForCausalLM:
         a missing lm_head means tied embeddings (:619-623).  Returns the set of loaded names."""
         sd = {}
         for name, t in weights:
+            if name.endswith(".gptq_codes"):          # (codes, scale, zero) of a GPTQ module (chatts_amd/gptq.py)
+                self._gptq_codes[name[:-len(".gptq_codes")]] = t
+                continue
             if name.startswith("ts_encoder."):
                 self.ts_encoder.load_tensor(name[len("ts_encoder."):], t)
                 self.loaded.add(name)
@@ -217,7 +246,25 @@ class ChatTSForCausalLM:
             L["down"] = block(p + "mlp.down_proj.weight", col0=plan.i0, cols=plan.inter)
             L["input_norm"] = block(p + "input_layernorm.weight", f32=True)
             L["post_norm"] = block(p + "post_attention_layernorm.weight", f32=True)
+            self._fuse_gptq_codes(L, p)
             self.layers.append(L)
+
+    def _fuse_gptq_codes(self, L, p):
+        """GPTQ checkpoint: pack the per-module 4-bit codes the way the weights were packed (q|k|v rows, gate/up interleaved) so
+        that the decode GEMV can stream them.  Only for tensor_parallel_size 1 (a K-slice of down_proj is not group aligned)."""
+        G = self._gptq_codes
+        names = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj",
+                 "mlp.down_proj"]
+        if self.plan.world != 1 or not all(p + n in G for n in names):
+            return
+        dev = self.device
+        c = {n: tuple(t.to(dev) for t in G.pop(p + n)) for n in names}
+        cat = lambda ns: tuple(torch.cat([c[n][i] for n in ns], dim=0).contiguous() for i in range(3))
+        fused = {"qkv": cat(names[:3]), "o": c[names[3]], "down": c[names[6]],
+                 "gate_up": tuple(interleave_gate_up(c[names[4]][i], c[names[5]][i]) for i in range(3))}
+        for k, (q, sc, z) in fused.items():
+            self.int4_group = q.shape[1] // sc.shape[1]
+            L[k + "4"], L[k + "4_sz"] = pack_int4(q, sc, z)
 
     def _finalize(self):
         """Allocate activations / KV cache and create the C-side decoder handle (borrowing all pointers)."""
@@ -237,6 +284,12 @@ class ChatTSForCausalLM:
             T["lm_head"] = deq
             if tied:
                 T["embed"] = deq
+        if self.weight_format == "int4" and self.layers and "qkv4" not in self.layers[0]:
+            # round-to-nearest 4-bit codes of every decoder projection; the bf16 tensors are REPLACED by the dequantised values
+            for lw in self.layers:
+                for name in ("qkv", "o", "gate_up", "down"):
+                    q, sc, z, lw[name] = quantize_int4_rows(lw[name], self.int4_group)
+                    lw[name + "4"], lw[name + "4_sz"] = pack_int4(q, sc, z)
         # decode attention: one wave per 16-key tile; slots beyond the live context exit immediately
         self.n_splits = max(1, min(64, (self.max_ctx + 15) // 16))
         dc = _lib.DecoderConfig(hidden=H, n_layers=cfg.num_hidden_layers, n_q=plan.nq, n_kv=plan.nkv, head_dim=d,
@@ -288,7 +341,12 @@ class ChatTSForCausalLM:
                                        qkv8=_lib.ptr(lw.get("qkv8")), qkv8_scale=_lib.ptr(lw.get("qkv8_scale")),
                                        o8=_lib.ptr(lw.get("o8")), o8_scale=_lib.ptr(lw.get("o8_scale")),
                                        gate_up8=_lib.ptr(lw.get("gate_up8")), gate_up8_scale=_lib.ptr(lw.get("gate_up8_scale")),
-                                       down8=_lib.ptr(lw.get("down8")), down8_scale=_lib.ptr(lw.get("down8_scale")))
+                                       down8=_lib.ptr(lw.get("down8")), down8_scale=_lib.ptr(lw.get("down8_scale")),
+                                       qkv4=_lib.ptr(lw.get("qkv4")), qkv4_sz=_lib.ptr(lw.get("qkv4_sz")),
+                                       o4=_lib.ptr(lw.get("o4")), o4_sz=_lib.ptr(lw.get("o4_sz")),
+                                       gate_up4=_lib.ptr(lw.get("gate_up4")), gate_up4_sz=_lib.ptr(lw.get("gate_up4_sz")),
+                                       down4=_lib.ptr(lw.get("down4")), down4_sz=_lib.ptr(lw.get("down4_sz")),
+                                       w4_group=self.int4_group)
         self._layer_arr = arr
         dw = _lib.DecoderWeights(layers=arr, final_norm=_lib.ptr(T["final_norm"]), lm_head=_lib.ptr(T["lm_head"]),
                                  lm_head8=_lib.ptr(T.get("lm_head8")), lm_head8_scale=_lib.ptr(T.get("lm_head8_scale")),
@@ -336,8 +394,8 @@ class ChatTSForCausalLM:
         n = 0
         for lw in self.layers:
             for k, t in lw.items():
-                if k + "8" in lw:
-                    continue                       # the fp8 copy is the one the decode GEMV reads
+                if k + "8" in lw or k + "4" in lw:
+                    continue                       # the fp8 / 4-bit copy is the one the decode GEMV reads
                 n += t.numel() * t.element_size()
         T = self._tensors
         head = (T["lm_head8"].numel() + T["lm_head8_scale"].numel() * 4) if "lm_head8" in T else T["lm_head"].numel() * 2

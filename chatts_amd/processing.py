@@ -114,6 +114,43 @@ class ChatTSProcessor:
         pfx = hf_prefix(x, mean, factor) if self.prefix_format == "hf" else sp_prefix(mean, factor)
         return enc, pfx, {"offset": float(-mean), "scale_factor": float(factor), "length": int(x.size)}
 
+    def encode_batch_on_device(self, series_list, device="cuda"):
+        """The batch form of encode_series with the statistics computed on the GPU (chatts_ts_normalise; SURVEY.md section 8f item
+        4): raw series go up once as float64, the padded (value, mask) tensor [N, 2*Lmax, 1] stays on the device, and 48 bytes of
+        statistics per series come back for the prompt prefixes.  -> (device tensor, [prefix...], [length...]).
+        Same numbers as encode_series except that the mean is summed in the kernel's own fixed order (may differ from np.mean in
+        the last bit: invisible at the prefix's %.4f and in the float32 values save for exact rounding ties)."""
+        import torch
+        from . import _lib
+        lib = _lib.load()
+        xs = [self._as_series(ts) for ts in series_list]
+        n = len(xs)
+        lens = [int(x.size) for x in xs]
+        lmax = max(lens) if lens else 0
+        if n == 0 or lmax == 0:
+            return torch.zeros((n, 0, 1), dtype=torch.float32, device=device), [PLACEHOLDER] * n, lens
+        raw = np.zeros((n, lmax), dtype=np.float64)
+        for i, x in enumerate(xs):
+            raw[i, :x.size] = x
+        raw_d = torch.from_numpy(raw).to(device)
+        len_d = torch.tensor(lens, dtype=torch.int32, device=device)
+        enc = torch.empty((n, 2 * lmax, 1), dtype=torch.float32, device=device)
+        stats = torch.empty((n, 6), dtype=torch.float64, device=device)
+        _lib.check(lib.chatts_ts_normalise(raw_d.data_ptr(), len_d.data_ptr(), n, lmax, enc.data_ptr(), stats.data_ptr(), _lib.stream_ptr()))
+        st = stats.cpu().numpy()
+        prefixes = []
+        for i in range(n):
+            if lens[i] == 0:
+                prefixes.append(PLACEHOLDER)
+                continue
+            mean, factor, mx, mn, left, right = (float(v) for v in st[i])
+            if self.prefix_format == "hf":
+                prefixes.append(f"[offset={-mean:.4f}|scaling={factor:.4f}|length={lens[i]}|max={mx:.4f}|min={mn:.4f}|"
+                                f"left={left:.4f}|right={right:.4f}]" + PLACEHOLDER)
+            else:
+                prefixes.append(sp_prefix(mean, factor))
+        return enc, prefixes, lens
+
     def splice(self, prompt, series_list):
         """eval_prompt_to_encoding (encoding_utils.py:65-86) for one prompt -> (text, [encoded...], lengths)."""
         parts = prompt.split(PLACEHOLDER)
@@ -140,12 +177,32 @@ class ChatTSProcessor:
         return out
 
     # ---- the call surface -----------------------------------------------------------------------
-    def __call__(self, text=None, timeseries=None, padding=True, return_tensors="pt", vllm_flag=False, **kw):
+    def __call__(self, text=None, timeseries=None, padding=True, return_tensors="pt", vllm_flag=False, device_stats=False, **kw):
+        """device_stats=True: normalisation statistics + the padded tensor are produced on the GPU (encode_batch_on_device);
+        the returned `timeseries` is then already a device tensor."""
         import torch
         if text is None:
             raise ValueError("text is required")
         texts = [text] if isinstance(text, str) else list(text)
         series = list(timeseries) if timeseries is not None else []
+        if device_stats and not vllm_flag:
+            enc_dev, prefixes, lens = self.encode_batch_on_device(series)
+            cursor, new_texts, per_prompt = 0, [], []
+            for t in texts:
+                parts = t.split(PLACEHOLDER)
+                n = len(parts) - 1
+                if cursor + n > len(series):
+                    raise ValueError("not enough time series for the <ts><ts/> placeholders in the batch")
+                new_texts.append("".join(parts[i] + prefixes[cursor + i] for i in range(n)) + parts[-1])
+                cursor += n
+                per_prompt.append(n)
+            if cursor != len(series):
+                raise ValueError(f"{len(series)} time series given but the prompts hold {cursor} placeholders")
+            out = BatchFeature(dict(self.tokenizer(new_texts, padding=padding, return_tensors=return_tensors)))
+            if series:
+                out["timeseries"] = enc_dev
+            self.last_lengths, self.last_series_per_prompt = lens, per_prompt
+            return out
         if vllm_flag:
             # one (ts_tokens, encoded_ts) tuple per series (chatts_vllm.py:319-348)
             items = []

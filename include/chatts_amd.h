@@ -59,6 +59,14 @@ int chatts_fill_hash(void* dst, int out_f32, uint32_t key, float base, int shift
  * and get_patch_cnt (:198-207).
  * ------------------------------------------------------------------------------------------- */
 
+/* Value-preserved normalisation ON THE DEVICE = sp_encoding (chatts/utils/encoding_utils.py:23-37) + the pad / stack of
+ * eval_prompt_to_encoding (:65-86) for a whole batch: raw [N, Lmax] float64 (rows padded arbitrarily beyond lengths[i]) ->
+ * enc [N, 2*Lmax] float32 (value, mask) interleaved, zero padded, and stats [N, 6] float64 = (mean, scale factor, max, min,
+ * first, last) - what the prompt prefix prints.  float64 throughout like numpy; the sum has a fixed order of its own, so the
+ * mean may differ from np.mean in the last bit (documented in DESIGN.md section 7); max / min / ends are exact. */
+int chatts_ts_normalise(const double* raw, const int32_t* lengths, int n_series, int lmax, float* enc, double* stats,
+                        chatts_stream_t stream);
+
 /* valid_len[i] = sum(long(mask_i)), patch_cnt[i] = ceil(valid_len/patch) from the padded
  * [N, 2*Lmax] (value, mask)-interleaved float32 tensor (chatts_vllm.py:94-100 / :198-207).
  * One wave per series, wave-shuffle reduction.  patch_cnt is int64 like the reference's. */
@@ -154,6 +162,13 @@ typedef struct ChattsLinearArgs {
   chatts_bf16* post_hi;
   chatts_bf16* post_lo;
   int ld_post;
+  /* optional 4-bit copy of W (GPTQ-Int4 checkpoints): codes row-major [N, ldw4 bytes], byte j of a row = code 2j | code 2j+1 << 4;
+   * w4_sz [N, K / w4_group, 2] float32 = (scale, scale * zero) per group of w4_group (multiple of 16) weights of a row.  The
+   * weight it encodes is bf16_rne(code * scale - scale * zero) and MUST equal `w`: the M == 1 GEMV streams the codes (a quarter
+   * of the bytes) and rebuilds exactly that bf16 value; every other kernel keeps streaming `w`. */
+  const uint8_t* w4;
+  const float* w4_sz;
+  int ldw4, w4_group;
   /* optional (M == 1, no norm_w, K = heads * 128): the input row is not read from `a` (may be NULL) but merged from the
    * partials chatts_attention_decode_parts left - x[h*128 + d] = sum_p 2^(m_p - M) o_p[d] / sum_p 2^(m_p - M) l_p over the live
    * parts of the position (attn_pos, or *attn_pos_dev) - while the GEMV stages it: the decode step's o_proj absorbs the
@@ -359,6 +374,12 @@ typedef struct ChattsLayerWeights {
   const uint8_t* o8; const float* o8_scale;
   const uint8_t* gate_up8; const float* gate_up8_scale;
   const uint8_t* down8; const float* down8_scale;
+  /* optional 4-bit copies (see ChattsLinearArgs.w4; row length K/2 bytes): NULL = stream bf16 / fp8 in decode */
+  const uint8_t* qkv4; const float* qkv4_sz;
+  const uint8_t* o4; const float* o4_sz;
+  const uint8_t* gate_up4; const float* gate_up4_sz;
+  const uint8_t* down4; const float* down4_sz;
+  int w4_group;
 } ChattsLayerWeights;
 
 typedef struct ChattsDecoderConfig {

@@ -50,9 +50,20 @@ def test_quantize_then_dequantize_and_pair_stream():
     pairs = [("model.norm.weight", torch.ones(4))] + [(f"model.layers.0.mlp.up_proj.{k}", v) for k, v in t.items()] + \
             [("model.layers.0.mlp.up_proj.bias", torch.zeros(32))]
     out = dict(gptq.dequantized_pairs(iter(pairs), {"bits": 4, "group_size": 128, "quant_method": "gptq"}))
-    assert set(out) == {"model.norm.weight", "model.layers.0.mlp.up_proj.weight", "model.layers.0.mlp.up_proj.bias"}
+    assert set(out) == {"model.norm.weight", "model.layers.0.mlp.up_proj.weight", "model.layers.0.mlp.up_proj.bias",
+                        "model.layers.0.mlp.up_proj.gptq_codes"}
     assert out["model.layers.0.mlp.up_proj.weight"].dtype == torch.bfloat16
     assert torch.equal(out["model.layers.0.mlp.up_proj.weight"], deq.to(torch.bfloat16))
+    # the codes that travel to the int4 decode GEMV describe the same matrix: scale * (code - zero), [N, K] orientation
+    q, sc, z = out["model.layers.0.mlp.up_proj.gptq_codes"]
+    assert q.shape == (32, 256) and q.dtype == torch.uint8 and sc.shape == z.shape == (32, 2)
+    rebuilt = sc.repeat_interleave(128, 1) * (q.float() - z.repeat_interleave(128, 1))
+    assert torch.equal(rebuilt, deq)
+    # act-order checkpoints (g_idx not sequential) only yield the dequantised matrix
+    shuffled = dict(t)
+    shuffled["g_idx"] = t["g_idx"].flip(0)
+    pairs2 = [(f"m.{k}", v) for k, v in shuffled.items()]
+    assert set(dict(gptq.dequantized_pairs(iter(pairs2), {"bits": 4, "group_size": 128, "desc_act": True}))) == {"m.weight"}
     with pytest.raises(ValueError, match="bits"):
         list(gptq.dequantized_pairs(iter(pairs), {"bits": 8}))
 
@@ -83,6 +94,12 @@ def test_gptq_checkpoint_generates_like_the_oracle(tmp_path):
     save_file(tensors, str(ckpt / "model.safetensors"))
     model = ChatTSForCausalLM.from_pretrained(str(ckpt), device_map="cuda:0", max_ctx=256, max_prefill_tokens=256)
     assert torch.equal(model.layers[1]["down"].float().cpu(), deq_sd["model.layers.1.mlp.down_proj.weight"])
+    # the checkpoint's own 4-bit codes were packed for the decode GEMV (q|k|v fused, gate/up interleaved): decode streams them
+    for name in ("qkv4", "o4", "gate_up4", "down4"):
+        assert name in model.layers[0] and model.layers[0][name].dtype == torch.uint8
+    assert model.layers[0]["down4"].shape == (cfg.hidden_size, cfg.intermediate_size // 2)
+    bf16_bytes = sum(model.layers[0][k].numel() * 2 for k in ("qkv", "o", "gate_up", "down"))
+    assert model.weight_bytes_local() < 0.45 * (bf16_bytes * cfg.num_hidden_layers) + model._tensors["lm_head"].numel() * 2 + 1e5
     proc = ChatTSProcessor.from_pretrained(str(ckpt))
     rng = np.random.default_rng(4)
     series = [random_walk_series(rng, 48)]

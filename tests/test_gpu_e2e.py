@@ -493,3 +493,32 @@ def test_prefix_reuse_matches_oracle():
     off = ChatTSForCausalLM.from_synthetic(cfg, seed=5, max_ctx=512, max_prefill_tokens=256, enable_prefix_caching=False)
     assert off.generate_one(ids, inp["timeseries"], list(lengths), 8) == want == off.generate_one(ids, inp["timeseries"], list(lengths), 8)
     assert off.prefix_stats["hits"] == 0
+
+
+def test_int4_weight_format_matches_oracle_on_dequantised_weights():
+    """weight_format='int4': decode streams 4-bit codes + (scale, scale*zero) per 128 weights and rebuilds bf16_rne(scale * (code -
+    zero)) in the kernel - exactly the bf16 matrix prefill streams and the oracle runs on."""
+    from chatts_amd.modeling import quantize_int4_rows
+    cfg = cfgmod.preset("tiny-qwen2")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(3)
+    lengths = [64, 21]
+    series = [random_walk_series(rng, L) for L in lengths]
+    inputs = proc(text=[chat_prompt(lengths)], timeseries=series, return_tensors="pt")
+    ids = inputs["input_ids"][0].tolist()
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=4, max_ctx=512, max_prefill_tokens=512, weight_format="int4")
+    assert model.weight_bytes_local() < 0.5 * ChatTSForCausalLM.from_synthetic(cfg, seed=4, max_ctx=64, max_prefill_tokens=64).weight_bytes_local()
+    sd = osynth.state_dict(synth.all_specs(cfg), 4)
+    for name in list(sd):
+        if name.endswith("_proj.weight"):
+            sd[name] = quantize_int4_rows(sd[name].to(torch.bfloat16))[3].float()
+    assert torch.equal(model.layers[1]["down"].float().cpu(), sd["model.layers.1.mlp.down_proj.weight"])
+    want = pipeline.generate(cfg, sd, ids, inputs["timeseries"].numpy(), 10)
+    toks, lg = model.generate_one(ids, inputs["timeseries"].cuda(), proc.last_lengths, 10, return_logits=True)
+    assert rel_err(lg.cpu().numpy(), want["logits"][0].numpy()) < TIGHT_TOL
+    assert toks == want["tokens"]
+    # per-step logits of the int4 GEMV path (decode) against the oracle
+    model.generate_one(ids, inputs["timeseries"].cuda(), proc.last_lengths, 1)
+    for i in range(1, 6):
+        model.decode_step()
+        assert rel_err(model.buf["logits"].cpu().numpy(), want["logits"][i].numpy()) < TIGHT_TOL

@@ -803,3 +803,65 @@ def test_linear_post_norm_planes_equal_separate_rmsnorm(lib, m, n, k, epi):
     o2, h2, l2 = run(True)
     assert torch.equal(o1, o2) and torch.equal(h1[:, :n], h2[:, :n]) and torch.equal(l1[:, :n], l2[:, :n])
     assert not torch.isnan(h2[:, :n].float()).any() and torch.isnan(h2[:, n:].float()).all()
+
+
+def test_ts_normalise_on_device_matches_the_reference_vectors(lib, golden):
+    """chatts_ts_normalise (GPU-side normalisation statistics) against the vectors the REFERENCE's
+    sp_encoding produced (tests/golden/sp_encoding.npz): identical prompt prefixes (the %.4f text), statistics within one
+    float64 ulp-scale, (value, mask) rows equal to the reference's float64 values rounded to float32 save for rounding ties."""
+    from chatts_amd import config as cfgmod
+    from chatts_amd.processing import ChatTSProcessor
+    g = golden("sp_encoding")
+    n = int(g["n"])
+    series = [g[f"in_{i}"] for i in range(n)]
+    proc = ChatTSProcessor.from_pretrained(cfgmod.preset("tiny-qwen2"), prefix_format="sp")
+    enc, prefixes, lens = proc.encode_batch_on_device(series)
+    lmax = max(lens)
+    assert enc.shape == (n, 2 * lmax, 1) and enc.is_cuda
+    e = enc.cpu().numpy().reshape(n, lmax, 2)
+    for i in range(n):
+        want = g[f"enc_{i}"].reshape(-1, 2)                     # float64 [L, 2] from the reference
+        L = want.shape[0]
+        assert prefixes[i] == str(g[f"prompt_{i}"])             # "[Value Offset: ...|Value Scaling: ...]<ts><ts/>"
+        assert np.all(e[i, :L, 1] == 1.0) and np.all(e[i, L:] == 0.0)
+        w32 = want[:, 0].astype(np.float32)
+        ulp = np.abs(np.spacing(w32))
+        assert np.all(np.abs(e[i, :L, 0] - w32) <= ulp)
+        assert np.mean(e[i, :L, 0] == w32) > 0.99
+    # the HF-style prefix of the stored notebook output (demo/demo_lora.ipynb:147)
+    x = np.arange(256)
+    ts1 = np.sin(x / 10) * 5.0
+    ts1[100:] -= 10.0
+    hf = ChatTSProcessor.from_pretrained(cfgmod.preset("tiny-qwen2"))
+    _, pf, _ = hf.encode_batch_on_device([ts1, []])
+    assert pf[0].startswith("[offset=6.0772|scaling=3.6917|length=256|max=4.9979|min=-15.0000|left=0.0000|right=-8.2047]")
+    assert pf[1] == "<ts><ts/>"
+    # whole call surface: same ids and the same tensor (to float32 rounding ties) as the host path
+    a = hf(text=["A <ts><ts/> B <ts><ts/>"], timeseries=[ts1, x * 0.05], return_tensors="pt")
+    b = hf(text=["A <ts><ts/> B <ts><ts/>"], timeseries=[ts1, x * 0.05], return_tensors="pt", device_stats=True)
+    assert torch.equal(a["input_ids"], b["input_ids"]) and b["timeseries"].is_cuda
+    assert (a["timeseries"] - b["timeseries"].cpu()).abs().max() <= 1e-6
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("n,k,gs", [(1024, 512, 128), (5120, 5120, 128), (96, 1024, 64), (5120, 13824, 128), (2048, 256, 32), (160, 3072, 16)])
+def test_gemv_int4_parity(lib, epi, norm, n, k, gs):
+    """4-bit decode GEMV: streams the codes and rebuilds bf16_rne(scale * (code - zero)); reference = float64 on that bf16 matrix."""
+    from chatts_amd.modeling import pack_int4, quantize_int4_rows
+    a, w, bias, resid, nw = _rand_problem(1, n, k, seed=n + k + epi + gs)
+    q, sc, z, deq = quantize_int4_rows(w, gs)
+    w4, sz = pack_int4(q, sc, z)
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    out = torch.full((1, ncols), float("nan"), dtype=torch.float32, device=DEV)
+    la = _lib.LinearArgs(a=a.data_ptr(), w=deq.data_ptr(), bias=bias.data_ptr(), resid=resid.data_ptr() if epi == _lib.EPI_RESID else None,
+                         c=out.data_ptr(), norm_w=nw.data_ptr() if norm else None, norm_eps=1e-6, m=1, n=n, k=k, lda=k, ldw=k, ldc=ncols,
+                         epilogue=epi, workspace=None, workspace_bytes=0, w4=w4.data_ptr(), w4_sz=sz.data_ptr(), ldw4=k // 2, w4_group=gs)
+    _lib.check(lib.chatts_linear(la, st()))
+    torch.cuda.synchronize()
+    want = _ref_linear(a, deq, bias, resid, epi, nw if norm else None)
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu().numpy(), want) < 2e-5
+    # and the bf16 GEMV on the dequantised matrix agrees to summation order
+    out2 = _linear(lib, a, deq, bias, resid if epi == _lib.EPI_RESID else None, epi, nw if norm else None)
+    assert rel_err(out.cpu().numpy(), out2.cpu().numpy()) < 1e-5
