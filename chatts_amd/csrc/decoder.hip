@@ -75,9 +75,9 @@ extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) 
     CHATTS_REQUIRE(a->w8_scale && a->ldw8 >= a->k && a->ldw8 % 16 == 0 && ((uintptr_t)a->w8 % 16) == 0 && a->k % 16 == 0,
                    CHATTS_E_SHAPE, "linear: fp8 weights need a scale, ldw8 >= K, 16-byte alignment");
   if (a->w4)
-    CHATTS_REQUIRE(a->w4_sz && a->w4_group >= 16 && a->w4_group % 16 == 0 && a->k % a->w4_group == 0 && a->ldw4 >= a->k / 2 &&
+    CHATTS_REQUIRE(a->w4_sz && a->w4_group >= 16 && (a->w4_group & (a->w4_group - 1)) == 0 && a->k % a->w4_group == 0 && a->ldw4 >= a->k / 2 &&
                        a->ldw4 % 8 == 0 && ((uintptr_t)a->w4 % 8) == 0 && ((uintptr_t)a->w4_sz % 8) == 0,
-                   CHATTS_E_SHAPE, "linear: 4-bit weights need w4_sz, a group size that is a multiple of 16 and divides K, ldw4 >= K/2 and %% 8");
+                   CHATTS_E_SHAPE, "linear: 4-bit weights need w4_sz, a power-of-two group size >= 16 that divides K, ldw4 >= K/2 and %% 8");
   if (a->post_norm_w)
     CHATTS_REQUIRE(a->m > 1 && a->c && a->post_hi && a->post_lo && a->ld_post >= a->n && a->ld_post % 4 == 0 && a->n % 4 == 0 &&
                        (a->epilogue == CHATTS_EPI_NONE || a->epilogue == CHATTS_EPI_RESID) && !cplanes,

@@ -319,38 +319,41 @@ __global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float dot16_int4(const u32x2 wv, const float sc, const float nsz, const f32x4 x0, const f32x4 x1,
-                                             const f32x4 x2, const f32x4 x3, float acc) {
-  // codes of a dword: element 2b = low nibble of byte b, element 2b+1 = high nibble
-  auto eight = [&](uint32_t d, const f32x4 xa, const f32x4 xb, float a) {
+// 16 codes (two dwords) of one row against 16 x values held as packed bf16 pairs (hi and lo planes of the float32 x):
+//   per byte b of a dword: codes 2b (low nibble) and 2b+1 (high nibble) -> v_cvt_f32_ubyte{b} of the masked dwords (no shifts),
+//   one packed FMA builds both float32 weights, one v_cvt_pk_bf16_f32 rounds them to THE bf16 weights as a pair, and two
+//   v_dot2c_f32_bf16 multiply the pair with x_hi and x_lo (exact products, float32 accumulate: the bf16x2 scheme of the
+//   MFMA GEMMs).  ~3.4 VALU instructions per weight (the first version, unpacking to float32 FMAs, needed 7.7 and ran at
+//   the speed of the bf16 kernel - profiles/r2_pmc_gemv4.txt).
+#define CHATTS_CVT_UBYTE(dst, src, n) asm("v_cvt_f32_ubyte" #n " %0, %1" : "=v"(dst) : "v"(src))
+__device__ __forceinline__ void dot16_int4(const u32x2 wv, const float sc, const float nsz, const u32x4 xh0, const u32x4 xh1,
+                                           const u32x4 xl0, const u32x4 xl1, float& acc_h, float& acc_l) {
+  auto eight = [&](uint32_t d, const u32x4 xh, const u32x4 xl) {
     const uint32_t lo = d & 0x0f0f0f0fu, hi = (d >> 4) & 0x0f0f0f0fu;      // bytes = codes of the even / odd elements
-    float q[8];
-    q[0] = (float)(lo & 0xffu); q[1] = (float)(hi & 0xffu);
-    q[2] = (float)((lo >> 8) & 0xffu); q[3] = (float)((hi >> 8) & 0xffu);
-    q[4] = (float)((lo >> 16) & 0xffu); q[5] = (float)((hi >> 16) & 0xffu);
-    q[6] = (float)(lo >> 24); q[7] = (float)(hi >> 24);
-    float w[8];
+    float qe[4], qo[4];
+    CHATTS_CVT_UBYTE(qe[0], lo, 0); CHATTS_CVT_UBYTE(qo[0], hi, 0);
+    CHATTS_CVT_UBYTE(qe[1], lo, 1); CHATTS_CVT_UBYTE(qo[1], hi, 1);
+    CHATTS_CVT_UBYTE(qe[2], lo, 2); CHATTS_CVT_UBYTE(qo[2], hi, 2);
+    CHATTS_CVT_UBYTE(qe[3], lo, 3); CHATTS_CVT_UBYTE(qo[3], hi, 3);
+    const uint32_t xhs[4] = {xh.x, xh.y, xh.z, xh.w}, xls[4] = {xl.x, xl.y, xl.z, xl.w};
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      f32x2 v = {fmaf(q[j], sc, nsz), fmaf(q[j + 1], sc, nsz)};
-      const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);             // round to nearest even: the bf16 weight
-      const uint32_t bits = __builtin_bit_cast(uint32_t, b);
-      w[j] = __uint_as_float(bits << 16);
-      w[j + 1] = __uint_as_float(bits & 0xffff0000u);
+    for (int b = 0; b < 4; ++b) {
+      f32x2 v = {fmaf(qe[b], sc, nsz), fmaf(qo[b], sc, nsz)};               // exact: fp16 scale x 5-bit integer
+      const bf16x2_t w = __builtin_convertvector(v, bf16x2_t);             // round to nearest even: the bf16 weights (k, k+1)
+      acc_h = __builtin_amdgcn_fdot2_f32_bf16(w, __builtin_bit_cast(bf16x2_t, xhs[b]), acc_h, false);
+      acc_l = __builtin_amdgcn_fdot2_f32_bf16(w, __builtin_bit_cast(bf16x2_t, xls[b]), acc_l, false);
     }
-    a = fmaf(w[0], xa.x, a); a = fmaf(w[1], xa.y, a); a = fmaf(w[2], xa.z, a); a = fmaf(w[3], xa.w, a);
-    a = fmaf(w[4], xb.x, a); a = fmaf(w[5], xb.y, a); a = fmaf(w[6], xb.z, a); a = fmaf(w[7], xb.w, a);
-    return a;
   };
-  acc = eight(wv.x, x0, x1, acc);
-  acc = eight(wv.y, x2, x3, acc);
-  return acc;
+  eight(wv.x, xh0, xl0);
+  eight(wv.y, xh1, xl1);
 }
 
 template <int ROWS, int UNR, int EPI, bool NORM>
 __global__ __launch_bounds__(1024) void gemv4_ldsx_kernel(GemvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  f32x4* xs4 = reinterpret_cast<f32x4*>(smem);            // permuted x: [chunk][quarter][lane] float4
+  // x as packed bf16 pairs: [chunk][part][lane] 16-byte entries; part 0 / 1 = hi pairs 0-3 / 4-7 of the lane's 16 elements,
+  // part 2 / 3 = the lo pairs (x = hi + lo to 2^-17: the bf16x2 split)
+  u32x4* xs4 = reinterpret_cast<u32x4*>(smem);
   const int K = p.k;
   const int nchunks = (K + 1023) >> 10;
   float* red = reinterpret_cast<float*>(smem) + (size_t)nchunks * 1024;
@@ -372,6 +375,7 @@ __global__ __launch_bounds__(1024) void gemv4_ldsx_kernel(GemvParams p) {
     rstd = rsqrtf(t / (float)K + p.eps);
   }
   const int nact = (!NORM && p.apo) ? attn_parts_live(p) : 0;
+  uint32_t* xs1 = reinterpret_cast<uint32_t*>(smem);
   for (int k4 = tid * 4; k4 < nchunks * 1024; k4 += nthreads * 4) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (k4 < K) {
@@ -385,12 +389,19 @@ __global__ __launch_bounds__(1024) void gemv4_ldsx_kernel(GemvParams p) {
         }
       }
     }
-    const int chunk = k4 >> 10, within = k4 & 1023;
-    xs4[chunk * 256 + ((within >> 2) & 3) * 64 + (within >> 4)] = v;
+    uint16_t h[4], l[4];
+    split_bf16x2(v.x, h[0], l[0]); split_bf16x2(v.y, h[1], l[1]); split_bf16x2(v.z, h[2], l[2]); split_bf16x2(v.w, h[3], l[3]);
+    const int chunk = k4 >> 10, within = k4 & 1023, ln = within >> 4, pair = (within & 15) >> 1;      // pair in {0, 2, 4, 6}
+    const int base = ((chunk * 4 + (pair >> 2)) * 64 + ln) * 4 + (pair & 3);                            // dword index of the hi pair
+    xs1[base] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+    xs1[base + 1] = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+    xs1[base + 2 * 64 * 4] = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
+    xs1[base + 2 * 64 * 4 + 1] = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
   }
   __syncthreads();
 
   const int ngroups = K / p.w4_group;
+  const int gshift = 31 - __builtin_clz(p.w4_group);        // group sizes are powers of two (checked by the launcher)
   for (int task = blockIdx.x * nw + wave; task < p.tasks; task += gridDim.x * nw) {
     const uint8_t* wrow[ROWS];
     const float2* szrow[ROWS];
@@ -401,9 +412,9 @@ __global__ __launch_bounds__(1024) void gemv4_ldsx_kernel(GemvParams p) {
       wrow[r] = p.w4 + (size_t)row * p.ldw4 + lane * 8;
       szrow[r] = reinterpret_cast<const float2*>(p.w4_sz) + (size_t)row * ngroups;
     }
-    float acc[ROWS];
+    float acc_h[ROWS], acc_l[ROWS];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+    for (int r = 0; r < ROWS; ++r) { acc_h[r] = 0.f; acc_l[r] = 0.f; }
     for (int c = 0; c < nchunks; c += UNR) {
       u32x2 wv[UNR][ROWS];
       float2 sz[UNR][ROWS];
@@ -417,22 +428,23 @@ __global__ __launch_bounds__(1024) void gemv4_ldsx_kernel(GemvParams p) {
           sz[u][r] = make_float2(0.f, 0.f);
           if (ok) {
             wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wrow[r] + ((c + u) << 9)));
-            sz[u][r] = szrow[r][k0 / p.w4_group];
+            sz[u][r] = szrow[r][k0 >> gshift];
           }
         }
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         if (c + u < nchunks) {
-          const f32x4* xb = xs4 + (c + u) * 256 + lane;
-          const f32x4 x0 = xb[0], x1 = xb[64], x2 = xb[128], x3 = xb[192];
+          const u32x4* xb = xs4 + (c + u) * 256 + lane;
+          const u32x4 xh0 = xb[0], xh1 = xb[64], xl0 = xb[128], xl1 = xb[192];
 #pragma unroll
-          for (int r = 0; r < ROWS; ++r) acc[r] = dot16_int4(wv[u][r], sz[u][r].x, -sz[u][r].y, x0, x1, x2, x3, acc[r]);
+          for (int r = 0; r < ROWS; ++r) dot16_int4(wv[u][r], sz[u][r].x, -sz[u][r].y, xh0, xh1, xl0, xl1, acc_h[r], acc_l[r]);
         }
       }
     }
+    float acc[ROWS];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
+    for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc_h[r] + acc_l[r]);
     gemv_epilogue<ROWS, EPI>(p, task, lane, acc);
   }
 }
@@ -536,7 +548,10 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
     const size_t lds4 = (size_t)nchunks4 * 1024 * 4 + 64 * 4;
     p.tasks = (units + (swiglu ? 1 : 2) - 1) / (swiglu ? 1 : 2);
     int blocks4 = (p.tasks + nw - 1) / nw;
-    if (blocks4 > cus * occ) blocks4 = cus * occ;
+    // ~5 VALU ops per weight make this kernel ALU-latency bound: it wants every wave slot the registers allow (89 VGPRs -> 5 per
+    // SIMD = 20 per CU), i.e. two workgroups per CU, not the one of the bf16 layouts
+    const int occ4 = env_int("CHATTS_GEMV_OCC", 20 / nw >= 1 ? 20 / nw : 1);
+    if (blocks4 > cus * occ4) blocks4 = cus * occ4;
     if (blocks4 < 1) blocks4 = 1;
     switch (a->epilogue) {
       case CHATTS_EPI_RESID: launch4_norm<CHATTS_EPI_RESID>(p, norm, blocks4, threads, lds4, s); break;

@@ -163,9 +163,10 @@ typedef struct ChattsLinearArgs {
   chatts_bf16* post_lo;
   int ld_post;
   /* optional 4-bit copy of W (GPTQ-Int4 checkpoints): codes row-major [N, ldw4 bytes], byte j of a row = code 2j | code 2j+1 << 4;
-   * w4_sz [N, K / w4_group, 2] float32 = (scale, scale * zero) per group of w4_group (multiple of 16) weights of a row.  The
+   * w4_sz [N, K / w4_group, 2] float32 = (scale, scale * zero) per group of w4_group (a power of two >= 16) weights of a row.  The
    * weight it encodes is bf16_rne(code * scale - scale * zero) and MUST equal `w`: the M == 1 GEMV streams the codes (a quarter
-   * of the bytes) and rebuilds exactly that bf16 value; every other kernel keeps streaming `w`. */
+   * of the bytes), rebuilds exactly that bf16 value and multiplies it with the bf16 hi / lo split of x (the bf16x2 scheme of the
+   * MFMA GEMMs: exact products, float32 accumulate, x to 2^-17); every other kernel keeps streaming `w`. */
   const uint8_t* w4;
   const float* w4_sz;
   int ldw4, w4_group;
