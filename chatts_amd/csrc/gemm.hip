@@ -43,7 +43,25 @@ struct GemmParams {
   uint16_t* c_hi;        // optional: the output goes out as bf16 hi / lo planes [M, ldcp] (the next GEMM's operand
   uint16_t* c_lo;        // format) instead of float32 c
   int ldcp;
+  int sk_T, sk_nk;       // stream-K (gemm_dma_kernel only): T = tiles * K-steps per tile, sk_nk = K-steps per tile; 0 = off
 };
+
+// ---- stream-K decomposition (gemm_dma_kernel) -------------------------------------------------------------------
+// The (tile, K-step) space of a GEMM is linear: tile t owns steps [t * nk, (t + 1) * nk), tiles in (N-panel major, M-tile
+// minor) order.  It is cut into kSkRanges = 256 equal contiguous ranges (range i = [b_i, b_{i+1}), b_i = floor(i * T / 256)),
+// one per CU, so every CU gets the same number of K-steps whatever the tile count (140 tiles of o_proj on 256 CUs: 43.75 steps
+// each instead of two rounds of 27).  A range shorter than a tile crosses at most one tile boundary, i.e. it is one or two
+// PIECES, each a (tile, K sub-range) the unchanged kernel body can run; a tile collects its <= S pieces as split-K slabs
+// (slab = ordinal of the piece within the tile) and the split-K epilogue sums the slabs a tile really has.
+// Nothing is sorted or tabulated: a workgroup derives its piece from blockIdx by integer arithmetic (below).
+constexpr int kSkRanges = 256;
+__device__ __host__ __forceinline__ int sk_bound(int i, int T) { return (int)(((long long)i * T) / kSkRanges); }
+__device__ __host__ __forceinline__ int sk_range_of(int step, int T) {          // the range that contains `step`
+  return (int)((((long long)(step + 1)) * kSkRanges + T - 1) / T) - 1;
+}
+__device__ __host__ __forceinline__ int sk_tile_nseg(int tile, int T, int nk) {
+  return sk_range_of((tile + 1) * nk - 1, T) - sk_range_of(tile * nk, T) + 1;
+}
 
 __device__ __forceinline__ void store_planes(uint16_t* hi, uint16_t* lo, size_t off, float v) {
   // no contraction: when v is a product (SwiGLU) the compiler would otherwise fold it into the subtraction as an FMA and
@@ -325,14 +343,56 @@ __global__ __launch_bounds__(kDmaThreads) void gemm_dma_kernel(GemmParams p, con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mt_count = (p.m + BM - 1) / BM, nt_count = (p.n + BN - 1) / BN;
   const int total = mt_count * nt_count, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int share = total >> 3, rem = total & 7;
-  if (local >= share + (xcd < rem)) return;                          // uniform exit of the padding workgroups
-  const int idx = xcd * share + (xcd < rem ? xcd : rem) + local;
+  int idx, kbeg, kend, slab = blockIdx.z;
+  if (p.sk_T > 0) {
+    // stream-K: grid = 8 XCDs x 64.  Workgroup (xcd, local < 32) runs the FIRST piece of range i = 32 xcd + local; workgroup
+    // (xcd, 32 + r) runs the SECOND piece of the range whose first piece is the r-th shortest of this XCD's two-piece ranges:
+    // workgroups start in blockIdx order, so the CU that finishes its short first piece first picks up exactly its own (long)
+    // second piece - every CU ends up with its own range, i.e. the same number of K-steps, without a table or a sort.
+    const int T = p.sk_T, nk_t = p.sk_nk;
+    auto first_len = [&](int i, int& b0, int& b1) {       // length of the first piece of range i; == b1 - b0 when it has one piece
+      b0 = sk_bound(i, T); b1 = sk_bound(i + 1, T);
+      const int tile_end = (b0 / nk_t + 1) * nk_t;
+      return tile_end < b1 ? tile_end - b0 : b1 - b0;
+    };
+    int i = xcd * 32 + (local & 31), b0, b1, s0, s1;
+    if (local < 32) {
+      const int a = first_len(i, b0, b1);
+      if (b1 <= b0) return;
+      s0 = b0; s1 = b0 + a;
+    } else {
+      // lane j < 32 evaluates range j of this XCD once; ranks by shuffle (every wave does the same: wave-uniform result)
+      const int r = local - 32, j = lane & 31;
+      int jb0, jb1;
+      const int aj = first_len(xcd * 32 + j, jb0, jb1);
+      const bool two = aj < jb1 - jb0;
+      int rank = 0;
+      for (int q = 0; q < 32; ++q) {
+        const int aq = __shfl(aj, q, 64);
+        const bool tq = __shfl((int)two, q, 64) != 0;
+        if (tq && (aq < aj || (aq == aj && q < j))) ++rank;
+      }
+      const unsigned long long hit = __ballot(two && rank == r && lane < 32);
+      const int found = __builtin_amdgcn_readfirstlane(hit ? (int)__builtin_ctzll(hit) : -1);     // wave-uniform -> scalar
+      if (found < 0) return;                                             // fewer two-piece ranges than slots: uniform exit
+      i = xcd * 32 + found;
+      const int a = first_len(i, b0, b1);
+      s0 = b0 + a; s1 = b1;
+    }
+    idx = s0 / nk_t;
+    kbeg = (s0 - idx * nk_t) * BK;
+    kend = (s1 - idx * nk_t) * BK;
+    slab = i - sk_range_of(idx * nk_t, T);
+  } else {
+    const int share = total >> 3, rem = total & 7;
+    if (local >= share + (xcd < rem)) return;                          // uniform exit of the padding workgroups
+    idx = xcd * share + (xcd < rem ? xcd : rem) + local;
+    kbeg = blockIdx.z * p.k_per_split;
+    kend = kbeg + p.k_per_split;
+    if (kend > p.k) kend = p.k;
+  }
   const int nt = idx / mt_count, mt = idx - nt * mt_count;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int kbeg = blockIdx.z * p.k_per_split;
-  int kend = kbeg + p.k_per_split;
-  if (kend > p.k) kend = p.k;
   const int nk = (kend - kbeg) / BK;           // the launcher makes k_per_split a multiple of 64; nk >= 1
 
   if (wave >= NCOMPUTE) {
@@ -474,7 +534,7 @@ __global__ __launch_bounds__(kDmaThreads) void gemm_dma_kernel(GemmParams p, con
     case 3: k_loop(std::integral_constant<int, 3>{}); break;
     default: k_loop(std::integral_constant<int, 4>{}); break;
   }
-  gemm_store<FM, FN, TM, TN, false>(p, acc, m0, n0, wm, wn, lane, blockIdx.z);
+  gemm_store<FM, FN, TM, TN, false>(p, acc, m0, n0, wm, wn, lane, slab);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -642,12 +702,17 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ resid, float* __restrict__ c,
                                                              int ldc, int epilogue, const float* __restrict__ scale,
-                                                             uint16_t* __restrict__ c_hi, uint16_t* __restrict__ c_lo, int ldcp) {
+                                                             uint16_t* __restrict__ c_hi, uint16_t* __restrict__ c_lo, int ldcp,
+                                                             int sk_T, int sk_nk) {
   const int ncols = epilogue == CHATTS_EPI_SWIGLU ? n / 2 : n;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)m * ncols) return;
   const int row = (int)(idx / ncols), col = (int)(idx % ncols);
   const size_t plane = (size_t)m * n;
+  if (sk_T > 0) {      // stream-K: a tile has as many slabs as pieces (the SwiGLU layout never takes this path)
+    const int wcol = col;
+    sk = sk_tile_nseg((wcol / 256) * ((m + 127) / 128) + row / 128, sk_T, sk_nk);
+  }
   if (epilogue == CHATTS_EPI_SWIGLU) {
     const int prow = (col >> 4) * 32 + (col & 15);
     float g = 0.f, u = 0.f;
@@ -680,13 +745,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
                                                                   float* __restrict__ c, int ldc, int epilogue,
                                                                   const float* __restrict__ scale, const float* __restrict__ norm_w,
                                                                   float eps, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
-                                                                  int ldp) {
+                                                                  int ldp, int sk_T, int sk_nk) {
   __shared__ float red[4];
   const int row = blockIdx.x;
   const size_t plane = (size_t)m * n;
   float ss = 0.f;
   for (int col = threadIdx.x * 4; col < n; col += 1024) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (sk_T > 0) sk = sk_tile_nseg((col / 256) * ((m + 127) / 128) + row / 128, sk_T, sk_nk);    // stream-K: slabs of THIS tile
     for (int s = 0; s < sk; ++s) {
       const f32x4 t = *reinterpret_cast<const f32x4*>(ws + s * plane + (size_t)row * n + col);
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
@@ -822,11 +888,47 @@ static int launch_stream_t(const GemmParams& p, const ChattsLinearArgs* a, int s
   return CHATTS_OK;
 }
 
+// Stream-K for the LDS-DMA kernel (see sk_bound): worth it when the tiles do not fill whole rounds of workgroups.  Estimates
+// in K-steps (+ kSkOv per workgroup for the pipeline fill / drain; + a partials round trip when the uniform choice would have
+// needed none): o_proj @ M = 798: 2 rounds x 27 -> 43.75; down_proj 2 x 72 -> 118; qkv 80 -> 61; gate_up (756 tiles = 2.95
+// rounds) keeps whole tiles.  Returns the slab count (max pieces per tile), 0 = keep the uniform split.
+static int pick_streamk(int m, int n, int k, int uniform_sk) {
+  // MEASURED (round 2, profiles/r2_streamk_ttft.txt): correct (tests) and balanced, but SLOWER - TTFT 54.6 ms against 45.6 with the
+  // uniform split.  The uniform split runs the M-tiles of a W panel in lockstep on one XCD, so a K-slice of the panel is fetched
+  // once into that L2 and reused by all 7 M-tiles; stream-K ranges walk the same panel at different K offsets at any moment,
+  // and every tile re-fetches its W slices.  Hence OFF unless CHATTS_GEMM_STREAMK=1 (kept for the tests and for shapes with one
+  // M-tile, where there is nothing to share).
+  const int force = gemm_env_int("CHATTS_GEMM_STREAMK", 0);
+  if (force <= 0 || m < 256 || k % kDmaBK != 0) return 0;
+  const int mt = (m + 127) / 128, nt = (n + kDmaBN - 1) / kDmaBN, tiles = mt * nt, nk = k / kDmaBK;
+  const long long T = (long long)tiles * nk;
+  if (T > (1ll << 30) || T < 2 * kSkRanges) return 0;
+  const double per = (double)T / kSkRanges;
+  if (per >= nk) return 0;                                  // a range would span whole tiles: plain tiles are as good
+  int slabs = 0;
+  for (int t = 0; t < tiles; ++t) {
+    const int ns = sk_tile_nseg(t, (int)T, nk);
+    if (ns > slabs) slabs = ns;
+  }
+  if (slabs > 4) return 0;                                  // too many partials per tile
+  if (force == 1) return slabs;
+  const double kSkOv = 2.0;
+  const int cus = device_cus();
+  const long long units = (long long)tiles * uniform_sk;
+  const double uniform = (double)((units + cus - 1) / cus) * ((double)nk / uniform_sk + kSkOv);
+  const double stream = per + 2 * kSkOv + (uniform_sk == 1 ? 8.0 : 0.0);
+  return stream < 0.93 * uniform ? slabs : 0;
+}
+
 size_t gemm_workspace(int m, int n, int k) {
   int bm, sk, sk2;
   pick_geometry(m, n, k, bm, sk);
   pick_dma_geometry(m, n, k, sk2);
   if (sk2 > sk) sk = sk2;
+  if (m >= 256 && k % kDmaBK == 0) {
+    const int slabs = pick_streamk(m, n, k, sk2);
+    if (slabs > sk) sk = slabs;
+  }
   if (m <= 16 && k % 64 == 0) {
     sk2 = pick_stream_sk(n, k, false);         // (the fp8 variant's K-steps are twice as long: never more splits)
     if (sk2 > sk) sk = sk2;
@@ -843,7 +945,7 @@ static int launch_dma(const GemmParams& p, const ChattsLinearArgs* a, int sk, hi
     configured = true;
   }
   const int tiles = ((a->n + kDmaBN - 1) / kDmaBN) * ((a->m + 127) / 128);
-  dim3 grid(8 * ((tiles + 7) / 8), 1, sk), block(kDmaThreads);
+  dim3 grid(p.sk_T > 0 ? 8 * 64 : 8 * ((tiles + 7) / 8), 1, p.sk_T > 0 ? 1 : sk), block(kDmaThreads);
   hipLaunchKernelGGL(gemm_dma_kernel, grid, block, kDmaLds, s, p, a->a_hi, a->a_lo, a->ld_planes);
   return CHATTS_OK;
 }
@@ -862,9 +964,20 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
     CHATTS_REQUIRE(a->a, CHATTS_E_SHAPE, "linear: a == NULL needs K %% %d == 0 (K=%d) for the plane path", kDmaBK, a->k);
     pick_geometry(a->m, a->n, a->k, bm, sk);
   }
-  const int kps = k_per_split(a->k, sk, stream ? stream_bk(a->w8 != nullptr) : (dma ? kDmaBK : 32));
+  int kps = k_per_split(a->k, sk, stream ? stream_bk(a->w8 != nullptr) : (dma ? kDmaBK : 32));
   sk = (a->k + kps - 1) / kps;
   GemmParams p;
+  p.sk_T = 0; p.sk_nk = 0;
+  if (dma && a->epilogue != CHATTS_EPI_SWIGLU) {
+    const int slabs = pick_streamk(a->m, a->n, a->k, sk);
+    if (slabs > 0) {                     // stream-K: every tile goes through `slabs` split-K slabs (some tiles use fewer)
+      const int tiles = ((a->n + kDmaBN - 1) / kDmaBN) * ((a->m + 127) / 128);
+      p.sk_nk = a->k / kDmaBK;
+      p.sk_T = tiles * p.sk_nk;
+      sk = slabs > 1 ? slabs : 2;        // > 1: results are summed by the split-K epilogue
+      kps = a->k;
+    }
+  }
   p.a = a->a; p.w = a->w; p.bias = a->bias; p.resid = a->resid;
   p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
   p.epilogue = a->epilogue; p.k_per_split = kps; p.direct = sk == 1;
@@ -911,7 +1024,7 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   if (sk > 1 && post_norm) {        // epilogue + the consumer's RMSNorm in one row-wise launch
     hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(a->m), dim3(256), 0, s, reinterpret_cast<const float*>(a->workspace), sk,
                        a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue, a->w8 ? a->w8_scale : nullptr, a->post_norm_w,
-                       a->post_norm_eps, a->post_hi, a->post_lo, a->ld_post);
+                       a->post_norm_eps, a->post_hi, a->post_lo, a->ld_post, p.sk_T, p.sk_nk);
     CHATTS_CHECK_LAUNCH("splitk_epilogue_norm");
     return CHATTS_OK;
   }
@@ -920,7 +1033,7 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
     const size_t total = (size_t)a->m * ncols;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float*>(a->workspace), sk, a->m, a->n, a->bias, a->resid, a->c,
-                       a->ldc, a->epilogue, a->w8 ? a->w8_scale : nullptr, a->c_hi, a->c_lo, a->ld_cplanes);
+                       a->ldc, a->epilogue, a->w8 ? a->w8_scale : nullptr, a->c_hi, a->c_lo, a->ld_cplanes, p.sk_T, p.sk_nk);
     CHATTS_CHECK_LAUNCH("splitk_epilogue");
   }
   if (post_norm)                  // no split-K epilogue to fuse into: the contract still holds, as its own launch

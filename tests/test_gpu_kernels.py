@@ -865,3 +865,49 @@ def test_gemv_int4_parity(lib, epi, norm, n, k, gs):
     # and the bf16 GEMV on the dequantised matrix agrees to summation order
     out2 = _linear(lib, a, deq, bias, resid if epi == _lib.EPI_RESID else None, epi, nw if norm else None)
     assert rel_err(out.cpu().numpy(), out2.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID])
+@pytest.mark.parametrize("m,n,k", [(798, 5120, 5120), (798, 7168, 5120), (798, 5120, 13824), (300, 2080, 640), (513, 768, 1024),
+                                   (1024, 4096, 4096), (260, 256, 2048)])
+def test_gemm_dma_stream_k_parity(lib, monkeypatch, epi, m, n, k):
+    """Stream-K decomposition of the LDS-DMA GEMM (every CU gets the same number of K-steps; a tile collects 2..4 pieces as
+    split-K slabs): forced on, against float64 and against the uniform split - ragged M / N tiles, K from 10 to 216 steps."""
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
+    r = resid if epi == _lib.EPI_RESID else None
+    monkeypatch.setenv("CHATTS_GEMM_STREAMK", "0")
+    base = _linear_planes(lib, a, w, bias, r, epi, with_a=False, ld=k + 64)
+    monkeypatch.setenv("CHATTS_GEMM_STREAMK", "1")
+    out = _linear_planes(lib, a, w, bias, r, epi, with_a=False, ld=k + 64)
+    want = _ref_linear(a, w, bias, resid, epi)
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu().numpy(), want) < 2e-5
+    assert rel_err(out.cpu().numpy(), base.cpu().numpy()) < 1e-5
+
+
+def test_gemm_dma_stream_k_post_norm_fused_epilogue(lib, monkeypatch):
+    """the row-wise split-K epilogue that also writes the consumer's RMSNorm planes sums the slabs each tile really has"""
+    m, n, k = 798, 5120, 5120
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=11, scale=2.0)
+    g = torch.Generator().manual_seed(3)
+    nw = (1 + 0.1 * torch.randn(n, generator=g)).to(DEV)
+    hi, lo = _split_planes(lib, a)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CHATTS_GEMM_STREAMK", mode)
+        wsb = int(lib.chatts_linear_workspace(m, n, k))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+        out = torch.full((m, n), float("nan"), device=DEV)
+        phi = torch.empty((m, n), dtype=torch.bfloat16, device=DEV)
+        plo = torch.empty((m, n), dtype=torch.bfloat16, device=DEV)
+        la = _lib.LinearArgs(a=None, w=w.data_ptr(), bias=None, resid=resid.data_ptr(), c=out.data_ptr(), norm_w=None, norm_eps=0.0, m=m,
+                             n=n, k=k, lda=k, ldw=k, ldc=n, epilogue=_lib.EPI_RESID, workspace=ws.data_ptr(), workspace_bytes=wsb,
+                             a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=k, post_norm_w=nw.data_ptr(), post_norm_eps=1e-6,
+                             post_hi=phi.data_ptr(), post_lo=plo.data_ptr(), ld_post=n)
+        _lib.check(lib.chatts_linear(la, st()))
+        torch.cuda.synchronize()
+        outs[mode] = (out, phi.float() + plo.float())
+    want = _ref_linear(a, w, None, resid, _lib.EPI_RESID)
+    assert rel_err(outs["1"][0].cpu().numpy(), want) < 2e-5
+    assert rel_err(outs["1"][0].cpu().numpy(), outs["0"][0].cpu().numpy()) < 1e-5
+    assert rel_err(outs["1"][1].cpu().numpy(), outs["0"][1].cpu().numpy()) < 1e-4
