@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kDmaThreads) void gemm_dma_kernel(GemmParams p, con
 // (52 MB of o_proj weights are only 40 N-tiles).  A comes as bf16 hi / lo planes ([M, K], M <= 16).
 constexpr int kStreamBN = 128;
 constexpr int stream_bk(bool w8) { return w8 ? 128 : 64; }                       // K per stage = one 128-byte line of a W row
-constexpr int stream_stage(bool w8) { return 2 * 16 * stream_bk(w8) * 2 + kStreamBN * 128; }   // A_hi | A_lo | W
+constexpr int stream_stage(bool w8, int mb = 1) { return 2 * mb * 16 * stream_bk(w8) * 2 + kStreamBN * 128; }   // A_hi | A_lo | W
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -559,19 +559,30 @@ __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
   else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
   else static_assert(N == 0, "add the vmcnt literal");
 }
 
 // W8: W is the fp8 (e4m3fn) copy: a 128-byte line of a row holds 128 K-values, so a stage is 128 deep; the 8-byte B fragments
 // are widened (exactly) to bf16 in registers and the per-row scale is applied in the epilogue.
-template <int NSTAGE, bool W8>
+// MB = 16-row blocks of A a workgroup carries (M <= 16 * MB).  MB = 1 is the batched-decode kernel described above.  MB = 2 / 4 / 8
+// serve the skinny GEMMs with FEW N-tiles (the TS-encoder MLP: P <= 128 patches x 5120 columns; short prefill chunks): the
+// LDS-DMA prefill kernel's 128 x 256 tiles give such a problem 20 tiles for 256 CUs and it needs ~10 K-splits - 26 MB of
+// partials and 8 K-steps per workgroup, mostly pipeline fill (33.7 us per TS layer at P = 128, profiles/r2_ts_gemm_sweep.txt).
+// Here the tile is (16 MB) x 128: 40 N-tiles x ~6 K-splits = one workgroup per CU, W streamed in whole lines exactly once per
+// split, the MB A blocks of a K-step (MB x 4 KB) staged next to the W tile (16 KB), 8 MB MFMAs per wave and K-step.
+template <int NSTAGE, bool W8, int MB>
 __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const uint16_t* __restrict__ a_hi,
                                                           const uint16_t* __restrict__ a_lo, int ldp) {
-  constexpr int BN = kStreamBN, BK = stream_bk(W8), STAGE = stream_stage(W8);
+  static_assert(!W8 || MB == 1, "the fp8 weight stream is a batched-decode format (M <= 16)");
+  constexpr int BN = kStreamBN, BK = stream_bk(W8), STAGE = stream_stage(W8, MB);
   constexpr int A_SUB = 16 * 128;                  // one A sub-block: 16 token rows x 64 K-values (128 B)
-  constexpr int NSUB = BK / 64;                    // sub-blocks per plane and stage
-  constexpr int A_PLANE = NSUB * A_SUB, W_OFF = 2 * A_PLANE;
-  constexpr int NPIECE = 4 + NSUB;                 // DMA pieces per wave and stage
+  constexpr int NSUB = BK / 64;                    // K sub-blocks per plane and stage (2 for fp8 W)
+  constexpr int A_PLANE = MB * NSUB * A_SUB, W_OFF = 2 * A_PLANE;
+  constexpr int NAP = W8 ? NSUB : MB;              // A pieces per wave and stage
+  constexpr int NPIECE = 4 + NAP;                  // DMA pieces per wave and stage
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -581,14 +592,14 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const ui
   if (kend > p.k) kend = p.k;
   const int nk = (kend - kbeg) / BK;
 
-  // 1 KB DMA pieces (8 rows x 128 B): W pieces {wave, wave+4, wave+8, wave+12}; of the 4 * NSUB A pieces (plane, K sub-block,
-  // token-row half) this wave takes row half wave & 1 of plane wave >> 1 [bf16 W], or of both planes for K sub-block
-  // wave >> 1 [fp8 W].  Every piece index this wave touches has parity wave & 1.
+  // 1 KB DMA pieces (8 rows x 128 B): W pieces {wave, wave+4, wave+8, wave+12}; of the A pieces (plane, block / K sub-block,
+  // token-row half) this wave takes row half wave & 1 of plane wave >> 1 of EVERY block [bf16 W], or of both planes for K
+  // sub-block wave >> 1 [fp8 W, MB = 1].  Every piece index this wave touches has parity wave & 1.
   const int lrow = lane >> 3;
   const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lrow >> 1));
   const char* wsrc[4];
-  const uint16_t* asrc[NSUB];
-  int adst[NSUB];
+  const uint16_t* asrc[NAP];
+  int adst[NAP];
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
     int wr = n0 + (wave + 4 * h) * 8 + lrow;
@@ -596,15 +607,13 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const ui
     wsrc[h] = W8 ? reinterpret_cast<const char*>(p.w8) + (size_t)wr * p.ldw8 + kbeg + lchunk * 16
                  : reinterpret_cast<const char*>(p.w + (size_t)wr * p.ldw + kbeg + lchunk * 8);
   }
-  {
-    int am = (wave & 1) * 8 + lrow;
-    if (am > p.m - 1) am = p.m - 1;
 #pragma unroll
-    for (int q = 0; q < NSUB; ++q) {
-      const int plane = W8 ? q : (wave >> 1), sub = W8 ? (wave >> 1) : 0;
-      asrc[q] = (plane ? a_lo : a_hi) + (size_t)am * ldp + kbeg + sub * 64 + lchunk * 8;
-      adst[q] = plane * A_PLANE + sub * A_SUB + (wave & 1) * 1024;
-    }
+  for (int q = 0; q < NAP; ++q) {
+    const int plane = W8 ? q : (wave >> 1), sub = W8 ? (wave >> 1) : 0, blk = W8 ? 0 : q;
+    int am = blk * 16 + (wave & 1) * 8 + lrow;
+    if (am > p.m - 1) am = p.m - 1;
+    asrc[q] = (plane ? a_lo : a_hi) + (size_t)am * ldp + kbeg + sub * 64 + lchunk * 8;
+    adst[q] = plane * A_PLANE + (blk * NSUB + sub) * A_SUB + (wave & 1) * 1024;
   }
   auto issue = [&](int kt) {
     char* base = smem + (kt % NSTAGE) * STAGE;
@@ -613,13 +622,13 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const ui
       __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[h] + (size_t)kt * 128), (lptr_t)(base + W_OFF + (wave + 4 * h) * 1024), 16, 0,
                                        2 /* nt: streamed once */);
 #pragma unroll
-    for (int q = 0; q < NSUB; ++q)
+    for (int q = 0; q < NAP; ++q)
       __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + (size_t)kt * BK), (lptr_t)(base + adst[q]), 16, 0, 0);
   };
 
-  f32x4 acc[1][2];
-  acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[0][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[MB][2];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) { acc[b][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[b][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s);
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const ui
     if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
     const char* base = smem + (kt % NSTAGE) * STAGE;
     constexpr int NH = BK / 32;                  // MFMA K-steps per stage
-    bf16x8_t bfrag[NH][2], alo[NH], ahi[NH];
+    bf16x8_t bfrag[NH][2];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
 #pragma unroll
@@ -654,19 +663,26 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const ui
           bfrag[h][j] = *reinterpret_cast<const bf16x8_t*>(base + W_OFF + lds_off128(r, h * 4 + fchunk));
         }
       }
-      const int aoff = (h >> 1) * A_SUB + lds_off128(frow, (h & 1) * 4 + fchunk);
-      alo[h] = *reinterpret_cast<const bf16x8_t*>(base + A_PLANE + aoff);
-      ahi[h] = *reinterpret_cast<const bf16x8_t*>(base + aoff);
     }
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
+    for (int b = 0; b < MB; ++b) {
+      bf16x8_t alo[NH], ahi[NH];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[h], bfrag[h][j], acc[0][j], 0, 0, 0);
+      for (int h = 0; h < NH; ++h) {
+        const int aoff = (b * NSUB + (h >> 1)) * A_SUB + lds_off128(frow, (h & 1) * 4 + fchunk);
+        alo[h] = *reinterpret_cast<const bf16x8_t*>(base + A_PLANE + aoff);
+        ahi[h] = *reinterpret_cast<const bf16x8_t*>(base + aoff);
+      }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[h], bfrag[h][j], acc[0][j], 0, 0, 0);
+      for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[h], bfrag[h][j], acc[b][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[h], bfrag[h][j], acc[b][j], 0, 0, 0);
+      }
     }
   }
-  gemm_store<1, 2, 16, 32, W8>(p, acc, 0, n0, 0, wave, lane, blockIdx.z);
+  gemm_store<MB, 2, 16 * MB, 32, W8>(p, acc, 0, n0, 0, wave, lane, blockIdx.z);
 }
 
 // x = hi + lo (to 16 mantissa bits): one thread per 8 consecutive elements.
@@ -855,9 +871,21 @@ static void pick_dma_geometry(int m, int n, int k, int& sk) {
 }
 
 // Streaming kernel (2 <= M <= 16 with planes): split-K so that ~2 workgroups per CU are busy, >= 4 K-steps per split.
+// ... and the multi-block form (17 <= M <= 128, bf16 W) when the 128 x 256 tiling would leave most CUs without a tile
+// (fewer N-panels than half the CUs: the TS-encoder MLP, o / down / qkv of a short prefill chunk)
+// Measured (round 2, one TS-MLP layer 5120 x 5120, profiles/r2_ts_gemm_sweep.txt + tools/jobs/r2_job15.sh): P = 32: 18.7 us (LDS-DMA
+// kernel 23.7), P = 64: 23.5 (26.0), P = 128: 35.7 (33.9) - with 8 row blocks the four waves issue 12 DMA pieces each per K-step
+// (~150 cycles apiece) in the same instruction stream as their 64 MFMAs, which is what the prefill kernel's loader waves exist
+// to avoid; and a short K (layer 0: 5 K-steps) is served better by the 2-way split of the 128 x 256 tiles.  Hence M <= 64, K >= 1024.
+static bool stream_multiblock(int m, int n, int k, bool w8) {
+  const int max_m = gemm_env_int("CHATTS_GEMM_STREAM_MB", 64);
+  return m > 16 && m <= max_m && m <= 128 && !w8 && k % 64 == 0 && k >= 1024 &&
+         2 * 8 * (((n + kDmaBN - 1) / kDmaBN + 7) / 8) <= device_cus();
+}
 static bool use_stream(const ChattsLinearArgs* a) {
-  return a->a_hi && a->a_lo && a->m >= 2 && a->m <= 16 && a->k % stream_bk(a->w8 != nullptr) == 0 &&
-         gemm_env_int("CHATTS_GEMM_STREAM", 1) != 0;
+  if (!(a->a_hi && a->a_lo) || gemm_env_int("CHATTS_GEMM_STREAM", 1) == 0) return false;
+  if (a->m >= 2 && a->m <= 16) return a->k % stream_bk(a->w8 != nullptr) == 0;
+  return stream_multiblock(a->m, a->n, a->k, a->w8 != nullptr);
 }
 
 static int pick_stream_sk(int n, int k, bool w8) {
@@ -873,18 +901,18 @@ static int pick_stream_sk(int n, int k, bool w8) {
   return sk;
 }
 
-template <int NSTAGE, bool W8>
+template <int NSTAGE, bool W8, int MB = 1>
 static int launch_stream_t(const GemmParams& p, const ChattsLinearArgs* a, int sk, hipStream_t s) {
-  constexpr int LDS = NSTAGE * stream_stage(W8);
+  constexpr int LDS = NSTAGE * stream_stage(W8, MB);
   static bool configured = false;
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NSTAGE, W8>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NSTAGE, W8, MB>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "gemm_stream: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
     configured = true;
   }
   dim3 grid((a->n + kStreamBN - 1) / kStreamBN, 1, sk), block(256);
-  hipLaunchKernelGGL((gemm_stream_kernel<NSTAGE, W8>), grid, block, LDS, s, p, a->a_hi, a->a_lo, a->ld_planes);
+  hipLaunchKernelGGL((gemm_stream_kernel<NSTAGE, W8, MB>), grid, block, LDS, s, p, a->a_hi, a->a_lo, a->ld_planes);
   return CHATTS_OK;
 }
 
@@ -929,7 +957,7 @@ size_t gemm_workspace(int m, int n, int k) {
     const int slabs = pick_streamk(m, n, k, sk2);
     if (slabs > sk) sk = slabs;
   }
-  if (m <= 16 && k % 64 == 0) {
+  if ((m <= 16 && k % 64 == 0) || stream_multiblock(m, n, k, false)) {
     sk2 = pick_stream_sk(n, k, false);         // (the fp8 variant's K-steps are twice as long: never more splits)
     if (sk2 > sk) sk = sk2;
   }
@@ -996,7 +1024,10 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   if (stream) {
     int rc;
     const int stages = gemm_env_int("CHATTS_GEMM_STREAM_STAGES", 4);
-    if (a->w8) rc = stages == 3 ? launch_stream_t<3, true>(p, a, sk, s) : launch_stream_t<4, true>(p, a, sk, s);
+    if (a->m > 64) rc = launch_stream_t<3, false, 8>(p, a, sk, s);          // 3 x 48 KB stages: one workgroup per CU
+    else if (a->m > 32) rc = launch_stream_t<4, false, 4>(p, a, sk, s);     // 4 x 32 KB
+    else if (a->m > 16) rc = launch_stream_t<4, false, 2>(p, a, sk, s);     // 4 x 24 KB
+    else if (a->w8) rc = stages == 3 ? launch_stream_t<3, true>(p, a, sk, s) : launch_stream_t<4, true>(p, a, sk, s);
     else if (stages == 3) rc = launch_stream_t<3, false>(p, a, sk, s);
     else if (stages == 5) rc = launch_stream_t<5, false>(p, a, sk, s);
     else rc = launch_stream_t<4, false>(p, a, sk, s);

@@ -911,3 +911,21 @@ def test_gemm_dma_stream_k_post_norm_fused_epilogue(lib, monkeypatch):
     assert rel_err(outs["1"][0].cpu().numpy(), want) < 2e-5
     assert rel_err(outs["1"][0].cpu().numpy(), outs["0"][0].cpu().numpy()) < 1e-5
     assert rel_err(outs["1"][1].cpu().numpy(), outs["0"][1].cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID])
+@pytest.mark.parametrize("m,n,k", [(17, 5120, 5120), (32, 5120, 320), (33, 1024, 512), (64, 5120, 5120), (65, 7168, 5120), (100, 384, 1024),
+                                   (128, 5120, 5120), (128, 5120, 13824), (128, 4096, 4096), (23, 96, 64)])
+def test_gemm_stream_multiblock_parity(lib, monkeypatch, epi, m, n, k):
+    """gemm_stream_kernel with 2 / 4 / 8 row blocks (17 <= M <= 128, few N-panels: the TS-encoder MLP shapes) vs float64 and
+    vs the LDS-DMA kernel it replaces there (CHATTS_GEMM_STREAM_MB=0)."""
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
+    r = resid if epi == _lib.EPI_RESID else None
+    monkeypatch.setenv("CHATTS_GEMM_STREAM_MB", "128")          # (the shipped default stops at 64 rows: measured crossover)
+    out = _linear_planes(lib, a, w, bias, r, epi, with_a=False, ld=k + 64)
+    monkeypatch.setenv("CHATTS_GEMM_STREAM_MB", "0")
+    base = _linear_planes(lib, a, w, bias, r, epi, with_a=False, ld=k + 64)
+    want = _ref_linear(a, w, bias, resid, epi)
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu().numpy(), want) < 2e-5
+    assert rel_err(out.cpu().numpy(), base.cpu().numpy()) < 1e-5

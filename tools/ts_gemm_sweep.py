@@ -50,7 +50,7 @@ def run(P, K, N, env, planes=True, nbuf=12, reps=5):
     return best
 
 
-def main():
+def main():  # noqa
     Ps = [int(v) for v in sys.argv[1:]] or [16, 128, 1100]
     for P in Ps:
         for K in (5120, 320):
