@@ -435,7 +435,7 @@ def main():
         T = len(full)
         emb = model.get_input_embeddings(torch.tensor(full, dtype=torch.int64), mm)
         model.reset()
-        last = model.prefill(emb, 0)
+        last = model.prefill(emb, 0, for_next_token=True)        # what generate() does: next token + KV cache, no hidden states
         model.buf["pos"].fill_(T)
         model._first_token(last)
         first = model.buf["out_tokens"][:1].tolist()

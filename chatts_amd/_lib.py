@@ -133,6 +133,7 @@ SIGNATURES = {
     "chatts_residual_add": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "chatts_decoder_layer_part_add": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "chatts_decoder_prefill": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "chatts_decoder_prefill_last": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "chatts_decoder_logits": (c_int, [c_void_p, c_int, c_void_p]),
     "chatts_decoder_decode_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                            c_void_p]),

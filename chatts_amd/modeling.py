@@ -499,10 +499,13 @@ class ChatTSForCausalLM:
     # ---------------------------------------------------------------------------------------------
     # engine
     # ---------------------------------------------------------------------------------------------
-    def _run_layers(self, T, pos0, pos_dev=None, n_splits=1):
+    def _run_layers(self, T, pos0, pos_dev=None, n_splits=1, last_only=False):
         lib, st = self.lib, _lib.stream_ptr()
         if self.plan.world == 1 and pos_dev is None:
-            _lib.check(lib.chatts_decoder_prefill(self._decoder, T, pos0, st))
+            if last_only:         # only the next token + the KV cache are wanted: the final layer runs for the last row only
+                _lib.check(lib.chatts_decoder_prefill_last(self._decoder, T, pos0, st))
+            else:
+                _lib.check(lib.chatts_decoder_prefill(self._decoder, T, pos0, st))
             return
         H = self.config.hidden_size
         delta = self.buf["delta"][:T]
@@ -525,18 +528,23 @@ class ChatTSForCausalLM:
         self.buf["pos"].zero_()
         self.buf["step"].zero_()
 
-    def prefill(self, inputs_embeds, pos0=0):
-        """Chunked prefill of [T,H] embeddings starting at cache position pos0; leaves the last chunk in x."""
+    def prefill(self, inputs_embeds, pos0=0, for_next_token=False):
+        """Chunked prefill of [T,H] embeddings starting at cache position pos0; leaves the last chunk in x and returns the
+        number of rows whose LAST one yields the next token's logits (chatts_decoder_logits(row = returned - 1)).
+        for_next_token: the hidden states are not wanted, only the next token and the cache - the final layer of the last chunk
+        then runs attention / o_proj / MLP for the last row only (chatts_decoder_prefill_last) and that row is row 0: returns 1."""
         T = inputs_embeds.shape[0]
         if pos0 + T > self.max_ctx:
             raise ValueError(f"sequence of {pos0 + T} tokens exceeds max_ctx={self.max_ctx}")
+        fast_last = for_next_token and self.plan.world == 1
         done, last = 0, 0
         while done < T:
             n = min(self.t_max, T - done)
             self.buf["x"][:n].copy_(inputs_embeds[done:done + n])
-            self._run_layers(n, pos0 + done)
+            final = done + n >= T
+            self._run_layers(n, pos0 + done, last_only=fast_last and final)
             done += n
-            last = n
+            last = 1 if (fast_last and final) else n
         return last
 
     def set_sampling(self, temperature=0.0, top_k=0, top_p=1.0, seed=0):
@@ -798,7 +806,7 @@ class ChatTSForCausalLM:
         self._slot_idents[slot] = idents
         self.prefix_stats["tokens_prefilled"] += T - n0
         self.select_sequence(slot)
-        last = self.prefill(emb[n0:], n0)
+        last = self.prefill(emb[n0:], n0, for_next_token=True)
         st = _lib.stream_ptr()
         _lib.check(self.lib.chatts_decoder_logits(self._decoder, last - 1, st))
         B["pos_all"][slot] = T
@@ -957,7 +965,7 @@ class ChatTSForCausalLM:
         self._slot_idents[0] = idents
         self.prefix_stats["tokens_prefilled"] += T - n0
         self.reset()
-        last = self.prefill(emb[n0:], n0)
+        last = self.prefill(emb[n0:], n0, for_next_token=True)
         self.buf["pos"].fill_(T)
         self._first_token(last)
         return T

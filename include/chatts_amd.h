@@ -480,6 +480,10 @@ int chatts_decoder_decode_step_batched(ChattsDecoder*, int batch, int32_t* pos_d
 
 /* TP=1 fast paths: all layers back to back on the stream (no host round trip, graph-capturable). */
 int chatts_decoder_prefill(ChattsDecoder*, int t, int pos0, chatts_stream_t stream);
+/* The same for a chunk whose hidden states nobody reads except to pick the NEXT token (the last chunk of a prompt): the final
+ * layer writes K / V of all t rows into the cache but runs attention, o_proj and the MLP for the last row only (as GEMVs).
+ * The row the next token is computed from ends up in ROW 0 of x (chatts_decoder_logits(d, 0, ..)); rows 1.. are stale. */
+int chatts_decoder_prefill_last(ChattsDecoder*, int t, int pos0, chatts_stream_t stream);
 /* final norm + lm_head on row `row` of x -> buffers.logits */
 int chatts_decoder_logits(ChattsDecoder*, int row, chatts_stream_t stream);
 /* one greedy decode step: x[0,:] holds the input embedding; reads the position from *pos_dev;

@@ -522,3 +522,29 @@ def test_int4_weight_format_matches_oracle_on_dequantised_weights():
     for i in range(1, 6):
         model.decode_step()
         assert rel_err(model.buf["logits"].cpu().numpy(), want["logits"][i].numpy()) < TIGHT_TOL
+
+
+@pytest.mark.parametrize("preset,T", [("tiny-qwen2", 201), ("tiny-qwen3", 37), ("tiny-qwen2", 1)])
+def test_prefill_for_next_token_equals_full_prefill(preset, T):
+    """prefill(for_next_token=True) (chatts_decoder_prefill_last: the final layer runs attention / o_proj / MLP for the last row
+    only) leaves the SAME KV cache (bit for bit) and the same next-token logits as the full prefill - also across chunks."""
+    cfg = cfgmod.preset(preset)
+    g = torch.Generator().manual_seed(T)
+    emb = (torch.randn((T, cfg.hidden_size), generator=g) * 0.5).cuda()
+    outs = []
+    for fast, chunk in ((False, 512), (True, 512), (True, 64)):
+        m = ChatTSForCausalLM.from_synthetic(cfg, seed=2, max_ctx=512, max_prefill_tokens=chunk)
+        m.reset()
+        last = m.prefill(emb, 0, for_next_token=fast)
+        assert last == (1 if fast else min(T, chunk))
+        m.buf["pos"].fill_(T)
+        m._first_token(last)
+        toks = [int(m.buf["out_tokens"][0])]
+        lg = m.buf["logits"].clone()
+        for _ in range(3):
+            m.decode_step()
+        outs.append((lg, m.buf["out_tokens"][:4].tolist(), m.buf["kv_k"][0, :, :, :T].clone(), m.buf["kv_v"][0, :, :, :T].clone()))
+    for lg, toks, kk, vv in outs[1:]:
+        assert rel_err(lg.cpu().numpy(), outs[0][0].cpu().numpy()) < 1e-5
+        assert toks == outs[0][1]
+    assert torch.equal(outs[1][2], outs[0][2]) and torch.equal(outs[1][3], outs[0][3])      # same chunking: identical cache
