@@ -296,13 +296,26 @@ def bench_batched(args, model, cfg, comm, world, device):
     comm.barrier()
     torch.cuda.synchronize()
     t_admit0 = time.perf_counter()
-    for slot, series in enumerate(reqs):
-        t0 = time.perf_counter()
+    pending = []
+    for series in reqs:
         inputs = proc(text=[prompt], timeseries=series, padding=True, return_tensors="pt")
-        ids = inputs["input_ids"][0].tolist()
-        T = model._admit(slot, ids, inputs["timeseries"], proc.last_lengths, budget)
+        pending.append((inputs["input_ids"][0].tolist(), inputs["timeseries"], list(proc.last_lengths), budget))
+    free = list(range(B))
+    packs = 0
+    while pending:              # the engine's admission loop: short prompts are prefilled together (chatts_decoder_prefill_packed)
+        t0 = time.perf_counter()
+        pack = [] if args.no_pack else model.plan_pack(pending[:len(free)], free)
+        group = [pending[j] for j in pack] if pack else pending[:1]
+        items = [(free.pop(0),) + g for g in group]
+        if len(items) > 1:
+            T = model._admit_packed(items)[0]
+            packs += 1
+        else:
+            T = model._admit(*items[0])
+        for g in group:
+            pending.remove(g)
         torch.cuda.synchronize()
-        ttfts.append((time.perf_counter() - t0) * 1e3)
+        ttfts += [(time.perf_counter() - t0) * 1e3] * len(items)
     admit_ms = (time.perf_counter() - t_admit0) * 1e3
     for _ in range(args.warmup):
         model.batched_step()
@@ -338,7 +351,8 @@ def bench_batched(args, model, cfg, comm, world, device):
                    "fp8 copies are streamed by the decode GEMMs and widened to bf16 while staged (no v_mfma fp8 issue: the 1e-3 "
                    "logit bar needs f32-exact products of the f32 activations); prefill keeps the bf16 copy",
                    "first_tokens_seq0": toks[0][:8]},
-        "ttft_ms_p50": median(ttfts), "batch_admit_ms_total": admit_ms, "per_sequence_tokens_per_s": args.steps / dt,
+        "ttft_ms_p50": median(ttfts), "batch_admit_ms_total": admit_ms, "packed_prefill_passes": packs,
+        "per_sequence_tokens_per_s": args.steps / dt,
         "decode_hbm_gbs_per_gpu": step_bytes / (dt / args.steps) / 1e9,
         "decode_hbm_frac_of_8TBs": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         "roofline": {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS,
@@ -365,6 +379,7 @@ def main():
     ap.add_argument("--max-ctx", type=int, default=2048, help="KV-cache length (longer prompts, e.g. --series 30, need more)")
     ap.add_argument("--batch", type=int, default=1, help="> 1: continuous-batching workload (BASELINE.json config 5): B prompts decode "
                     "together; a step = one B-wide decode step; value = aggregate tokens/s")
+    ap.add_argument("--no-pack", action="store_true", help="--batch: admit the prompts one by one instead of packed prefill passes")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "int4"],
                     help="fp8 = BASELINE.json config 5 weight format, int4 = the GPTQ-Int4 checkpoint's (NOT the headline: separate workloads)")
     args = ap.parse_args()

@@ -56,6 +56,10 @@ class LayerWeights(C.Structure):
                 ("gate_up4_sz", c_void_p), ("down4", c_void_p), ("down4_sz", c_void_p), ("w4_group", c_int)]
 
 
+class PrefillSegment(C.Structure):
+    _fields_ = [("row0", c_int), ("t", c_int), ("pos0", c_int), ("slot", c_int)]
+
+
 class SamplingArgs(C.Structure):
     _fields_ = [("temperature", c_float), ("top_k", c_int), ("top_p", c_float), ("seed", c_uint32), ("n_kept", c_void_p),
                 ("kept_mass", c_void_p)]
@@ -134,6 +138,7 @@ SIGNATURES = {
     "chatts_decoder_layer_part_add": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "chatts_decoder_prefill": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "chatts_decoder_prefill_last": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "chatts_decoder_prefill_packed": (c_int, [c_void_p, C.POINTER(PrefillSegment), c_int, c_void_p]),
     "chatts_decoder_logits": (c_int, [c_void_p, c_int, c_void_p]),
     "chatts_decoder_decode_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                            c_void_p]),

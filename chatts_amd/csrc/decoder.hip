@@ -546,6 +546,72 @@ extern "C" int chatts_decoder_prefill_last(ChattsDecoder* d, int t, int pos0, ch
   return rc;
 }
 
+// Packed multi-prompt prefill: the rows of several prompts (or of their not-yet-cached tails) sit
+// back to back in x; everything row-wise - norms, the four projections, SwiGLU, residuals - runs ONCE over all rows (one big-M
+// GEMM instead of one ragged small-M GEMM per prompt), only RoPE / cache write / attention run per segment, each against
+// its own cache slot and positions.
+static int layer_part0_packed(ChattsDecoder* d, int layer, int t, const ChattsPrefillSegment* segs, int n_segs,
+                              chatts_stream_t stream) {
+  const ChattsDecoderConfig& c = d->cfg;
+  const ChattsLayerWeights& lw = d->layers[layer];
+  const int H = c.hidden, qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim, na = c.n_q * kHeadDim;
+  int rc;
+  ChattsLinearArgs la{};
+  la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = t; la.n = qkv_n; la.k = H;
+  la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
+  if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+  for (int i = 0; i < n_segs; ++i) {
+    const ChattsPrefillSegment& sg = segs[i];
+    ChattsKvCache kc = layer_cache(d, layer, sg.slot);
+    float* q = d->b.qkv + (size_t)sg.row0 * qkv_n;
+    if ((rc = chatts_rope_kv_write(q, sg.t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, sg.pos0,
+                                   nullptr, &kc, stream)) != 0) return rc;
+    int ks = sg.t >= 256 ? 2 : 1;
+    if (chatts_attn_workspace(sg.t, c.n_q, ks) > d->b.workspace_bytes) ks = 1;
+    if ((rc = attention_impl(q, sg.t, c.n_q, c.n_kv, sg.pos0, nullptr, &kc, d->b.attn + (size_t)sg.row0 * na, nullptr, nullptr, ks,
+                             d->b.workspace, d->b.workspace_bytes, stream)) != 0) return rc;
+  }
+  la = ChattsLinearArgs{};
+  la.a = d->b.attn; la.w = lw.o; la.m = t; la.n = H; la.k = na; la.lda = na; la.ldw = na; la.ldc = H;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  if (t > 1 && planes_path(d, t, na)) {
+    if ((rc = chatts_split_bf16x2(d->b.attn, t, na, na, d->b.planes_hi, d->b.planes_lo, na, stream)) != 0) return rc;
+    la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = na;
+  }
+  la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID;
+  request_post_norm(d, &la, lw.post_norm, false);
+  return chatts_linear(&la, stream);
+}
+
+extern "C" int chatts_decoder_prefill_packed(ChattsDecoder* d, const ChattsPrefillSegment* segs, int n_segs, chatts_stream_t stream) {
+  CHATTS_REQUIRE(d && segs && n_segs >= 1, CHATTS_E_BADARG, "decoder_prefill_packed: bad arguments");
+  CHATTS_REQUIRE(d->cfg.tp_world == 1, CHATTS_E_BADARG, "decoder_prefill_packed: tensor_parallel_size 1 only");
+  const int maxb = d->b.max_batch > 0 ? d->b.max_batch : 1;
+  int t = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    const ChattsPrefillSegment& sg = segs[i];
+    CHATTS_REQUIRE(sg.t >= 1 && sg.row0 == t && sg.pos0 >= 0 && sg.pos0 + sg.t <= d->cfg.max_ctx && sg.slot >= 0 && sg.slot < maxb,
+                   CHATTS_E_SHAPE, "decoder_prefill_packed: segment %d (row0 %d, t %d, pos0 %d, slot %d) is not contiguous / out of range",
+                   i, sg.row0, sg.t, sg.pos0, sg.slot);
+    for (int j = 0; j < i; ++j)
+      CHATTS_REQUIRE(segs[j].slot != sg.slot, CHATTS_E_BADARG, "decoder_prefill_packed: cache slot %d appears twice", sg.slot);
+    t += sg.t;
+  }
+  CHATTS_REQUIRE(t <= d->b.t_max, CHATTS_E_SHAPE, "decoder_prefill_packed: %d rows exceed buffers (%d)", t, d->b.t_max);
+  d->chain = true;
+  d->normed = false;
+  int rc = CHATTS_OK;
+  for (int l = 0; l < d->cfg.n_layers && rc == CHATTS_OK; ++l) {
+    rc = layer_part0_packed(d, l, t, segs, n_segs, stream);
+    if (rc == CHATTS_OK) rc = chatts_decoder_layer_part(d, l, 1, t, 0, nullptr, 1, stream);
+  }
+  d->chain = false;
+  d->normed = false;
+  return rc;
+}
+
 extern "C" int chatts_decoder_logits(ChattsDecoder* d, int row, chatts_stream_t stream) {
   CHATTS_REQUIRE(d && row >= 0 && row < d->b.t_max, CHATTS_E_BADARG, "decoder_logits: bad row");
   const ChattsDecoderConfig& c = d->cfg;

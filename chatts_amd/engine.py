@@ -91,26 +91,49 @@ class Engine:
             self._apply_sampling(self.waiting[0].sampling_key)
         # admission: free slots take waiting requests that share the running batch's sampling configuration
         while self.waiting and any(v is None for v in self.slots):
-            r = next((q for q in self.waiting if q.sampling_key == self.active_key), None)
-            if r is None:
+            free = [i for i, v in enumerate(self.slots) if v is None]
+            cands = [q for q in self.waiting if q.sampling_key == self.active_key][:len(free)]
+            if not cands:
                 break
-            self.waiting.remove(r)
-            s = 0
-            try:
-                ids, ser, lens = self._encode(r)
-                r.prompt_tokens = len(ids)
-                free = [i for i, v in enumerate(self.slots) if v is None]
-                s = m.pick_slot(free, m._request_idents(ids, ser, lens))      # the slot whose resident prefix matches best
-                if self.nslots == 1:
-                    m._prefill_request(ids, ser, lens, r.max_tokens)
-                else:
-                    m._admit(s, ids, ser, lens, r.max_tokens)
-            except Exception as e:          # a bad request must not take the engine down
-                r.error = e
-                self._emit(r, True, "error")
-                done.append(r)
+            ready = []
+            for r in cands:                              # tokenise / sp-encode once per request
+                if getattr(r, "_enc", None) is None:
+                    try:
+                        r._enc = self._encode(r)
+                        r.prompt_tokens = len(r._enc[0])
+                    except Exception as e:               # a bad request must not take the engine down
+                        self.waiting.remove(r)
+                        r.error = e
+                        self._emit(r, True, "error")
+                        done.append(r)
+                        continue
+                ready.append(r)
+            if not ready:
                 continue
-            self.slots[s], self.produced[s] = r, 1
+            pack = m.plan_pack([r._enc + (r.max_tokens,) for r in ready], free) if self.nslots > 1 else []
+            group = [ready[j] for j in pack] if pack else ready[:1]
+            items = []
+            for r in group:
+                ids, ser, lens = r._enc
+                s = m.pick_slot(free, m._request_idents(ids, ser, lens))      # the slot whose resident prefix matches best
+                free.remove(s)
+                items.append((s, ids, ser, lens, r.max_tokens))
+                self.waiting.remove(r)
+            try:
+                if len(items) > 1:
+                    m._admit_packed(items)               # several short prompts: one packed prefill pass
+                elif self.nslots == 1:
+                    m._prefill_request(*items[0][1:])
+                else:
+                    m._admit(*items[0])
+            except Exception as e:
+                for r in group:
+                    r.error = e
+                    self._emit(r, True, "error")
+                    done.append(r)
+                continue
+            for r, it in zip(group, items):
+                self.slots[it[0]], self.produced[it[0]] = r, 1
             self._since_sync = self.sync_every          # read the first token right away (time to first token)
         live = [s for s in range(self.nslots) if self.slots[s] is not None]
         if not live:

@@ -735,15 +735,12 @@ class ChatTSForCausalLM:
             return None
         return self._token_idents(full, series, lengths, counts, self.config.ts_token_start_index)
 
-    def _reuse_prefix(self, slot, idents, T):
-        """Longest prefix of `idents` already resident in some slot's cache -> copy those K/V rows into `slot` (nothing to copy
-        when it is the slot itself) and return how many leading tokens need no prefill (at most T - 1: the last prompt
-        position is always recomputed, it yields the logits)."""
-        self.prefix_stats["requests"] += 1
-        if not self.enable_prefix_caching:
-            return 0
+    def _match_prefix(self, slot, idents, exclude=()):
+        """(n, src): the longest prefix of `idents` resident in some cache slot (ties prefer `slot` itself: zero copy)."""
         best, src = 0, -1
         for s, have in enumerate(self._slot_idents):
+            if s in exclude:
+                continue
             n = 0
             for a, b in zip(idents, have):
                 if a != b:
@@ -751,6 +748,16 @@ class ChatTSForCausalLM:
                 n += 1
             if n > best or (n == best and s == slot and n > 0):
                 best, src = n, s
+        return best, src
+
+    def _reuse_prefix(self, slot, idents, T, exclude=()):
+        """Longest prefix of `idents` already resident in some slot's cache -> copy those K/V rows into `slot` (nothing to copy
+        when it is the slot itself) and return how many leading tokens need no prefill (at most T - 1: the last prompt
+        position is always recomputed, it yields the logits)."""
+        self.prefix_stats["requests"] += 1
+        if not self.enable_prefix_caching:
+            return 0
+        best, src = self._match_prefix(slot, idents, exclude)
         n = min(best, T - 1)
         if n < 16:                                   # not worth a copy + a ragged prefill start
             return 0
@@ -807,8 +814,14 @@ class ChatTSForCausalLM:
         self.prefix_stats["tokens_prefilled"] += T - n0
         self.select_sequence(slot)
         last = self.prefill(emb[n0:], n0, for_next_token=True)
-        st = _lib.stream_ptr()
-        _lib.check(self.lib.chatts_decoder_logits(self._decoder, last - 1, st))
+        self._first_token_into_slot(slot, last - 1, T)
+        self.select_sequence(0)
+        return T
+
+    def _first_token_into_slot(self, slot, row, T):
+        """logits of x[row] -> first token of the sequence in cache slot `slot` (out_tokens_all[slot, 0]); position / step set."""
+        B, st = self.buf, _lib.stream_ptr()
+        _lib.check(self.lib.chatts_decoder_logits(self._decoder, row, st))
         B["pos_all"][slot] = T
         B["step_all"][slot] = 0
         sa = getattr(self, "_sampling", None)
@@ -820,8 +833,101 @@ class ChatTSForCausalLM:
             self._decoder, _lib.ptr(B["logits"]), 1, self.plan.vocab, B["token_all"][slot:].data_ptr(),
             B["token_logit_all"][slot:].data_ptr(), B["out_tokens_all"][slot].data_ptr(), B["out_tokens_all"].shape[1],
             B["step_all"][slot:].data_ptr(), None, 0, None if sa1 is None else C.byref(sa1), st))
-        self.select_sequence(0)
-        return T
+
+    def plan_pack(self, candidates, free_slots):
+        """Which of the waiting requests should be prefilled TOGETHER (chatts_decoder_prefill_packed).  candidates: list of
+        (ids, series, lengths, max_new_tokens) in arrival order.  Greedy: take requests while their not-yet-cached rows fit the
+        prefill buffers and slots are free; a request that shares most of its prompt with one already in the pack is left for the
+        next round (it will then reuse that request's K/V rows instead of computing them again).  -> indices into candidates."""
+        if self.plan.world != 1 or len(free_slots) < 2 or len(candidates) < 2:
+            return []
+        ps = self.config.ts["patch_size"]
+        pack, rows, pack_idents = [], 0, []
+        for i, (ids, series, lengths, max_new) in enumerate(candidates):
+            if len(pack) >= len(free_slots):
+                break
+            idents = self._request_idents(ids, series, lengths)
+            if idents is None:          # lengths unknown / prefix caching off: size by the expanded prompt alone
+                counts = [(int(v) + ps - 1) // ps for v in (lengths or [])]
+                try:
+                    T = len(self.expand_input_ids(list(ids), counts))
+                except ValueError:
+                    continue
+                need, idents = T, None
+            else:
+                T = len(idents)
+                n, _ = self._match_prefix(-1, idents)
+                n = min(n, T - 1)
+                need = T - (n if n >= 16 else 0)
+                dup = False
+                for other in pack_idents:
+                    if other is None:
+                        continue
+                    k = 0
+                    for a, b in zip(idents, other):
+                        if a != b:
+                            break
+                        k += 1
+                    if k >= max(16, T // 2):
+                        dup = True
+                        break
+                if dup:
+                    continue
+            if T + max_new > self.max_ctx or rows + need > self.t_max:
+                continue
+            pack.append(i)
+            pack_idents.append(idents)
+            rows += need
+        return pack if len(pack) >= 2 else []
+
+    def _admit_packed(self, items):
+        """Prefill several requests in ONE packed pass.  items: list of (slot, ids, series, lengths, max_new_tokens) with distinct
+        free slots whose uncached rows fit max_prefill_tokens together (plan_pack).  Returns the prompt lengths."""
+        cfg, B = self.config, self.buf
+        ps = cfg.ts["patch_size"]
+        slots = [it[0] for it in items]
+        segs, embs, Ts, row, late = [], [], [], 0, []
+        for slot, ids, series, lengths, max_new in items:
+            mm, counts = None, []
+            if series is not None and series.shape[0] > 0:
+                series = series.to(self.device, dtype=torch.float32)
+                if lengths is None:
+                    lengths = self.ts_encoder.get_patch_cnt(series)[0].tolist()
+                counts = [(int(v) + ps - 1) // ps for v in lengths]
+                mm = self.get_multimodal_embeddings(timeseries=series, valid_lengths=lengths)
+            full = self.expand_input_ids(list(ids), counts)
+            T = len(full)
+            if T + max_new > self.max_ctx:
+                raise ValueError(f"prompt ({T}) + max_new_tokens ({max_new}) exceeds max_ctx={self.max_ctx}")
+            emb = self.get_input_embeddings(torch.tensor(full, dtype=torch.int64), mm)
+            idents = self._token_idents(full, series, lengths, counts, cfg.ts_token_start_index)
+            # reuse from ANY slot, the member's own and other members' included: every K/V row copy is enqueued here, i.e. before
+            # the packed pass overwrites anything; a slot stops being a source once its member has been processed (idents cleared)
+            n0 = self._reuse_prefix(slot, idents, T)
+            self._slot_idents[slot] = []
+            if row + T - n0 > self.t_max:                    # an earlier member's copy took away the prefix this one counted on
+                late.append((slot, ids, series, lengths, max_new))
+                self.prefix_stats["requests"] -= 1
+                self.prefix_stats["hits"] -= int(n0 > 0)
+                self.prefix_stats["tokens_reused"] -= n0
+                Ts.append(None)
+                continue
+            self.prefix_stats["tokens_prefilled"] += T - n0
+            segs.append((row, T - n0, n0, slot, idents))
+            embs.append(emb[n0:])
+            Ts.append(T)
+            row += T - n0
+        if segs:
+            B["x"][:row].copy_(torch.cat(embs, dim=0))
+            arr = (_lib.PrefillSegment * len(segs))(*[_lib.PrefillSegment(row0=r0, t=t, pos0=p0, slot=sl) for r0, t, p0, sl, _ in segs])
+            _lib.check(self.lib.chatts_decoder_prefill_packed(self._decoder, arr, len(segs), _lib.stream_ptr()))
+            self.prefix_stats["packed_prefills"] = self.prefix_stats.get("packed_prefills", 0) + 1
+            for r0, t, p0, sl, idents in segs:
+                self._slot_idents[sl] = idents
+                self._first_token_into_slot(sl, r0 + t - 1, p0 + t)
+        for it in late:                                      # (rare) did not fit after all: the ordinary path
+            Ts[Ts.index(None)] = self._admit(*it)
+        return Ts
 
     @torch.no_grad()
     def generate_batch(self, requests, max_new_tokens=64, eos_token_id=None, sync_every=8):
@@ -855,9 +961,24 @@ class ChatTSForCausalLM:
 
         while waiting or any(r is not None for r in slots):
             while waiting and any(v is None for v in slots):
+                free = [i for i, v in enumerate(slots) if v is None]
+                cands = waiting[::-1][:len(free)]            # the next requests in arrival order
+                pack = self.plan_pack([requests[r] + (max_new_tokens,) for r in cands], free)
+                if pack:                                     # several short prompts: one packed prefill pass
+                    items = []
+                    for j in pack:
+                        r = cands[j]
+                        ids, series, lengths = requests[r]
+                        s = self.pick_slot(free, self._request_idents(ids, series, lengths))
+                        free.remove(s)
+                        items.append((s, ids, series, lengths, max_new_tokens))
+                        slots[s], produced[s] = r, 1
+                        waiting.remove(r)
+                    self._admit_packed(items)
+                    continue
                 r = waiting.pop()
                 ids, series, lengths = requests[r]
-                s = self.pick_slot([i for i, v in enumerate(slots) if v is None], self._request_idents(ids, series, lengths))
+                s = self.pick_slot(free, self._request_idents(ids, series, lengths))
                 self._admit(s, ids, series, lengths, max_new_tokens)
                 slots[s], produced[s] = r, 1
             if all(r is None or produced[s] >= max_new_tokens for s, r in enumerate(slots)):

@@ -484,6 +484,13 @@ int chatts_decoder_prefill(ChattsDecoder*, int t, int pos0, chatts_stream_t stre
  * layer writes K / V of all t rows into the cache but runs attention, o_proj and the MLP for the last row only (as GEMVs).
  * The row the next token is computed from ends up in ROW 0 of x (chatts_decoder_logits(d, 0, ..)); rows 1.. are stale. */
 int chatts_decoder_prefill_last(ChattsDecoder*, int t, int pos0, chatts_stream_t stream);
+/* Packed multi-prompt prefill (the vLLM scheduler's batched prefill; demo/demo_vllm.py:55 submits 100 prompts at once): the rows of
+ * n_segs prompts - or of the tails that prefix reuse left to compute - lie back to back in x (segment i = rows row0 .. row0 + t - 1,
+ * positions pos0 .. of cache slot `slot`; row0 of segment 0 is 0, segments are contiguous, slots distinct).  Row-wise work runs
+ * once over all rows, RoPE / cache write / attention per segment.  Afterwards x holds every segment's hidden states;
+ * chatts_decoder_logits(d, row0 + t - 1, ..) gives a segment's next-token logits.  `segs` is a HOST array. */
+typedef struct ChattsPrefillSegment { int row0, t, pos0, slot; } ChattsPrefillSegment;
+int chatts_decoder_prefill_packed(ChattsDecoder*, const ChattsPrefillSegment* segs, int n_segs, chatts_stream_t stream);
 /* final norm + lm_head on row `row` of x -> buffers.logits */
 int chatts_decoder_logits(ChattsDecoder*, int row, chatts_stream_t stream);
 /* one greedy decode step: x[0,:] holds the input embedding; reads the position from *pos_dev;
