@@ -194,12 +194,68 @@ class Engine:
         return out
 
 
+class ControlPlane:
+    """Tensor-parallel serving: rank 0 owns the HTTP front end, the other ranks follow.  Every rank's Engine must see the SAME
+    sequence of add_request() / step() calls (slot choice, packing and harvest points are deterministic functions of it, and the
+    decode steps rendezvous inside the exchange kernels), so before every engine iteration the leader publishes what it is about
+    to do - the requests it admits now (usually none) or a shutdown - over a CPU (gloo) group: followers block there without
+    spinning a GPU.  One small broadcast per iteration (a count), a pickled list only when there is something to say."""
+
+    def __init__(self, rank, world, group=None, dist=None):
+        self.rank, self.world, self.group = rank, world, group
+        if dist is None:
+            import torch.distributed as dist
+        self.dist = dist
+
+    @classmethod
+    def create(cls):
+        """collective: a gloo group over all ranks of the default process group"""
+        import torch.distributed as dist
+        group = dist.new_group(backend="gloo")
+        return cls(dist.get_rank(), dist.get_world_size(), group, dist)
+
+    def publish(self, new_requests, stop=False):
+        """leader: new_requests = list of add_request kwargs (picklable: no callbacks)"""
+        import torch
+        head = torch.tensor([-1 if stop else len(new_requests)], dtype=torch.int64)
+        self.dist.broadcast(head, src=0, group=self.group)
+        if new_requests and not stop:
+            self.dist.broadcast_object_list([new_requests], src=0, group=self.group)
+
+    def receive(self):
+        """follower: -> (list of add_request kwargs, stop)"""
+        import torch
+        head = torch.zeros(1, dtype=torch.int64)
+        self.dist.broadcast(head, src=0, group=self.group)
+        n = int(head.item())
+        if n < 0:
+            return [], True
+        if n == 0:
+            return [], False
+        box = [None]
+        self.dist.broadcast_object_list(box, src=0, group=self.group)
+        return box[0], False
+
+
+def follow(engine, control):
+    """The loop of a non-zero TP rank: replay the leader's admissions and step whenever it steps."""
+    while True:
+        new, stop = control.receive()
+        if stop:
+            return
+        for kw in new:
+            engine.add_request(**kw)
+        if engine.has_work():
+            engine.step()
+
+
 class EngineThread:
     """Owns an Engine on one thread; other threads (the HTTP server's event loop) submit requests through a queue and get
-    their tokens through the per-request callback."""
+    their tokens through the per-request callback.  With a ControlPlane (tensor parallel) this is the LEADER: every iteration is
+    announced to the follower ranks first."""
 
-    def __init__(self, engine, device=None):
-        self.engine, self.device = engine, device
+    def __init__(self, engine, device=None, control=None):
+        self.engine, self.device, self.control = engine, device, control
         self.inbox = queue.Queue()
         self.error = None
         self._stop = threading.Event()
@@ -249,19 +305,28 @@ class EngineThread:
         if isinstance(idx, int):
             torch.cuda.set_device(idx)
         while not self._stop.is_set():
+            new = []
             try:
                 block = not self.engine.has_work()
                 while True:
                     kw = self.inbox.get(timeout=0.05) if block else self.inbox.get_nowait()
-                    holder = kw.pop("holder", None)
-                    r = self.engine.add_request(**kw)
-                    if holder is not None:
-                        holder.append(r)
+                    new.append(kw)
                     block = False
             except queue.Empty:
                 pass
+            if self.control is not None:
+                if not new and not self.engine.has_work():
+                    continue                       # idle: nothing to announce, the followers keep waiting
+                self.control.publish([{k: v for k, v in kw.items() if k not in ("holder", "on_tokens")} for kw in new])
+            for kw in new:
+                holder = kw.pop("holder", None)
+                r = self.engine.add_request(**kw)
+                if holder is not None:
+                    holder.append(r)
             if self.engine.has_work():
                 self.engine.step()
+        if self.control is not None:
+            self.control.publish([], stop=True)
 
     def close(self):
         self._stop.set()

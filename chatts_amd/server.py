@@ -237,12 +237,19 @@ def create_app(engine_thread, tokenizer, served_model_name="chatts", limit_times
 
 def build_server(model, tensor_parallel_size=1, max_model_len=6000, max_num_seqs=1, seed=0, tokenizer=None,
                  served_model_name="chatts", limit_timeseries=15):
-    """LLM (model + processor) -> Engine -> EngineThread -> FastAPI app."""
-    from .engine import Engine, EngineThread
+    """LLM (model + processor) -> Engine -> EngineThread -> FastAPI app.
+    Tensor parallel (one process per GPU under torchrun, process group initialised): rank 0 gets the app, the other ranks get
+    None after serving as followers until the leader shuts down (engine.follow)."""
+    from .engine import ControlPlane, Engine, EngineThread, follow
     from .llm import LLM
     llm = LLM(model, tensor_parallel_size=tensor_parallel_size, max_model_len=max_model_len, max_num_seqs=max_num_seqs, seed=seed,
               tokenizer=tokenizer, limit_mm_per_prompt={"timeseries": limit_timeseries})
-    et = EngineThread(Engine(llm.model, llm.processor), device=llm.model.device)
+    control = ControlPlane.create() if tensor_parallel_size > 1 else None
+    engine = Engine(llm.model, llm.processor)
+    if control is not None and control.rank != 0:
+        follow(engine, control)                  # returns when the leader publishes the shutdown
+        return None
+    et = EngineThread(engine, device=llm.model.device, control=control)
     app = create_app(et, llm.processor.tokenizer, served_model_name, limit_timeseries)
     app.state.engine_thread, app.state.llm = et, llm
     return app
@@ -262,9 +269,24 @@ def main():
     args = ap.parse_args()
     limit = int(dict(kv.split("=") for kv in args.limit_mm_per_prompt.split(",")).get("timeseries", 15))
     import uvicorn
+    if args.tensor_parallel_size > 1:            # torchrun --nproc-per-node N -m chatts_amd.server --tensor-parallel-size N ...
+        import os
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dev = int(os.environ.get("CHATTS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        backend = os.environ.get("CHATTS_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend=backend, **({"device_id": torch.device(f"cuda:{dev}")} if backend == "nccl" else {}))
     app = build_server(args.model, args.tensor_parallel_size, args.max_model_len, args.max_num_seqs, args.seed,
                        served_model_name=args.served_model_name, limit_timeseries=limit)
-    uvicorn.run(app, host=args.host, port=args.port, log_level="info")
+    if app is None:
+        return                                   # a follower rank: the leader has shut down
+    try:
+        uvicorn.run(app, host=args.host, port=args.port, log_level="info")
+    finally:
+        app.state.engine_thread.close()          # tells the follower ranks to leave
 
 
 if __name__ == "__main__":

@@ -119,3 +119,72 @@ def test_tensor_parallel_plan_and_comm_gloo_world2():
     assert hid_err < 1e-4
     assert rel < 1e-5
     assert tie == 107            # min(100 + 7*2, 100 + 7*1): lowest id among equal maxima
+
+
+# ---- tensor-parallel SERVING: the leader's engine iterations are replayed by the follower ranks -------------------------
+class _ScriptEngine:
+    """stands in for chatts_amd.engine.Engine: records the call sequence; a request lives for max_tokens steps"""
+
+    def __init__(self):
+        self.log, self.live = [], []
+
+    def add_request(self, prompt, max_tokens=2, **kw):
+        self.log.append(("add", prompt, max_tokens, tuple(sorted(kw))))
+        self.live.append(max_tokens)
+
+        class R:
+            pass
+        return R()
+
+    def has_work(self):
+        return bool(self.live)
+
+    def step(self):
+        self.log.append(("step", len(self.live)))
+        self.live = [n - 1 for n in self.live if n > 1]
+
+
+def _serve_worker(rank, world, port, q):
+    import time
+    from chatts_amd.engine import ControlPlane, EngineThread, follow
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        control = ControlPlane.create()
+        eng = _ScriptEngine()
+        if rank == 0:
+            et = EngineThread(eng, control=control)
+            et.submit(prompt="a <ts><ts/>", timeseries=[[1.0, 2.0]], max_tokens=3, temperature=0.5, on_tokens=lambda *a: None, holder=[])
+            time.sleep(0.3)                       # an idle gap: nothing is announced, followers wait on the CPU
+            et.submit(prompt="b", max_tokens=2, holder=[])
+            et.submit(prompt="c", max_tokens=4, holder=[])
+            deadline = time.time() + 20
+            while (eng.has_work() or not et.inbox.empty() or len([e for e in eng.log if e[0] == "add"]) < 3) and time.time() < deadline:
+                time.sleep(0.02)
+            et.close()                            # publishes the shutdown
+        else:
+            follow(eng, control)
+        q.put((rank, eng.log))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tensor_parallel_serving_followers_replay_the_leader():
+    """chatts_amd.engine.ControlPlane: rank 0 (HTTP front end + EngineThread) announces every engine iteration over a gloo
+    group; the follower's Engine sees exactly the same add_request / step sequence - callbacks and holders stay on rank 0."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_serve_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    logs = dict(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    strip = lambda log: [e[:3] + (tuple(k for k in e[3] if k != "on_tokens"),) if e[0] == "add" else e for e in log]
+    assert strip(logs[0]) == logs[1]              # same sequence; only the leader holds callbacks
+    adds = [e for e in logs[1] if e[0] == "add"]
+    assert [a[1] for a in adds] == ["a <ts><ts/>", "b", "c"]
+    assert adds[0][3] == ("temperature", "timeseries")                                        # no callback crossed the wire
+    assert sum(1 for e in logs[0] if e[0] == "step") >= 4
