@@ -786,6 +786,231 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// prefill, bf16x3 form: the same flash loop as attn_prefill_mfma_kernel, but Q.K^T and P.V run on the bf16 matrix pipe
+// (v_mfma_f32_16x16x32_bf16, 16x the rate of the float32 MFMA) with BOTH operands split x = hi + lo into bf16 planes and three
+// passes per product (hi.hi + hi.lo + lo.hi; the dropped lo.lo term is 2^-16 of the product - the accuracy class of the
+// bf16x2 GEMMs, where only one operand needs the split).  Per 32-key tile and wave: 24 + 24 MFMAs of ~17 cycles instead of
+// 64 + 64 of 32.  K / V tiles are split once, by all 256 threads, while they are staged: K as [key][d] planes (272-byte rows:
+// the B fragments of Q.K^T are conflict-free ds_read_b128), V TRANSPOSED as [d][key] planes (80-byte rows) because the B
+// operand of P.V needs 8 consecutive KEYS of one head dim per lane - the staging threads of V therefore vary over keys
+// within a wave (contiguous 2-byte LDS writes) and pay with 16-byte global reads at a 512-byte stride (L2-resident rows).
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 abf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 abf16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split8(const float (&x)[8], abf16x8_t& hi, abf16x8_t& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)x[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(x[j] - (float)h);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_prefill_bf16x3_kernel(AttnParams p) {
+  constexpr int KT = 32, NB = 2, KROW = 272, VROW = 80, PS = 36;
+  __shared__ __attribute__((aligned(16))) char k_hi[KT * KROW];
+  __shared__ __attribute__((aligned(16))) char k_lo[KT * KROW];
+  __shared__ __attribute__((aligned(16))) char vt_hi[kHeadDim * VROW];
+  __shared__ __attribute__((aligned(16))) char vt_lo[kHeadDim * VROW];
+  __shared__ __attribute__((aligned(16))) float p_all[4 * 16 * PS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hq = blockIdx.y;
+  const int G = p.n_q / p.n_kv, hk = hq / G;
+  const int heads = p.n_q + 2 * p.n_kv;
+  const int T = p.t, pos0 = p.pos0_dev ? *p.pos0_dev : p.pos0;
+  const int qt = gridDim.x - 1 - blockIdx.x;                // heaviest query tiles (most key tiles) first
+  const int q0 = qt * 64;
+  const int arow = lane & 15, kq = lane >> 4;              // A/B fragment coordinates: row / column, group of 8 K-values
+  const int ccol = lane & 15, crow0 = (lane >> 4) * 4;     // C layout
+  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // d^-1/2 * log2(e): the softmax runs on exp2
+  float* p_s = p_all + wave * 16 * PS;
+
+  abf16x8_t q_hi[4], q_lo[4];                                // A fragments of this wave's 16 query rows, 4 K-steps of 32 dims
+  {
+    int qrow = q0 + wave * 16 + arow;
+    if (qrow > T - 1) qrow = T - 1;                         // padded rows compute garbage that is never stored
+    const float* qp = p.qkv + ((size_t)qrow * heads + hq) * kHeadDim + kq * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + ks * 32), b = *reinterpret_cast<const f32x4*>(qp + ks * 32 + 4);
+      const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      split8(x, q_hi[ks], q_lo[ks]);
+    }
+  }
+  int qpos[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) qpos[r] = pos0 + q0 + wave * 16 + crow0 + r;
+  float m_run[4], l_run[4];
+  f32x4 o_acc[8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+#pragma unroll
+  for (int db = 0; db < 8; ++db) o_acc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int last_q = q0 + 63 < T - 1 ? q0 + 63 : T - 1;
+  const int kmax = pos0 + last_q;                           // last key any row of this workgroup may see
+  const int nkt = kmax / KT + 1;
+  const float* kbase = p.kc + (size_t)hk * p.max_ctx * kHeadDim;
+  const float* vbase = p.vc + (size_t)hk * p.max_ctx * kHeadDim;
+
+  // tile kt+1 is loaded into registers before the MFMAs of tile kt (as in the float32 kernel)
+  f32x4 kreg[4], vreg[4];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int kkey = idx >> 5, kc4 = idx & 31;            // K: a wave reads 2 whole key rows (coalesced)
+      const int vkey = idx & 31, vc4 = idx >> 5;            // V: a wave reads 16 bytes of each of the 32 key rows
+      const int kr = kt * KT + kkey <= kmax ? kt * KT + kkey : kmax;    // clamped address; masked by key index below
+      const int vr = kt * KT + vkey <= kmax ? kt * KT + vkey : kmax;
+      kreg[i] = *reinterpret_cast<const f32x4*>(kbase + (size_t)kr * kHeadDim + kc4 * 4);
+      vreg[i] = *reinterpret_cast<const f32x4*>(vbase + (size_t)vr * kHeadDim + vc4 * 4);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int kkey = idx >> 5, kc4 = idx & 31, vkey = idx & 31, vc4 = idx >> 5;
+      const float kx[4] = {kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w}, vx[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+      abf16x4_t kh, kl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 h = (__bf16)kx[e];
+        kh[e] = h;
+        kl[e] = (__bf16)(kx[e] - (float)h);
+        const __bf16 vh = (__bf16)vx[e];
+        *reinterpret_cast<__bf16*>(vt_hi + (vc4 * 4 + e) * VROW + vkey * 2) = vh;
+        *reinterpret_cast<__bf16*>(vt_lo + (vc4 * 4 + e) * VROW + vkey * 2) = (__bf16)(vx[e] - (float)vh);
+      }
+      *reinterpret_cast<abf16x4_t*>(k_hi + kkey * KROW + kc4 * 8) = kh;
+      *reinterpret_cast<abf16x4_t*>(k_lo + kkey * KROW + kc4 * 8) = kl;
+    }
+  };
+  const int NS = p.n_splits, split = blockIdx.z;
+  if (split < nkt) load_tile(split);
+  for (int kt = split; kt < nkt; kt += NS) {
+    const int k0 = kt * KT;
+    __syncthreads();                                        // the previous tile has been consumed by every wave
+    store_tile();
+    __syncthreads();
+    if (kt + NS < nkt) load_tile(kt + NS);
+
+    f32x4 s_acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) s_acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int off = (nb * 16 + arow) * KROW + ks * 64 + kq * 16;
+        const abf16x8_t bh = *reinterpret_cast<const abf16x8_t*>(k_hi + off);
+        const abf16x8_t bl = *reinterpret_cast<const abf16x8_t*>(k_lo + off);
+        s_acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q_lo[ks], bh, s_acc[nb], 0, 0, 0);
+        s_acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q_hi[ks], bl, s_acc[nb], 0, 0, 0);
+        s_acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q_hi[ks], bh, s_acc[nb], 0, 0, 0);
+      }
+    }
+    // online softmax in the log2 domain: identical to attn_prefill_mfma_kernel (C layout: column = key, 4 rows per lane)
+    float mx[4], ps[4], alpha[4], m_ref[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      mx[r] = -INFINITY;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float sc = s_acc[nb][r] * scale2;
+        if (k0 + nb * 16 + ccol > qpos[r]) sc = -INFINITY;  // causal mask
+        s_acc[nb][r] = sc;
+        mx[r] = fmaxf(mx[r], sc);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], lane_xor1(mx[r]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], lane_xor2(mx[r]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], row_ror4(mx[r]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], row_ror8(mx[r]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float m_new = fmaxf(m_run[r], mx[r]);
+      m_ref[r] = m_new == -INFINITY ? 0.f : m_new;           // a key split may start on a tile this row cannot see at all
+      alpha[r] = __builtin_amdgcn_exp2f(m_run[r] - m_ref[r]);
+      m_run[r] = m_new;
+      ps[r] = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float e = __builtin_amdgcn_exp2f(s_acc[nb][r] - m_ref[r]);
+        s_acc[nb][r] = e;
+        ps[r] += e;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps[r] += lane_xor1(ps[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps[r] += lane_xor2(ps[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps[r] += row_ror4(ps[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps[r] += row_ror8(ps[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      l_run[r] = l_run[r] * alpha[r] + ps[r];
+#pragma unroll
+      for (int db = 0; db < 8; ++db) o_acc[db][r] *= alpha[r];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) p_s[(crow0 + r) * PS + nb * 16 + ccol] = s_acc[nb][r];
+    }
+    __builtin_amdgcn_wave_barrier();                        // P is wave private: LDS ops of one wave stay in order
+    // P as the A operand of P.V: query row arow, keys kq*8 .. kq*8+7 (two conflict-free ds_read_b128 of the [16][36] tile)
+    abf16x8_t p_hi, p_lo;
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p_s + arow * PS + kq * 8), b = *reinterpret_cast<const f32x4*>(p_s + arow * PS + kq * 8 + 4);
+      const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      split8(x, p_hi, p_lo);
+    }
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {                        // head dims db*16 .. db*16+15: B fragment = 8 keys of dim db*16 + arow
+      const int off = (db * 16 + arow) * VROW + kq * 16;
+      const abf16x8_t vh = *reinterpret_cast<const abf16x8_t*>(vt_hi + off);
+      const abf16x8_t vl = *reinterpret_cast<const abf16x8_t*>(vt_lo + off);
+      o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p_lo, vh, o_acc[db], 0, 0, 0);
+      o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p_hi, vl, o_acc[db], 0, 0, 0);
+      o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p_hi, vh, o_acc[db], 0, 0, 0);
+    }
+  }
+  // C layout of the output: lane holds head dims db*16 + ccol (db = 0..7) of query rows crow0 + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qrow = q0 + wave * 16 + crow0 + r;
+    if (qrow >= T) continue;
+    if (NS > 1) {                                           // partial (unnormalised) result of this key split
+      const size_t pi = ((size_t)qrow * p.n_q + hq) * NS + split;
+#pragma unroll
+      for (int db = 0; db < 8; ++db) p.part_o[pi * kHeadDim + db * 16 + ccol] = o_acc[db][r];
+      if (ccol == 0) { p.part_ml[pi * 2] = m_run[r] * 0.6931471805599453f; p.part_ml[pi * 2 + 1] = l_run[r]; }   // m back to nats
+    } else {
+      const float inv = 1.0f / l_run[r];
+      const size_t oi = ((size_t)qrow * p.n_q + hq) * kHeadDim;
+#pragma unroll
+      for (int db = 0; db < 8; ++db) {
+#pragma clang fp contract(off)   // lo = split of the ROUNDED product, as chatts_split_bf16x2 of the float32 output would give
+        const float v = o_acc[db][r] * inv;
+        if (p.out_hi) {
+          const __bf16 h = (__bf16)v;
+          p.out_hi[oi + db * 16 + ccol] = __builtin_bit_cast(uint16_t, h);
+          p.out_lo[oi + db * 16 + ccol] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+        } else {
+          p.out[oi + db * 16 + ccol] = v;
+        }
+      }
+    }
+  }
+}
+
 // merge the split partials of attn_rows_kernel (splits that saw no tile hold m = -inf, l = 0)
 __global__ __launch_bounds__(128) void attn_combine_kernel(AttnParams p) {
   const int hq = blockIdx.x, row = blockIdx.y, d = threadIdx.x;
@@ -905,7 +1130,9 @@ int chatts::attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0,
   static const bool force_rows = getenv("CHATTS_ATTN_ROWS") != nullptr;   // debugging aid: VALU kernel for every T
   if (t >= 16 && n_splits <= 4 && (!force_rows || out_hi)) {
     // (64-key tiles were measured too: 155 us vs 148 us at T = 798 - the per-tile work is not what is slow)
-    hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, dim3((t + 63) / 64, n_q, n_splits), dim3(256), 0, as_stream(stream), p);
+    const int bf16x3 = getenv("CHATTS_ATTN_BF16X3") ? atoi(getenv("CHATTS_ATTN_BF16X3")) : 1;      // 0: the float32-MFMA kernel
+    if (bf16x3) hipLaunchKernelGGL(attn_prefill_bf16x3_kernel, dim3((t + 63) / 64, n_q, n_splits), dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, dim3((t + 63) / 64, n_q, n_splits), dim3(256), 0, as_stream(stream), p);
     CHATTS_CHECK_LAUNCH("attn_prefill_mfma");
     if (n_splits > 1) {
       hipLaunchKernelGGL(attn_combine_rows_kernel, dim3(t), dim3(256), 0, as_stream(stream), p);

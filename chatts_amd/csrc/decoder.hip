@@ -300,7 +300,10 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
                                      d->w.sin_tab, pos0, pos0_dev, &kc, stream)) != 0) return rc;
       // long chunks: split the keys over 2 workgroups per (query tile, head) - one sequence has too few waves otherwise
       static const int env_ks = getenv("CHATTS_ATTN_KSPLIT") ? atoi(getenv("CHATTS_ATTN_KSPLIT")) : 0;
-      int ks = env_ks >= 1 && env_ks <= 4 ? env_ks : (t >= 256 ? 2 : 1);
+      // (the bf16x3 kernel is fast enough per tile that the second key split + its combine launch no longer pay: 73.3 us
+      // against 74.0 + 12 at T = 798; the float32-MFMA kernel, CHATTS_ATTN_BF16X3=0, still wants the split)
+      const bool f32_attn = getenv("CHATTS_ATTN_BF16X3") && atoi(getenv("CHATTS_ATTN_BF16X3")) == 0;
+      int ks = env_ks >= 1 && env_ks <= 4 ? env_ks : (t >= 256 && f32_attn ? 2 : 1);
       if (chatts_attn_workspace(t, c.n_q, ks) > d->b.workspace_bytes) ks = 1;
       // ... and, on the plane path, let the attention kernel (or its combine) write o_proj's operand format itself
       const bool out_planes = t >= 16 && planes_path(d, t, c.n_q * kHeadDim) && !getenv("CHATTS_ATTN_ROWS");
@@ -568,8 +571,7 @@ static int layer_part0_packed(ChattsDecoder* d, int layer, int t, const ChattsPr
     float* q = d->b.qkv + (size_t)sg.row0 * qkv_n;
     if ((rc = chatts_rope_kv_write(q, sg.t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, sg.pos0,
                                    nullptr, &kc, stream)) != 0) return rc;
-    int ks = sg.t >= 256 ? 2 : 1;
-    if (chatts_attn_workspace(sg.t, c.n_q, ks) > d->b.workspace_bytes) ks = 1;
+    const int ks = 1;
     if ((rc = attention_impl(q, sg.t, c.n_q, c.n_kv, sg.pos0, nullptr, &kc, d->b.attn + (size_t)sg.row0 * na, nullptr, nullptr, ks,
                              d->b.workspace, d->b.workspace_bytes, stream)) != 0) return rc;
   }

@@ -929,3 +929,31 @@ def test_gemm_stream_multiblock_parity(lib, monkeypatch, epi, m, n, k):
     assert not torch.isnan(out).any()
     assert rel_err(out.cpu().numpy(), want) < 2e-5
     assert rel_err(out.cpu().numpy(), base.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("nq,nkv", [(4, 2), (5, 1), (8, 8)])
+@pytest.mark.parametrize("T,pos0,splits", [(16, 0, 1), (64, 0, 1), (65, 31, 1), (130, 100, 1), (200, 0, 1), (300, 17, 2), (70, 0, 2), (33, 400, 4)])
+def test_attention_prefill_bf16x3_parity(lib, monkeypatch, nq, nkv, T, pos0, splits):
+    """attn_prefill_bf16x3_kernel (CHATTS_ATTN_BF16X3=1): Q.K^T and P.V on the bf16 matrix pipe, both operands split into hi / lo
+    planes, three passes per product - against the float64 reference and against the float32-MFMA kernel."""
+    max_ctx = 512
+    g = torch.Generator().manual_seed(nq * 100 + T + pos0)
+    qkv = torch.randn((T, (nq + 2 * nkv) * 128), generator=g)
+    kc = torch.randn((nkv, max_ctx, 128), generator=g)
+    vc = torch.randn((nkv, max_ctx, 128), generator=g)
+    kc[:, 17] *= 4.0     # a spiky key so the online-softmax rescale path is exercised
+    want = _ref_attention(qkv.view(T, nq + 2 * nkv, 128)[:, :nq], kc, vc, pos0)
+    qd, kd, vd = qkv.to(DEV), kc.to(DEV), vc.to(DEV)
+    cache = _lib.KvCache(k=kd.data_ptr(), v=vd.data_ptr(), max_ctx=max_ctx)
+    wsb = int(lib.chatts_attn_workspace(T, nq, splits))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CHATTS_ATTN_BF16X3", mode)
+        out = torch.full((T, nq * 128), float("nan"), device=DEV)
+        _lib.check(lib.chatts_attention(qd.data_ptr(), T, nq, nkv, pos0, None, C.byref(cache), out.data_ptr(), splits, ws.data_ptr(), wsb, st()))
+        torch.cuda.synchronize()
+        outs[mode] = out.cpu().numpy().reshape(T, nq, 128)
+    assert not np.isnan(outs["1"]).any()
+    assert rel_err(outs["1"], want.numpy()) < 3e-5
+    assert rel_err(outs["1"], outs["0"]) < 3e-5
