@@ -855,38 +855,61 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16x3_kernel(AttnParams 
   const float* kbase = p.kc + (size_t)hk * p.max_ctx * kHeadDim;
   const float* vbase = p.vc + (size_t)hk * p.max_ctx * kHeadDim;
 
-  // tile kt+1 is loaded into registers before the MFMAs of tile kt (as in the float32 kernel)
+  // tile kt+1 is loaded into registers before the MFMAs of tile kt (as in the float32 kernel).
+  // K: thread (key = idx >> 5, 4 dims idx & 31): a wave reads two whole key rows.  V: a lane takes the SAME 4 dims of the key
+  // pair (2j, 2j+1), j = lane & 15, so that the transposed store is one 4-byte write per dim - the two keys' bf16 values side
+  // by side, 16 lanes = 16 consecutive dwords (the first version wrote 2 bytes per lane: 35 % of all LDS cycles were conflicts).
   f32x4 kreg[4], vreg[4];
+  const int vj = lane & 15;
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 256;
-      const int kkey = idx >> 5, kc4 = idx & 31;            // K: a wave reads 2 whole key rows (coalesced)
-      const int vkey = idx & 31, vc4 = idx >> 5;            // V: a wave reads 16 bytes of each of the 32 key rows
+      const int kkey = idx >> 5, kc4 = idx & 31;
       const int kr = kt * KT + kkey <= kmax ? kt * KT + kkey : kmax;    // clamped address; masked by key index below
-      const int vr = kt * KT + vkey <= kmax ? kt * KT + vkey : kmax;
       kreg[i] = *reinterpret_cast<const f32x4*>(kbase + (size_t)kr * kHeadDim + kc4 * 4);
-      vreg[i] = *reinterpret_cast<const f32x4*>(vbase + (size_t)vr * kHeadDim + vc4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int vc4 = (tid >> 4) + 16 * i;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int vkey = 2 * vj + h;
+        const int vr = kt * KT + vkey <= kmax ? kt * KT + vkey : kmax;
+        vreg[2 * i + h] = *reinterpret_cast<const f32x4*>(vbase + (size_t)vr * kHeadDim + vc4 * 4);
+      }
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 256;
-      const int kkey = idx >> 5, kc4 = idx & 31, vkey = idx & 31, vc4 = idx >> 5;
-      const float kx[4] = {kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w}, vx[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+      const int kkey = idx >> 5, kc4 = idx & 31;
+      const float kx[4] = {kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w};
       abf16x4_t kh, kl;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const __bf16 h = (__bf16)kx[e];
         kh[e] = h;
         kl[e] = (__bf16)(kx[e] - (float)h);
-        const __bf16 vh = (__bf16)vx[e];
-        *reinterpret_cast<__bf16*>(vt_hi + (vc4 * 4 + e) * VROW + vkey * 2) = vh;
-        *reinterpret_cast<__bf16*>(vt_lo + (vc4 * 4 + e) * VROW + vkey * 2) = (__bf16)(vx[e] - (float)vh);
       }
       *reinterpret_cast<abf16x4_t*>(k_hi + kkey * KROW + kc4 * 8) = kh;
       *reinterpret_cast<abf16x4_t*>(k_lo + kkey * KROW + kc4 * 8) = kl;
+    }
+    typedef __bf16 abf16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int vc4 = (tid >> 4) + 16 * i;
+      const float v0[4] = {vreg[2 * i].x, vreg[2 * i].y, vreg[2 * i].z, vreg[2 * i].w};
+      const float v1[4] = {vreg[2 * i + 1].x, vreg[2 * i + 1].y, vreg[2 * i + 1].z, vreg[2 * i + 1].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        abf16x2_t h, l;
+        h[0] = (__bf16)v0[e]; h[1] = (__bf16)v1[e];
+        l[0] = (__bf16)(v0[e] - (float)h[0]); l[1] = (__bf16)(v1[e] - (float)h[1]);
+        *reinterpret_cast<abf16x2_t*>(vt_hi + (vc4 * 4 + e) * VROW + vj * 4) = h;
+        *reinterpret_cast<abf16x2_t*>(vt_lo + (vc4 * 4 + e) * VROW + vj * 4) = l;
+      }
     }
   };
   const int NS = p.n_splits, split = blockIdx.z;
