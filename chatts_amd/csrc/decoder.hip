@@ -515,7 +515,12 @@ static int layer_last_row(ChattsDecoder* d, int layer, int t, int pos0, chatts_s
   ChattsKvCache kc = layer_cache(d, layer, d->cur_seq);
   if ((rc = chatts_rope_kv_write(d->b.qkv, t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, pos0,
                                  nullptr, &kc, stream)) != 0) return rc;
-  if ((rc = chatts_attention(d->b.qkv + (size_t)(t - 1) * qkv_n, 1, c.n_q, c.n_kv, pos0 + t - 1, nullptr, &kc, d->b.attn, 1,
+  // one query row against pos0 + t keys: spread the 64-key tiles over up to 16 workgroups per kv head (one workgroup walking 800
+  // keys alone took 137 us in the round-2 trace)
+  int ks = (pos0 + t + 63) / 64;
+  if (ks > 16) ks = 16;
+  if (ks < 1 || chatts_attn_workspace(1, c.n_q, ks) > d->b.workspace_bytes) ks = 1;
+  if ((rc = chatts_attention(d->b.qkv + (size_t)(t - 1) * qkv_n, 1, c.n_q, c.n_kv, pos0 + t - 1, nullptr, &kc, d->b.attn, ks,
                              d->b.workspace, d->b.workspace_bytes, stream)) != 0) return rc;
   if (t > 1) {
     const hipError_t e = hipMemcpyAsync(d->b.x, d->b.x + (size_t)(t - 1) * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice,
