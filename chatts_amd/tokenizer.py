@@ -30,6 +30,7 @@ class SyntheticTokenizer:
         self.pad_token_id = eos
         self.eos_token_id = im_end
         self._inv = {}
+        self._ids = {}                             # piece -> id memo (a serving loop re-tokenises the same words)
 
     @classmethod
     def for_config(cls, cfg):
@@ -40,14 +41,20 @@ class SyntheticTokenizer:
         return cls(cfg.vocab_size, cfg.ts_token_start_index, im_start, im_end, eos)
 
     def _piece_id(self, piece):
+        tid = self._ids.get(piece)
+        if tid is not None:
+            return tid
         b = piece.encode("utf-8")
         if len(b) == 1:
+            self._ids[piece] = b[0]
             return b[0]
         h = 0x811C9DC5
         for x in b:
             h = ((h ^ x) * 0x01000193) & 0xFFFFFFFF
         tid = self.word_lo + h % (self.word_hi - self.word_lo)
         self._inv.setdefault(tid, piece)
+        if len(self._ids) < (1 << 20):
+            self._ids[piece] = tid
         return tid
 
     def encode(self, text, add_special_tokens=False):
@@ -56,7 +63,7 @@ class SyntheticTokenizer:
             if seg in self.special:
                 ids.append(self.special[seg])
             else:
-                ids.extend(self._piece_id(m.group(0)) for m in _PRE.finditer(seg))
+                ids.extend(map(self._piece_id, _PRE.findall(seg)))   # _PRE has no groups: findall yields the whole matches
         return ids
 
     def convert_tokens_to_ids(self, tok):
