@@ -367,7 +367,26 @@ class ChatTSForCausalLM:
         self._graph_batched = None
         if plan.world > 1 and self.use_p2p and getattr(self.comm, "dist", None) is not None and self._tp is None:
             from .tp import P2PExchange
-            self.attach_exchange(P2PExchange.create(self.comm, self.exchange_elems()))
+            ex, err = None, None
+            try:
+                ex = P2PExchange.create(self.comm, self.exchange_elems())
+            except Exception as e:               # e.g. no IPC mapping between these two devices
+                err = e
+            # every rank must take the same path: agree before anyone attaches
+            oks = [None] * plan.world
+            self.comm.dist.all_gather_object(oks, err is None, group=self.comm.group)
+            if all(oks):
+                self.attach_exchange(ex)
+            else:
+                if ex is not None:
+                    ex.close()
+                if self.max_batch > 1:
+                    raise RuntimeError(f"the peer-to-peer exchange could not be set up on ranks {[r for r, ok in enumerate(oks) if not ok]} "
+                                       f"({err}); batched decode under tensor parallelism needs it")
+                import warnings
+                warnings.warn(f"peer-to-peer exchange unavailable on ranks {[r for r, ok in enumerate(oks) if not ok]} ({err}): "
+                              "decode-sized sums go through RCCL from the host (slower, no hipGraph)")
+                self.use_p2p = False
 
     def exchange_elems(self):
         """float32 elements per rank the largest in-step collective moves: [max_batch, H] partial sums, or the logits gather."""
