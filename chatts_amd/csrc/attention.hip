@@ -920,6 +920,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16x3_kernel(AttnParams 
     store_tile();
     __syncthreads();
     if (kt + NS < nkt) load_tile(kt + NS);
+    // the workgroup walks the keys its LAST query row sees; a wave whose 16 rows all lie before this tile has nothing to add
+    // (every score masked): wave-uniform skip, the barriers above keep the cadence
+    if (k0 > pos0 + q0 + wave * 16 + 15) continue;
 
     f32x4 s_acc[NB];
 #pragma unroll
