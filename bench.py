@@ -345,7 +345,7 @@ def bench_batched(args, model, cfg, comm, world, device):
         "dtype": "bf16" if args.weights == "bf16" else "fp8-e4m3 weights (pow2 row scales, exactly representable in bf16), bf16x2 MFMA / f32 accumulate",
         "data": "synthetic",
         "config": {"workload": label, "model": args.model, "batch": B, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
-                   "parallelism": f"tp{world}", "decode_graph": model.graph_capturable(),
+                   "parallelism": f"tp{world}", "decode_graph": model.graph_capturable(), "kv_block": model.kv_block_size or None,
                    "tp_exchange": None if world == 1 else ("p2p one-shot kernels (csrc/tp.hip)" if model._tp is not None else "rccl, host-driven"),
                    "weights_note": None if args.weights == "bf16" else
                    "fp8 copies are streamed by the decode GEMMs and widened to bf16 while staged (no v_mfma fp8 issue: the 1e-3 "
@@ -379,6 +379,8 @@ def main():
     ap.add_argument("--max-ctx", type=int, default=2048, help="KV-cache length (longer prompts, e.g. --series 30, need more)")
     ap.add_argument("--batch", type=int, default=1, help="> 1: continuous-batching workload (BASELINE.json config 5): B prompts decode "
                     "together; a step = one B-wide decode step; value = aggregate tokens/s")
+    ap.add_argument("--kv-block", type=int, default=0, help="block-paged KV cache with this many positions per block (0 = one "
+                    "contiguous cache per slot, the default)")
     ap.add_argument("--no-pack", action="store_true", help="--batch: admit the prompts one by one instead of packed prefill passes")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "int4"],
                     help="fp8 = BASELINE.json config 5 weight format, int4 = the GPTQ-Int4 checkpoint's (NOT the headline: separate workloads)")
@@ -419,7 +421,8 @@ def main():
     max_ctx = args.max_ctx
     model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, device=device, comm=comm, max_ctx=max_ctx,
                                              max_prefill_tokens=1024, use_graph=not args.no_graph,
-                                             weight_format=args.weights, max_batch=max(1, args.batch))
+                                             weight_format=args.weights, max_batch=max(1, args.batch),
+                                             kv_block_size=args.kv_block or None)
     torch.cuda.synchronize()
     log(f"[bench] {args.model} TP={world} materialised in {time.time() - t0:.1f}s, "
         f"{model.weight_bytes_local() / 1e9:.2f} GB decoder weights on this rank")
@@ -499,7 +502,7 @@ def main():
                   "int4": "int4 codes + fp16 group scales (round-to-nearest, groups of 128) = a bf16 matrix, f32 math"}[args.weights], "data": "synthetic",
         "config": {"workload": workload_name(args, world),
                    "model": args.model, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
-                   "parallelism": f"tp{world}", "batch": 1, "decode_graph": model.graph_capturable(),
+                   "parallelism": f"tp{world}", "batch": 1, "decode_graph": model.graph_capturable(), "kv_block": model.kv_block_size or None,
                    "tp_exchange": None if world == 1 else ("p2p one-shot kernels (csrc/tp.hip)" if model._tp is not None else "rccl, host-driven"),
                    "precision": "bf16 weights; f32 activations, KV cache and accumulation (bf16x2 MFMA split in "
                                 "prefill, exact f32 FMA in decode)",

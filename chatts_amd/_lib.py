@@ -43,7 +43,8 @@ class LinearArgs(C.Structure):
 
 
 class KvCache(C.Structure):
-    _fields_ = [("k", c_void_p), ("v", c_void_p), ("max_ctx", c_int)]
+    _fields_ = [("k", c_void_p), ("v", c_void_p), ("max_ctx", c_int),
+                ("block_table", c_void_p), ("block_size", c_int), ("table_stride", c_int)]      # paged form: block_table != NULL
 
 
 class LayerWeights(C.Structure):
@@ -82,7 +83,8 @@ class DecoderBuffers(C.Structure):
                 ("attn", c_void_p), ("act", c_void_p), ("delta", c_void_p), ("logits", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("t_max", c_int), ("max_batch", c_int),
                 ("planes_hi", c_void_p), ("planes_lo", c_void_p), ("planes2_hi", c_void_p), ("planes2_lo", c_void_p),
-                ("tp_pair_logit", c_void_p), ("tp_pair_token", c_void_p), ("logits_full", c_void_p)]
+                ("tp_pair_logit", c_void_p), ("tp_pair_token", c_void_p), ("logits_full", c_void_p),
+                ("kv_block_table", c_void_p), ("kv_block_size", c_int), ("kv_table_stride", c_int), ("kv_pool_blocks", c_int)]
 
 
 # name -> (restype, argtypes); this table IS the list of symbols include/chatts_amd.h declares

@@ -41,6 +41,10 @@ struct AttnParams {
   const float* sin_tab;
   float eps;
   size_t seq_stride;   // batched decode: floats between the caches of consecutive sequences (same layer)
+  // block-paged cache (ChattsKvCache.block_table != NULL): kc / vc are the layer's pool [n_blocks, n_kv, 2^log_block, 128];
+  // sequence b looks its blocks up in table + b * table_stride, seq_stride is not used
+  const int32_t* table;
+  int log_block, table_stride;
   uint16_t* out_hi;    // decode combine, optional: the output as bf16 hi / lo planes [T, n_q * 128] (the o_proj operand of the
   uint16_t* out_lo;    // weight-streaming kernel) instead of float32 `out`
 };
@@ -77,12 +81,11 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
   const int ntiles = pos / kDTile + 1;
   if (slot >= ntiles) return;                  // the combine only reads slots < min(ntiles, NS)
   const float* qkv = p.qkv + (size_t)seq * (p.n_q + 2 * p.n_kv) * kHeadDim;
-  float* kcache = p.kc + (size_t)seq * p.seq_stride;
-  float* vcache = p.vc + (size_t)seq * p.seq_stride;
+  float* kcache = p.kc + (p.table ? 0 : (size_t)seq * p.seq_stride);
+  float* vcache = p.vc + (p.table ? 0 : (size_t)seq * p.seq_stride);
+  const KvLayout kvl{p.table ? p.table + (size_t)seq * p.table_stride : nullptr, p.n_kv, p.max_ctx, p.log_block};
   const bool owner = ((pos / kDTile) % NS) == slot;
   const float scale = 0.08838834764831845f * 1.4426950408889634f;    // 128^-1/2 * log2(e): the softmax runs on v_exp_f32 (exp2)
-  const float* kbase = kcache + (size_t)hk * p.max_ctx * kHeadDim;
-  const float* vbase = vcache + (size_t)hk * p.max_ctx * kHeadDim;
   const int key_l = lane >> 2, quarter = lane & 3;
 
   // K and V of the first tile only depend on `pos`: issue them before the q prologue so that the cache rows,
@@ -92,14 +95,15 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
   auto load_tile = [&](int tile) {
     const int j0 = tile * kDTile;
     const int j = j0 + key_l;
-    const int jc = j <= pos ? j : pos;          // clamped address; masked below
-    const float* kr = kbase + (size_t)jc * kHeadDim + quarter * 4;
+    const int jc = j <= pos ? j : pos;          // clamped address (stays inside this tile: pos lies in it); masked below
+    const size_t toff = kv_tile_off(kvl, hk, j0);   // the tile's first row: one table lookup per tile when the cache is paged
+    const float* kr = kcache + toff + (size_t)(jc - j0) * kHeadDim + quarter * 4;
 #pragma unroll
     for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
 #pragma unroll
     for (int u = 0; u < kDTile; ++u) {
       const int ju = j0 + u <= pos ? j0 + u : pos;
-      vv[u] = *reinterpret_cast<const float2*>(vbase + (size_t)ju * kHeadDim + lane * 2);
+      vv[u] = *reinterpret_cast<const float2*>(vcache + toff + (size_t)(ju - j0) * kHeadDim + lane * 2);
     }
   };
   load_tile(slot);
@@ -122,14 +126,15 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
       norm_rope(a, b, p.k_norm_w, p.eps, c, s, lane);
       knew_s[lane] = a;
       knew_s[lane + 64] = b;
-      float* kd = kcache + ((size_t)hk * p.max_ctx + pos) * kHeadDim;
+      const size_t noff = kv_tile_off(kvl, hk, pos);      // row of the new token
+      float* kd = kcache + noff;
       kd[lane] = a;
       kd[lane + 64] = b;
       const float* vs = qkv + (size_t)(p.n_q + p.n_kv + hk) * kHeadDim;
       const float va = vs[lane], vb = vs[lane + 64];
       vnew_s[lane] = va;
       vnew_s[lane + 64] = vb;
-      float* vd = vcache + ((size_t)hk * p.max_ctx + pos) * kHeadDim;
+      float* vd = vcache + noff;
       vd[lane] = va;
       vd[lane + 64] = vb;
     }
@@ -245,12 +250,11 @@ __global__ __launch_bounds__(1024) void attn_decode_parts_kernel(AttnParams p) {
   const int nslots = nparts * kPartWaves, slot = part * kPartWaves + wave;
   const bool active = slot < ntiles;
   const float* qkv = p.qkv + (size_t)seq * (p.n_q + 2 * p.n_kv) * kHeadDim;
-  float* kcache = p.kc + (size_t)seq * p.seq_stride;
-  float* vcache = p.vc + (size_t)seq * p.seq_stride;
+  float* kcache = p.kc + (p.table ? 0 : (size_t)seq * p.seq_stride);
+  float* vcache = p.vc + (p.table ? 0 : (size_t)seq * p.seq_stride);
+  const KvLayout kvl{p.table ? p.table + (size_t)seq * p.table_stride : nullptr, p.n_kv, p.max_ctx, p.log_block};
   const bool owner = active && ((pos / kDTile) % nslots) == slot;
   const float scale = 0.08838834764831845f * 1.4426950408889634f;    // 128^-1/2 * log2(e)
-  const float* kbase = kcache + (size_t)hk * p.max_ctx * kHeadDim;
-  const float* vbase = vcache + (size_t)hk * p.max_ctx * kHeadDim;
   const int key_l = lane >> 2, quarter = lane & 3;
 
   f32x4 kv[8];
@@ -259,13 +263,14 @@ __global__ __launch_bounds__(1024) void attn_decode_parts_kernel(AttnParams p) {
     const int j0 = tile * kDTile;
     const int j = j0 + key_l;
     const int jc = j <= pos ? j : pos;
-    const float* kr = kbase + (size_t)jc * kHeadDim + quarter * 4;
+    const size_t toff = kv_tile_off(kvl, hk, j0);
+    const float* kr = kcache + toff + (size_t)(jc - j0) * kHeadDim + quarter * 4;
 #pragma unroll
     for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
 #pragma unroll
     for (int u = 0; u < kDTile; ++u) {
       const int ju = j0 + u <= pos ? j0 + u : pos;
-      vv[u] = *reinterpret_cast<const float2*>(vbase + (size_t)ju * kHeadDim + lane * 2);
+      vv[u] = *reinterpret_cast<const float2*>(vcache + toff + (size_t)(ju - j0) * kHeadDim + lane * 2);
     }
   };
   if (active) load_tile(slot);
@@ -284,14 +289,15 @@ __global__ __launch_bounds__(1024) void attn_decode_parts_kernel(AttnParams p) {
       norm_rope(a, b, p.k_norm_w, p.eps, c, s, lane);
       knew_s[lane] = a;
       knew_s[lane + 64] = b;
-      float* kd = kcache + ((size_t)hk * p.max_ctx + pos) * kHeadDim;
+      const size_t noff = kv_tile_off(kvl, hk, pos);      // row of the new token
+      float* kd = kcache + noff;
       kd[lane] = a;
       kd[lane + 64] = b;
       const float* vs = qkv + (size_t)(p.n_q + p.n_kv + hk) * kHeadDim;
       const float va = vs[lane], vb = vs[lane + 64];
       vnew_s[lane] = va;
       vnew_s[lane + 64] = vb;
-      float* vd = vcache + ((size_t)hk * p.max_ctx + pos) * kHeadDim;
+      float* vd = vcache + noff;
       vd[lane] = va;
       vd[lane + 64] = vb;
     }
@@ -460,8 +466,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
     q_s[i] = p.qkv[((size_t)row * heads + hk * G) * kHeadDim + i];
   __syncthreads();
 
-  const float* kbase = p.kc + (size_t)hk * p.max_ctx * kHeadDim;
-  const float* vbase = p.vc + (size_t)hk * p.max_ctx * kHeadDim;
+  const KvLayout kvl{p.table, p.n_kv, p.max_ctx, p.log_block};
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};   // heads wave, wave + 4
   float acc[kMaxGroup];
 #pragma unroll
@@ -471,10 +476,11 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
 
   for (int tile = split; tile < ntiles; tile += p.n_splits) {
     const int j0 = tile * kTile;
+    const size_t toff = kv_tile_off(kvl, hk, j0);     // first row of the tile (one block-table lookup when paged)
     {
       const int j = j0 + key_l;
       const int jc = j <= pos ? j : pos;
-      const float* kr = kbase + (size_t)jc * kHeadDim + quarter * 4;
+      const float* kr = p.kc + toff + (size_t)(jc - j0) * kHeadDim + quarter * 4;
       f32x4 kv[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnParams p) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int j = jb + b8 + u;
-          vv[u] = vbase[(size_t)(j <= pos ? j : pos) * kHeadDim + d_o];
+          vv[u] = p.vc[toff + (size_t)((j <= pos ? j : pos) - j0) * kHeadDim + d_o];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -633,20 +639,20 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
   const int last_q = q0 + 63 < T - 1 ? q0 + 63 : T - 1;
   const int kmax = pos0 + last_q;                           // last key any row of this workgroup may see
   const int nkt = kmax / KT + 1;
-  const float* kbase = p.kc + (size_t)hk * p.max_ctx * kHeadDim;
-  const float* vbase = p.vc + (size_t)hk * p.max_ctx * kHeadDim;
+  const KvLayout kvl{p.table, p.n_kv, p.max_ctx, p.log_block};
 
   // K/V tiles go global -> registers -> LDS; the loads of tile kt+1 are issued BEFORE the MFMAs of tile kt, so their L2
   // latency hides under the tile's 128 MFMAs per wave instead of sitting between two barriers.
   constexpr int SLOTS = KT * 32 / 256;                      // float4 slots per thread and operand
   f32x4 kreg[SLOTS], vreg[SLOTS];
   auto load_tile = [&](int kt) {
+    const size_t toff = kv_tile_off(kvl, hk, kt * KT);      // first row of the tile (one block-table lookup when paged)
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       const int idx = tid + i * 256, key = idx >> 5, c4 = idx & 31;
-      const int kr = kt * KT + key <= kmax ? kt * KT + key : kmax;    // clamped address; masked by key index below
-      kreg[i] = *reinterpret_cast<const f32x4*>(kbase + (size_t)kr * kHeadDim + c4 * 4);
-      vreg[i] = *reinterpret_cast<const f32x4*>(vbase + (size_t)kr * kHeadDim + c4 * 4);
+      const int kr = kt * KT + key <= kmax ? key : kmax - kt * KT;    // clamped row inside the tile; masked by key index below
+      kreg[i] = *reinterpret_cast<const f32x4*>(p.kc + toff + (size_t)kr * kHeadDim + c4 * 4);
+      vreg[i] = *reinterpret_cast<const f32x4*>(p.vc + toff + (size_t)kr * kHeadDim + c4 * 4);
     }
   };
   auto store_tile = [&]() {
@@ -852,8 +858,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16x3_kernel(AttnParams 
   const int last_q = q0 + 63 < T - 1 ? q0 + 63 : T - 1;
   const int kmax = pos0 + last_q;                           // last key any row of this workgroup may see
   const int nkt = kmax / KT + 1;
-  const float* kbase = p.kc + (size_t)hk * p.max_ctx * kHeadDim;
-  const float* vbase = p.vc + (size_t)hk * p.max_ctx * kHeadDim;
+  const KvLayout kvl{p.table, p.n_kv, p.max_ctx, p.log_block};
 
   // tile kt+1 is loaded into registers before the MFMAs of tile kt (as in the float32 kernel).
   // K: thread (key = idx >> 5, 4 dims idx & 31): a wave reads two whole key rows.  V: a lane takes the SAME 4 dims of the key
@@ -862,12 +867,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16x3_kernel(AttnParams 
   f32x4 kreg[4], vreg[4];
   const int vj = lane & 15;
   auto load_tile = [&](int kt) {
+    const size_t toff = kv_tile_off(kvl, hk, kt * KT);      // first row of the tile (one block-table lookup when paged)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 256;
       const int kkey = idx >> 5, kc4 = idx & 31;
-      const int kr = kt * KT + kkey <= kmax ? kt * KT + kkey : kmax;    // clamped address; masked by key index below
-      kreg[i] = *reinterpret_cast<const f32x4*>(kbase + (size_t)kr * kHeadDim + kc4 * 4);
+      const int kr = kt * KT + kkey <= kmax ? kkey : kmax - kt * KT;    // clamped row inside the tile; masked by key index below
+      kreg[i] = *reinterpret_cast<const f32x4*>(p.kc + toff + (size_t)kr * kHeadDim + kc4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -875,8 +881,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16x3_kernel(AttnParams 
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int vkey = 2 * vj + h;
-        const int vr = kt * KT + vkey <= kmax ? kt * KT + vkey : kmax;
-        vreg[2 * i + h] = *reinterpret_cast<const f32x4*>(vbase + (size_t)vr * kHeadDim + vc4 * 4);
+        const int vr = kt * KT + vkey <= kmax ? vkey : kmax - kt * KT;
+        vreg[2 * i + h] = *reinterpret_cast<const f32x4*>(p.vc + toff + (size_t)vr * kHeadDim + vc4 * 4);
       }
     }
   };
@@ -1119,6 +1125,19 @@ static int bind_workspace(AttnParams& p, void* workspace, size_t workspace_bytes
   return CHATTS_OK;
 }
 
+// cache -> kernel parameters; the block-paged form is validated here (every entry point goes through this)
+static int bind_cache(AttnParams& p, const ChattsKvCache* cache) {
+  p.kc = cache->k; p.vc = cache->v; p.max_ctx = cache->max_ctx;
+  p.table = cache->block_table; p.log_block = 0; p.table_stride = cache->table_stride;
+  if (cache->block_table) {
+    p.log_block = kv_log_block(cache->block_size);
+    CHATTS_REQUIRE(p.log_block > 0, CHATTS_E_BADARG, "attention: block_size %d is not a power of two in 64..32768", cache->block_size);
+    CHATTS_REQUIRE(cache->max_ctx % cache->block_size == 0, CHATTS_E_BADARG,
+                   "attention: a paged cache of %d positions needs whole blocks of %d", cache->max_ctx, cache->block_size);
+  }
+  return CHATTS_OK;
+}
+
 namespace chatts {
 int attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev, const ChattsKvCache* cache, float* out,
                    uint16_t* out_hi, uint16_t* out_lo, int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream);
@@ -1146,8 +1165,9 @@ int chatts::attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0,
   if (!pos0_dev)
     CHATTS_REQUIRE(pos0 >= 0 && pos0 + t <= cache->max_ctx, CHATTS_E_SHAPE, "attention: positions exceed the cache");
   AttnParams p{};
-  p.qkv = qkv; p.kc = cache->k; p.vc = cache->v; p.out = out; p.pos0_dev = pos0_dev; p.pos0 = pos0;
-  p.t = t; p.n_q = n_q; p.n_kv = n_kv; p.max_ctx = cache->max_ctx; p.n_splits = n_splits;
+  p.qkv = qkv; p.out = out; p.pos0_dev = pos0_dev; p.pos0 = pos0;
+  p.t = t; p.n_q = n_q; p.n_kv = n_kv; p.n_splits = n_splits;
+  if (const int rc = bind_cache(p, cache)) return rc;
   p.out_hi = out_hi; p.out_lo = out_lo;
   if (n_splits > 1) {
     const int rc = bind_workspace(p, workspace, workspace_bytes);
@@ -1195,8 +1215,9 @@ int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int 
   if (!pos_dev)
     CHATTS_REQUIRE(pos >= 0 && pos < cache->max_ctx, CHATTS_E_SHAPE, "attention_decode: position exceeds the cache");
   AttnParams p{};
-  p.qkv = qkv_raw; p.kc = cache->k; p.vc = cache->v; p.out = out; p.pos0_dev = pos_dev; p.pos0 = pos;
-  p.t = batch; p.n_q = n_q; p.n_kv = n_kv; p.max_ctx = cache->max_ctx; p.n_splits = n_splits;
+  p.qkv = qkv_raw; p.out = out; p.pos0_dev = pos_dev; p.pos0 = pos;
+  p.t = batch; p.n_q = n_q; p.n_kv = n_kv; p.n_splits = n_splits;
+  if (const int rc = bind_cache(p, cache)) return rc;
   p.q_norm_w = q_norm_w; p.k_norm_w = k_norm_w; p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.eps = norm_eps;
   p.seq_stride = seq_stride; p.out_hi = out_hi; p.out_lo = out_lo;
   const int rc = bind_workspace(p, workspace, workspace_bytes);
@@ -1245,8 +1266,9 @@ extern "C" int chatts_attention_decode_parts(const float* qkv_raw, int batch, in
   CHATTS_REQUIRE(batch == 1 || pos_dev, CHATTS_E_BADARG, "attention_decode_parts: batch > 1 needs per-sequence positions on the device");
   if (!pos_dev) CHATTS_REQUIRE(pos >= 0 && pos < cache->max_ctx, CHATTS_E_SHAPE, "attention_decode_parts: position exceeds the cache");
   AttnParams p{};
-  p.qkv = qkv_raw; p.kc = cache->k; p.vc = cache->v; p.pos0_dev = pos_dev; p.pos0 = pos;
-  p.t = batch; p.n_q = n_q; p.n_kv = n_kv; p.max_ctx = cache->max_ctx; p.n_splits = n_parts;
+  p.qkv = qkv_raw; p.pos0_dev = pos_dev; p.pos0 = pos;
+  p.t = batch; p.n_q = n_q; p.n_kv = n_kv; p.n_splits = n_parts;
+  if (const int rc = bind_cache(p, cache)) return rc;
   p.q_norm_w = q_norm_w; p.k_norm_w = k_norm_w; p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.eps = norm_eps; p.seq_stride = seq_stride;
   const int rc = bind_workspace(p, workspace, workspace_bytes);
   if (rc) return rc;

@@ -108,6 +108,29 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
   return t;
 }
 
+// ---- KV cache addressing ------------------------------------------------------------------------------------------------
+// Contiguous form: one sequence's layer cache is [n_kv, max_ctx, 128].  Block-paged form (table != nullptr,
+// ChattsKvCache.block_table): the layer's pool is [n_blocks, n_kv, 2^log_block, 128] and logical key j of the sequence lives
+// in block table[j >> log_block], row j & (2^log_block - 1).  Every kernel walks the keys in tiles of 16 / 32 / 64 consecutive
+// keys that start at a multiple of the tile size, and a block holds a multiple of 64 keys: ONE lookup per tile gives the
+// tile's first row, the rows of a tile are contiguous in both forms.
+struct KvLayout {
+  const int32_t* table;
+  int n_kv, max_ctx, log_block;
+};
+// float offset (from the cache / pool base) of row `key` of kv head `hk`
+__device__ __forceinline__ size_t kv_tile_off(const KvLayout& L, int hk, int key) {
+  if (L.table == nullptr) return ((size_t)hk * L.max_ctx + key) * kHeadDim;
+  const int blk = L.table[key >> L.log_block];
+  return ((((size_t)blk * L.n_kv + hk) << L.log_block) + (key & ((1 << L.log_block) - 1))) * kHeadDim;
+}
+// host: log2 of a valid block size (power of two, 64 .. 32768), -1 otherwise
+inline int kv_log_block(int block_size) {
+  for (int l = 6; l <= 15; ++l)
+    if (block_size == (1 << l)) return l;
+  return -1;
+}
+
 inline hipStream_t as_stream(chatts_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 int device_cus();

@@ -123,6 +123,15 @@ extern "C" ChattsDecoder* chatts_decoder_create(const ChattsDecoderConfig* c, co
   if (c->head_dim != kHeadDim) { set_error("decoder_create: head_dim %d != 128", c->head_dim); return nullptr; }
   if (c->n_q % c->n_kv != 0 || c->n_q / c->n_kv > 8) { set_error("decoder_create: unsupported GQA group"); return nullptr; }
   if (c->hidden % 32 || c->inter % 32) { set_error("decoder_create: hidden/inter must be multiples of 32"); return nullptr; }
+  if (b->kv_block_table) {
+    const int B = b->kv_block_size;
+    if (kv_log_block(B) < 0 || c->max_ctx % B != 0 || b->kv_table_stride < c->max_ctx / B || b->kv_pool_blocks < 1) {
+      set_error("decoder_create: paged KV needs a power-of-two block size in 64..32768 dividing max_ctx (%d), a table row of >= "
+                "max_ctx / block_size entries and a non-empty pool (block %d, row %d, pool %d)", c->max_ctx, B, b->kv_table_stride,
+                b->kv_pool_blocks);
+      return nullptr;
+    }
+  }
   ChattsDecoder* d = new (std::nothrow) ChattsDecoder();
   if (!d) { set_error("decoder_create: out of host memory"); return nullptr; }
   d->cfg = *c;
@@ -140,11 +149,20 @@ static size_t seq_stride(const ChattsDecoder* d) {      // floats between the ca
 }
 
 static ChattsKvCache layer_cache(const ChattsDecoder* d, int layer, int seq) {
+  ChattsKvCache c{};
+  c.max_ctx = d->cfg.max_ctx;
+  if (d->b.kv_block_table) {      // block-paged: the layer's pool + this sequence's row of the block table
+    const size_t pool = (size_t)d->b.kv_pool_blocks * d->cfg.n_kv * d->b.kv_block_size * kHeadDim;
+    c.k = d->b.kv_k + pool * layer;
+    c.v = d->b.kv_v + pool * layer;
+    c.block_table = d->b.kv_block_table + (size_t)seq * d->b.kv_table_stride;
+    c.block_size = d->b.kv_block_size;
+    c.table_stride = d->b.kv_table_stride;
+    return c;
+  }
   const size_t per = (size_t)d->cfg.n_kv * d->cfg.max_ctx * kHeadDim;
-  ChattsKvCache c;
   c.k = d->b.kv_k + seq_stride(d) * seq + per * layer;
   c.v = d->b.kv_v + seq_stride(d) * seq + per * layer;
-  c.max_ctx = d->cfg.max_ctx;
   return c;
 }
 

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(float* __restrict__ qkv, i
                                                      const float* __restrict__ cos_tab,
                                                      const float* __restrict__ sin_tab, int pos0,
                                                      const int32_t* __restrict__ pos0_dev, float* __restrict__ kc,
-                                                     float* __restrict__ vc, int max_ctx) {
+                                                     float* __restrict__ vc, KvLayout kvl) {
   const int heads = n_q + 2 * n_kv;
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(float* __restrict__ qkv, i
   float* row = qkv + ((size_t)tok * heads + h) * kHeadDim;
   float a = row[lane], b = row[lane + 64];
   if (h >= n_q + n_kv) {   // v head: straight copy into the cache
-    float* dst = vc + ((size_t)(h - n_q - n_kv) * max_ctx + pos) * kHeadDim;
+    float* dst = vc + kv_tile_off(kvl, h - n_q - n_kv, pos);
     dst[lane] = a;
     dst[lane + 64] = b;
     return;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(float* __restrict__ qkv, i
     row[lane] = oa;
     row[lane + 64] = ob;
   } else {
-    float* dst = kc + ((size_t)(h - n_q) * max_ctx + pos) * kHeadDim;
+    float* dst = kc + kv_tile_off(kvl, h - n_q, pos);
     dst[lane] = oa;
     dst[lane + 64] = ob;
   }
@@ -269,10 +269,16 @@ extern "C" int chatts_rope_kv_write(float* qkv, int t, int n_q, int n_kv, const 
   if (!pos0_dev)
     CHATTS_REQUIRE(pos0 >= 0 && pos0 + t <= cache->max_ctx, CHATTS_E_SHAPE,
                    "rope_kv_write: positions %d..%d exceed the cache (%d)", pos0, pos0 + t, cache->max_ctx);
+  KvLayout kvl{cache->block_table, n_kv, cache->max_ctx, 0};
+  if (cache->block_table) {
+    kvl.log_block = kv_log_block(cache->block_size);
+    CHATTS_REQUIRE(kvl.log_block > 0 && cache->max_ctx % cache->block_size == 0, CHATTS_E_BADARG,
+                   "rope_kv_write: block_size %d must be a power of two in 64..32768 that divides max_ctx %d", cache->block_size,
+                   cache->max_ctx);
+  }
   const int waves = t * (n_q + 2 * n_kv);
   hipLaunchKernelGGL(rope_kv_kernel, dim3((waves + 3) / 4), dim3(256), 0, as_stream(stream), qkv, t, n_q, n_kv,
-                     q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos0, pos0_dev, cache->k, cache->v,
-                     cache->max_ctx);
+                     q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos0, pos0_dev, cache->k, cache->v, kvl);
   CHATTS_CHECK_LAUNCH("rope_kv_write");
   return CHATTS_OK;
 }

@@ -112,6 +112,20 @@ class Engine:
                 continue
             pack = m.plan_pack([r._enc + (r.max_tokens,) for r in ready], free) if self.nslots > 1 else []
             group = [ready[j] for j in pack] if pack else ready[:1]
+            if getattr(m, "_kv_dynamic", False):         # block-paged cache with an oversubscribed pool: admit only what it can hold
+                def need(q):
+                    return m.request_tokens(*q._enc) + q.max_tokens
+                if len(group) > 1 and not m.kv_fits([need(q) for q in group]):
+                    group = group[:1]
+                if not m.kv_fits([need(group[0])]):
+                    if any(v is not None for v in self.slots):
+                        break                            # wait until a running sequence finishes: its blocks become evictable
+                    r = group[0]                         # nothing is running: this request can never fit
+                    self.waiting.remove(r)
+                    r.error = RuntimeError(f"request needs {need(r)} KV positions, more than the block pool can hold ({m.kv_stats()})")
+                    self._emit(r, True, "error")
+                    done.append(r)
+                    continue
             items = []
             for r in group:
                 ids, ser, lens = r._enc

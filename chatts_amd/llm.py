@@ -49,7 +49,7 @@ def _load_checkpoint_tokenizer(path):
 class LLM:
     def __init__(self, model, tensor_parallel_size=1, max_model_len=6000, limit_mm_per_prompt=None,
                  trust_remote_code=True, gpu_memory_utilization=None, seed=0, tokenizer=None, comm=None,
-                 max_num_seqs=1, **kw):
+                 max_num_seqs=1, block_size=None, num_gpu_blocks_override=None, **kw):
         from .config import PRESETS, ChatTSConfig, preset
         from .modeling import ChatTSForCausalLM
         from .processing import ChatTSProcessor
@@ -61,8 +61,10 @@ class LLM:
             raise ValueError(f"tensor_parallel_size={tensor_parallel_size} needs {tensor_parallel_size} ranks launched "
                              f"one per GPU (torchrun); this process group has {comm.world}")
         # max_num_seqs (vLLM's name): cache slots decoded together (continuous batching); 1 = one request at a time
+        # block_size / num_gpu_blocks_override (vLLM's names): block-paged KV cache; fewer blocks than
+        # max_num_seqs x max_model_len / block_size oversubscribes the slots (requests then wait for blocks at admission)
         mk = dict(comm=comm, max_ctx=max_model_len, max_prefill_tokens=min(2048, max_model_len),
-                  max_batch=max(1, int(max_num_seqs)))
+                  max_batch=max(1, int(max_num_seqs)), kv_block_size=block_size, kv_pool_blocks=num_gpu_blocks_override)
         if isinstance(model, ChatTSConfig):
             self.model = ChatTSForCausalLM.from_synthetic(model, seed=seed, **mk)
         elif isinstance(model, str) and model in PRESETS:

@@ -82,7 +82,8 @@ class ChatTSForCausalLM:
     packed_modules_mapping = packed_modules_mapping
 
     def __init__(self, config, device="cuda", comm=None, max_ctx=2048, max_prefill_tokens=2048, use_graph=True,
-                 max_batch=1, weight_format="bf16", use_p2p=True, enable_prefix_caching=True):
+                 max_batch=1, weight_format="bf16", use_p2p=True, enable_prefix_caching=True, kv_block_size=None,
+                 kv_pool_blocks=None):
         if not torch.cuda.is_available():
             raise RuntimeError("chatts_amd needs a ROCm GPU: there is no CPU fallback for the model")
         self.lib = _lib.load()
@@ -91,6 +92,18 @@ class ChatTSForCausalLM:
         self.comm = comm or LocalComm()
         self.plan = ShardPlan(config, self.comm.rank, self.comm.world)
         self.max_ctx = int(max_ctx)
+        # block-paged KV cache (vLLM's block_size / num_gpu_blocks): kv_block_size = positions per block (power of two >= 64),
+        # None = one contiguous cache per slot.  kv_pool_blocks < max_batch * max_ctx / block oversubscribes the slots: requests
+        # reserve blocks for prompt + max_new_tokens at admission and wait while the pool cannot cover them (chatts_amd/kv_blocks.py)
+        self.kv_block_size = int(kv_block_size or 0)
+        if self.kv_block_size:
+            if self.kv_block_size < 64 or self.kv_block_size & (self.kv_block_size - 1):
+                raise ValueError(f"kv_block_size={kv_block_size} must be a power of two >= 64")
+            self.max_ctx = -(-self.max_ctx // self.kv_block_size) * self.kv_block_size      # whole blocks
+        self._kv_pool_blocks = None if kv_pool_blocks is None else int(kv_pool_blocks)
+        self._kv = None                          # kv_blocks.BlockPool once the buffers exist
+        self._kv_dynamic = False
+        self._cur_slot = 0
         if weight_format not in ("bf16", "fp8", "int4"):
             raise ValueError("weight_format must be 'bf16', 'fp8' or 'int4'")
         # "fp8": decode GEMVs stream an e4m3 copy (BASELINE.json config 5); "int4": they stream 4-bit codes + group scales (what a
@@ -99,7 +112,7 @@ class ChatTSForCausalLM:
         self.int4_group = 128
         self._gptq_codes = {}                    # HF module name -> (codes, scale, zero) of a GPTQ checkpoint, consumed by _load_with
         self.max_batch = int(max_batch)          # KV-cache slots for batched decode (continuous batching)
-        self.t_max = int(max(min(max_prefill_tokens, max_ctx), self.max_batch))
+        self.t_max = int(max(min(max_prefill_tokens, self.max_ctx), self.max_batch))
         self.use_graph = use_graph
         self.use_p2p = use_p2p                   # TP: decode-sized exchanges through csrc/tp.hip instead of RCCL (chatts_amd/tp.py)
         self._tp = None                          # P2PExchange of this rank once attached
@@ -305,9 +318,21 @@ class ChatTSForCausalLM:
         f32 = dict(dtype=torch.float32, device=dev)
         qkv_n = (plan.nq + 2 * plan.nkv) * d
         L = cfg.num_hidden_layers
+        if self.kv_block_size:
+            from .kv_blocks import BlockPool
+            bps = self.max_ctx // self.kv_block_size
+            nblk = MB * bps if self._kv_pool_blocks is None else self._kv_pool_blocks
+            if nblk < 1 or nblk > MB * bps:
+                raise ValueError(f"kv_pool_blocks={nblk} must lie in 1..{MB * bps} (max_batch x max_ctx / kv_block_size)")
+            kv_shape = (L, nblk, plan.nkv, self.kv_block_size, d)             # layer-major block pools
+            self._kv = BlockPool(nblk, self.kv_block_size, MB, bps)
+            self._kv_dynamic = nblk < MB * bps
+        else:
+            kv_shape = (MB, L, plan.nkv, self.max_ctx, d)                     # slot-major: one contiguous cache per sequence
         B = {
-            "kv_k": torch.zeros((MB, L, plan.nkv, self.max_ctx, d), **f32),      # slot-major: one cache per sequence
-            "kv_v": torch.zeros((MB, L, plan.nkv, self.max_ctx, d), **f32),
+            "kv_k": torch.zeros(kv_shape, **f32),
+            "kv_v": torch.zeros(kv_shape, **f32),
+            "kv_table": torch.zeros((MB, self.max_ctx // self.kv_block_size), dtype=torch.int32, device=dev) if self.kv_block_size else None,
             "x": torch.zeros((self.t_max, H), **f32), "xn": torch.zeros((self.t_max, H), **f32),
             "qkv": torch.zeros((self.t_max, qkv_n), **f32), "attn": torch.zeros((self.t_max, plan.nq * d), **f32),
             "act": torch.zeros((self.t_max, plan.inter), **f32), "delta": torch.zeros((self.t_max, H), **f32),
@@ -331,6 +356,11 @@ class ChatTSForCausalLM:
         B["pos"], B["step"], B["token"], B["token_logit"] = B["pos_all"][:1], B["step_all"][:1], B["token_all"][:1], B["token_logit_all"][:1]
         B["out_tokens"] = B["out_tokens_all"][0]
         self.buf = B
+        if self._kv is not None and not self._kv_dynamic:       # a full pool: every slot owns max_ctx positions for good
+            for sl in range(MB):
+                self._kv.reserve(sl, self.max_ctx)
+                self._kv.retire(sl)
+                self._push_kv_row(sl)
         arr = (_lib.LayerWeights * L)()
         for i, lw in enumerate(self.layers):
             arr[i] = _lib.LayerWeights(input_norm=_lib.ptr(lw["input_norm"]), qkv=_lib.ptr(lw["qkv"]),
@@ -358,7 +388,10 @@ class ChatTSForCausalLM:
                                  max_batch=self.max_batch, planes_hi=_lib.ptr(B["planes"][0]),
                                  planes_lo=_lib.ptr(B["planes"][1]), planes2_hi=_lib.ptr(B["planes"][2]),
                                  planes2_lo=_lib.ptr(B["planes"][3]), tp_pair_logit=_lib.ptr(B["tp_pair_logit"]),
-                                 tp_pair_token=_lib.ptr(B["tp_pair_token"]), logits_full=_lib.ptr(B["logits_full"]))
+                                 tp_pair_token=_lib.ptr(B["tp_pair_token"]), logits_full=_lib.ptr(B["logits_full"]),
+                                 kv_block_table=_lib.ptr(B["kv_table"]), kv_block_size=self.kv_block_size,
+                                 kv_table_stride=(self.max_ctx // self.kv_block_size) if self.kv_block_size else 0,
+                                 kv_pool_blocks=self._kv.n_blocks if self._kv is not None else 0)
         h = lib.chatts_decoder_create(C.byref(dc), C.byref(dw), C.byref(db))
         if not h:
             raise _lib.ChattsError(-1, lib.chatts_last_error().decode())
@@ -543,6 +576,50 @@ class ChatTSForCausalLM:
         if pending:
             _lib.check(lib.chatts_residual_add(_lib.ptr(self.buf["x"]), _lib.ptr(delta), T * H, st))
 
+    # ---- block-paged KV cache: host bookkeeping (chatts_amd/kv_blocks.py) ------------------------------------------------
+    def _push_kv_row(self, slot):
+        row = self._kv.rows[slot]
+        if row:                                  # stream-ordered: kernels enqueued after this see the new row
+            self.buf["kv_table"][slot, :len(row)] = torch.tensor(row, dtype=torch.int32)
+
+    def _kv_evicted(self, victim):
+        self._slot_idents[victim] = []           # nothing is resident there any more (its stale table row is never read: parked)
+
+    def reserve_kv(self, slot, n_tokens, idents=None, protect=()):
+        """Make cache slot `slot` able to hold n_tokens positions (no-op with a contiguous cache or a full pool) and mark it
+        active.  The slot whose resident prefix `idents` would be copied from is protected from eviction, like `protect`.
+        Raises kv_blocks.KvPoolExhausted when even evicting every finished sequence does not free enough blocks."""
+        if self._kv is None:
+            return
+        if n_tokens > self.max_ctx:
+            raise ValueError(f"{n_tokens} positions exceed max_ctx={self.max_ctx}")
+        keep = set(protect)
+        if idents is not None and self.enable_prefix_caching:
+            n, src = self._match_prefix(slot, idents)
+            if src >= 0 and n >= 16:
+                keep.add(src)
+        order = sorted(range(self.max_batch), key=lambda sl: len(self._slot_idents[sl]))       # least resident first
+        if self._kv.reserve(slot, n_tokens, protect=keep, evict_order=order, on_evict=self._kv_evicted):
+            self._push_kv_row(slot)
+
+    def kv_fits(self, token_counts):
+        """could requests needing these many positions (prompt + new tokens each) be admitted into free slots now?"""
+        return self._kv is None or self._kv.fits(token_counts)
+
+    def request_tokens(self, ids, series=None, lengths=None):
+        """expanded prompt length of a request (host arithmetic when the series lengths are known)"""
+        ps = self.config.ts["patch_size"]
+        if series is not None and series.shape[0] > 0 and lengths is None:
+            lengths = self.ts_encoder.get_patch_cnt(series.to(self.device, dtype=torch.float32))[0].tolist()
+        counts = [(int(v) + ps - 1) // ps for v in (lengths or [])]
+        return len(self.expand_input_ids(list(ids), counts))
+
+    def kv_stats(self):
+        if self._kv is None:
+            return None
+        return {"block_size": self._kv.block_size, "blocks": self._kv.n_blocks, "free": len(self._kv.free),
+                "active_slots": len(self._kv.active), "evictions": self._kv.evictions, "dynamic": self._kv_dynamic}
+
     def reset(self):
         self.buf["pos"].zero_()
         self.buf["step"].zero_()
@@ -555,6 +632,8 @@ class ChatTSForCausalLM:
         T = inputs_embeds.shape[0]
         if pos0 + T > self.max_ctx:
             raise ValueError(f"sequence of {pos0 + T} tokens exceeds max_ctx={self.max_ctx}")
+        if self._kv_dynamic and self._kv.capacity_tokens(self._cur_slot) < pos0 + T:
+            self.reserve_kv(self._cur_slot, pos0 + T)        # direct callers; generate_* reserve prompt + new tokens up front
         fast_last = for_next_token and self.plan.world == 1
         done, last = 0, 0
         while done < T:
@@ -673,6 +752,7 @@ class ChatTSForCausalLM:
     # ---------------------------------------------------------------------------------------------
     def select_sequence(self, slot):
         _lib.check(self.lib.chatts_decoder_select_sequence(self._decoder, int(slot)))
+        self._cur_slot = int(slot)
 
     def _n_splits_batched(self):
         """16-key slots per sequence of the batched decode attention: with many sequences in flight the grid is full anyway and
@@ -782,8 +862,17 @@ class ChatTSForCausalLM:
             return 0
         if src != slot:
             B = self.buf
-            B["kv_k"][slot, :, :, :n].copy_(B["kv_k"][src, :, :, :n])
-            B["kv_v"][slot, :, :, :n].copy_(B["kv_v"][src, :, :, :n])
+            if self._kv is not None:             # paged: whole blocks, pool to pool (the rows past n are overwritten by the prefill)
+                nb = self._kv.blocks_for(n)
+                if len(self._kv.rows[slot]) < nb or len(self._kv.rows[src]) < nb:
+                    return 0                     # (not reserved by the caller: recompute rather than touch foreign blocks)
+                si = torch.tensor(self._kv.rows[src][:nb], dtype=torch.int64, device=self.device)
+                di = torch.tensor(self._kv.rows[slot][:nb], dtype=torch.int64, device=self.device)
+                B["kv_k"].index_copy_(1, di, B["kv_k"].index_select(1, si))
+                B["kv_v"].index_copy_(1, di, B["kv_v"].index_select(1, si))
+            else:
+                B["kv_k"][slot, :, :, :n].copy_(B["kv_k"][src, :, :, :n])
+                B["kv_v"][slot, :, :, :n].copy_(B["kv_v"][src, :, :, :n])
         self.prefix_stats["hits"] += 1
         self.prefix_stats["tokens_reused"] += n
         return n
@@ -793,6 +882,8 @@ class ChatTSForCausalLM:
         the slot - a follow-up turn that re-sends prompt + answer reuses them."""
         if self.enable_prefix_caching and tokens:
             self._slot_idents[slot] = self._slot_idents[slot] + [int(t) for t in tokens[:-1]]
+        if self._kv is not None:
+            self._kv.retire(slot)                # blocks stay resident for prefix reuse; evictable from now on
 
     def pick_slot(self, free_slots, idents=None):
         """Which free cache slot a new request should take: the one whose resident prefix matches best (zero copy), else the
@@ -828,6 +919,7 @@ class ChatTSForCausalLM:
             raise ValueError(f"prompt ({T}) + max_new_tokens ({max_new_tokens}) exceeds max_ctx={self.max_ctx}")
         emb = self.get_input_embeddings(torch.tensor(full, dtype=torch.int64), mm)
         idents = self._token_idents(full, series, lengths, counts, cfg.ts_token_start_index)
+        self.reserve_kv(slot, T + max_new_tokens, idents)
         n0 = self._reuse_prefix(slot, idents, T)
         self._slot_idents[slot] = idents
         self.prefix_stats["tokens_prefilled"] += T - n0
@@ -922,6 +1014,7 @@ class ChatTSForCausalLM:
             idents = self._token_idents(full, series, lengths, counts, cfg.ts_token_start_index)
             # reuse from ANY slot, the member's own and other members' included: every K/V row copy is enqueued here, i.e. before
             # the packed pass overwrites anything; a slot stops being a source once its member has been processed (idents cleared)
+            self.reserve_kv(slot, T + max_new, idents, protect=slots)
             n0 = self._reuse_prefix(slot, idents, T)
             self._slot_idents[slot] = []
             if row + T - n0 > self.t_max:                    # an earlier member's copy took away the prefix this one counted on
@@ -983,6 +1076,9 @@ class ChatTSForCausalLM:
                 free = [i for i, v in enumerate(slots) if v is None]
                 cands = waiting[::-1][:len(free)]            # the next requests in arrival order
                 pack = self.plan_pack([requests[r] + (max_new_tokens,) for r in cands], free)
+                if pack and self._kv_dynamic and not self.kv_fits(
+                        [self.request_tokens(*requests[cands[j]]) + max_new_tokens for j in pack]):
+                    pack = []                                # the block pool cannot take them all at once: one at a time
                 if pack:                                     # several short prompts: one packed prefill pass
                     items = []
                     for j in pack:
@@ -995,8 +1091,13 @@ class ChatTSForCausalLM:
                         waiting.remove(r)
                     self._admit_packed(items)
                     continue
+                ids, series, lengths = requests[waiting[-1]]
+                if self._kv_dynamic and not self.kv_fits([self.request_tokens(ids, series, lengths) + max_new_tokens]):
+                    if all(v is None for v in slots):        # nothing left to finish and free blocks: it can never fit
+                        from .kv_blocks import KvPoolExhausted
+                        raise KvPoolExhausted(f"request {waiting[-1]} needs more KV blocks than the pool holds ({self.kv_stats()})")
+                    break                                    # wait until a running sequence finishes and its blocks become evictable
                 r = waiting.pop()
-                ids, series, lengths = requests[r]
                 s = self.pick_slot(free, self._request_idents(ids, series, lengths))
                 self._admit(s, ids, series, lengths, max_new_tokens)
                 slots[s], produced[s] = r, 1
@@ -1101,6 +1202,7 @@ class ChatTSForCausalLM:
             raise ValueError(f"prompt ({T}) + max_new_tokens ({max_new_tokens}) exceeds max_ctx={self.max_ctx}")
         emb = self.get_input_embeddings(torch.tensor(full, dtype=torch.int64), mm)
         idents = self._token_idents(full, series, lengths, counts, cfg.ts_token_start_index)
+        self.reserve_kv(0, T + max_new_tokens, idents)
         n0 = self._reuse_prefix(0, idents, T)
         self._slot_idents[0] = idents
         self.prefix_stats["tokens_prefilled"] += T - n0

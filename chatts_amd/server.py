@@ -236,14 +236,15 @@ def create_app(engine_thread, tokenizer, served_model_name="chatts", limit_times
 
 
 def build_server(model, tensor_parallel_size=1, max_model_len=6000, max_num_seqs=1, seed=0, tokenizer=None,
-                 served_model_name="chatts", limit_timeseries=15):
+                 served_model_name="chatts", limit_timeseries=15, block_size=None, num_gpu_blocks_override=None):
     """LLM (model + processor) -> Engine -> EngineThread -> FastAPI app.
     Tensor parallel (one process per GPU under torchrun, process group initialised): rank 0 gets the app, the other ranks get
     None after serving as followers until the leader shuts down (engine.follow)."""
     from .engine import ControlPlane, Engine, EngineThread, follow
     from .llm import LLM
     llm = LLM(model, tensor_parallel_size=tensor_parallel_size, max_model_len=max_model_len, max_num_seqs=max_num_seqs, seed=seed,
-              tokenizer=tokenizer, limit_mm_per_prompt={"timeseries": limit_timeseries})
+              tokenizer=tokenizer, limit_mm_per_prompt={"timeseries": limit_timeseries}, block_size=block_size,
+              num_gpu_blocks_override=num_gpu_blocks_override)
     control = ControlPlane.create() if tensor_parallel_size > 1 else None
     engine = Engine(llm.model, llm.processor)
     if control is not None and control.rank != 0:
@@ -266,6 +267,10 @@ def main():
     ap.add_argument("--tensor-parallel-size", type=int, default=1)
     ap.add_argument("--limit-mm-per-prompt", default="timeseries=15")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--block-size", type=int, default=None, help="block-paged KV cache: positions per block (power of two >= 64); "
+                    "default: one contiguous cache per sequence slot")
+    ap.add_argument("--num-gpu-blocks-override", type=int, default=None, help="with --block-size: blocks in the pool (fewer than "
+                    "max-num-seqs x max-model-len / block-size oversubscribes the slots)")
     args = ap.parse_args()
     limit = int(dict(kv.split("=") for kv in args.limit_mm_per_prompt.split(",")).get("timeseries", 15))
     import uvicorn
@@ -280,7 +285,8 @@ def main():
         backend = os.environ.get("CHATTS_DIST_BACKEND", "nccl")
         dist.init_process_group(backend=backend, **({"device_id": torch.device(f"cuda:{dev}")} if backend == "nccl" else {}))
     app = build_server(args.model, args.tensor_parallel_size, args.max_model_len, args.max_num_seqs, args.seed,
-                       served_model_name=args.served_model_name, limit_timeseries=limit)
+                       served_model_name=args.served_model_name, limit_timeseries=limit, block_size=args.block_size,
+                       num_gpu_blocks_override=args.num_gpu_blocks_override)
     if app is None:
         return                                   # a follower rank: the leader has shut down
     try:

@@ -36,7 +36,7 @@ const char* chatts_last_error(void);
 /* ABI version of this header: bumped whenever a struct grows or a signature changes
  * (2: plane operands, sampler, decoder plane buffers; 3: post-norm planes of chatts_linear;
  *  4: tensor-parallel exchange chatts_tp_* / chatts_allreduce, decoder embed_rows + TP buffers, chatts_decoder_select_tokens). */
-#define CHATTS_ABI_VERSION 4
+#define CHATTS_ABI_VERSION 5
 int chatts_abi_version(void);
 /* Number of CUs of the current device (grid sizing), or <0. */
 int chatts_device_cus(void);
@@ -217,7 +217,15 @@ int chatts_rmsnorm_planes(const float* x, const float* w, chatts_bf16* hi, chatt
 typedef struct ChattsKvCache {
   float* k;                /* [n_kv, max_ctx, 128] float32 of ONE layer of ONE sequence */
   float* v;
-  int max_ctx;
+  int max_ctx;             /* positions the sequence may reach */
+  /* Block-paged form (the vLLM engine's KV layout), selected by block_table != NULL: k / v then
+   * point at ONE layer's block POOL [n_blocks, n_kv, block_size, 128] shared by all sequences, and position j of this
+   * sequence lives in block block_table[j / block_size], row j % block_size.  block_size: a power of two, 64..32768;
+   * max_ctx must be a multiple of it; the table holds max_ctx / block_size entries (entries past the sequence's length are
+   * never read).  Batched entry points: sequence b uses block_table + b * table_stride and seq_stride is ignored. */
+  const int32_t* block_table;
+  int block_size;
+  int table_stride;
 } ChattsKvCache;
 
 /* In-place on qkv [T, (n_q+2*n_kv)*128] (after bias): optional per-head RMSNorm of q and k (Qwen3
@@ -405,7 +413,7 @@ typedef struct ChattsDecoderWeights {
 } ChattsDecoderWeights;
 
 typedef struct ChattsDecoderBuffers {
-  float* kv_k;        /* [n_layers, n_kv, max_ctx, 128] */
+  float* kv_k;        /* [n_layers, n_kv, max_ctx, 128] per sequence (or block pools, see kv_block_table below) */
   float* kv_v;
   float* x;           /* [T_max, H] residual stream */
   float* xn;          /* [T_max, H] normed scratch (prefill) */
@@ -430,6 +438,14 @@ typedef struct ChattsDecoderBuffers {
   float* tp_pair_logit;    /* [max(max_batch,1)] */
   int64_t* tp_pair_token;  /* [max(max_batch,1)] */
   float* logits_full;      /* or NULL: sampling under TP is then refused */
+  /* block-paged KV cache (optional; ChattsKvCache's paged form): when kv_block_table != NULL, kv_k / kv_v are block pools
+   * [n_layers, kv_pool_blocks, n_kv, kv_block_size, 128] and sequence (cache slot) s reads its blocks from
+   * kv_block_table[s * kv_table_stride ...] (int32, device memory, max_ctx / kv_block_size entries used; the caller keeps the
+   * table current - a captured decode graph reads it at replay time). */
+  const int32_t* kv_block_table;
+  int kv_block_size;
+  int kv_table_stride;
+  int kv_pool_blocks;
 } ChattsDecoderBuffers;
 
 typedef struct ChattsDecoder ChattsDecoder;  /* opaque; host memory only */

@@ -632,3 +632,76 @@ def test_inference_drivers_answer_an_eval_set(tmp_path):
                                                          [np.asarray(s) for s in (recs[i]["timeseries"] or [])])[0]))
         assert m["num_tokens"] == n_series_tokens + n_prompt
         assert isinstance(m["response"], str)
+
+
+def _paged_requests(cfg, proc, rng, shapes):
+    reqs = []
+    for lengths in shapes:
+        series = [random_walk_series(rng, L) for L in lengths]
+        inp = proc(text=[chat_prompt(lengths)], timeseries=series, return_tensors="pt") if lengths else \
+            proc(text=["<|im_start|>user\nNo series here, just words to fill a few tokens.<|im_end|><|im_start|>assistant\n"],
+                 timeseries=[], return_tensors="pt")
+        reqs.append((inp["input_ids"][0].tolist(), inp["timeseries"] if lengths else None, list(lengths) if lengths else None))
+    return reqs
+
+
+@pytest.mark.parametrize("preset,block", [("tiny-qwen2", 64), ("tiny-qwen3", 128)])
+def test_paged_kv_cache_equals_contiguous(preset, block):
+    """kv_block_size: the same tokens and logits, bit for bit, whether a sequence's K/V rows sit in one contiguous cache or in
+    64 / 128-position blocks of a pool (single-sequence path incl. chunked prefill + decode graph, batched path incl. packed
+    prefill and prefix reuse)."""
+    cfg = cfgmod.preset(preset)
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(21)
+    reqs = _paged_requests(cfg, proc, rng, [[256, 64], [40], [], [100, 17, 64], [40]])
+    kw = dict(seed=4, max_ctx=700, max_prefill_tokens=96)          # 96-row chunks: the long prompt prefills in several passes
+    a = ChatTSForCausalLM.from_synthetic(cfg, **kw)
+    b = ChatTSForCausalLM.from_synthetic(cfg, kv_block_size=block, **kw)
+    assert b.max_ctx % block == 0 and b.max_ctx >= 700 and b.kv_stats()["dynamic"] is False
+    for ids, ser, lens in reqs[:2]:
+        ta, la = a.generate_one(ids, ser, lens, 10, return_logits=True)
+        tb, lb = b.generate_one(ids, ser, lens, 10, return_logits=True)
+        assert ta == tb and torch.equal(la, lb)
+    kw = dict(seed=4, max_ctx=700, max_prefill_tokens=512, max_batch=3)
+    a = ChatTSForCausalLM.from_synthetic(cfg, **kw)
+    b = ChatTSForCausalLM.from_synthetic(cfg, kv_block_size=block, **kw)
+    ra, rb = a.generate_batch(reqs, 9), b.generate_batch(reqs, 9)
+    assert ra == rb
+    assert a.prefix_stats == b.prefix_stats and b.prefix_stats["hits"] >= 1       # request 4 repeats request 1
+    assert b._kv.check()
+
+
+def test_paged_kv_oversubscribed_pool_waits_and_evicts():
+    """kv_pool_blocks below max_batch x max_ctx / block: requests reserve prompt + max_new_tokens at admission, wait while the
+    pool cannot cover them, and finished sequences' blocks are evicted for newcomers.  Tokens equal the one-at-a-time run."""
+    from chatts_amd.kv_blocks import KvPoolExhausted
+    cfg = cfgmod.preset("tiny-qwen2")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(33)
+    shapes = [[256, 64], [40], [100, 17, 64], [64], [], [256], [30, 30], [128]]
+    reqs = _paged_requests(cfg, proc, rng, shapes)
+    ref = ChatTSForCausalLM.from_synthetic(cfg, seed=6, max_ctx=512, max_prefill_tokens=512, enable_prefix_caching=False)
+    want = [ref.generate_one(i, s, l, 7) for i, s, l in reqs]
+    # 4 slots x 8 blocks would be 32; 7 blocks hold at most ~2-3 of these requests at a time
+    m = ChatTSForCausalLM.from_synthetic(cfg, seed=6, max_ctx=512, max_prefill_tokens=512, max_batch=4, kv_block_size=64, kv_pool_blocks=7)
+    assert m.kv_stats()["dynamic"] and m.kv_stats()["free"] == 7
+    got = m.generate_batch(reqs, 7)
+    assert got == want
+    st = m.kv_stats()
+    assert st["evictions"] >= 1 and st["active_slots"] == 0 and m._kv.check()
+    # a request that can never fit (8 blocks needed, 7 exist) is refused, not deadlocked
+    big = _paged_requests(cfg, proc, rng, [[256, 256, 256, 256]])[0]
+    assert 7 * 64 < m.request_tokens(*big) + 60 <= m.max_ctx
+    with pytest.raises(KvPoolExhausted):
+        m.generate_batch([big], 60)
+    # the serving engine on the same pool
+    from chatts_amd.engine import Engine
+    eng = Engine(m, proc)
+    outs = {}
+    rng2 = np.random.default_rng(33)
+    for k, lengths in enumerate(shapes):
+        series = [random_walk_series(rng2, L) for L in lengths]
+        prompt = chat_prompt(lengths) if lengths else "<|im_start|>user\nNo series here, just words to fill a few tokens.<|im_end|><|im_start|>assistant\n"
+        eng.add_request(prompt, series, max_tokens=7, ignore_eos=True, on_tokens=lambda r, new, fin, k=k: outs.setdefault(k, []).extend(new))
+    eng.run_until_done()
+    assert [outs[k] for k in range(len(shapes))] == want and m._kv.check()

@@ -957,3 +957,150 @@ def test_attention_prefill_bf16x3_parity(lib, monkeypatch, nq, nkv, T, pos0, spl
     assert not np.isnan(outs["1"]).any()
     assert rel_err(outs["1"], want.numpy()) < 3e-5
     assert rel_err(outs["1"], outs["0"]) < 3e-5
+
+
+# ---- block-paged KV cache (ChattsKvCache.block_table): same arithmetic, blocks scattered through a pool -------------------------
+def _to_pool(kc, vc, block, seed, spare=3):
+    """contiguous [nkv, max_ctx, 128] caches -> (pool_k, pool_v [n_blocks, nkv, block, 128], table [max_ctx / block] int32) with the
+    logical blocks at shuffled pool positions; the spare blocks hold NaN (nothing may ever read them)"""
+    nkv, max_ctx, _ = kc.shape
+    nb = max_ctx // block
+    ids = torch.randperm(nb + spare, generator=torch.Generator().manual_seed(seed))[:nb]
+    pk = torch.full((nb + spare, nkv, block, 128), float("nan"), device=kc.device)
+    pv = torch.full((nb + spare, nkv, block, 128), float("nan"), device=kc.device)
+    for i, b in enumerate(ids.tolist()):
+        pk[b] = kc[:, i * block:(i + 1) * block]
+        pv[b] = vc[:, i * block:(i + 1) * block]
+    return pk, pv, ids.to(torch.int32).to(kc.device)
+
+
+def _from_pool(pool, table, block):
+    return torch.cat([pool[int(b)] for b in table.tolist()], dim=1)        # -> [nkv, max_ctx, 128]
+
+
+@pytest.mark.parametrize("block", [64, 256])
+@pytest.mark.parametrize("bf16x3", ["0", "1"])
+@pytest.mark.parametrize("T,pos0,splits", [(1, 0, 1), (1, 333, 16), (7, 60, 1), (70, 0, 1), (65, 31, 1), (130, 100, 2), (200, 300, 1)])
+def test_attention_paged_equals_contiguous(lib, monkeypatch, block, bf16x3, T, pos0, splits):
+    """chatts_attention (VALU rows kernel, float32-MFMA and bf16x3 prefill kernels) through a shuffled block table == the
+    contiguous cache, bit for bit"""
+    monkeypatch.setenv("CHATTS_ATTN_BF16X3", bf16x3)
+    nq, nkv, max_ctx = 10, 2, 512
+    g = torch.Generator().manual_seed(T * 31 + pos0)
+    qkv = torch.randn((T, (nq + 2 * nkv) * 128), generator=g).to(DEV)
+    kc = torch.randn((nkv, max_ctx, 128), generator=g).to(DEV)
+    vc = torch.randn((nkv, max_ctx, 128), generator=g).to(DEV)
+    kc[:, pos0 + T:] = float("nan")                    # rows past the context must not be touched in either form
+    vc[:, pos0 + T:] = float("nan")
+    wsb = int(lib.chatts_attn_workspace(T, nq, splits))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    out_a = torch.full((T, nq * 128), float("nan"), device=DEV)
+    ca = _lib.KvCache(k=kc.data_ptr(), v=vc.data_ptr(), max_ctx=max_ctx)
+    _lib.check(lib.chatts_attention(qkv.data_ptr(), T, nq, nkv, pos0, None, C.byref(ca), out_a.data_ptr(), splits, ws.data_ptr(), wsb, st()))
+    pk, pv, table = _to_pool(kc, vc, block, seed=T + block)
+    out_b = torch.full((T, nq * 128), float("nan"), device=DEV)
+    cb = _lib.KvCache(k=pk.data_ptr(), v=pv.data_ptr(), max_ctx=max_ctx, block_table=table.data_ptr(), block_size=block,
+                      table_stride=table.numel())
+    _lib.check(lib.chatts_attention(qkv.data_ptr(), T, nq, nkv, pos0, None, C.byref(cb), out_b.data_ptr(), splits, ws.data_ptr(), wsb, st()))
+    torch.cuda.synchronize()
+    assert not torch.isnan(out_a).any() and torch.equal(out_a, out_b)
+
+
+def test_paged_cache_argument_errors(lib):
+    kc = torch.zeros((2, 192, 128), device=DEV)
+    table = torch.zeros(3, dtype=torch.int32, device=DEV)
+    q = torch.zeros((1, 6 * 128), device=DEV)
+    out = torch.zeros((1, 2 * 128), device=DEV)
+    ws = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    for bs, ctx in ((48, 192), (32, 192), (64, 200)):       # not a power of two / below 64 / max_ctx not whole blocks
+        c = _lib.KvCache(k=kc.data_ptr(), v=kc.data_ptr(), max_ctx=ctx, block_table=table.data_ptr(), block_size=bs, table_stride=3)
+        assert lib.chatts_attention(q.data_ptr(), 1, 2, 2, 0, None, C.byref(c), out.data_ptr(), 1, ws.data_ptr(), 4096, st()) == _lib.E_BADARG
+        cos, sin = _rope_tables(8)
+        assert lib.chatts_rope_kv_write(q.data_ptr(), 1, 2, 2, None, None, 1e-6, cos.data_ptr(), sin.data_ptr(), 0, None, C.byref(c),
+                                        st()) == _lib.E_BADARG
+
+
+@pytest.mark.parametrize("qk_norm", [False, True])
+def test_rope_kv_write_paged(lib, qk_norm):
+    T, nq, nkv, pos0, max_ctx, block = 150, 4, 2, 37, 256, 64         # the rows straddle three blocks
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn((T, (nq + 2 * nkv) * 128), generator=g).to(DEV)
+    qn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV) if qk_norm else None
+    kn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV) if qk_norm else None
+    cos, sin = _rope_tables(max_ctx)
+    kc = torch.randn((nkv, max_ctx, 128), generator=g).to(DEV)
+    vc = torch.randn((nkv, max_ctx, 128), generator=g).to(DEV)
+    pk, pv, table = _to_pool(kc, vc, block, seed=11)
+    qa, qb = qkv.clone(), qkv.clone()
+    ca = _lib.KvCache(k=kc.data_ptr(), v=vc.data_ptr(), max_ctx=max_ctx)
+    cb = _lib.KvCache(k=pk.data_ptr(), v=pv.data_ptr(), max_ctx=max_ctx, block_table=table.data_ptr(), block_size=block,
+                      table_stride=table.numel())
+    for q, c in ((qa, ca), (qb, cb)):
+        _lib.check(lib.chatts_rope_kv_write(q.data_ptr(), T, nq, nkv, _lib.ptr(qn), _lib.ptr(kn), 1e-6, cos.data_ptr(), sin.data_ptr(),
+                                            pos0, None, C.byref(c), st()))
+    torch.cuda.synchronize()
+    assert torch.equal(qa, qb)
+    assert torch.equal(_from_pool(pk, table, block), kc) and torch.equal(_from_pool(pv, table, block), vc)
+    spare = [b for b in range(pk.shape[0]) if b not in table.tolist()]
+    assert torch.isnan(pk[spare]).all()                 # blocks outside the table were not written
+
+
+@pytest.mark.parametrize("block", [64, 128])
+def test_attention_decode_batched_paged_equals_contiguous(lib, block):
+    """batched fused decode attention: every sequence reads and writes through its own row of the block table"""
+    nq, nkv, max_ctx, B, splits = 10, 2, 256, 5, 16
+    g = torch.Generator().manual_seed(77)
+    raw = torch.randn((B, (nq + 2 * nkv) * 128), generator=g).to(DEV)
+    kc0 = torch.randn((B, nkv, max_ctx, 128), generator=g).to(DEV)
+    vc0 = torch.randn((B, nkv, max_ctx, 128), generator=g).to(DEV)
+    pos = [0, 63, 64, 200, -1]                          # block edges, and a parked slot
+    qn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV)
+    kn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV)
+    cos, sin = _rope_tables(max_ctx)
+    wsb = int(lib.chatts_attn_workspace(B, nq, splits))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    pos_dev = torch.tensor(pos, dtype=torch.int32, device=DEV)
+    ka, va = kc0.clone(), vc0.clone()
+    ca = _lib.KvCache(k=ka.data_ptr(), v=va.data_ptr(), max_ctx=max_ctx)
+    out_a = torch.zeros((B, nq * 128), device=DEV)
+    _lib.check(lib.chatts_attention_decode_batched(raw.data_ptr(), B, nq, nkv, qn.data_ptr(), kn.data_ptr(), 1e-6, cos.data_ptr(),
+                                                   sin.data_ptr(), 0, pos_dev.data_ptr(), C.byref(ca), nkv * max_ctx * 128,
+                                                   out_a.data_ptr(), splits, ws.data_ptr(), wsb, st()))
+    torch.cuda.synchronize()
+    # one pool for all sequences: sequence b's logical blocks are interleaved with the others'
+    nb = max_ctx // block
+    order = torch.randperm(B * nb, generator=g)
+    table = order.view(B, nb).to(torch.int32).to(DEV)
+    pk = torch.empty((B * nb, nkv, block, 128), device=DEV)
+    pv = torch.empty((B * nb, nkv, block, 128), device=DEV)
+    for b in range(B):
+        for i in range(nb):
+            pk[int(table[b, i])] = kc0[b, :, i * block:(i + 1) * block]
+            pv[int(table[b, i])] = vc0[b, :, i * block:(i + 1) * block]
+    cb = _lib.KvCache(k=pk.data_ptr(), v=pv.data_ptr(), max_ctx=max_ctx, block_table=table.data_ptr(), block_size=block, table_stride=nb)
+    out_b = torch.zeros((B, nq * 128), device=DEV)
+    _lib.check(lib.chatts_attention_decode_batched(raw.data_ptr(), B, nq, nkv, qn.data_ptr(), kn.data_ptr(), 1e-6, cos.data_ptr(),
+                                                   sin.data_ptr(), 0, pos_dev.data_ptr(), C.byref(cb), 0,
+                                                   out_b.data_ptr(), splits, ws.data_ptr(), wsb, st()))
+    torch.cuda.synchronize()
+    live = [b for b in range(B) if pos[b] >= 0]
+    assert torch.equal(out_a[live], out_b[live])
+    for b in range(B):
+        assert torch.equal(_from_pool(pk, table[b], block), ka[b]) and torch.equal(_from_pool(pv, table[b], block), va[b])
+    # the "parts" form of the same kernel (its consumer is o_proj; compare the raw partials)
+    for parts in (1, 2):
+        wsp = int(lib.chatts_attn_workspace(1, nq, parts))
+        w_a = torch.zeros(wsp, dtype=torch.uint8, device=DEV)
+        w_b = torch.zeros(wsp, dtype=torch.uint8, device=DEV)
+        b = 3
+        ka1, va1 = kc0[b].clone(), vc0[b].clone()
+        c1 = _lib.KvCache(k=ka1.data_ptr(), v=va1.data_ptr(), max_ctx=max_ctx)
+        pk2, pv2 = pk.clone(), pv.clone()
+        c2 = _lib.KvCache(k=pk2.data_ptr(), v=pv2.data_ptr(), max_ctx=max_ctx, block_table=table[b].contiguous().data_ptr(),
+                          block_size=block, table_stride=nb)
+        for cch, wbuf in ((c1, w_a), (c2, w_b)):
+            _lib.check(lib.chatts_attention_decode_parts(raw[b:b + 1].contiguous().data_ptr(), 1, nq, nkv, qn.data_ptr(), kn.data_ptr(), 1e-6,
+                                                         cos.data_ptr(), sin.data_ptr(), pos[b], None, C.byref(cch), 0, parts,
+                                                         wbuf.data_ptr(), wsp, st()))
+        torch.cuda.synchronize()
+        assert torch.equal(w_a, w_b)
