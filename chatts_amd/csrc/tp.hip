@@ -27,6 +27,10 @@ namespace chatts {
 
 constexpr int kMaxWorld = 8;
 constexpr uint64_t kSpinTicks = 200000000ull;      // wall_clock64 runs at 100 MHz: 2 s
+constexpr uint64_t kSpinTicksBroken = 2000ull;     // 20 us once a timeout has been recorded
+// A communicator that has timed out once is broken until chatts_tp_reset: a step holds ~100 collectives, and each of them
+// waiting its own 2 s would keep the GPU busy for minutes before the host reads the status at its next sync point.
+__device__ __forceinline__ uint64_t spin_limit(const uint32_t* status) { return *status ? kSpinTicksBroken : kSpinTicks; }
 
 struct TpParams {
   uint64_t* peer[kMaxWorld];   // peer[p]: rank p's exchange buffer as mapped in this process (peer[rank] = local)
@@ -50,7 +54,7 @@ __device__ __forceinline__ bool take(uint64_t* g, uint32_t epoch, uint32_t& bits
       __builtin_amdgcn_s_sleep(1);
       v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if ((uint32_t)(v >> 32) == epoch) break;
-      if (wall_clock64() - t0 > kSpinTicks) { atomicOr(status, 1u); bits = 0; return false; }
+      if (wall_clock64() - t0 > spin_limit(status)) { atomicOr(status, 1u); bits = 0; return false; }
     } while (true);
   }
   bits = (uint32_t)v;
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(1024) void tp_allreduce_kernel(TpParams p, const fl
           }
       if (pending) {
         if (t0 == 0) t0 = wall_clock64();
-        else if (wall_clock64() - t0 > kSpinTicks) { atomicOr(&p.ctr[2], 1u); break; }
+        else if (wall_clock64() - t0 > spin_limit(&p.ctr[2])) { atomicOr(&p.ctr[2], 1u); break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
