@@ -19,7 +19,9 @@
 //   * every spin is bounded (~2 s of the 100 MHz wall clock); a timeout sets a status word instead of hanging the GPU.
 #include <string.h>
 
+#include <mutex>
 #include <new>
+#include <vector>
 
 #include "common.h"
 
@@ -221,22 +223,50 @@ extern "C" size_t chatts_tp_buffer_bytes(int world, int64_t max_elems) {
   return (size_t)2 * world * per * sizeof(uint64_t) + 256;        // + the counter words at the end
 }
 
+// Exchange buffers are NEVER handed back to the driver while the process lives: a freed buffer goes to a free list and serves a
+// later chatts_tp_buffer_alloc.  Measured (round 2): after hipFree of a hipDeviceMallocUncached allocation, memory the driver
+// then hands to OTHER allocations (torch's next hipMalloc segment) misbehaved - kernels reading what earlier kernels of the same
+// stream had just written saw stale data until the next hipDeviceSynchronize (first model built after an exchange was closed:
+// logits off by 20 %; the same sequence with plain hipMalloc buffers, or with this free list: exact).  A long-lived server
+// allocates its buffer once; tests and notebooks that create and drop TP models repeatedly are what this protects.
+extern "C" int chatts_tp_buffer_free(void* dev_ptr);
+struct TpBufRec { void* ptr; size_t bytes; bool in_use; };
+static std::mutex g_buf_mu;
+static std::vector<TpBufRec> g_bufs;
+
 extern "C" int chatts_tp_buffer_alloc(size_t bytes, void** dev_ptr, uint8_t* handle /* [CHATTS_TP_HANDLE_BYTES] */) {
   CHATTS_REQUIRE(dev_ptr && bytes >= 512, CHATTS_E_BADARG, "tp_buffer_alloc: bad arguments");
   void* ptr = nullptr;
-  // fine-grained (uncached) device memory: remote stores and local polls must not sit in a non-coherent L2
-  hipError_t e = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocUncached);
-  if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocFinegrained); }
-  if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&ptr, bytes); }
-  CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "tp_buffer_alloc: %s", hipGetErrorString(e));
-  e = hipMemset(ptr, 0, bytes);
-  CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "tp_buffer_alloc: memset: %s", hipGetErrorString(e));
+  {
+    std::lock_guard<std::mutex> lk(g_buf_mu);
+    TpBufRec* best = nullptr;
+    for (auto& r : g_bufs)
+      if (!r.in_use && r.bytes >= bytes && (!best || r.bytes < best->bytes)) best = &r;
+    if (best) { best->in_use = true; ptr = best->ptr; }
+  }
+  hipError_t e = hipSuccess;
+  if (!ptr) {
+    // fine-grained (uncached) device memory: remote stores and local polls must not sit in a non-coherent L2
+    e = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&ptr, bytes); }
+    CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "tp_buffer_alloc: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(g_buf_mu);
+    g_bufs.push_back(TpBufRec{ptr, bytes, true});
+  }
+  e = hipMemset(ptr, 0, bytes);           // tags 0: no epoch ever matches what an earlier owner left behind
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)chatts_tp_buffer_free(ptr);
+    set_error("tp_buffer_alloc: memset: %s", hipGetErrorString(e));
+    return CHATTS_E_LAUNCH;
+  }
   if (handle) {
     static_assert(sizeof(hipIpcMemHandle_t) <= CHATTS_TP_HANDLE_BYTES, "IPC handle does not fit");
     hipIpcMemHandle_t h;
     e = hipIpcGetMemHandle(&h, ptr);
     if (e != hipSuccess) {
-      (void)hipFree(ptr);
+      (void)chatts_tp_buffer_free(ptr);
       set_error("tp_buffer_alloc: hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)", hipGetErrorString(e));
       return CHATTS_E_LAUNCH;
     }
@@ -248,8 +278,16 @@ extern "C" int chatts_tp_buffer_alloc(size_t bytes, void** dev_ptr, uint8_t* han
 }
 
 extern "C" int chatts_tp_buffer_free(void* dev_ptr) {
-  if (dev_ptr && hipFree(dev_ptr) != hipSuccess) { (void)hipGetLastError(); return CHATTS_E_LAUNCH; }
-  return CHATTS_OK;
+  if (!dev_ptr) return CHATTS_OK;
+  std::lock_guard<std::mutex> lk(g_buf_mu);
+  for (auto& r : g_bufs)
+    if (r.ptr == dev_ptr) {
+      CHATTS_REQUIRE(r.in_use, CHATTS_E_BADARG, "tp_buffer_free: buffer %p freed twice", dev_ptr);
+      r.in_use = false;                   // parked for the next chatts_tp_buffer_alloc; the driver gets it back at process exit
+      return CHATTS_OK;
+    }
+  set_error("tp_buffer_free: %p was not allocated by chatts_tp_buffer_alloc", dev_ptr);
+  return CHATTS_E_BADARG;
 }
 
 static ChattsTpComm* tp_make(int rank, int world, int64_t max_elems, size_t bytes) {

@@ -141,6 +141,9 @@ class Engine:
                 else:
                     m._admit(*items[0])
             except Exception as e:
+                if type(e).__name__ == "KvPoolExhausted" and any(v is not None for v in self.slots):
+                    self.waiting[0:0] = group            # the block pool is full (nothing was changed): back to the head of the
+                    break                                # queue until a running sequence finishes
                 for r in group:
                     r.error = e
                     self._emit(r, True, "error")

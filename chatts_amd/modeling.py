@@ -996,8 +996,20 @@ class ChatTSForCausalLM:
         free slots whose uncached rows fit max_prefill_tokens together (plan_pack).  Returns the prompt lengths."""
         cfg, B = self.config, self.buf
         ps = cfg.ts["patch_size"]
-        slots = [it[0] for it in items]
         segs, embs, Ts, row, late = [], [], [], 0, []
+        if self._kv_dynamic:        # oversubscribed block pool: reserve for EVERY member before anything changes, or for none
+            from .kv_blocks import KvPoolExhausted
+            newly = []
+            try:
+                for slot, ids, series, lengths, max_new in items:
+                    was_active = slot in self._kv.active
+                    self.reserve_kv(slot, self.request_tokens(ids, series, lengths) + max_new, self._request_idents(ids, series, lengths))
+                    if not was_active:
+                        newly.append(slot)
+            except KvPoolExhausted:
+                for sl in newly:
+                    self._kv.retire(sl)
+                raise
         for slot, ids, series, lengths, max_new in items:
             mm, counts = None, []
             if series is not None and series.shape[0] > 0:
@@ -1014,7 +1026,7 @@ class ChatTSForCausalLM:
             idents = self._token_idents(full, series, lengths, counts, cfg.ts_token_start_index)
             # reuse from ANY slot, the member's own and other members' included: every K/V row copy is enqueued here, i.e. before
             # the packed pass overwrites anything; a slot stops being a source once its member has been processed (idents cleared)
-            self.reserve_kv(slot, T + max_new, idents, protect=slots)
+            self.reserve_kv(slot, T + max_new, idents)       # (dynamic pool: already covered by the pre-pass above)
             n0 = self._reuse_prefix(slot, idents, T)
             self._slot_idents[slot] = []
             if row + T - n0 > self.t_max:                    # an earlier member's copy took away the prefix this one counted on
@@ -1080,16 +1092,23 @@ class ChatTSForCausalLM:
                         [self.request_tokens(*requests[cands[j]]) + max_new_tokens for j in pack]):
                     pack = []                                # the block pool cannot take them all at once: one at a time
                 if pack:                                     # several short prompts: one packed prefill pass
-                    items = []
+                    items, members = [], []
                     for j in pack:
                         r = cands[j]
                         ids, series, lengths = requests[r]
                         s = self.pick_slot(free, self._request_idents(ids, series, lengths))
                         free.remove(s)
                         items.append((s, ids, series, lengths, max_new_tokens))
+                        members.append((s, r))
+                    try:
+                        self._admit_packed(items)
+                    except RuntimeError as e:                # the pool could not cover the pack after all (a protected prefix
+                        if type(e).__name__ != "KvPoolExhausted" or all(v is None for v in slots):     # source): nothing was changed
+                            raise
+                        break
+                    for s, r in members:
                         slots[s], produced[s] = r, 1
                         waiting.remove(r)
-                    self._admit_packed(items)
                     continue
                 ids, series, lengths = requests[waiting[-1]]
                 if self._kv_dynamic and not self.kv_fits([self.request_tokens(ids, series, lengths) + max_new_tokens]):
@@ -1097,9 +1116,14 @@ class ChatTSForCausalLM:
                         from .kv_blocks import KvPoolExhausted
                         raise KvPoolExhausted(f"request {waiting[-1]} needs more KV blocks than the pool holds ({self.kv_stats()})")
                     break                                    # wait until a running sequence finishes and its blocks become evictable
-                r = waiting.pop()
                 s = self.pick_slot(free, self._request_idents(ids, series, lengths))
-                self._admit(s, ids, series, lengths, max_new_tokens)
+                try:
+                    self._admit(s, ids, series, lengths, max_new_tokens)
+                except RuntimeError as e:                    # (the reservation is _admit's first change: nothing to undo)
+                    if type(e).__name__ != "KvPoolExhausted" or all(v is None for v in slots):
+                        raise
+                    break
+                r = waiting.pop()
                 slots[s], produced[s] = r, 1
             if all(r is None or produced[s] >= max_new_tokens for s, r in enumerate(slots)):
                 harvest()

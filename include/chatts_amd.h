@@ -336,6 +336,8 @@ typedef struct ChattsTpComm ChattsTpComm;     /* opaque; host memory only */
 size_t chatts_tp_buffer_bytes(int world, int64_t max_elems);
 /* hipExtMallocWithFlags(uncached) + zero fill + (handle != NULL) hipIpcGetMemHandle into handle[CHATTS_TP_HANDLE_BYTES] */
 int chatts_tp_buffer_alloc(size_t bytes, void** dev_ptr, uint8_t* handle);
+/* Returns the buffer to the library's free list (a later chatts_tp_buffer_alloc re-uses it, zero-filled); the driver gets the
+ * memory back at process exit.  Uncached allocations are deliberately never hipFree'd mid-process: see csrc/tp.hip. */
 int chatts_tp_buffer_free(void* dev_ptr);
 /* handles: [world][CHATTS_TP_HANDLE_BYTES] in rank order (entry `rank` is ignored); maps every peer buffer (hipIpcOpenMemHandle). */
 ChattsTpComm* chatts_tp_init(int rank, int world, void* local_buf, const uint8_t* handles, size_t bytes, int64_t max_elems);

@@ -28,3 +28,18 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return load
+
+
+@pytest.fixture(autouse=True)
+def _collect_gpu_garbage(request):
+    """GPU tests: destroy what the test left behind (models, captured graphs, exchange buffers in reference cycles) at the test's
+    end, with the device idle - not at whatever allocation of a LATER test happens to trigger the collector."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import gc
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()

@@ -43,6 +43,7 @@ def _retry_if_peer_stalled(test):
             try:
                 return test(*a, **kw)
             except _PeerStalled:
+                print(f"[tp emulation] attempt {attempt}: a rank stalled, repeating on fresh streams", flush=True)
                 torch.cuda.synchronize()
                 _STREAMS.clear()
         pytest.skip("the two emulated ranks never ran concurrently in this process (3 attempts)")
@@ -155,6 +156,41 @@ def test_exchange_timeout_sets_status_instead_of_hanging():
             e.close()
 
 
+def test_exchange_buffers_are_recycled_not_freed():
+    """chatts_tp_buffer_free parks the (uncached) buffer for the next chatts_tp_buffer_alloc instead of hipFree: handing such
+    memory back to the driver mid-process left the NEXT model built in this process reading stale data (csrc/tp.hip).  The
+    recycled buffer comes back zero-filled; a double free and a foreign pointer are refused."""
+    import ctypes as C
+    lib = _lib.load()
+    n = int(lib.chatts_tp_buffer_bytes(2, 4096))
+    a = C.c_void_p()
+    _lib.check(lib.chatts_tp_buffer_alloc(n, C.byref(a), None))
+    view = torch.empty(0, dtype=torch.uint8, device="cuda")
+    # scribble over it through a throw-away exchange (the kernels own the layout), then free
+    exs = P2PExchange.create_local_group(1, 4096)
+    _lib.check(lib.chatts_tp_buffer_free(a))
+    assert lib.chatts_tp_buffer_free(a) == _lib.E_BADARG                      # double free
+    assert lib.chatts_tp_buffer_free(C.c_void_p(view.data_ptr() or 64)) == _lib.E_BADARG     # not ours
+    b = C.c_void_p()
+    _lib.check(lib.chatts_tp_buffer_alloc(n - 512, C.byref(b), None))          # a smaller request takes the parked buffer
+    assert b.value == a.value
+    _lib.check(lib.chatts_tp_buffer_free(b))
+    for e in exs:
+        e.close()
+    # the sequence that used to go wrong: close an exchange, then build and run a model (new driver memory) right away
+    cfg = cfgmod.preset("tiny-qwen3")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(3)
+    lengths = [64, 33]
+    series = [random_walk_series(rng, L) for L in lengths]
+    inputs = proc(text=[chat_prompt(lengths)], timeseries=series, padding=True, return_tensors="pt")
+    ids = inputs["input_ids"][0].tolist()
+    want = pipeline.generate(cfg, osynth.state_dict(synth.all_specs(cfg), 9), ids, inputs["timeseries"].numpy(), 4)
+    m = ChatTSForCausalLM.from_synthetic(cfg, seed=9, max_ctx=256, max_prefill_tokens=256, use_graph=False)
+    toks, lg = m.generate_one(ids, inputs["timeseries"], proc.last_lengths, 4, return_logits=True)
+    assert toks == want["tokens"] and rel_err(lg.cpu().numpy(), want["logits"][0].numpy()) < 1e-3
+
+
 def _shards(cfg, world, seed, **kw):
     ms = [ChatTSForCausalLM.from_synthetic(cfg, seed=seed, comm=FakeComm(r, world), **kw) for r in range(world)]
     exs = P2PExchange.create_local_group(world, ms[0].exchange_elems())
@@ -205,8 +241,10 @@ def test_tp2_decode_step_through_the_exchange_matches_oracle(use_graph):
         full = ms[0].expand_input_ids(ids, [(L + 15) // 16 for L in lengths])
         emb = ms[0].get_input_embeddings(torch.tensor(full), mm)
         T = len(full)
+        assert rel_err(torch.cat(mm).cpu().numpy(), np.asarray(want["ts_features"])) < 1e-4      # stage boundaries first
         _emulated_prefill(ms, emb, T)
         torch.cuda.synchronize()
+        assert torch.equal(ms[0].buf["x"][:T], ms[1].buf["x"][:T])       # replicated residual stream after the prefill
         _on_streams(world, lambda r: ms[r]._first_token(T))          # vocab-parallel logits + (max, idx) agreement
         torch.cuda.synchronize()
         if any(m._tp.status() for m in ms):
