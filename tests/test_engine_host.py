@@ -1,0 +1,202 @@
+"""The request scheduler (chatts_amd/engine.py) on a stub model: admission order, packed admission, sampling groups, the
+block-pool gate of an oversubscribed paged KV cache, stop / length retirement, failed requests.  No GPU: the stub produces
+token t = 1000 * request + step for the sequence in a slot, and keeps the same slot / pool bookkeeping the real model keeps."""
+import pytest
+import torch
+
+from chatts_amd.engine import Engine
+from chatts_amd.kv_blocks import BlockPool, KvPoolExhausted
+
+
+class _Cfg:
+    eos_token_id = [7]
+    ts = {"patch_size": 16}
+
+
+class _Tok:
+    def encode(self, text):
+        return [ord(c) for c in text]
+
+
+class _Proc:
+    tokenizer = _Tok()
+
+    def splice(self, prompt, series):
+        if "BAD" in prompt:
+            raise ValueError("malformed request")
+        return prompt, [], []
+
+    def pad_stack(self, encs):
+        return None
+
+
+class StubModel:
+    def __init__(self, max_batch, pool=None, pack=True, t_max=64):
+        self.max_batch, self.config, self.t_max, self.pack = max_batch, _Cfg(), t_max, pack
+        self.buf = {"pos_all": torch.zeros(max_batch, dtype=torch.int32), "out_tokens_all": torch.zeros((max_batch, 64), dtype=torch.int64),
+                    "out_tokens": torch.zeros(64, dtype=torch.int64)}
+        self.seq = [None] * max_batch                 # (request tag, steps produced) per slot
+        self._kv = pool
+        self._kv_dynamic = pool is not None
+        self.sampling, self.log, self.steps = [], [], 0
+        self.stop_at = {}                             # request tag -> step at which it emits the eos token
+
+    # ---- what Engine calls ---------------------------------------------------------------------------------
+    def set_sampling(self, *a):
+        self.sampling.append(a)
+
+    def _request_idents(self, ids, series, lens):
+        return None
+
+    def pick_slot(self, free, idents=None):
+        return free[0]
+
+    def request_tokens(self, ids, series=None, lens=None):
+        return len(ids)
+
+    def kv_fits(self, counts):
+        return self._kv is None or self._kv.fits(counts)
+
+    def kv_stats(self):
+        return None if self._kv is None else {"free": len(self._kv.free)}
+
+    def plan_pack(self, cands, free):
+        if not self.pack or len(cands) < 2 or len(free) < 2:
+            return []
+        take, rows = [], 0
+        for i, (ids, _, _, _) in enumerate(cands):
+            if len(take) < len(free) and rows + len(ids) <= self.t_max:
+                take.append(i); rows += len(ids)
+        return take if len(take) >= 2 else []
+
+    def _start(self, slot, ids, max_new):
+        if self._kv is not None:
+            self._kv.reserve(slot, len(ids) + max_new)
+        tag = ids[0]
+        self.seq[slot] = [tag, 1]
+        self.buf["out_tokens_all"][slot, 0] = self._token(tag, 0)
+        self.buf["pos_all"][slot] = len(ids)
+
+    def _token(self, tag, step):
+        return 7 if self.stop_at.get(tag) == step else 1000 * tag + step
+
+    def _admit(self, slot, ids, series, lens, max_new):
+        if len(ids) + max_new > 100:
+            raise ValueError("exceeds max_ctx")
+        self.log.append(("admit", slot, ids[0]))
+        self._start(slot, ids, max_new)
+
+    def _admit_packed(self, items):
+        if self._kv is not None and not self._kv.fits([len(i[1]) + i[4] for i in items]):
+            raise KvPoolExhausted("pack")
+        self.log.append(("pack", [i[0] for i in items], [i[1][0] for i in items]))
+        for slot, ids, _, _, max_new in items:
+            self._start(slot, ids, max_new)
+
+    def _prefill_request(self, ids, series, lens, max_new):
+        self._admit(0, ids, series, lens, max_new)
+        self.buf["out_tokens"][0] = self.buf["out_tokens_all"][0, 0]
+
+    def batched_step(self):
+        self.steps += 1
+        for s, st in enumerate(self.seq):
+            if st is not None and int(self.buf["pos_all"][s]) >= 0:
+                self.buf["out_tokens_all"][s, st[1]] = self._token(st[0], st[1])
+                st[1] += 1
+
+    def decode_step(self):
+        self.batched_step()
+        self.buf["out_tokens"][:] = self.buf["out_tokens_all"][0]
+
+    def note_generated(self, slot, tokens):
+        self.log.append(("retire", slot, len(tokens)))
+        self.seq[slot] = None
+        if self._kv is not None:
+            self._kv.retire(slot)
+
+
+def _run(eng, reqs):
+    out = {}
+    for tag, n, kw in reqs:
+        eng.add_request(chr(tag) * 10, max_tokens=n, on_tokens=lambda r, new, fin, tag=tag: out.setdefault(tag, []).extend(new), **kw)
+    done = eng.run_until_done()
+    return out, done
+
+
+def test_continuous_batching_order_length_and_stop():
+    m = StubModel(max_batch=2, pack=False)
+    m.stop_at[66] = 2                                  # request 'B' stops at its third token
+    eng = Engine(m, _Proc(), sync_every=2)
+    out, done = _run(eng, [(65, 5, {}), (66, 9, {}), (67, 3, {})])
+    assert out[65] == [65000 + i for i in range(5)]
+    assert out[66] == [66000, 66001, 7]                # the eos token is delivered, nothing after it
+    assert out[67] == [67000, 67001, 67002]
+    assert [r.finish_reason for r in sorted(done, key=lambda r: r.rid)] == ["length", "stop", "length"]
+    admits = [e for e in m.log if e[0] == "admit"]
+    assert [a[2] for a in admits] == [65, 66, 67] and admits[2][1] in (0, 1)      # the third request took a freed slot
+    assert all(s is None for s in eng.slots) and int(m.buf["pos_all"].max()) == -1   # every slot parked again
+
+
+def test_packed_admission_and_single_slot_path():
+    m = StubModel(max_batch=3, pack=True, t_max=25)    # two 10-token prompts fit one packed pass, the third waits its turn
+    eng = Engine(m, _Proc())
+    out, _ = _run(eng, [(65, 2, {}), (66, 2, {}), (67, 2, {})])
+    assert m.log[0] == ("pack", [0, 1], [65, 66]) and ("admit", 2, 67) in m.log
+    assert all(out[t] == [1000 * t, 1000 * t + 1] for t in (65, 66, 67))
+    m1 = StubModel(max_batch=1)
+    eng1 = Engine(m1, _Proc())
+    out1, _ = _run(eng1, [(65, 3, {}), (66, 2, {})])
+    assert out1[65] == [65000, 65001, 65002] and out1[66] == [66000, 66001]
+
+
+def test_sampling_groups_do_not_mix():
+    m = StubModel(max_batch=2, pack=False)
+    eng = Engine(m, _Proc())
+    out, _ = _run(eng, [(65, 3, {}), (66, 3, {"temperature": 0.5, "seed": 4}), (67, 3, {})])
+    # greedy A and C share a batch; the sampled B waits until they drained, then the step is re-configured once
+    order = [e[2] for e in m.log if e[0] == "admit"]
+    assert order == [65, 67, 66]
+    assert m.sampling[-1][0] == 0.5 and len(out[66]) == 3
+
+
+def test_block_pool_gate_defers_then_admits():
+    pool = BlockPool(n_blocks=3, block_size=64, n_slots=3, blocks_per_slot=4)
+    m = StubModel(max_batch=3, pool=pool, pack=True, t_max=64)
+    eng = Engine(m, _Proc(), sync_every=1)
+    out, fin = {}, {}
+
+    def add(tag, prompt_len, n):
+        def cb(r, new, finished, tag=tag):
+            out.setdefault(tag, []).extend(new)
+            if finished:
+                fin[tag] = r
+        eng.add_request(chr(tag) * prompt_len, max_tokens=n, ignore_eos=True, on_tokens=cb)
+    add(65, 10, 6)          # A: 1 block
+    add(66, 10, 3)          # B: 1 block
+    add(68, 30, 40)         # D: 70 positions = 2 blocks: must wait for B's block to become evictable
+    add(67, 10, 2)          # C: 1 block, queued behind D
+    add(69, 10, 95)         # E: 105 positions fit two blocks, but prompt + max_tokens > the stub's max_ctx: refused by _admit
+    while eng.has_work():
+        eng.step()
+        assert pool.check()
+    assert out[65] == [65000 + i for i in range(6)] and out[66] == [66000 + i for i in range(3)]
+    assert out[68] == [68000 + i for i in range(40)] and out[67] == [67000, 67001]
+    tags = []
+    for e in m.log:                                                      # admission order, whatever mix of packed / single passes
+        if e[0] == "admit":
+            tags.append(e[2])
+        elif e[0] == "pack":
+            tags += e[2]
+    assert tags == [65, 66, 68, 67]                                      # D before C: nobody overtakes the head of the queue
+    d_admit = next(i for i, e in enumerate(m.log) if e[0] == "admit" and e[2] == 68)
+    assert d_admit > m.log.index(("retire", 1, 3))                       # ... and D only after B had finished and freed a block
+    assert fin[69].error is not None and fin[69].finish_reason == "error" and 69 not in tags
+    assert not pool.active and pool.check()
+
+    # a request larger than the whole pool is refused once nothing is left to wait for
+    eng2 = Engine(StubModel(max_batch=2, pool=BlockPool(2, 64, 2, 4), pack=False), _Proc())
+    got = {}
+    eng2.add_request("Z" * 20, max_tokens=15, ignore_eos=True, on_tokens=lambda r, new, f: got.setdefault("ok", r))
+    eng2.add_request("Y" * 130, max_tokens=10, ignore_eos=True, on_tokens=lambda r, new, f: got.setdefault("big", r))
+    eng2.run_until_done()
+    assert got["ok"].error is None and got["big"].error is not None and "block pool" in str(got["big"].error)
