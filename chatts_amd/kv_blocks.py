@@ -9,6 +9,10 @@ mirrors a changed row into its device table (`ChatTSForCausalLM.reserve_kv`).
 Policy: a request reserves `ceil((prompt + max_new_tokens) / block_size)` blocks at admission (nothing is allocated during
 decode, so a captured decode graph never sees the table change under it); blocks return to the pool when the slot is
 re-used or evicted, not when the request finishes - the finished sequence's K/V rows stay resident for prefix reuse.
+Prefix reuse across slots SHARES whole blocks by reference count (`adopt`) instead of copying rows: a request whose prompt
+starts with what another slot holds points its first blocks at the same memory and prefills from the next block boundary;
+a slot never writes a shared block - `reserve(private_from=...)` swaps the shared blocks it is about to overwrite for private
+ones first.
 """
 
 
@@ -26,8 +30,10 @@ class BlockPool:
         self.n_slots, self.blocks_per_slot = int(n_slots), int(blocks_per_slot)
         self.free = list(range(self.n_blocks))[::-1]          # pop() hands out block 0 first
         self.rows = [[] for _ in range(self.n_slots)]         # blocks of each slot in logical order
+        self.refs = [0] * self.n_blocks                       # table rows that hold the block (> 1: a shared prefix block)
         self.active = set()                                   # slots with a running request: never evicted
         self.evictions = 0
+        self.last_replaced = set()                            # logical indices the last reserve() swapped for private blocks
 
     # ---- queries --------------------------------------------------------------------------------------------------------
     def blocks_for(self, n_tokens):
@@ -36,36 +42,59 @@ class BlockPool:
     def capacity_tokens(self, slot):
         return len(self.rows[slot]) * self.block_size
 
+    def _freeable(self, slots):
+        """blocks that return to the free list if every row of `slots` is released (shared blocks only when all holders go)"""
+        cnt = {}
+        for s in slots:
+            for b in self.rows[s]:
+                cnt[b] = cnt.get(b, 0) + 1
+        return sum(1 for b, c in cnt.items() if c == self.refs[b])
+
     def available(self, for_slot=None):
         """blocks a reservation for `for_slot` could obtain: the free ones, the slot's own, every inactive slot's"""
-        n = len(self.free)
-        for s, row in enumerate(self.rows):
-            if s == for_slot or s not in self.active:
-                n += len(row)
-        return n
+        return len(self.free) + self._freeable([s for s in range(self.n_slots) if s == for_slot or s not in self.active])
 
     def fits(self, token_counts):
-        """could requests of these sizes (prompt + new tokens each) all be admitted into free slots right now?"""
+        """could requests of these sizes (prompt + new tokens each) all be admitted into free slots right now?  (Counts every
+        request as if it shared nothing: prefix sharing only ever needs fewer blocks.)"""
         need = sum(self.blocks_for(t) for t in token_counts)
-        return need <= len(self.free) + sum(len(r) for s, r in enumerate(self.rows) if s not in self.active)
+        return need <= len(self.free) + self._freeable([s for s in range(self.n_slots) if s not in self.active])
+
+    def shared_blocks(self):
+        return sum(1 for r in self.refs if r > 1)
 
     # ---- changes --------------------------------------------------------------------------------------------------------
-    def reserve(self, slot, n_tokens, protect=(), evict_order=None, on_evict=None):
-        """Make slot's row cover n_tokens positions and mark the slot active.  Missing blocks come from the free list, then from
-        inactive slots (never `slot`, `protect` or active ones) in `evict_order` (default: fewest blocks first), whose whole row
-        is released; `on_evict(victim)` lets the owner forget what was resident there.  -> True when the row changed."""
+    def _take(self):
+        b = self.free.pop()
+        self.refs[b] = 1
+        return b
+
+    def _drop(self, b):
+        self.refs[b] -= 1
+        if self.refs[b] == 0:
+            self.free.append(b)
+
+    def reserve(self, slot, n_tokens, protect=(), evict_order=None, on_evict=None, private_from=None):
+        """Make slot's row cover n_tokens positions and mark the slot active.  private_from = first logical block the request will
+        WRITE (None: nothing is known, same as 0 for an empty row): every block of the row from there on that is shared with
+        another slot is swapped for a private one (`last_replaced`; its old content is NOT copied - the caller recomputes those
+        positions).  Missing blocks come from the free list, then from inactive slots (never `slot`, `protect` or active ones) in
+        `evict_order` (default: fewest blocks first), whose whole row is released; `on_evict(victim)` lets the owner forget what
+        was resident there.  Nothing changes when the pool cannot cover the request (KvPoolExhausted).  -> True when the row changed."""
         need = self.blocks_for(n_tokens)
         if need > self.blocks_per_slot:
             raise ValueError(f"{n_tokens} positions need {need} blocks, a slot's table row holds {self.blocks_per_slot}")
         row = self.rows[slot]
-        missing = need - len(row)
-        if missing > 0 and missing > len(self.free):
+        swap = [] if private_from is None else [i for i in range(max(int(private_from), 0), len(row)) if self.refs[row[i]] > 1]
+        missing = max(need - len(row), 0) + len(swap)
+        self.last_replaced = set()
+        if missing > len(self.free):
             keep = set(protect) | {slot} | self.active
             victims = [s for s in (evict_order if evict_order is not None else
                                    sorted(range(self.n_slots), key=lambda s: len(self.rows[s]))) if s not in keep and self.rows[s]]
-            if len(self.free) + sum(len(self.rows[s]) for s in victims) < missing:
+            if len(self.free) + self._freeable(victims) < missing:
                 raise KvPoolExhausted(f"{n_tokens} positions need {missing} more blocks of {self.block_size}; {len(self.free)} free, "
-                                      f"{sum(len(self.rows[s]) for s in victims)} evictable of {self.n_blocks}")
+                                      f"{self._freeable(victims)} evictable of {self.n_blocks}")
             for v in victims:
                 if len(self.free) >= missing:
                     break
@@ -73,23 +102,52 @@ class BlockPool:
                 self.evictions += 1
                 if on_evict:
                     on_evict(v)
-        for _ in range(max(missing, 0)):
-            row.append(self.free.pop())
+        for i in swap:
+            if self.refs[row[i]] > 1:                         # (an eviction above may just have made it private)
+                self.refs[row[i]] -= 1
+                row[i] = self._take()
+                self.last_replaced.add(i)
+        while len(row) < need:
+            row.append(self._take())
         self.active.add(slot)
         return missing > 0
+
+    def adopt(self, slot, src, n_blocks):
+        """Prefix sharing: the first n_blocks logical blocks of `slot` become the SAME physical blocks as `src`'s (reference
+        counted; what `slot` held there goes back to the pool).  The caller guarantees that neither slot writes those positions
+        again without going through reserve(private_from=...)."""
+        if n_blocks > len(self.rows[src]) or n_blocks > len(self.rows[slot]):
+            raise ValueError("adopt: a row is shorter than the shared prefix")
+        changed = False
+        for i in range(n_blocks):
+            old, new = self.rows[slot][i], self.rows[src][i]
+            if old == new:
+                continue
+            self.refs[new] += 1
+            self.rows[slot][i] = new
+            self._drop(old)
+            changed = True
+        return changed
 
     def retire(self, slot):
         """the slot's request finished: its blocks stay (prefix reuse) but may be evicted from now on"""
         self.active.discard(slot)
 
     def release(self, slot):
-        self.free.extend(reversed(self.rows[slot]))
+        for b in reversed(self.rows[slot]):
+            self._drop(b)
         self.rows[slot] = []
         self.active.discard(slot)
 
     def check(self):
-        """every block is owned exactly once (tests)"""
-        owned = [b for r in self.rows for b in r]
-        assert len(owned) == len(set(owned)) and not (set(owned) & set(self.free))
-        assert sorted(owned + self.free) == list(range(self.n_blocks))
+        """reference counts match the rows, and every block is either held or free (tests)"""
+        cnt = [0] * self.n_blocks
+        for r in self.rows:
+            assert len(r) == len(set(r))                      # a row never holds a block twice
+            for b in r:
+                cnt[b] += 1
+        assert cnt == self.refs
+        held = {b for b, c in enumerate(cnt) if c}
+        assert not (held & set(self.free)) and len(self.free) == len(set(self.free))
+        assert sorted(held | set(self.free)) == list(range(self.n_blocks))
         return True

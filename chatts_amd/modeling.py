@@ -102,6 +102,7 @@ class ChatTSForCausalLM:
             self.max_ctx = -(-self.max_ctx // self.kv_block_size) * self.kv_block_size      # whole blocks
         self._kv_pool_blocks = None if kv_pool_blocks is None else int(kv_pool_blocks)
         self._kv = None                          # kv_blocks.BlockPool once the buffers exist
+        self._kv_replaced = {}                   # slot -> logical blocks swapped for private ones since its last prefix decision
         self._kv_dynamic = False
         self._cur_slot = 0
         if weight_format not in ("bf16", "fp8", "int4"):
@@ -585,21 +586,28 @@ class ChatTSForCausalLM:
     def _kv_evicted(self, victim):
         self._slot_idents[victim] = []           # nothing is resident there any more (its stale table row is never read: parked)
 
-    def reserve_kv(self, slot, n_tokens, idents=None, protect=()):
-        """Make cache slot `slot` able to hold n_tokens positions (no-op with a contiguous cache or a full pool) and mark it
-        active.  The slot whose resident prefix `idents` would be copied from is protected from eviction, like `protect`.
-        Raises kv_blocks.KvPoolExhausted when even evicting every finished sequence does not free enough blocks."""
+    def reserve_kv(self, slot, n_tokens, idents=None, protect=(), write_from=0):
+        """Make cache slot `slot` able to hold n_tokens positions (no-op with a contiguous cache) and mark it active.  idents = the
+        request's token identities: the slot whose resident prefix will be reused is protected from eviction (like `protect`), and
+        every block the request is going to WRITE - everything past the reused prefix; `write_from` positions for direct callers -
+        is made private first if another slot shares it.  Raises kv_blocks.KvPoolExhausted (nothing changed) when even evicting
+        every finished sequence does not free enough blocks."""
         if self._kv is None:
             return
         if n_tokens > self.max_ctx:
             raise ValueError(f"{n_tokens} positions exceed max_ctx={self.max_ctx}")
         keep = set(protect)
+        first = int(write_from) // self._kv.block_size
         if idents is not None and self.enable_prefix_caching:
             n, src = self._match_prefix(slot, idents)
+            n = min(n, len(idents) - 1)
             if src >= 0 and n >= 16:
                 keep.add(src)
+                first = n // self._kv.block_size          # own slot: rows below stay; other slot: blocks below get adopted
         order = sorted(range(self.max_batch), key=lambda sl: len(self._slot_idents[sl]))       # least resident first
-        if self._kv.reserve(slot, n_tokens, protect=keep, evict_order=order, on_evict=self._kv_evicted):
+        changed = self._kv.reserve(slot, n_tokens, protect=keep, evict_order=order, on_evict=self._kv_evicted, private_from=first)
+        self._kv_replaced[slot] = self._kv_replaced.get(slot, set()) | self._kv.last_replaced
+        if changed:
             self._push_kv_row(slot)
 
     def kv_fits(self, token_counts):
@@ -618,7 +626,8 @@ class ChatTSForCausalLM:
         if self._kv is None:
             return None
         return {"block_size": self._kv.block_size, "blocks": self._kv.n_blocks, "free": len(self._kv.free),
-                "active_slots": len(self._kv.active), "evictions": self._kv.evictions, "dynamic": self._kv_dynamic}
+                "active_slots": len(self._kv.active), "evictions": self._kv.evictions, "dynamic": self._kv_dynamic,
+                "shared_blocks": self._kv.shared_blocks()}
 
     def reset(self):
         self.buf["pos"].zero_()
@@ -632,8 +641,8 @@ class ChatTSForCausalLM:
         T = inputs_embeds.shape[0]
         if pos0 + T > self.max_ctx:
             raise ValueError(f"sequence of {pos0 + T} tokens exceeds max_ctx={self.max_ctx}")
-        if self._kv_dynamic and self._kv.capacity_tokens(self._cur_slot) < pos0 + T:
-            self.reserve_kv(self._cur_slot, pos0 + T)        # direct callers; generate_* reserve prompt + new tokens up front
+        if self._kv is not None and (self._kv.capacity_tokens(self._cur_slot) < pos0 + T or self._kv.shared_blocks()):
+            self.reserve_kv(self._cur_slot, pos0 + T, write_from=pos0)      # direct callers; generate_* reserve prompt + new tokens up front
         fast_last = for_next_token and self.plan.world == 1
         done, last = 0, 0
         while done < T:
@@ -854,25 +863,34 @@ class ChatTSForCausalLM:
         when it is the slot itself) and return how many leading tokens need no prefill (at most T - 1: the last prompt
         position is always recomputed, it yields the logits)."""
         self.prefix_stats["requests"] += 1
+        replaced = self._kv_replaced.pop(slot, set())      # (paged) blocks reserve_kv swapped for private, EMPTY ones
         if not self.enable_prefix_caching:
             return 0
         best, src = self._match_prefix(slot, idents, exclude)
         n = min(best, T - 1)
         if n < 16:                                   # not worth a copy + a ragged prefill start
             return 0
-        if src != slot:
-            B = self.buf
-            if self._kv is not None:             # paged: whole blocks, pool to pool (the rows past n are overwritten by the prefill)
-                nb = self._kv.blocks_for(n)
-                if len(self._kv.rows[slot]) < nb or len(self._kv.rows[src]) < nb:
-                    return 0                     # (not reserved by the caller: recompute rather than touch foreign blocks)
-                si = torch.tensor(self._kv.rows[src][:nb], dtype=torch.int64, device=self.device)
-                di = torch.tensor(self._kv.rows[slot][:nb], dtype=torch.int64, device=self.device)
-                B["kv_k"].index_copy_(1, di, B["kv_k"].index_select(1, si))
-                B["kv_v"].index_copy_(1, di, B["kv_v"].index_select(1, si))
+        if self._kv is not None:
+            # paged: nothing is copied.  Another slot's prefix is SHARED block by block (reference counted), so the reuse ends at a
+            # block boundary; the slot's own prefix ends where reserve_kv had to swap a shared block for a private (empty) one.
+            bs = self._kv.block_size
+            if src != slot:
+                nshare = n // bs
+                if nshare == 0 or len(self._kv.rows[slot]) < nshare or len(self._kv.rows[src]) < nshare:
+                    return 0                     # less than a block in common (or not reserved by the caller): recompute
+                if self._kv.adopt(slot, src, nshare):
+                    self._push_kv_row(slot)
+                n = nshare * bs
             else:
-                B["kv_k"][slot, :, :, :n].copy_(B["kv_k"][src, :, :, :n])
-                B["kv_v"][slot, :, :, :n].copy_(B["kv_v"][src, :, :, :n])
+                lost = [i for i in replaced if i * bs < n]
+                if lost:
+                    n = min(lost) * bs
+                if n < 16:
+                    return 0
+        elif src != slot:
+            B = self.buf
+            B["kv_k"][slot, :, :, :n].copy_(B["kv_k"][src, :, :, :n])
+            B["kv_v"][slot, :, :, :n].copy_(B["kv_v"][src, :, :, :n])
         self.prefix_stats["hits"] += 1
         self.prefix_stats["tokens_reused"] += n
         return n

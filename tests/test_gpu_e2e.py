@@ -667,8 +667,68 @@ def test_paged_kv_cache_equals_contiguous(preset, block):
     b = ChatTSForCausalLM.from_synthetic(cfg, kv_block_size=block, **kw)
     ra, rb = a.generate_batch(reqs, 9), b.generate_batch(reqs, 9)
     assert ra == rb
-    assert a.prefix_stats == b.prefix_stats and b.prefix_stats["hits"] >= 1       # request 4 repeats request 1
+    # request 4 repeats request 1: the contiguous cache copies / keeps the matching rows, the paged one shares whole blocks
+    assert a.prefix_stats["hits"] == b.prefix_stats["hits"] >= 1
+    assert 0 < b.prefix_stats["tokens_reused"] <= a.prefix_stats["tokens_reused"]
     assert b._kv.check()
+
+
+def test_paged_kv_prefix_blocks_are_shared_between_running_sequences():
+    """Two requests with the same long prompt head in flight together: the second one's table row points at the first one's
+    blocks (reference counted, nothing copied), it prefills from the block boundary, both produce the oracle's tokens; when the
+    donor slot takes a new, different request it first swaps the blocks it is about to overwrite for private ones."""
+    cfg = cfgmod.preset("tiny-qwen2")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(41)
+    lengths = [256, 64, 100]
+    series = [random_walk_series(rng, L) for L in lengths]
+    base = chat_prompt(lengths)
+    head = base[:base.index("Please analyze")]
+    prompts = [base, head + "Which one is the most volatile?<|im_end|><|im_start|>assistant\n", base]
+    reqs = []
+    for p_ in prompts:
+        inp = proc(text=[p_], timeseries=series, return_tensors="pt")
+        reqs.append((inp["input_ids"][0].tolist(), inp["timeseries"], list(lengths)))
+    ref = ChatTSForCausalLM.from_synthetic(cfg, seed=2, max_ctx=768, max_prefill_tokens=768, enable_prefix_caching=False)
+    want = [ref.generate_one(i, s, l, 8) for i, s, l in reqs]
+    m = ChatTSForCausalLM.from_synthetic(cfg, seed=2, max_ctx=768, max_prefill_tokens=768, max_batch=2, kv_block_size=64)
+    T0 = m.request_tokens(*reqs[0])
+    assert T0 > 3 * 64
+    # (1) admit the first two by hand so that both are resident, then look at the tables
+    m.buf["pos_all"].fill_(-1)
+    m._admit(0, *reqs[0], 8)
+    m._admit(1, *reqs[1], 8)
+    common = 0
+    for a_, b_ in zip(m._slot_idents[0], m._slot_idents[1]):
+        if a_ != b_:
+            break
+        common += 1
+    nshare = min(common, m.request_tokens(*reqs[1]) - 1) // 64
+    assert nshare >= 2
+    assert m._kv.rows[1][:nshare] == m._kv.rows[0][:nshare] and m._kv.rows[1][nshare] != m._kv.rows[0][nshare]
+    assert m.kv_stats()["shared_blocks"] == nshare and m.prefix_stats["tokens_reused"] == nshare * 64
+    assert torch.equal(m.buf["kv_table"][1, :nshare].cpu(), torch.tensor(m._kv.rows[0][:nshare], dtype=torch.int32))
+    for _ in range(7):
+        m.batched_step()
+    toks = m.buf["out_tokens_all"][:2, :8].tolist()
+    assert toks == want[:2]
+    m.note_generated(0, toks[0]); m.note_generated(1, toks[1])
+    m.buf["pos_all"].fill_(-1)
+    # (2) slot 0 (the donor) now takes a request that only shares the first tokens: it must not write into what slot 1 still reads
+    short = proc(text=[chat_prompt([64])], timeseries=[series[1]], return_tensors="pt")
+    sreq = (short["input_ids"][0].tolist(), short["timeseries"], [64])
+    swant = ref.generate_one(*sreq, 6)
+    before = list(m._kv.rows[1])
+    m._admit(0, *sreq, 6)
+    assert m._kv.rows[1] == before and not (set(m._kv.rows[0]) & set(before)) and m._kv.check()
+    # ... and slot 1's cached prefix is still intact: the third request (== the first) re-uses it from slot 1 and matches the oracle
+    for _ in range(5):
+        m.batched_step()
+    assert m.buf["out_tokens_all"][0, :6].tolist() == swant
+    m.note_generated(0, swant)
+    m.buf["pos_all"].fill_(-1)
+    got = m.generate_batch([reqs[2]], 8)
+    assert got == [want[2]] and m._kv.check()
 
 
 def test_paged_kv_oversubscribed_pool_waits_and_evicts():

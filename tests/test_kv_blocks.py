@@ -53,3 +53,52 @@ def test_evict_order_and_own_blocks_count():
     # a re-used slot keeps its own blocks and only asks for the difference
     p.retire(2)
     assert p.reserve(2, 300) is False and 2 in p.active
+
+
+def test_prefix_blocks_are_shared_by_reference_and_never_written_while_shared():
+    p = BlockPool(n_blocks=10, block_size=64, n_slots=3, blocks_per_slot=6)
+    p.reserve(0, 300); p.retire(0)                       # 5 blocks: a finished sequence, resident
+    p.reserve(1, 200)                                    # 4 blocks of its own
+    own = list(p.rows[1])
+    assert p.adopt(1, 0, 3) is True                      # the first 3 blocks of slot 1 are now slot 0's
+    assert p.rows[1][:3] == p.rows[0][:3] and p.rows[1][3] == own[3]
+    assert [p.refs[b] for b in p.rows[0][:3]] == [2, 2, 2] and p.shared_blocks() == 3
+    assert set(own[:3]) <= set(p.free)                   # what slot 1 held there went back to the pool
+    assert p.adopt(1, 0, 3) is False and p.check()       # idempotent
+    # the donor is evictable, but its shared blocks stay alive for the other holder
+    assert p._freeable([0]) == 2 and p.fits([64 * 6]) and not p.fits([64 * 7])       # 4 free + 2 of the donor's own
+    p.release(0)
+    assert [p.refs[b] for b in p.rows[1][:3]] == [1, 1, 1] and p.shared_blocks() == 0 and p.check()
+    # a slot that is about to overwrite from block 1 on gets private copies of the shared blocks there (block 0 stays shared)
+    p.reserve(2, 128); p.adopt(2, 1, 2); p.retire(1)
+    shared = list(p.rows[1][:2])
+    assert p.rows[2][:2] == shared
+    p.reserve(1, 200, private_from=1)
+    assert p.last_replaced == {1} and p.rows[1][0] == shared[0] and p.rows[1][1] != shared[1]
+    assert p.rows[2][:2] == shared and p.refs[shared[1]] == 1 and p.refs[shared[0]] == 2 and p.check()
+    with pytest.raises(ValueError):
+        p.adopt(2, 1, 5)                                 # longer than slot 2's row
+
+
+def test_eviction_counts_shared_blocks_once_and_swap_needs_room():
+    p = BlockPool(n_blocks=5, block_size=64, n_slots=3, blocks_per_slot=4)
+    p.reserve(0, 192); p.retire(0)                       # 3 blocks
+    p.reserve(1, 128); p.adopt(1, 0, 2); p.retire(1)     # shares 2 of them; its own 2 went back: 2 free, 3 held
+    assert len(p.free) == 2 and p.shared_blocks() == 2 and p.check()
+    assert p.fits([64 * 5]) and not p.fits([64 * 6])     # evicting both inactive slots frees everything exactly once
+    p.reserve(2, 64 * 4)                                 # needs 4: 2 free + slot 1 frees nothing alone, slot 0 and 1 together free 3
+    assert len(p.rows[2]) == 4 and p.check() and p.evictions >= 1
+    # privatising a shared block is part of the same all-or-nothing reservation
+    q = BlockPool(n_blocks=4, block_size=64, n_slots=2, blocks_per_slot=3)
+    q.reserve(0, 128); q.reserve(1, 128); q.adopt(1, 0, 2)       # both rows hold the same 2 blocks; slot 1's own two are free again
+    free0 = len(q.free)
+    assert free0 == 2
+    q.reserve(1, 128, private_from=0)                    # wants 2 private blocks: enough room?
+    assert q.check() and len(q.rows[1]) == 2 and not (set(q.rows[1]) & set(q.rows[0])) and len(q.free) == free0 - 2
+    r = BlockPool(n_blocks=2, block_size=64, n_slots=2, blocks_per_slot=2)
+    r.reserve(0, 128); r.retire(0)
+    r.rows[1] = list(r.rows[0]); r.refs = [2, 2]; r.active.add(1)  # both hold both blocks, nothing free
+    before = ([list(x) for x in r.rows], list(r.refs), list(r.free))
+    with pytest.raises(KvPoolExhausted):
+        r.reserve(1, 128, private_from=0, protect={0})   # no room to privatise and the donor is protected: nothing changes
+    assert ([list(x) for x in r.rows], list(r.refs), list(r.free)) == before
