@@ -30,9 +30,14 @@ class Request:
 class Engine:
     """add_request() / step() like vLLM's LLMEngine.  `on_tokens(request, new_token_ids, finished)` is called from step()."""
 
-    def __init__(self, model, processor, sync_every=4):
+    def __init__(self, model, processor, sync_every=4, prefill_chunk_tokens=None):
         self.model, self.processor = model, processor
         self.sync_every = max(1, int(sync_every))       # decode steps between device->host token reads
+        # chunked-prefill scheduling (vLLM: enable_chunked_prefill / max_num_batched_tokens): while other sequences are decoding, a
+        # long prompt is prefilled this many rows per scheduler iteration, each followed by one decode step of the running batch,
+        # instead of stalling them for the whole prefill.  None: a prompt is always prefilled in one go.
+        self.prefill_chunk_tokens = None if not prefill_chunk_tokens else max(16, int(prefill_chunk_tokens))
+        self.prefilling = None                          # (request, slot, admission state) of the prompt being prefilled in chunks
         self.waiting = deque()
         self.nslots = max(1, model.max_batch)
         self.slots = [None] * self.nslots
@@ -56,7 +61,7 @@ class Engine:
         return r
 
     def has_work(self):
-        return bool(self.waiting) or any(s is not None for s in self.slots)
+        return bool(self.waiting) or self.prefilling is not None or any(s is not None for s in self.slots)
 
     def _encode(self, r):
         import torch
@@ -89,8 +94,20 @@ class Engine:
         running = any(s is not None for s in self.slots)
         if not running and self.waiting and self.waiting[0].sampling_key != self.active_key:
             self._apply_sampling(self.waiting[0].sampling_key)
+        if self.prefilling is not None:                  # a long prompt is on its way in: its next chunk, no other admission meanwhile
+            r, s, st = self.prefilling
+            try:
+                if m.admit_step(st, self.prefill_chunk_tokens):
+                    self.prefilling = None
+                    self.slots[s], self.produced[s] = r, 1
+                    self._since_sync = self.sync_every   # read the first token right away
+            except Exception as e:
+                self.prefilling = None
+                r.error = e
+                self._emit(r, True, "error")
+                done.append(r)
         # admission: free slots take waiting requests that share the running batch's sampling configuration
-        while self.waiting and any(v is None for v in self.slots):
+        while self.prefilling is None and self.waiting and any(v is None for v in self.slots):
             free = [i for i, v in enumerate(self.slots) if v is None]
             cands = [q for q in self.waiting if q.sampling_key == self.active_key][:len(free)]
             if not cands:
@@ -138,12 +155,20 @@ class Engine:
                     m._admit_packed(items)               # several short prompts: one packed prefill pass
                 elif self.nslots == 1:
                     m._prefill_request(*items[0][1:])
+                elif self.prefill_chunk_tokens and any(v is not None for v in self.slots):
+                    st = m.admit_begin(*items[0])         # others are decoding: feed a long prompt in chunks between their steps
+                    if st["T"] - st["done"] > self.prefill_chunk_tokens:
+                        self.prefilling = (group[0], items[0][0], st)
+                        m.admit_step(st, self.prefill_chunk_tokens)
+                        break
+                    m.admit_step(st)
                 else:
                     m._admit(*items[0])
             except Exception as e:
+                self.prefilling = None
                 if type(e).__name__ == "KvPoolExhausted" and any(v is not None for v in self.slots):
-                    self.waiting[0:0] = group            # the block pool is full (nothing was changed): back to the head of the
-                    break                                # queue until a running sequence finishes
+                    self.waiting.extendleft(reversed(group))      # the block pool is full (nothing was changed): back to the head
+                    break                                         # of the queue until a running sequence finishes
                 for r in group:
                     r.error = e
                     self._emit(r, True, "error")
@@ -297,6 +322,9 @@ class EngineThread:
     def _fail_all(self, e):
         eng = self.engine
         pending = list(eng.waiting) + [r for r in eng.slots if r is not None]
+        if getattr(eng, "prefilling", None) is not None:
+            pending.append(eng.prefilling[0])
+            eng.prefilling = None
         eng.waiting.clear()
         eng.slots = [None] * eng.nslots
         while True:

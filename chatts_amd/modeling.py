@@ -920,9 +920,10 @@ class ChatTSForCausalLM:
             return best
         return min(free_slots, key=lambda s: len(self._slot_idents[s]))
 
-    def _admit(self, slot, ids, series, lengths, max_new_tokens=1):
-        """Prefill one request into cache slot `slot` and produce its first token (out_tokens_all[slot, 0])."""
-        cfg, B = self.config, self.buf
+    def admit_begin(self, slot, ids, series, lengths, max_new_tokens=1):
+        """First half of an admission into cache slot `slot`: TS encoder, prompt expansion, embeddings, KV reservation and prefix
+        reuse - everything but the prefill itself.  -> the state admit_step() consumes."""
+        cfg = self.config
         ps = cfg.ts["patch_size"]
         mm, counts = None, []
         if series is not None and series.shape[0] > 0:
@@ -939,13 +940,33 @@ class ChatTSForCausalLM:
         idents = self._token_idents(full, series, lengths, counts, cfg.ts_token_start_index)
         self.reserve_kv(slot, T + max_new_tokens, idents)
         n0 = self._reuse_prefix(slot, idents, T)
-        self._slot_idents[slot] = idents
+        self._slot_idents[slot] = []                # not a prefix source for others until all of its rows exist
         self.prefix_stats["tokens_prefilled"] += T - n0
+        return {"slot": slot, "emb": emb, "T": T, "done": n0, "idents": idents}
+
+    def admit_step(self, st, max_rows=None):
+        """Prefill the next <= max_rows prompt rows of an admission begun with admit_begin (all that is left when None).  Between two
+        calls the engine may run decode steps of the OTHER slots (vLLM's chunked prefill: a long prompt does not stall the running
+        sequences for its whole prefill); this slot stays parked until its last row is in, then its first token is produced.
+        -> True when the admission is complete."""
+        slot, T, a = st["slot"], st["T"], st["done"]
+        b = T if max_rows is None else min(T, a + max(int(max_rows), 1))
+        final = b >= T
         self.select_sequence(slot)
-        last = self.prefill(emb[n0:], n0, for_next_token=True)
-        self._first_token_into_slot(slot, last - 1, T)
+        last = self.prefill(st["emb"][a:b], a, for_next_token=final)
+        st["done"] = b
+        if final:
+            self._first_token_into_slot(slot, last - 1, T)
+            self._slot_idents[slot] = st["idents"]
+            st["emb"] = None
         self.select_sequence(0)
-        return T
+        return final
+
+    def _admit(self, slot, ids, series, lengths, max_new_tokens=1):
+        """Prefill one request into cache slot `slot` and produce its first token (out_tokens_all[slot, 0])."""
+        st = self.admit_begin(slot, ids, series, lengths, max_new_tokens)
+        self.admit_step(st)
+        return st["T"]
 
     def _first_token_into_slot(self, slot, row, T):
         """logits of x[row] -> first token of the sequence in cache slot `slot` (out_tokens_all[slot, 0]); position / step set."""

@@ -236,7 +236,8 @@ def create_app(engine_thread, tokenizer, served_model_name="chatts", limit_times
 
 
 def build_server(model, tensor_parallel_size=1, max_model_len=6000, max_num_seqs=1, seed=0, tokenizer=None,
-                 served_model_name="chatts", limit_timeseries=15, block_size=None, num_gpu_blocks_override=None):
+                 served_model_name="chatts", limit_timeseries=15, block_size=None, num_gpu_blocks_override=None,
+                 enable_chunked_prefill=False, max_num_batched_tokens=512):
     """LLM (model + processor) -> Engine -> EngineThread -> FastAPI app.
     Tensor parallel (one process per GPU under torchrun, process group initialised): rank 0 gets the app, the other ranks get
     None after serving as followers until the leader shuts down (engine.follow)."""
@@ -246,7 +247,7 @@ def build_server(model, tensor_parallel_size=1, max_model_len=6000, max_num_seqs
               tokenizer=tokenizer, limit_mm_per_prompt={"timeseries": limit_timeseries}, block_size=block_size,
               num_gpu_blocks_override=num_gpu_blocks_override)
     control = ControlPlane.create() if tensor_parallel_size > 1 else None
-    engine = Engine(llm.model, llm.processor)
+    engine = Engine(llm.model, llm.processor, prefill_chunk_tokens=max_num_batched_tokens if enable_chunked_prefill else None)
     if control is not None and control.rank != 0:
         follow(engine, control)                  # returns when the leader publishes the shutdown
         return None
@@ -267,6 +268,9 @@ def main():
     ap.add_argument("--tensor-parallel-size", type=int, default=1)
     ap.add_argument("--limit-mm-per-prompt", default="timeseries=15")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--enable-chunked-prefill", action="store_true", help="while other sequences decode, prefill a long prompt "
+                    "--max-num-batched-tokens rows at a time between their decode steps")
+    ap.add_argument("--max-num-batched-tokens", type=int, default=512)
     ap.add_argument("--block-size", type=int, default=None, help="block-paged KV cache: positions per block (power of two >= 64); "
                     "default: one contiguous cache per sequence slot")
     ap.add_argument("--num-gpu-blocks-override", type=int, default=None, help="with --block-size: blocks in the pool (fewer than "
@@ -286,7 +290,8 @@ def main():
         dist.init_process_group(backend=backend, **({"device_id": torch.device(f"cuda:{dev}")} if backend == "nccl" else {}))
     app = build_server(args.model, args.tensor_parallel_size, args.max_model_len, args.max_num_seqs, args.seed,
                        served_model_name=args.served_model_name, limit_timeseries=limit, block_size=args.block_size,
-                       num_gpu_blocks_override=args.num_gpu_blocks_override)
+                       num_gpu_blocks_override=args.num_gpu_blocks_override, enable_chunked_prefill=args.enable_chunked_prefill,
+                       max_num_batched_tokens=args.max_num_batched_tokens)
     if app is None:
         return                                   # a follower rank: the leader has shut down
     try:

@@ -86,6 +86,27 @@ class StubModel:
         self.log.append(("admit", slot, ids[0]))
         self._start(slot, ids, max_new)
 
+    def admit_begin(self, slot, ids, series, lens, max_new):
+        if len(ids) + max_new > 100:
+            raise ValueError("exceeds max_ctx")
+        if self._kv is not None:
+            self._kv.reserve(slot, len(ids) + max_new)
+        return {"slot": slot, "T": len(ids), "done": 0, "ids": ids, "max_new": max_new}
+
+    def admit_step(self, st, max_rows=None):
+        a = st["done"]
+        b = st["T"] if max_rows is None else min(st["T"], a + max_rows)
+        self.log.append(("chunk", st["slot"], a, b))
+        st["done"] = b
+        if b >= st["T"]:
+            self.log.append(("admit", st["slot"], st["ids"][0]))
+            tag = st["ids"][0]
+            self.seq[st["slot"]] = [tag, 1]
+            self.buf["out_tokens_all"][st["slot"], 0] = self._token(tag, 0)
+            self.buf["pos_all"][st["slot"]] = st["T"]
+            return True
+        return False
+
     def _admit_packed(self, items):
         if self._kv is not None and not self._kv.fits([len(i[1]) + i[4] for i in items]):
             raise KvPoolExhausted("pack")
@@ -200,3 +221,58 @@ def test_block_pool_gate_defers_then_admits():
     eng2.add_request("Y" * 130, max_tokens=10, ignore_eos=True, on_tokens=lambda r, new, f: got.setdefault("big", r))
     eng2.run_until_done()
     assert got["ok"].error is None and got["big"].error is not None and "block pool" in str(got["big"].error)
+
+
+def test_chunked_prefill_interleaves_with_the_running_batch():
+    m = StubModel(max_batch=2, pack=False)
+    eng = Engine(m, _Proc(), sync_every=1, prefill_chunk_tokens=16)
+    out = {}
+    eng.add_request("A" * 10, max_tokens=12, ignore_eos=True, on_tokens=lambda r, new, f: out.setdefault("A", []).extend(new))
+    eng.step()                                             # A is running
+    eng.add_request("B" * 50, max_tokens=3, ignore_eos=True, on_tokens=lambda r, new, f: out.setdefault("B", []).extend(new))
+    eng.add_request("C" * 10, max_tokens=2, ignore_eos=True, on_tokens=lambda r, new, f: out.setdefault("C", []).extend(new))
+    steps_before = m.steps
+    while eng.has_work():
+        eng.step()
+    chunks = [e for e in m.log if e[0] == "chunk" and e[1] == 1]
+    assert [(c[2], c[3]) for c in chunks[:4]] == [(0, 16), (16, 32), (32, 48), (48, 50)]       # B came in 16 rows at a time
+    # ... and A kept decoding in between: one batched step per scheduler iteration while B was still being prefilled
+    first, last = m.log.index(chunks[0]), m.log.index(chunks[3])
+    assert out["A"] == [65000 + i for i in range(12)] and out["B"] == [66000, 66001, 66002] and out["C"] == [67000, 67001]
+    assert m.steps - steps_before >= 3 and last > first
+    # C (short, arrived behind B) was not admitted while B's prefill was in flight
+    assert m.log.index(("admit", 1, 66)) < next(i for i, e in enumerate(m.log) if e[0] == "admit" and e[2] == 67)
+    # nothing else is running: a long prompt goes in with one call (no reason to chunk)
+    m2 = StubModel(max_batch=2, pack=False)
+    eng2 = Engine(m2, _Proc(), prefill_chunk_tokens=16)
+    eng2.add_request("D" * 50, max_tokens=2, ignore_eos=True)
+    eng2.run_until_done()
+    assert not [e for e in m2.log if e[0] == "chunk"] or [e for e in m2.log if e[0] == "chunk"] == [("chunk", 0, 0, 50)]
+
+
+def test_failed_chunk_and_pool_requeue():
+    m = StubModel(max_batch=2, pack=False)
+    eng = Engine(m, _Proc(), sync_every=1, prefill_chunk_tokens=16)
+    got = {}
+    eng.add_request("A" * 10, max_tokens=6, ignore_eos=True)
+    eng.step()
+    eng.add_request("B" * 50, max_tokens=3, ignore_eos=True, on_tokens=lambda r, new, f: got.setdefault("B", r))
+    eng.step()
+    assert eng.prefilling is not None
+    def boom(st, max_rows=None):
+        raise RuntimeError("device lost")
+    m.admit_step = boom
+    eng.step()
+    assert eng.prefilling is None and got["B"].error is not None and got["B"].finish_reason == "error"
+    eng.run_until_done()                                    # A still finishes
+    # an admission that finds the pool exhausted after all goes back to the HEAD of the queue (deque), not to an error
+    pool = BlockPool(n_blocks=2, block_size=64, n_slots=2, blocks_per_slot=2)
+    m3 = StubModel(max_batch=2, pool=pool, pack=False)
+    m3.kv_fits = lambda counts: True                        # the optimistic pre-check lets it through ...
+    eng3 = Engine(m3, _Proc(), sync_every=1)
+    order = []
+    eng3.add_request("A" * 70, max_tokens=10, ignore_eos=True, on_tokens=lambda r, new, f: f and order.append("A"))
+    eng3.add_request("B" * 70, max_tokens=10, ignore_eos=True, on_tokens=lambda r, new, f: f and order.append("B"))
+    eng3.add_request("C" * 10, max_tokens=2, ignore_eos=True, on_tokens=lambda r, new, f: f and order.append("C"))
+    eng3.run_until_done()                                   # ... B's reservation raises KvPoolExhausted while A runs: requeued
+    assert order == ["A", "B", "C"] and pool.check()

@@ -765,3 +765,41 @@ def test_paged_kv_oversubscribed_pool_waits_and_evicts():
         eng.add_request(prompt, series, max_tokens=7, ignore_eos=True, on_tokens=lambda r, new, fin, k=k: outs.setdefault(k, []).extend(new))
     eng.run_until_done()
     assert [outs[k] for k in range(len(shapes))] == want and m._kv.check()
+
+
+@pytest.mark.parametrize("kv_block", [None, 64])
+def test_engine_chunked_prefill_keeps_the_running_batch_decoding(kv_block):
+    """Engine(prefill_chunk_tokens=N): a long prompt that arrives while another sequence is decoding is prefilled N rows per
+    scheduler iteration with a decode step of the running batch in between; both requests still produce the oracle's tokens
+    (admit_begin / admit_step == _admit, the scratch buffers the decode step clobbers are re-initialised by every chunk)."""
+    from chatts_amd.engine import Engine
+    cfg = cfgmod.preset("tiny-qwen2")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(77)
+    sd = osynth.state_dict(synth.all_specs(cfg), 12)
+    m = ChatTSForCausalLM.from_synthetic(cfg, seed=12, max_ctx=768, max_prefill_tokens=512, max_batch=2, kv_block_size=kv_block)
+    eng = Engine(m, proc, sync_every=2, prefill_chunk_tokens=64)
+    shapes = [[40], [256, 100, 64]]
+    cases, out = [], {}
+    for k, lengths in enumerate(shapes):
+        series = [random_walk_series(rng, L) for L in lengths]
+        prompt = chat_prompt(lengths)
+        inp = proc(text=[prompt], timeseries=series, return_tensors="pt")
+        n_new = 24 if k == 0 else 6
+        want = pipeline.generate(cfg, sd, inp["input_ids"][0].tolist(), inp["timeseries"].numpy(), n_new)["tokens"]
+        cases.append((prompt, series, n_new, want))
+    eng.add_request(cases[0][0], cases[0][1], max_tokens=cases[0][2], ignore_eos=True,
+                    on_tokens=lambda r, new, fin: out.setdefault(0, []).extend(new))
+    eng.step(); eng.step()                                   # the short request is decoding
+    eng.add_request(cases[1][0], cases[1][1], max_tokens=cases[1][2], ignore_eos=True,
+                    on_tokens=lambda r, new, fin: out.setdefault(1, []).extend(new))
+    chunked_iterations, produced_meanwhile = 0, 0
+    while eng.has_work():
+        before = eng.produced[0] if eng.slots[0] is not None else None
+        eng.step()
+        if eng.prefilling is not None:
+            chunked_iterations += 1
+            if before is not None and eng.slots[0] is not None and eng.produced[0] > before:
+                produced_meanwhile += 1
+    assert chunked_iterations >= 3 and produced_meanwhile >= 2            # > 250 prompt rows in 64-row chunks, decode went on
+    assert out[0] == cases[0][3] and out[1] == cases[1][3]
