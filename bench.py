@@ -251,6 +251,8 @@ def parity_check(args, toks):
     (tools/parity_full_depth.py -> profiles/r2_parity_<model>_full.json: CPU float32 oracle, all layers, same prompt, seed 0)."""
     tag = {"chatts-14b": "14b", "chatts-8b": "8b"}.get(args.model)
     path = os.path.join(ROOT, "profiles", f"r2_parity_{tag}_full.json")
+    if getattr(args, "precision", "bf16x2") != "bf16x2":
+        return False, {"reason": "speed mode: logits are outside the 1e-3 tolerance by construction (profiles/r2_speed_mode_14b.json)"}
     if tag is None or args.layers is not None or args.weights != "bf16" or not os.path.exists(path):
         return False, {"reason": "no committed full-depth oracle run for this workload"}
     with open(path) as f:
@@ -379,6 +381,8 @@ def main():
     ap.add_argument("--max-ctx", type=int, default=2048, help="KV-cache length (longer prompts, e.g. --series 30, need more)")
     ap.add_argument("--batch", type=int, default=1, help="> 1: continuous-batching workload (BASELINE.json config 5): B prompts decode "
                     "together; a step = one B-wide decode step; value = aggregate tokens/s")
+    ap.add_argument("--precision", default="bf16x2", choices=["bf16x2", "bf16"], help="bf16 = the optional speed mode (single-pass "
+                    "bf16 activations in the prefill GEMMs; not parity grade, labelled as such); default bf16x2")
     ap.add_argument("--kv-block", type=int, default=0, help="block-paged KV cache with this many positions per block (0 = one "
                     "contiguous cache per slot, the default)")
     ap.add_argument("--no-pack", action="store_true", help="--batch: admit the prompts one by one instead of packed prefill passes")
@@ -421,7 +425,7 @@ def main():
     max_ctx = args.max_ctx
     model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, device=device, comm=comm, max_ctx=max_ctx,
                                              max_prefill_tokens=1024, use_graph=not args.no_graph,
-                                             weight_format=args.weights, max_batch=max(1, args.batch),
+                                             weight_format=args.weights, max_batch=max(1, args.batch), precision=args.precision,
                                              kv_block_size=args.kv_block or None)
     torch.cuda.synchronize()
     log(f"[bench] {args.model} TP={world} materialised in {time.time() - t0:.1f}s, "
@@ -524,8 +528,10 @@ def main():
                    "model": args.model, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
                    "parallelism": f"tp{world}", "batch": 1, "decode_graph": model.graph_capturable(), "kv_block": model.kv_block_size or None,
                    "tp_exchange": tp_exchange,
-                   "precision": "bf16 weights; f32 activations, KV cache and accumulation (bf16x2 MFMA split in "
-                                "prefill, exact f32 FMA in decode)",
+                   "precision": ("bf16 weights; f32 activations, KV cache and accumulation (bf16x2 MFMA split in "
+                                 "prefill, exact f32 FMA in decode)") if model.precision == "bf16x2" else
+                                ("SPEED MODE precision=bf16 - NOT the parity-grade line: prefill GEMMs multiply bf16-rounded activations "
+                                 "(one MFMA pass), logits ~3e-2 of the default mode (profiles/r2_speed_mode_14b.json); decode as in the default"),
                    "first_tokens": toks[:8]},
         "ttft_ms_p50": ttft, "ts_encode_ms_p50": median(enc_ms),
         "decode_hbm_gbs_per_gpu": step_bytes / (dt / args.steps) / 1e9,

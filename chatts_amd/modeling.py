@@ -83,11 +83,24 @@ class ChatTSForCausalLM:
 
     def __init__(self, config, device="cuda", comm=None, max_ctx=2048, max_prefill_tokens=2048, use_graph=True,
                  max_batch=1, weight_format="bf16", use_p2p=True, enable_prefix_caching=True, kv_block_size=None,
-                 kv_pool_blocks=None):
+                 kv_pool_blocks=None, precision=None):
         if not torch.cuda.is_available():
             raise RuntimeError("chatts_amd needs a ROCm GPU: there is no CPU fallback for the model")
         self.lib = _lib.load()
         self.config = config
+        # precision: None / "bf16x2" = the parity-grade default (float32 activations carried as bf16 hi + lo planes, two MFMA passes
+        # in the prefill GEMMs: logits ~5e-5 of the float32 oracle).  "bf16" = SPEED mode: the prefill GEMMs
+        # multiply the bf16-rounded activations only - half the matrix work, logits ~1e-2, what a bf16 HF / vLLM run computes.
+        # PROCESS-WIDE (the library reads CHATTS_GEMM_PRECISION per call): every model of this process follows the last setting.
+        if precision not in (None, "bf16x2", "bf16"):
+            raise ValueError("precision must be None / 'bf16x2' (parity grade) or 'bf16' (speed mode)")
+        if precision is not None:
+            import os
+            if precision == "bf16":
+                os.environ["CHATTS_GEMM_PRECISION"] = "bf16"
+            else:
+                os.environ.pop("CHATTS_GEMM_PRECISION", None)
+        self.precision = precision or "bf16x2"
         self.device = torch.device(device)
         self.comm = comm or LocalComm()
         self.plan = ShardPlan(config, self.comm.rank, self.comm.world)

@@ -320,6 +320,24 @@ def test_gemm_dma_parity(lib, epi, m, n, k):
     assert rel_err(out.cpu().numpy(), want) < 2e-5
 
 
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k", [(96, 256, 64), (130, 384, 1024), (798, 2080, 640), (360, 7168, 5120)])
+def test_gemm_dma_single_pass_speed_mode(lib, monkeypatch, epi, m, n, k):
+    """CHATTS_GEMM_PRECISION=bf16 (the optional speed mode): the LDS-DMA GEMM multiplies the hi plane only - exactly the product of
+    the bf16-ROUNDED activations with the weights (float64 reference on the rounded operand: 2e-5), and measurably not the
+    float32-activation product the default mode delivers."""
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi + 5, scale=3.0)
+    want_exact = _ref_linear(a, w, bias, resid, epi)
+    want_rounded = _ref_linear(a.to(torch.bfloat16).float(), w, bias, resid, epi)
+    monkeypatch.setenv("CHATTS_GEMM_PRECISION", "bf16")
+    out = _linear_planes(lib, a, w, bias, resid if epi == _lib.EPI_RESID else None, epi, with_a=False, ld=k + 64)
+    monkeypatch.delenv("CHATTS_GEMM_PRECISION")
+    ref = _linear_planes(lib, a, w, bias, resid if epi == _lib.EPI_RESID else None, epi, with_a=False, ld=k + 64)
+    assert rel_err(out.cpu().numpy(), want_rounded) < 2e-5
+    assert rel_err(ref.cpu().numpy(), want_exact) < 2e-5
+    assert 1e-4 < rel_err(out.cpu().numpy(), want_exact) < 2e-2          # the price of the mode: ~2^-9 per operand
+
+
 @pytest.mark.parametrize("sk", [1, 2, 3])
 def test_gemm_dma_equals_register_staged_bitwise(lib, sk, monkeypatch):
     """Same products, same accumulation order: with the split-K factor pinned the two GEMM kernels agree bit for bit."""
