@@ -32,12 +32,23 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def build_inputs(cfg, n_series=8, length=256):
+def workload_lengths(rng, n_series, length, mode="uniform"):
+    """Series lengths of a workload.  "uniform": n_series x length.  "mixed" (BASELINE.json config 4):
+    rng.integers(64, 1025, n_series) drawn from the workload's generator BEFORE the values, with two entries forced to ragged
+    tails (L % 16 != 0: the last-value pad / padding_idx branch of chatts_vllm.py:121-129 must be on the path)."""
+    if mode != "mixed":
+        return [int(length)] * n_series
+    lengths = [int(v) for v in rng.integers(64, 1025, n_series)]
+    lengths[3 % n_series], lengths[17 % n_series] = 1000, 65
+    return lengths
+
+
+def build_inputs(cfg, n_series=8, length=256, mode="uniform"):
     import numpy as np
     from chatts_amd.processing import ChatTSProcessor
     proc = ChatTSProcessor.from_pretrained(cfg)
     rng = np.random.default_rng(1234)                       # SURVEY.md section 8d synthetic inputs
-    lengths = [length] * n_series
+    lengths = workload_lengths(rng, n_series, length, mode)
     series = [50 + 2 * np.cumsum(rng.standard_normal(L)) for L in lengths]
     body = f"I have {n_series} time series. " + " ".join(
         f"TS{i} is of length {L}: <ts><ts/>;" for i, L in enumerate(lengths)) + \
@@ -46,6 +57,47 @@ def build_inputs(cfg, n_series=8, length=256):
     prompt = ("<|im_start|>system\nYou are a helpful assistant.<|im_end|><|im_start|>user\n" + body +
               "<|im_end|><|im_start|>assistant\n")
     return proc, prompt, series, lengths
+
+
+def build_batched_requests(cfg, batch, n_series=8, length=1024):
+    """BASELINE.json config 5 inputs: `batch` DIFFERENT prompts of n_series x length (one generator, series drawn request by request)."""
+    import numpy as np
+    from chatts_amd.processing import ChatTSProcessor
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(1234)
+    lengths = [length] * n_series
+    body = f"I have {n_series} time series. " + " ".join(f"TS{i} is of length {L}: <ts><ts/>;" for i, L in enumerate(lengths)) + \
+        " Please analyze the local changes in these time series first and then conclude if these time series show local changes near the same time?"
+    prompt = "<|im_start|>system\nYou are a helpful assistant.<|im_end|><|im_start|>user\n" + body + "<|im_end|><|im_start|>assistant\n"
+    reqs = [[50 + 2 * np.cumsum(rng.standard_normal(L)) for L in lengths] for _ in range(batch)]
+    return proc, prompt, reqs, lengths
+
+
+def admit_batched(model, proc, prompt, reqs, budget, pack=True):
+    """The engine's admission loop over all cache slots: short prompts are prefilled together (chatts_decoder_prefill_packed).
+    -> (prompt tokens, per-request TTFT ms, packed passes)."""
+    import torch
+    pending = []
+    for series in reqs:
+        inputs = proc(text=[prompt], timeseries=series, padding=True, return_tensors="pt")
+        pending.append((inputs["input_ids"][0].tolist(), inputs["timeseries"], list(proc.last_lengths), budget))
+    free = list(range(len(reqs)))
+    packs, ttfts, T = 0, [], None
+    while pending:
+        t0 = time.perf_counter()
+        pk = model.plan_pack(pending[:len(free)], free) if pack else []
+        group = [pending[j] for j in pk] if pk else pending[:1]
+        items = [(free.pop(0),) + g for g in group]
+        if len(items) > 1:
+            T = model._admit_packed(items)[0]
+            packs += 1
+        else:
+            T = model._admit(*items[0])
+        for g in group:
+            pending.remove(g)
+        torch.cuda.synchronize()
+        ttfts += [(time.perf_counter() - t0) * 1e3] * len(items)
+    return T, ttfts, packs
 
 
 def median(xs):
@@ -246,32 +298,67 @@ def cpu_baseline(model, prompt_tokens, depth=8):
                 wall_s=time.time() - t_start)
 
 
-def parity_check(args, toks):
-    """Compare the tokens this run generated with the committed FULL-DEPTH oracle run of the same workload
-    (tools/parity_full_depth.py -> profiles/r2_parity_<model>_full.json: CPU float32 oracle, all layers, same prompt, seed 0)."""
+def workload_key(args):
+    """file-name key of a workload: model tag + series x length (or 'mixed') + weight format + batch"""
     tag = {"chatts-14b": "14b", "chatts-8b": "8b"}.get(args.model)
-    path = os.path.join(ROOT, "profiles", f"r2_parity_{tag}_full.json")
+    if tag is None:
+        return None
+    shape = f"{args.series}xmixed" if getattr(args, "lengths", "uniform") == "mixed" else f"{args.series}x{args.length}"
+    return f"{tag}_{shape}_{args.weights}_b{max(1, args.batch)}"
+
+
+def parity_reference(args):
+    """The committed FULL-DEPTH oracle run of this workload (tools/parity_full_depth.py: CPU float32 oracle, all layers, same
+    inputs, seed 0), or None.  Round-3 files are keyed by the workload; the two round-2 files cover the headline / config-2 lines."""
+    key = workload_key(args)
+    if key is None:
+        return None, None
+    cands = [os.path.join(ROOT, "profiles", f"r3_parity_{key}_full.json")]
+    if args.weights == "bf16" and args.batch <= 1 and getattr(args, "lengths", "uniform") == "uniform":
+        cands.append(os.path.join(ROOT, "profiles", f"r2_parity_{key.split('_')[0]}_full.json"))
+    for path in cands:
+        if os.path.exists(path):
+            with open(path) as f:
+                ref = json.load(f)
+            if (ref.get("series"), ref.get("length")) == (args.series, args.length) or ref.get("workload_key") == key:
+                return path, ref
+    return None, None
+
+
+def parity_check(args, toks):
+    """Compare the tokens this run generated with the committed full-depth oracle run of the SAME workload.  toks: the token list
+    (batch 1) or one list per cache slot (batched workloads: the oracle run records the slots it covered)."""
     if getattr(args, "precision", "bf16x2") != "bf16x2":
         return False, {"reason": "speed mode: logits are outside the 1e-3 tolerance by construction (profiles/r2_speed_mode_14b.json)"}
-    if tag is None or args.layers is not None or args.weights != "bf16" or not os.path.exists(path):
+    if args.layers is not None:
+        return False, {"reason": "truncated depth (debug run)"}
+    path, ref = parity_reference(args)
+    if ref is None:
         return False, {"reason": "no committed full-depth oracle run for this workload"}
-    with open(path) as f:
-        ref = json.load(f)
-    if (ref.get("series"), ref.get("length")) != (args.series, args.length):
-        return False, {"reason": f"oracle run is for {ref.get('series')}x{ref.get('length')}"}
     want = ref["tokens_oracle"]
-    n = min(len(want), len(toks))
-    ok = n > 0 and toks[:n] == want[:n]
-    return ok, {"source": os.path.relpath(path, ROOT), "tokens_compared": n, "tokens_match": ok,
-                "first_token_logits_rel_err_recorded": ref.get("first_token_logits_rel_err"),
-                "max_step_logits_rel_err_recorded": max(ref.get("step_logits_rel_err", [0.0])), "tolerance": ref.get("tolerance", 1e-3)}
+    if isinstance(want, dict):              # batched: {slot: tokens}
+        pairs = [(toks[int(sl)], w) for sl, w in sorted(want.items(), key=lambda kv: int(kv[0]))]
+        slots = sorted(int(sl) for sl in want)
+    else:
+        pairs, slots = [(toks, want)], None
+    n = min(min(len(w), len(t)) for t, w in pairs)
+    ok = n > 0 and all(t[:n] == w[:n] for t, w in pairs)
+    out = {"source": os.path.relpath(path, ROOT), "tokens_compared": n, "tokens_match": ok,
+           "first_token_logits_rel_err_recorded": ref.get("first_token_logits_rel_err"),
+           "max_step_logits_rel_err_recorded": ref.get("max_step_logits_rel_err", max(ref.get("step_logits_rel_err", [0.0]))),
+           "max_abs_err_over_max_logit_recorded": ref.get("max_abs_err_over_max_logit"), "tolerance": ref.get("tolerance", 1e-3)}
+    if slots is not None:
+        out["slots_compared"] = slots
+    return ok, out
 
 
 def workload_name(args, world):
     names = {"chatts-14b": "ChatTS-14B", "chatts-8b": "ChatTS-8B"}
     if args.model not in names or args.layers is not None:
         return f"DEBUG {args.model} layers={args.layers}"
-    return (f"{names[args.model]} {args.weights} weights, {args.series} series x {args.length} steps, greedy decode, TP={world}")
+    shape = (f"{args.series} series x mixed lengths 64-1024 (rng 1234, ragged tails forced)" if args.lengths == "mixed"
+             else f"{args.series} series x {args.length} steps")
+    return f"{names[args.model]} {args.weights} weights, {shape}, greedy decode, TP={world}"
 
 
 def bench_batched(args, model, cfg, comm, world, device):
@@ -279,45 +366,17 @@ def bench_batched(args, model, cfg, comm, world, device):
     into the cache slots (TTFT = per-request processor + TS encode + merge + prefill + first token, p50 over the requests),
     then decode TOGETHER: a step = one B-wide decode step (one hipGraph: M = B weight-streaming GEMMs, per-sequence
     attention, per-sequence token selection); value = B * steps / max-over-ranks time."""
-    import numpy as np
     import torch
     import torch.distributed as dist
-    from chatts_amd.processing import ChatTSProcessor
     B = args.batch
-    proc = ChatTSProcessor.from_pretrained(cfg)
-    rng = np.random.default_rng(1234)
-    lengths = [args.length] * args.series
-    body = f"I have {args.series} time series. " + " ".join(f"TS{i} is of length {L}: <ts><ts/>;" for i, L in enumerate(lengths)) + \
-        " Please analyze the local changes in these time series first and then conclude if these time series show local changes near the same time?"
-    prompt = "<|im_start|>system\nYou are a helpful assistant.<|im_end|><|im_start|>user\n" + body + "<|im_end|><|im_start|>assistant\n"
-    reqs = [[50 + 2 * np.cumsum(rng.standard_normal(L)) for L in lengths] for _ in range(B)]
+    proc, prompt, reqs, lengths = build_batched_requests(cfg, B, args.series, args.length)
     budget = 1 + args.warmup + args.steps
     Bf = model.buf
     Bf["pos_all"].zero_(); Bf["step_all"].zero_(); Bf["token_all"].zero_()
-    ttfts, T = [], None
     comm.barrier()
     torch.cuda.synchronize()
     t_admit0 = time.perf_counter()
-    pending = []
-    for series in reqs:
-        inputs = proc(text=[prompt], timeseries=series, padding=True, return_tensors="pt")
-        pending.append((inputs["input_ids"][0].tolist(), inputs["timeseries"], list(proc.last_lengths), budget))
-    free = list(range(B))
-    packs = 0
-    while pending:              # the engine's admission loop: short prompts are prefilled together (chatts_decoder_prefill_packed)
-        t0 = time.perf_counter()
-        pack = [] if args.no_pack else model.plan_pack(pending[:len(free)], free)
-        group = [pending[j] for j in pack] if pack else pending[:1]
-        items = [(free.pop(0),) + g for g in group]
-        if len(items) > 1:
-            T = model._admit_packed(items)[0]
-            packs += 1
-        else:
-            T = model._admit(*items[0])
-        for g in group:
-            pending.remove(g)
-        torch.cuda.synchronize()
-        ttfts += [(time.perf_counter() - t0) * 1e3] * len(items)
+    T, ttfts, packs = admit_batched(model, proc, prompt, reqs, budget, pack=not args.no_pack)
     admit_ms = (time.perf_counter() - t_admit0) * 1e3
     for _ in range(args.warmup):
         model.batched_step()
@@ -339,7 +398,7 @@ def bench_batched(args, model, cfg, comm, world, device):
     names = {"chatts-14b": "ChatTS-14B", "chatts-8b": "ChatTS-8B"}
     label = (f"{names.get(args.model, args.model)} {args.weights} weights, {args.series} series x {args.length} steps, batch {B} continuous "
              f"prompts, TP={world}") if args.layers is None and args.model in names else f"DEBUG {args.model} layers={args.layers}"
-    return {
+    res = {
         "metric": f"generated tokens/sec (aggregate over {B} sequences decoding together) + p50 TTFT, {names.get(args.model, args.model)}, "
                   f"{args.series}x{args.length}-step TS prompts, TP=N",
         "value": B * args.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -360,10 +419,54 @@ def bench_batched(args, model, cfg, comm, world, device):
         "roofline": {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS,
                      "traffic": None, "kernel": roof["kernel"], "avg_us": roof["avg_us"], "bytes_per_launch": roof["bytes_per_launch"],
                      "launches_timed": roof["launches"]},
-        "parity_checked": False,
-        "parity": {"reason": "no full-depth oracle run is committed for this workload; per-slot oracle parity of the batched path is "
-                             "tests/test_gpu_e2e.py::test_continuous_batching_matches_oracle"},
     }
+    res["parity_checked"], res["parity"] = parity_check(args, toks)
+    res["config"]["rccl_world_size"] = dist.get_world_size() if world > 1 else 1
+    return res
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (the driver's call shape; the reference's is one process asking vLLM for
+    tensor_parallel_size=N, demo/demo_vllm.py:30): re-execute this command under torch.distributed.run, one rank per GPU on this
+    node, rendezvous on 127.0.0.1.  Rank 0 of the re-executed job prints the one JSON line."""
+    from chatts_amd.tp_spawn import free_port
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {n} without a launcher: re-executing under torch.distributed.run ({n} ranks)")
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+def launch_check(args):
+    """--launch-check: prove the N-rank launch path without touching a model (CPU-testable with gloo): every rank joins the
+    process group, the ranks sum a one, rank 0 prints what it saw."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("CHATTS_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("CHATTS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{torch.cuda.current_device()}"))
+        else:
+            dist.init_process_group(backend=backend)
+        one = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        seen = int(one.item())
+        backend_name = dist.get_backend()
+        ws = dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        backend_name, ws = None, 1
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "requested_gpus": args.gpus, "ranks_summed": seen,
+                          "rccl_world_size": ws, "backend": backend_name}), flush=True)
 
 
 def main():
@@ -374,6 +477,8 @@ def main():
     ap.add_argument("--model", default="chatts-14b")
     ap.add_argument("--series", type=int, default=8)
     ap.add_argument("--length", type=int, default=256)
+    ap.add_argument("--lengths", default="uniform", choices=["uniform", "mixed"], help="mixed = BASELINE.json config 4: --series lengths "
+                    "drawn from rng(1234).integers(64, 1025) with ragged tails forced (use with --series 30)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: truncate depth (result marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -388,7 +493,13 @@ def main():
     ap.add_argument("--no-pack", action="store_true", help="--batch: admit the prompts one by one instead of packed prefill passes")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "int4"],
                     help="fp8 = BASELINE.json config 5 weight format, int4 = the GPTQ-Int4 checkpoint's (NOT the headline: separate workloads)")
+    ap.add_argument("--launch-check", action="store_true", help="only prove the N-rank launch path (no model): rank 0 prints the world it saw")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)          # does not return
+    if args.launch_check:
+        return launch_check(args)
 
     import torch
     import torch.distributed as dist
@@ -400,7 +511,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: pass the same N to both "
+                         "(or run `python bench.py --gpus N` alone: it launches its own ranks)")
     # test hooks (functional TP check on a single-GPU box): CHATTS_FORCE_DEVICE pins every rank to one device,
     # CHATTS_DIST_BACKEND=gloo replaces RCCL.  Never set by the driver.
     dev_index = int(os.environ.get("CHATTS_FORCE_DEVICE", local_rank))
@@ -420,9 +532,13 @@ def main():
 
     over = {} if args.layers is None else {"num_hidden_layers": args.layers}
     cfg = cfgmod.preset(args.model, **over)
-    proc, prompt, series, lengths = build_inputs(cfg, args.series, args.length)
+    proc, prompt, series, lengths = build_inputs(cfg, args.series, args.length, args.lengths)
     t0 = time.time()
     max_ctx = args.max_ctx
+    if args.batch <= 1:         # the cache must hold prompt + every generated token (config 4's prompt alone is ~2.2k tokens)
+        n_ids = len(proc(text=[prompt], timeseries=series, padding=True, return_tensors="pt")["input_ids"][0])
+        need = n_ids - 2 * len(lengths) + sum((L + 15) // 16 for L in lengths) + args.warmup + args.steps + 16
+        max_ctx = max(max_ctx, -(-need // 256) * 256)
     model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, device=device, comm=comm, max_ctx=max_ctx,
                                              max_prefill_tokens=1024, use_graph=not args.no_graph,
                                              weight_format=args.weights, max_batch=max(1, args.batch), precision=args.precision,
@@ -519,7 +635,7 @@ def main():
     step_bytes = model.weight_bytes_local()
     result = {
         "metric": f"generated tokens/sec (greedy, batch 1) + p50 TTFT, {'ChatTS-8B' if args.model == 'chatts-8b' else 'ChatTS-14B'}, "
-                  f"{args.series}x{args.length}-step TS prompt, TP=N",
+                  f"{args.series}x{'mixed(64-1024)' if args.lengths == 'mixed' else args.length}-step TS prompt, TP=N",
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": {"bf16": "bf16", "fp8": "fp8-e4m3 weights (pow2 row scales), f32 math",
@@ -527,7 +643,7 @@ def main():
         "config": {"workload": workload_name(args, world),
                    "model": args.model, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
                    "parallelism": f"tp{world}", "batch": 1, "decode_graph": model.graph_capturable(), "kv_block": model.kv_block_size or None,
-                   "tp_exchange": tp_exchange,
+                   "tp_exchange": tp_exchange, "rccl_world_size": dist.get_world_size() if world > 1 else 1,
                    "precision": ("bf16 weights; f32 activations, KV cache and accumulation (bf16x2 MFMA split in "
                                  "prefill, exact f32 FMA in decode)") if model.precision == "bf16x2" else
                                 ("SPEED MODE precision=bf16 - NOT the parity-grade line: prefill GEMMs multiply bf16-rounded activations "

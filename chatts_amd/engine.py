@@ -17,6 +17,23 @@ from collections import deque
 import numpy as np
 
 
+def validate_sampling(max_tokens=64, temperature=0.0, top_p=1.0, top_k=0, **_):
+    """The ranges vLLM's SamplingParams accepts (what the reference's drivers pass: inference_tsmllm_vllm.py:43-46,
+    llm_utils.py:153).  Raises ValueError - the server turns it into a 400 - BEFORE the request can reach the engine thread, where
+    an out-of-range value would otherwise surface inside set_sampling / chatts_decoder_set_sampling."""
+    import math
+    t = 0.0 if temperature is None else float(temperature)
+    if not math.isfinite(t) or t < 0.0:
+        raise ValueError(f"temperature must be a finite number >= 0, got {temperature}")
+    p = 1.0 if top_p is None else float(top_p)
+    if not math.isfinite(p) or not (0.0 < p <= 1.0):
+        raise ValueError(f"top_p must be in (0, 1], got {top_p}")
+    if int(top_k or 0) < -1:
+        raise ValueError(f"top_k must be -1 / 0 (off) or positive, got {top_k}")
+    if int(max_tokens) < 1:
+        raise ValueError(f"max_tokens must be at least 1, got {max_tokens}")
+
+
 class Request:
     def __init__(self, rid, prompt, timeseries, max_tokens, sampling_key, eos, on_tokens):
         self.rid, self.prompt, self.timeseries, self.max_tokens = rid, prompt, timeseries, int(max_tokens)
@@ -25,6 +42,7 @@ class Request:
         self.prompt_tokens = 0
         self.t_arrival, self.t_first = time.perf_counter(), None
         self.error = None
+        self.bypassed = 0                    # later arrivals admitted past this request while it waited for its sampling group
 
 
 class Engine:
@@ -38,6 +56,7 @@ class Engine:
         # instead of stalling them for the whole prefill.  None: a prompt is always prefilled in one go.
         self.prefill_chunk_tokens = None if not prefill_chunk_tokens else max(16, int(prefill_chunk_tokens))
         self.prefilling = None                          # (request, slot, admission state) of the prompt being prefilled in chunks
+        self.max_bypass = 8                             # admissions that may overtake a request waiting for another sampling group
         self.waiting = deque()
         self.nslots = max(1, model.max_batch)
         self.slots = [None] * self.nslots
@@ -51,10 +70,11 @@ class Engine:
     # ---- requests ---------------------------------------------------------------------------------
     def add_request(self, prompt, timeseries=None, max_tokens=64, temperature=0.0, top_p=1.0, top_k=0, seed=0,
                     stop_token_ids=None, ignore_eos=False, on_tokens=None):
+        validate_sampling(max_tokens, temperature, top_p, top_k)
         e = self.model.config.eos_token_id
         eos = [] if ignore_eos else (list(e) if isinstance(e, (list, tuple)) else [e])
         eos += list(stop_token_ids or [])
-        key = None if not temperature else (float(temperature), int(top_k or 0), float(top_p), int(seed))
+        key = None if not temperature else (float(temperature), max(int(top_k or 0), 0), float(top_p), int(seed))
         self._rid += 1
         r = Request(self._rid, prompt, list(timeseries or []), max_tokens, key, eos, on_tokens)
         self.waiting.append(r)
@@ -91,9 +111,16 @@ class Engine:
         Returns the requests that finished in this call."""
         m = self.model
         done = []
-        running = any(s is not None for s in self.slots)
-        if not running and self.waiting and self.waiting[0].sampling_key != self.active_key:
-            self._apply_sampling(self.waiting[0].sampling_key)
+        # (a prompt that is being prefilled in chunks draws its first token with the CURRENT configuration: it counts as running)
+        running = any(s is not None for s in self.slots) or self.prefilling is not None
+        while not running and self.waiting and self.waiting[0].sampling_key != self.active_key:
+            try:
+                self._apply_sampling(self.waiting[0].sampling_key)
+            except Exception as e:                       # a configuration the library refuses fails THAT request, not the engine
+                r = self.waiting.popleft()
+                r.error = e
+                self._emit(r, True, "error")
+                done.append(r)
         if self.prefilling is not None:                  # a long prompt is on its way in: its next chunk, no other admission meanwhile
             r, s, st = self.prefilling
             try:
@@ -109,9 +136,17 @@ class Engine:
         # admission: free slots take waiting requests that share the running batch's sampling configuration
         while self.prefilling is None and self.waiting and any(v is None for v in self.slots):
             free = [i for i, v in enumerate(self.slots) if v is None]
+            # requests that share the running batch's sampling configuration may overtake a head of the queue that waits for ANOTHER
+            # one (it joins when the batch has drained) - but only `max_bypass` times, or a steady stream of same-key arrivals
+            # would starve it
+            head = self.waiting[0]
+            if head.sampling_key != self.active_key and head.bypassed >= self.max_bypass:
+                break
             cands = [q for q in self.waiting if q.sampling_key == self.active_key][:len(free)]
             if not cands:
                 break
+            if head.sampling_key != self.active_key:
+                head.bypassed += len(cands)
             ready = []
             for r in cands:                              # tokenise / sp-encode once per request
                 if getattr(r, "_enc", None) is None:
@@ -167,7 +202,7 @@ class Engine:
             except Exception as e:
                 self.prefilling = None
                 if type(e).__name__ == "KvPoolExhausted" and any(v is not None for v in self.slots):
-                    self.waiting.extendleft(reversed(group))      # the block pool is full (nothing was changed): back to the head
+                    self.waiting.extendleft(reversed(group))      # the block pool is full (resident-prefix claims of the touched slots were dropped): back to the head
                     break                                         # of the queue until a running sequence finishes
                 for r in group:
                     r.error = e
@@ -201,6 +236,24 @@ class Engine:
         done = []
         self._since_sync = 0
         toks_all = B["out_tokens_all"].cpu() if self.nslots > 1 else B["out_tokens"][None].cpu()
+        tp = getattr(m, "_tp", None)
+        if tp is not None and tp.status():
+            # a peer's contribution did not arrive (csrc/tp.hip sets a sticky bit and every later collective sums garbage): the
+            # tokens read above are worthless - fail what is running instead of serving them, and reset the exchange
+            err = RuntimeError("tensor-parallel exchange timed out (a peer rank did not reach a collective): tokens discarded")
+            for s in range(self.nslots):
+                r = self.slots[s]
+                if r is None:
+                    continue
+                self.slots[s] = None
+                if self.nslots > 1:
+                    B["pos_all"][s] = -1
+                m._slot_idents[s] = []
+                r.error = err
+                self._emit(r, True, "error")
+                done.append(r)
+            return done                  # (the exchange stays broken - every later harvest fails the same way - until the ranks
+                                         # are restarted: a one-sided reset would let the ranks' engines diverge)
         for s in range(self.nslots):
             r = self.slots[s]
             if r is None:
@@ -318,6 +371,11 @@ class EngineThread:
             import traceback
             traceback.print_exc()
             self._fail_all(e)
+            if self.control is not None:     # the follower ranks block in control.receive(): release them
+                try:
+                    self.control.publish([], stop=True)
+                except Exception:
+                    pass
 
     def _fail_all(self, e):
         eng = self.engine

@@ -46,6 +46,11 @@ def _load_checkpoint_tokenizer(path):
     return AutoTokenizer.from_pretrained(path, trust_remote_code=False)
 
 
+def _build_llm(model, kw):
+    """factory of chatts_amd.tp_spawn.TpGroup: every spawned rank (and the leader) builds the same LLM"""
+    return LLM(model, **kw)
+
+
 class LLM:
     def __init__(self, model, tensor_parallel_size=1, max_model_len=6000, limit_mm_per_prompt=None,
                  trust_remote_code=True, gpu_memory_utilization=None, seed=0, tokenizer=None, comm=None,
@@ -54,6 +59,21 @@ class LLM:
         from .modeling import ChatTSForCausalLM
         from .processing import ChatTSProcessor
         from .tp import Comm, LocalComm
+        self._tp_group = None
+        if tensor_parallel_size > 1 and comm is None and "WORLD_SIZE" not in os.environ:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                # the reference's call shape (demo/demo_vllm.py:30, llm_utils.py:154): ONE plain process asks for k GPUs and the
+                # engine spawns its own workers, like vLLM does.  This process becomes rank 0; the followers replay every generate()
+                from .tp_spawn import TpGroup
+                args = dict(tensor_parallel_size=tensor_parallel_size, max_model_len=max_model_len,
+                            limit_mm_per_prompt=limit_mm_per_prompt, trust_remote_code=trust_remote_code,
+                            gpu_memory_utilization=gpu_memory_utilization, seed=seed, tokenizer=tokenizer,
+                            max_num_seqs=max_num_seqs, block_size=block_size, num_gpu_blocks_override=num_gpu_blocks_override, **kw)
+                group, inner = TpGroup.launch(tensor_parallel_size, _build_llm, (model, args))
+                self.__dict__.update(inner.__dict__)
+                self._tp_group = group
+                return
         self._seed = int(seed)              # also the default seed of sampled generation (SamplingParams.seed overrides)
         if comm is None:
             comm = Comm() if tensor_parallel_size > 1 else LocalComm()
@@ -82,7 +102,21 @@ class LLM:
     def get_tokenizer(self):
         return self.processor.tokenizer
 
+    def shutdown(self):
+        """stop the tensor-parallel workers this object spawned (no-op otherwise)"""
+        if self._tp_group is not None:
+            self._tp_group.shutdown()
+            self._tp_group = None
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass
+
     def generate(self, prompts, sampling_params=None, use_tqdm=False):
+        if self._tp_group is not None:      # spawned followers run the same call now; all ranks meet inside the exchange kernels
+            self._tp_group.call("generate", prompts, sampling_params)
         sp = sampling_params or SamplingParams()
         self.model.set_sampling(sp.temperature or 0.0, max(int(sp.top_k or 0), 0), sp.top_p,
                                 self._seed if sp.seed is None else sp.seed)

@@ -1051,14 +1051,20 @@ class ChatTSForCausalLM:
         segs, embs, Ts, row, late = [], [], [], 0, []
         if self._kv_dynamic:        # oversubscribed block pool: reserve for EVERY member before anything changes, or for none
             from .kv_blocks import KvPoolExhausted
-            newly = []
+            newly, touched = [], []
             try:
                 for slot, ids, series, lengths, max_new in items:
                     was_active = slot in self._kv.active
+                    touched.append(slot)
                     self.reserve_kv(slot, self.request_tokens(ids, series, lengths) + max_new, self._request_idents(ids, series, lengths))
                     if not was_active:
                         newly.append(slot)
             except KvPoolExhausted:
+                # roll back: the members reserved so far may already have had shared prefix blocks swapped for EMPTY private ones, so
+                # what their slots advertise as resident is no longer true - forget it (a later request must not adopt those blocks)
+                for sl in touched:
+                    self._slot_idents[sl] = []
+                    self._kv_replaced.pop(sl, None)
                 for sl in newly:
                     self._kv.retire(sl)
                 raise
@@ -1124,6 +1130,8 @@ class ChatTSForCausalLM:
 
         def harvest(final=False):
             toks_all = B["out_tokens_all"].cpu()
+            if self._tp is not None and self._tp.status():
+                raise RuntimeError("tensor-parallel exchange timed out (a peer rank did not reach the collective): tokens are invalid")
             for s, r in enumerate(slots):
                 if r is None:
                     continue
@@ -1155,7 +1163,7 @@ class ChatTSForCausalLM:
                     try:
                         self._admit_packed(items)
                     except RuntimeError as e:                # the pool could not cover the pack after all (a protected prefix
-                        if type(e).__name__ != "KvPoolExhausted" or all(v is None for v in slots):     # source): nothing was changed
+                        if type(e).__name__ != "KvPoolExhausted" or all(v is None for v in slots):     # source): the touched slots forgot their resident prefixes
                             raise
                         break
                     for s, r in members:
@@ -1250,6 +1258,8 @@ class ChatTSForCausalLM:
         while True:
             if produced - sent >= chunk or produced >= max_new_tokens:
                 toks = self.buf["out_tokens"][sent:produced].tolist()
+                if self._tp is not None and self._tp.status():
+                    raise RuntimeError("tensor-parallel exchange timed out (a peer rank did not reach the collective): tokens are invalid")
                 hit = next((i for i, t in enumerate(toks) if t in eos), None)
                 if hit is not None:
                     yield toks[:hit + 1]

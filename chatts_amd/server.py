@@ -77,9 +77,16 @@ def render_chat(messages, default_system=DEFAULT_SYSTEM):
 def sampling_from_body(body, default_max_tokens=512):
     mt = body.get("max_completion_tokens") or body.get("max_tokens") or default_max_tokens
     temp = body.get("temperature")
-    return dict(max_tokens=int(mt), temperature=0.0 if temp is None else float(temp), top_p=float(body.get("top_p") or 1.0),
-                top_k=int(body.get("top_k") or 0), seed=int(body.get("seed") or 0),
-                stop_token_ids=list(body.get("stop_token_ids") or []), ignore_eos=bool(body.get("ignore_eos", False)))
+    top_p = body.get("top_p")
+    try:
+        out = dict(max_tokens=int(mt), temperature=0.0 if temp is None else float(temp), top_p=1.0 if top_p is None else float(top_p),
+                   top_k=int(body.get("top_k") or 0), seed=int(body.get("seed") or 0),
+                   stop_token_ids=[int(t) for t in (body.get("stop_token_ids") or [])], ignore_eos=bool(body.get("ignore_eos", False)))
+    except (TypeError, ValueError) as e:
+        raise ValueError(f"malformed sampling parameter: {e}")
+    from .engine import validate_sampling
+    validate_sampling(**out)             # ValueError -> 400 (never reaches the engine thread)
+    return out
 
 
 class IncrementalDecoder:

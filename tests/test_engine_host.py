@@ -276,3 +276,54 @@ def test_failed_chunk_and_pool_requeue():
     eng3.add_request("C" * 10, max_tokens=2, ignore_eos=True, on_tokens=lambda r, new, f: f and order.append("C"))
     eng3.run_until_done()                                   # ... B's reservation raises KvPoolExhausted while A runs: requeued
     assert order == ["A", "B", "C"] and pool.check()
+
+
+def test_out_of_range_sampling_parameters_are_refused_before_the_engine():
+    """{"temperature": -1} used to reach set_sampling inside step() and kill the engine thread for everybody."""
+    from chatts_amd.engine import validate_sampling
+    from chatts_amd.server import sampling_from_body
+    for bad in ({"temperature": -1}, {"temperature": float("nan")}, {"top_p": 1.5}, {"top_p": 0}, {"top_p": float("nan")},
+                {"top_k": -5}, {"max_tokens": -3}, {"temperature": "hot"}):
+        with pytest.raises(ValueError):
+            sampling_from_body(bad)
+    ok = sampling_from_body({"temperature": 0.2, "top_p": 0.95, "top_k": -1, "max_tokens": 7})
+    assert ok["temperature"] == 0.2 and ok["top_p"] == 0.95 and ok["max_tokens"] == 7
+    validate_sampling(max_tokens=1, temperature=0.0, top_p=1.0, top_k=0)
+
+
+def test_a_sampling_configuration_the_library_refuses_fails_only_that_request():
+    model = StubModel(max_batch=2)
+    eng = Engine(model, _Proc())
+
+    def refuse(*a, **k):
+        if a and a[0] == 0.123:
+            raise ValueError("refused by the library")
+    model.set_sampling = refuse
+    bad = eng.add_request("p1", max_tokens=3, temperature=0.123)
+    good = eng.add_request("p2", max_tokens=3)
+    done = eng.run_until_done()
+    assert bad in done and bad.error is not None and bad.finish_reason == "error"
+    assert good in done and good.error is None and len(good.tokens) == 3
+    with pytest.raises(ValueError):
+        eng.add_request("p3", temperature=-1.0)
+
+
+def test_head_of_the_queue_with_another_sampling_key_is_overtaken_a_bounded_number_of_times():
+    """a request waiting for another sampling group could be starved by a steady stream of same-key arrivals"""
+    model = StubModel(max_batch=2, pack=False)
+    eng = Engine(model, _Proc(), sync_every=1)
+    eng.max_bypass = 3
+    eng.add_request("A", max_tokens=2)
+    eng.step()
+    b = eng.add_request("B", max_tokens=2, temperature=0.5)      # waits for the greedy batch to drain
+    finished, fed = [], 0
+    for _ in range(200):
+        if fed < 40:                                             # a steady stream of greedy requests arriving after B
+            eng.add_request(chr(ord("C") + fed % 20), max_tokens=2)
+            fed += 1
+        finished += [r.rid for r in eng.step()]
+        if b.finished:
+            break
+    assert b.finished and b.error is None and 1 <= b.bypassed <= 3 + 1
+    later = [r for r in finished if r > b.rid]
+    assert len(later) <= 3 + 2                                   # only the bounded number of latecomers finished before B

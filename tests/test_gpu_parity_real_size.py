@@ -70,3 +70,73 @@ def test_bench_prompt_full_width_4_layers_vs_oracle(preset, n_series, length, mi
         worst = max(worst, e)
         assert e < LOGIT_TOL, (i, e)
     assert worst < 2e-4, worst                 # what the f32 / bf16x2 design delivers at this depth
+
+
+def _max_abs_over_max(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_config4_mixed_lengths_full_width_4_layers_vs_oracle():
+    """BASELINE.json config 4 at ChatTS-14B widths: 30 series of mixed lengths 64..1024 (rng 1234, ragged tails forced; the
+    envelope of NetManAIOps/ChatTS README.md:108) -> a > 2048-token prompt, i.e. THREE prefill chunks through the LDS-DMA GEMMs
+    and the MFMA attention against a growing cache, then graph-replayed decode steps."""
+    seed, depth = 0, 4
+    cfg = cfgmod.preset("chatts-14b", num_hidden_layers=depth)
+    proc, prompt, series, lengths = bench.build_inputs(cfg, 30, 256, "mixed")
+    assert any(L % 16 for L in lengths) and min(lengths) >= 64 and max(lengths) <= 1024
+    inputs = proc(text=[prompt], timeseries=series, padding=True, return_tensors="pt")
+    ids = inputs["input_ids"][0].tolist()
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=seed, max_ctx=4096, max_prefill_tokens=1024)
+    sd = {**from_device.ts_encoder_state_dict(model), **from_device.decoder_state_dict(model)}
+    want = pipeline.generate(cfg, sd, ids, inputs["timeseries"].numpy(), NEW)
+    assert len(want["expanded_ids"]) > 2048
+    ser = inputs["timeseries"].cuda()
+    mm = model.get_multimodal_embeddings(timeseries=ser, valid_lengths=proc.last_lengths)
+    assert rel_err(torch.cat(mm).cpu().numpy(), want["ts_features"]) < 5e-5          # ~1.1k patches: the M > 16 encoder GEMMs
+    model.use_graph = True
+    toks, logits0 = model.generate_one(ids, ser, proc.last_lengths, NEW, eos_token_id=None, return_logits=True)
+    e0 = rel_err(logits0.cpu().numpy(), want["logits"][0].numpy())
+    assert e0 < LOGIT_TOL and _max_abs_over_max(logits0.cpu().numpy(), want["logits"][0].numpy()) < LOGIT_TOL, e0
+    assert toks == want["tokens"]
+    model.generate_one(ids, ser, proc.last_lengths, 1, eos_token_id=None)
+    for i in range(1, NEW):
+        model.decode_step()
+        e = rel_err(model.buf["logits"].cpu().numpy(), want["logits"][i].numpy())
+        assert e < 2e-4, (i, e)
+
+
+def test_config5_fp8_batch16_full_width_4_layers_vs_oracle():
+    """BASELINE.json config 5 at ChatTS-14B widths: fp8 weights, 16 DIFFERENT prompts of 8 x 1024 steps (1207 tokens each)
+    admitted the way bench.py --batch 16 admits them (plan_pack / _admit_packed where they fit, single admissions otherwise),
+    then the batched decode graph (M = 16 fp8 weight-streaming GEMMs, per-sequence attention).  Every slot: identical tokens,
+    every decode step's logits within 1e-3 (norm-wise and max-abs over max logit) of the oracle run on the dequantised weights."""
+    seed, depth, B, new = 0, 4, 16, 5
+    cfg = cfgmod.preset("chatts-14b", num_hidden_layers=depth)
+    proc, prompt, reqs, lengths = bench.build_batched_requests(cfg, B, 8, 1024)
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=seed, max_ctx=2048, max_prefill_tokens=1024, weight_format="fp8", max_batch=B)
+    assert "gate_up8" in model.layers[0]
+    model.use_graph = True
+    Bf = model.buf
+    Bf["pos_all"].zero_(); Bf["step_all"].zero_(); Bf["token_all"].zero_()
+    T, _, _ = bench.admit_batched(model, proc, prompt, reqs, new)
+    assert T >= 1200
+    step_logits = []
+    for _ in range(1, new):
+        model.batched_step()
+        step_logits.append(Bf["logits_all"].cpu().numpy().copy())
+    toks = Bf["out_tokens_all"][:, :new].tolist()
+    # oracle on what the device holds: the bf16 tensors ARE the dequantised fp8 values
+    sd = {**from_device.ts_encoder_state_dict(model), **from_device.decoder_state_dict(model)}
+    worst = 0.0
+    for s in range(B):
+        inp = proc(text=[prompt], timeseries=reqs[s], padding=True, return_tensors="pt")
+        want = pipeline.generate(cfg, sd, inp["input_ids"][0].tolist(), inp["timeseries"].numpy(), new)
+        assert toks[s] == want["tokens"], (s, toks[s], want["tokens"])
+        for i in range(1, new):
+            g, w = step_logits[i - 1][s], want["logits"][i].numpy()
+            e = rel_err(g, w)
+            worst = max(worst, e)
+            assert e < LOGIT_TOL and _max_abs_over_max(g, w) < LOGIT_TOL, (s, i, e)
+    assert len({tuple(t) for t in toks}) > 1          # the prompts really differ
+    assert worst < 2e-4, worst

@@ -107,6 +107,12 @@ def test_errors_and_completions_endpoint():
     assert r.status_code == 400 and "max_ctx" in r.json()["error"]["message"]
     r = client.post("/v1/chat/completions", content=b"{not json", headers={"content-type": "application/json"})
     assert r.status_code == 400
+    # out-of-range sampling parameters never reach the engine thread ({"temperature": -1} used to kill it for everybody)
+    n_seen = len(et.seen)
+    for bad in ({"temperature": -1}, {"top_p": 1.5}, {"top_p": 0}, {"top_k": -7}, {"max_tokens": -2}, {"temperature": "x"}):
+        r = client.post("/v1/chat/completions", json=dict({"messages": [{"role": "user", "content": "hi"}]}, **bad))
+        assert r.status_code == 400 and r.json()["error"]["message"], bad
+    assert len(et.seen) == n_seen
     # raw completions: prompt + multi_modal_data like the offline LLM.generate schema
     r = client.post("/v1/completions", json={"prompt": "X <ts><ts/>", "multi_modal_data": {"timeseries": [ts]}, "max_tokens": 4})
     assert r.status_code == 200 and r.json()["object"] == "text_completion" and len(r.json()["token_ids"]) == 4
