@@ -37,9 +37,7 @@ class LinearArgs(C.Structure):
                 ("a_hi", c_void_p), ("a_lo", c_void_p), ("ld_planes", c_int),
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("ld_cplanes", c_int),
                 ("post_norm_w", c_void_p), ("post_norm_eps", c_float), ("post_hi", c_void_p), ("post_lo", c_void_p), ("ld_post", c_int),
-                ("w4", c_void_p), ("w4_sz", c_void_p), ("ldw4", c_int), ("w4_group", c_int),
-                ("attn_part_o", c_void_p), ("attn_part_ml", c_void_p), ("attn_pos_dev", c_void_p), ("attn_pos", c_int),
-                ("attn_parts", c_int)]
+                ("w4", c_void_p), ("w4_sz", c_void_p), ("ldw4", c_int), ("w4_group", c_int)]
 
 
 class KvCache(C.Structure):
@@ -117,8 +115,6 @@ SIGNATURES = {
     "chatts_attention_decode_batched": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                                                 c_void_p, c_int, c_void_p, C.POINTER(KvCache), c_size_t, c_void_p, c_int,
                                                 c_void_p, c_size_t, c_void_p]),
-    "chatts_attention_decode_parts": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int,
-                                              c_void_p, C.POINTER(KvCache), c_size_t, c_int, c_void_p, c_size_t, c_void_p]),
     "chatts_argmax_batched": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_int, c_void_p]),
     "chatts_sample_batched": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, C.POINTER(SamplingArgs), c_void_p, c_void_p,

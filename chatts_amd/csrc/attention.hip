@@ -20,51 +20,9 @@
 
 namespace chatts {
 
-constexpr int kMaxGroup = 8;
-constexpr int kTile = 64;    // prefill kernel: keys per tile
-constexpr int kDTile = 16;   // decode kernel: keys per wave-tile
-constexpr int kMaxSlots = 64;    // decode: tile slots per kv head (one lane of the combine wave each)
-
-struct AttnParams {
-  const float* qkv;   // [T, (n_q + 2 n_kv) * 128]; q already rotated for attn_rows, raw for attn_decode
-  float* kc;          // [n_kv, max_ctx, 128]
-  float* vc;
-  float* out;         // [T, n_q * 128]
-  float* part_ml;     // [T, n_q, n_splits, 2]
-  float* part_o;      // [T, n_q, n_splits, 128]
-  const int32_t* pos0_dev;
-  int pos0, t, n_q, n_kv, max_ctx, n_splits;
-  // decode only
-  const float* q_norm_w;
-  const float* k_norm_w;
-  const float* cos_tab;
-  const float* sin_tab;
-  float eps;
-  size_t seq_stride;   // batched decode: floats between the caches of consecutive sequences (same layer)
-  // block-paged cache (ChattsKvCache.block_table != NULL): kc / vc are the layer's pool [n_blocks, n_kv, 2^log_block, 128];
-  // sequence b looks its blocks up in table + b * table_stride, seq_stride is not used
-  const int32_t* table;
-  int log_block, table_stride;
-  uint16_t* out_hi;    // decode combine, optional: the output as bf16 hi / lo planes [T, n_q * 128] (the o_proj operand of the
-  uint16_t* out_lo;    // weight-streaming kernel) instead of float32 `out`
-};
-
-// rotate one 128-wide head held as (a = x[lane], b = x[lane+64]) by the wave; optional RMSNorm first
-__device__ __forceinline__ void norm_rope(float& a, float& b, const float* nw, float eps, float c, float s, int lane) {
-  if (nw) {
-    const float ss = wave_sum(a * a + b * b);
-    const float rstd = rsqrtf(ss / (float)kHeadDim + eps);
-    a = nw[lane] * (a * rstd);
-    b = nw[lane + 64] * (b * rstd);
-  }
-  const float oa = a * c - b * s, ob = b * c + a * s;
-  a = oa;
-  b = ob;
-}
-
-__device__ __forceinline__ float readlane_f(float v, int l) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
+}  // namespace chatts
+#include "attn_decode.h"
+namespace chatts {
 
 // ---------------------------------------------------------------------------------------------------
 // decode: grid (n_kv, n_slots), 64 threads.  Slot s walks tiles s, s + n_slots, ... of 16 keys.
@@ -73,373 +31,13 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) float q_s[kMaxGroup * kHeadDim];
   __shared__ __attribute__((aligned(16))) float knew_s[kHeadDim];
   __shared__ __attribute__((aligned(16))) float vnew_s[kHeadDim];
-  const int hk = blockIdx.x, slot = blockIdx.y, NS = p.n_splits, seq = blockIdx.z;
-  const int lane = threadIdx.x;
-  const int G = p.n_q / p.n_kv;
-  const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;     // batched decode: one position per sequence
-  if (pos < 0) return;                         // parked slot of a batched step: no cache write, no attention (its row is ignored)
-  const int ntiles = pos / kDTile + 1;
-  if (slot >= ntiles) return;                  // the combine only reads slots < min(ntiles, NS)
-  const float* qkv = p.qkv + (size_t)seq * (p.n_q + 2 * p.n_kv) * kHeadDim;
-  float* kcache = p.kc + (p.table ? 0 : (size_t)seq * p.seq_stride);
-  float* vcache = p.vc + (p.table ? 0 : (size_t)seq * p.seq_stride);
-  const KvLayout kvl{p.table ? p.table + (size_t)seq * p.table_stride : nullptr, p.n_kv, p.max_ctx, p.log_block};
-  const bool owner = ((pos / kDTile) % NS) == slot;
-  const float scale = 0.08838834764831845f * 1.4426950408889634f;    // 128^-1/2 * log2(e): the softmax runs on v_exp_f32 (exp2)
-  const int key_l = lane >> 2, quarter = lane & 3;
-
-  // K and V of the first tile only depend on `pos`: issue them before the q prologue so that the cache rows,
-  // q, cos/sin all travel in the same memory round trip.
-  f32x4 kv[8];
-  float2 vv[kDTile];
-  auto load_tile = [&](int tile) {
-    const int j0 = tile * kDTile;
-    const int j = j0 + key_l;
-    const int jc = j <= pos ? j : pos;          // clamped address (stays inside this tile: pos lies in it); masked below
-    const size_t toff = kv_tile_off(kvl, hk, j0);   // the tile's first row: one table lookup per tile when the cache is paged
-    const float* kr = kcache + toff + (size_t)(jc - j0) * kHeadDim + quarter * 4;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
-#pragma unroll
-    for (int u = 0; u < kDTile; ++u) {
-      const int ju = j0 + u <= pos ? j0 + u : pos;
-      vv[u] = *reinterpret_cast<const float2*>(vcache + toff + (size_t)(ju - j0) * kHeadDim + lane * 2);
-    }
-  };
-  load_tile(slot);
-
-  {
-    const float c = p.cos_tab[(size_t)pos * 64 + lane], s = p.sin_tab[(size_t)pos * 64 + lane];
-#pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g) {
-      if (g < G) {
-        const float* src = qkv + (size_t)(hk * G + g) * kHeadDim;
-        float a = src[lane], b = src[lane + 64];
-        norm_rope(a, b, p.q_norm_w, p.eps, c, s, lane);
-        q_s[g * kHeadDim + lane] = a;
-        q_s[g * kHeadDim + lane + 64] = b;
-      }
-    }
-    if (owner) {                                // the new K/V row: to the cache and to LDS
-      const float* ks = qkv + (size_t)(p.n_q + hk) * kHeadDim;
-      float a = ks[lane], b = ks[lane + 64];
-      norm_rope(a, b, p.k_norm_w, p.eps, c, s, lane);
-      knew_s[lane] = a;
-      knew_s[lane + 64] = b;
-      const size_t noff = kv_tile_off(kvl, hk, pos);      // row of the new token
-      float* kd = kcache + noff;
-      kd[lane] = a;
-      kd[lane + 64] = b;
-      const float* vs = qkv + (size_t)(p.n_q + p.n_kv + hk) * kHeadDim;
-      const float va = vs[lane], vb = vs[lane + 64];
-      vnew_s[lane] = va;
-      vnew_s[lane + 64] = vb;
-      float* vd = vcache + noff;
-      vd[lane] = va;
-      vd[lane + 64] = vb;
-    }
-  }
-  __syncthreads();                              // single wave: orders the LDS writes above
-
-  float m_run[kMaxGroup], l_run[kMaxGroup], acc0[kMaxGroup], acc1[kMaxGroup];
-#pragma unroll
-  for (int g = 0; g < kMaxGroup; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.f; acc0[g] = 0.f; acc1[g] = 0.f; }
-
-  for (int tile = slot; tile < ntiles; tile += NS) {
-    if (tile != slot) load_tile(tile);
-    const int j0 = tile * kDTile;
-    const int j = j0 + key_l;
-    const int jc = j <= pos ? j : pos;
-    if (owner && jc == pos) {                   // the row just produced is not in the cache for this wave yet
-#pragma unroll
-      for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(knew_s + quarter * 4 + i * 16);
-    }
-    if (owner) {
-      const float2 vn = *reinterpret_cast<const float2*>(vnew_s + lane * 2);
-#pragma unroll
-      for (int u = 0; u < kDTile; ++u)
-        if (j0 + u >= pos) vv[u] = vn;
-    }
-    float dot[kMaxGroup];
-#pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g) dot[g] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int g = 0; g < kMaxGroup; ++g) {
-        if (g < G) {
-          const f32x4 qv = *reinterpret_cast<const f32x4*>(q_s + g * kHeadDim + quarter * 4 + i * 16);
-          dot[g] = fmaf(kv[i].x, qv.x, dot[g]);
-          dot[g] = fmaf(kv[i].y, qv.y, dot[g]);
-          dot[g] = fmaf(kv[i].z, qv.z, dot[g]);
-          dot[g] = fmaf(kv[i].w, qv.w, dot[g]);
-        }
-      }
-    }
-    float pr[kMaxGroup];
-#pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g) {
-      pr[g] = 0.f;
-      if (g < G) {
-        float sc = dot[g];
-        sc += lane_xor1(sc);
-        sc += lane_xor2(sc);                    // all 4 lanes of a key now hold its score (DPP, no LDS round trip)
-        sc = j <= pos ? sc * scale : -INFINITY;
-        // max / sum over the 16 keys: keys of one 16-lane row with row_ror (DPP), the four rows with v_readlane
-        const float mt = rows4_max(fmaxf(fmaxf(sc, row_ror4(sc)), row_ror8(fmaxf(sc, row_ror4(sc)))));
-        const float m_new = fmaxf(m_run[g], mt);  // finite: key j0 <= pos is always valid
-        const float e = __builtin_amdgcn_exp2f(sc - m_new);
-        float es = e + row_ror4(e);
-        es = rows4_sum(es + row_ror8(es));
-        const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
-        l_run[g] = l_run[g] * alpha + es;
-        m_run[g] = m_new;
-        acc0[g] *= alpha;
-        acc1[g] *= alpha;
-        pr[g] = e;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kDTile; ++u) {
-#pragma unroll
-      for (int g = 0; g < kMaxGroup; ++g) {
-        if (g < G) {
-          const float pu = readlane_f(pr[g], u * 4);   // p of key u, wave-uniform (0 for masked keys)
-          acc0[g] = fmaf(pu, vv[u].x, acc0[g]);
-          acc1[g] = fmaf(pu, vv[u].y, acc1[g]);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < kMaxGroup; ++g) {
-    if (g < G) {
-      const size_t pi = ((size_t)seq * p.n_q + hk * G + g) * NS + slot;
-      *reinterpret_cast<float2*>(p.part_o + pi * kHeadDim + lane * 2) = make_float2(acc0[g], acc1[g]);
-      if (lane == 0) { p.part_ml[pi * 2] = m_run[g] * 0.6931471805599453f; p.part_ml[pi * 2 + 1] = l_run[g]; }   // m back to nats for the combine
-    }
-  }
+  attn_decode_wave<false>(p, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, q_s, knew_s, vnew_s);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// decode, "parts" form (the batch-1 decode step): grid (n_kv, n_parts, batch), 16 waves per workgroup.  Wave w of part b is
-// tile slot b * 16 + w of n_parts * 16 slots (slot s walks tiles s, s + n_slots, ...) and does exactly what attn_decode_kernel
-// does; the 16 (m, l, o) partials of a workgroup are then merged through LDS, so that a head leaves ONE unnormalised partial
-// per part - at most 8 per head instead of up to 64.  That makes the final merge cheap enough to live in the prologue of the
-// o_proj GEMV (gemv.hip: x is built from the parts while it is staged), and the decode step loses the separate combine
-// launch (4.9 us + a kernel boundary per layer).  m stays in the log2 domain end to end.
-// Partials: part_o [batch, n_q, n_parts, 128], part_ml [batch, n_q, n_parts, 2]; parts whose first tile is beyond the context
-// are not written - the consumer derives the number of live parts from the position.
-// ---------------------------------------------------------------------------------------------------
-constexpr int kPartWaves = 16;
-
-__global__ __launch_bounds__(1024) void attn_decode_parts_kernel(AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) float psm[];
-  const int hk = blockIdx.x, part = blockIdx.y, nparts = gridDim.y, seq = blockIdx.z;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int G = p.n_q / p.n_kv;
-  float* q_s = psm;                                   // [G][128]
-  float* knew_s = q_s + G * kHeadDim;                 // [128]
-  float* vnew_s = knew_s + kHeadDim;                  // [128]
-  float* ml_s = vnew_s + kHeadDim;                    // [16][G][2]
-  float* o_s = ml_s + kPartWaves * G * 2;             // [16][G][128]
-  const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;
-  if (pos < 0) return;                                // parked slot (workgroup-uniform)
-  const int ntiles = pos / kDTile + 1;
-  if (part * kPartWaves >= ntiles) return;            // no key in this part (workgroup-uniform)
-  const int nslots = nparts * kPartWaves, slot = part * kPartWaves + wave;
-  const bool active = slot < ntiles;
-  const float* qkv = p.qkv + (size_t)seq * (p.n_q + 2 * p.n_kv) * kHeadDim;
-  float* kcache = p.kc + (p.table ? 0 : (size_t)seq * p.seq_stride);
-  float* vcache = p.vc + (p.table ? 0 : (size_t)seq * p.seq_stride);
-  const KvLayout kvl{p.table ? p.table + (size_t)seq * p.table_stride : nullptr, p.n_kv, p.max_ctx, p.log_block};
-  const bool owner = active && ((pos / kDTile) % nslots) == slot;
-  const float scale = 0.08838834764831845f * 1.4426950408889634f;    // 128^-1/2 * log2(e)
-  const int key_l = lane >> 2, quarter = lane & 3;
-
-  f32x4 kv[8];
-  float2 vv[kDTile];
-  auto load_tile = [&](int tile) {
-    const int j0 = tile * kDTile;
-    const int j = j0 + key_l;
-    const int jc = j <= pos ? j : pos;
-    const size_t toff = kv_tile_off(kvl, hk, j0);
-    const float* kr = kcache + toff + (size_t)(jc - j0) * kHeadDim + quarter * 4;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
-#pragma unroll
-    for (int u = 0; u < kDTile; ++u) {
-      const int ju = j0 + u <= pos ? j0 + u : pos;
-      vv[u] = *reinterpret_cast<const float2*>(vcache + toff + (size_t)(ju - j0) * kHeadDim + lane * 2);
-    }
-  };
-  if (active) load_tile(slot);
-  {
-    const float c = p.cos_tab[(size_t)pos * 64 + lane], s = p.sin_tab[(size_t)pos * 64 + lane];
-    if (wave < G) {                                   // wave g prepares query head g for the whole workgroup
-      const float* src = qkv + (size_t)(hk * G + wave) * kHeadDim;
-      float a = src[lane], b = src[lane + 64];
-      norm_rope(a, b, p.q_norm_w, p.eps, c, s, lane);
-      q_s[wave * kHeadDim + lane] = a;
-      q_s[wave * kHeadDim + lane + 64] = b;
-    }
-    if (owner) {                                      // the new K/V row: to the cache and to LDS (only this wave reads it)
-      const float* ks = qkv + (size_t)(p.n_q + hk) * kHeadDim;
-      float a = ks[lane], b = ks[lane + 64];
-      norm_rope(a, b, p.k_norm_w, p.eps, c, s, lane);
-      knew_s[lane] = a;
-      knew_s[lane + 64] = b;
-      const size_t noff = kv_tile_off(kvl, hk, pos);      // row of the new token
-      float* kd = kcache + noff;
-      kd[lane] = a;
-      kd[lane + 64] = b;
-      const float* vs = qkv + (size_t)(p.n_q + p.n_kv + hk) * kHeadDim;
-      const float va = vs[lane], vb = vs[lane + 64];
-      vnew_s[lane] = va;
-      vnew_s[lane + 64] = vb;
-      float* vd = vcache + noff;
-      vd[lane] = va;
-      vd[lane + 64] = vb;
-    }
-  }
-  __syncthreads();
-
-  float m_run[kMaxGroup], l_run[kMaxGroup], acc0[kMaxGroup], acc1[kMaxGroup];
-#pragma unroll
-  for (int g = 0; g < kMaxGroup; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.f; acc0[g] = 0.f; acc1[g] = 0.f; }
-  if (active) {
-    for (int tile = slot; tile < ntiles; tile += nslots) {
-      if (tile != slot) load_tile(tile);
-      const int j0 = tile * kDTile;
-      const int j = j0 + key_l;
-      const int jc = j <= pos ? j : pos;
-      if (owner && jc == pos) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(knew_s + quarter * 4 + i * 16);
-      }
-      if (owner) {
-        const float2 vn = *reinterpret_cast<const float2*>(vnew_s + lane * 2);
-#pragma unroll
-        for (int u = 0; u < kDTile; ++u)
-          if (j0 + u >= pos) vv[u] = vn;
-      }
-      float dot[kMaxGroup];
-#pragma unroll
-      for (int g = 0; g < kMaxGroup; ++g) dot[g] = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int g = 0; g < kMaxGroup; ++g) {
-          if (g < G) {
-            const f32x4 qv = *reinterpret_cast<const f32x4*>(q_s + g * kHeadDim + quarter * 4 + i * 16);
-            dot[g] = fmaf(kv[i].x, qv.x, dot[g]);
-            dot[g] = fmaf(kv[i].y, qv.y, dot[g]);
-            dot[g] = fmaf(kv[i].z, qv.z, dot[g]);
-            dot[g] = fmaf(kv[i].w, qv.w, dot[g]);
-          }
-        }
-      }
-      float pr[kMaxGroup];
-#pragma unroll
-      for (int g = 0; g < kMaxGroup; ++g) {
-        pr[g] = 0.f;
-        if (g < G) {
-          float sc = dot[g];
-          sc += lane_xor1(sc);
-          sc += lane_xor2(sc);
-          sc = j <= pos ? sc * scale : -INFINITY;
-          const float mt = rows4_max(fmaxf(fmaxf(sc, row_ror4(sc)), row_ror8(fmaxf(sc, row_ror4(sc)))));
-          const float m_new = fmaxf(m_run[g], mt);
-          const float e = __builtin_amdgcn_exp2f(sc - m_new);
-          float es = e + row_ror4(e);
-          es = rows4_sum(es + row_ror8(es));
-          const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
-          l_run[g] = l_run[g] * alpha + es;
-          m_run[g] = m_new;
-          acc0[g] *= alpha;
-          acc1[g] *= alpha;
-          pr[g] = e;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kDTile; ++u) {
-#pragma unroll
-        for (int g = 0; g < kMaxGroup; ++g) {
-          if (g < G) {
-            const float pu = readlane_f(pr[g], u * 4);
-            acc0[g] = fmaf(pu, vv[u].x, acc0[g]);
-            acc1[g] = fmaf(pu, vv[u].y, acc1[g]);
-          }
-        }
-      }
-    }
-  }
-  // the workgroup's 16 partials -> LDS (inactive waves contribute m = -inf, l = 0, o = 0)
-#pragma unroll
-  for (int g = 0; g < kMaxGroup; ++g) {
-    if (g < G) {
-      *reinterpret_cast<float2*>(o_s + ((size_t)wave * G + g) * kHeadDim + lane * 2) = make_float2(acc0[g], acc1[g]);
-      if (lane == 0) { ml_s[(wave * G + g) * 2] = m_run[g]; ml_s[(wave * G + g) * 2 + 1] = l_run[g]; }
-    }
-  }
-  __syncthreads();
-  if (wave < G) {                                     // wave g merges head g (fixed slot order)
-    const int g = wave;
-    float M = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < kPartWaves; ++s) M = fmaxf(M, ml_s[(s * G + g) * 2]);
-    float den = 0.f, n0 = 0.f, n1 = 0.f;
-#pragma unroll
-    for (int s = 0; s < kPartWaves; ++s) {
-      const float w = __builtin_amdgcn_exp2f(ml_s[(s * G + g) * 2] - M);       // 0 for empty slots (m = -inf; M is finite)
-      den = fmaf(w, ml_s[(s * G + g) * 2 + 1], den);
-      const float2 o = *reinterpret_cast<const float2*>(o_s + ((size_t)s * G + g) * kHeadDim + lane * 2);
-      n0 = fmaf(w, o.x, n0);
-      n1 = fmaf(w, o.y, n1);
-    }
-    const size_t pi = ((size_t)seq * p.n_q + hk * G + g) * nparts + part;
-    *reinterpret_cast<float2*>(p.part_o + pi * kHeadDim + lane * 2) = make_float2(n0, n1);
-    if (lane == 0) { p.part_ml[pi * 2] = M; p.part_ml[pi * 2 + 1] = den; }
-  }
-}
-
-// out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots).  One workgroup
-// (2 waves) per head; lane s of each wave holds (m_s, l_s), weights are broadcast by shuffle, and 16 independent
-// o_s[d] loads are in flight per thread: no LDS, no barrier.
+// out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots): attn_combine_wave
+// (attn_decode.h), one workgroup (2 waves) per head.
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnParams p) {
-  const int hq = blockIdx.x, seq = blockIdx.y, d = threadIdx.x, lane = threadIdx.x & 63;
-  const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;
-  const int ntiles = pos < 0 ? 0 : pos / kDTile + 1;         // parked slot: no partials exist, the row is written as zeros
-  const int ns = ntiles < p.n_splits ? ntiles : p.n_splits;
-  const size_t base = ((size_t)seq * p.n_q + hq) * p.n_splits;
-  float m = -INFINITY, l = 0.f;
-  if (lane < ns) { m = p.part_ml[(base + lane) * 2]; l = p.part_ml[(base + lane) * 2 + 1]; }
-  const float M = wave_max(m);
-  const float w = lane < ns ? expf(m - M) : 0.f;
-  const float den = wave_sum(w * l);
-  float num = 0.f;
-  for (int s0 = 0; s0 < ns; s0 += 16) {
-    float o[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int s = s0 + u < ns ? s0 + u : ns - 1;
-      o[u] = p.part_o[(base + s) * kHeadDim + d];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const float ws = __shfl(w, (s0 + u) & 63, 64);     // 0 for slots >= ns
-      num = fmaf(ws, o[u], num);
-    }
-  }
-  const size_t oi = ((size_t)seq * p.n_q + hq) * kHeadDim + d;
-  const float v = ns > 0 ? num / den : 0.f;
-  if (p.out_hi) {
-    const __bf16 h = (__bf16)v;
-    p.out_hi[oi] = __builtin_bit_cast(uint16_t, h);
-    p.out_lo[oi] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
-  } else {
-    p.out[oi] = v;
-  }
+  attn_combine_wave<false>(p, blockIdx.x, blockIdx.y, threadIdx.x, threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1249,41 +847,3 @@ extern "C" int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int 
                                          cache, 0, out, n_splits, workspace, workspace_bytes, stream);
 }
 
-// Decode attention in "parts" form (see attn_decode_parts_kernel): leaves n_parts (<= 8) unnormalised partials per head in the
-// workspace - part_o [batch, n_q, n_parts, 128] then part_ml [batch, n_q, n_parts, 2], m in the log2 domain - for a consumer
-// that merges them while staging its input (chatts_linear with ChattsLinearArgs.attn_parts: the o_proj GEMV).
-extern "C" int chatts_attention_decode_parts(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w,
-                                             const float* k_norm_w, float norm_eps, const float* cos_tab, const float* sin_tab,
-                                             int pos, const int32_t* pos_dev, const ChattsKvCache* cache, size_t seq_stride,
-                                             int n_parts, void* workspace, size_t workspace_bytes, chatts_stream_t stream) {
-  CHATTS_REQUIRE(batch >= 1 && n_q > 0 && n_kv > 0 && n_parts >= 1 && n_parts <= 8, CHATTS_E_BADARG,
-                 "attention_decode_parts: bad sizes (batch >= 1, 1 <= n_parts <= 8)");
-  CHATTS_REQUIRE(qkv_raw && cos_tab && sin_tab && cache && cache->k && cache->v, CHATTS_E_BADARG, "attention_decode_parts: null pointer");
-  CHATTS_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), CHATTS_E_BADARG,
-                 "attention_decode_parts: q_norm and k_norm must both be set or both be null");
-  CHATTS_REQUIRE(n_q % n_kv == 0 && n_q / n_kv <= kMaxGroup, CHATTS_E_SHAPE, "attention: GQA group %d/%d unsupported (max %d)", n_q, n_kv,
-                 kMaxGroup);
-  CHATTS_REQUIRE(batch == 1 || pos_dev, CHATTS_E_BADARG, "attention_decode_parts: batch > 1 needs per-sequence positions on the device");
-  if (!pos_dev) CHATTS_REQUIRE(pos >= 0 && pos < cache->max_ctx, CHATTS_E_SHAPE, "attention_decode_parts: position exceeds the cache");
-  AttnParams p{};
-  p.qkv = qkv_raw; p.pos0_dev = pos_dev; p.pos0 = pos;
-  p.t = batch; p.n_q = n_q; p.n_kv = n_kv; p.n_splits = n_parts;
-  if (const int rc = bind_cache(p, cache)) return rc;
-  p.q_norm_w = q_norm_w; p.k_norm_w = k_norm_w; p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.eps = norm_eps; p.seq_stride = seq_stride;
-  const int rc = bind_workspace(p, workspace, workspace_bytes);
-  if (rc) return rc;
-  const int G = n_q / n_kv;
-  const size_t lds = ((size_t)G * kHeadDim + 2 * kHeadDim + (size_t)kPartWaves * G * 2 + (size_t)kPartWaves * G * kHeadDim) * sizeof(float);
-  if (lds > 64 * 1024) {
-    static bool configured = false;
-    if (!configured) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_parts_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "attn_decode_parts: cannot reserve LDS: %s", hipGetErrorString(e));
-      configured = true;
-    }
-  }
-  hipLaunchKernelGGL(attn_decode_parts_kernel, dim3(n_kv, n_parts, batch), dim3(kPartWaves * 64), lds, as_stream(stream), p);
-  CHATTS_CHECK_LAUNCH("attn_decode_parts");
-  return CHATTS_OK;
-}

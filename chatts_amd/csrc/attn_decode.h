@@ -1,0 +1,271 @@
+// attn_decode.h - the batch-1 decode attention as per-wave device functions, shared by the stand-alone kernels (attention.hip)
+// and the persistent decode step (decode_mega.hip): same instructions, same summation order, bit-identical results.
+#pragma once
+#include <math.h>
+
+#include "common.h"
+
+namespace chatts {
+
+// write-through stores for data another workgroup reads inside the SAME launch (agent-scope relaxed atomic store = `sc1`)
+__device__ __forceinline__ void wt_store1(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wt_store2(float* p, float a, float b) {      // p 8-byte aligned
+  const unsigned long long bits = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int kMaxGroup = 8;
+constexpr int kTile = 64;    // prefill kernel: keys per tile
+constexpr int kDTile = 16;   // decode kernel: keys per wave-tile
+constexpr int kMaxSlots = 64;    // decode: tile slots per kv head (one lane of the combine wave each)
+
+struct AttnParams {
+  const float* qkv;   // [T, (n_q + 2 n_kv) * 128]; q already rotated for attn_rows, raw for attn_decode
+  float* kc;          // [n_kv, max_ctx, 128]
+  float* vc;
+  float* out;         // [T, n_q * 128]
+  float* part_ml;     // [T, n_q, n_splits, 2]
+  float* part_o;      // [T, n_q, n_splits, 128]
+  const int32_t* pos0_dev;
+  int pos0, t, n_q, n_kv, max_ctx, n_splits;
+  // decode only
+  const float* q_norm_w;
+  const float* k_norm_w;
+  const float* cos_tab;
+  const float* sin_tab;
+  float eps;
+  size_t seq_stride;   // batched decode: floats between the caches of consecutive sequences (same layer)
+  // block-paged cache (ChattsKvCache.block_table != NULL): kc / vc are the layer's pool [n_blocks, n_kv, 2^log_block, 128];
+  // sequence b looks its blocks up in table + b * table_stride, seq_stride is not used
+  const int32_t* table;
+  int log_block, table_stride;
+  uint16_t* out_hi;    // decode combine, optional: the output as bf16 hi / lo planes [T, n_q * 128] (the o_proj operand of the
+  uint16_t* out_lo;    // weight-streaming kernel) instead of float32 `out`
+};
+
+// rotate one 128-wide head held as (a = x[lane], b = x[lane+64]) by the wave; optional RMSNorm first
+__device__ __forceinline__ void norm_rope(float& a, float& b, const float* nw, float eps, float c, float s, int lane) {
+  if (nw) {
+    const float ss = wave_sum(a * a + b * b);
+    const float rstd = rsqrtf(ss / (float)kHeadDim + eps);
+    a = nw[lane] * (a * rstd);
+    b = nw[lane + 64] * (b * rstd);
+  }
+  const float oa = a * c - b * s, ob = b * c + a * s;
+  a = oa;
+  b = ob;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decode: grid (n_kv, n_slots), 64 threads.  Slot s walks tiles s, s + n_slots, ... of 16 keys.
+// ---------------------------------------------------------------------------------------------------
+// One wave's work: kv head hk, tile slot `slot` of sequence `seq`.  q_s [kMaxGroup * 128], knew_s / vnew_s [128] are this wave's
+// private LDS scratch (16-byte aligned).  WT: the partials are stored write-through (agent-scope relaxed atomics = `sc1` stores),
+// for consumers inside the SAME launch (decode_mega.hip); the stand-alone kernel uses plain stores.
+template <bool WT>
+__device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
+                                                 float* q_s, float* knew_s, float* vnew_s) {
+  const int NS = p.n_splits;
+  const int G = p.n_q / p.n_kv;
+  const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;     // batched decode: one position per sequence
+  if (pos < 0) return;                         // parked slot of a batched step: no cache write, no attention (its row is ignored)
+  const int ntiles = pos / kDTile + 1;
+  if (slot >= ntiles) return;                  // the combine only reads slots < min(ntiles, NS)
+  const float* qkv = p.qkv + (size_t)seq * (p.n_q + 2 * p.n_kv) * kHeadDim;
+  float* kcache = p.kc + (p.table ? 0 : (size_t)seq * p.seq_stride);
+  float* vcache = p.vc + (p.table ? 0 : (size_t)seq * p.seq_stride);
+  const KvLayout kvl{p.table ? p.table + (size_t)seq * p.table_stride : nullptr, p.n_kv, p.max_ctx, p.log_block};
+  const bool owner = ((pos / kDTile) % NS) == slot;
+  const float scale = 0.08838834764831845f * 1.4426950408889634f;    // 128^-1/2 * log2(e): the softmax runs on v_exp_f32 (exp2)
+  const int key_l = lane >> 2, quarter = lane & 3;
+
+  // K and V of the first tile only depend on `pos`: issue them before the q prologue so that the cache rows,
+  // q, cos/sin all travel in the same memory round trip.
+  f32x4 kv[8];
+  float2 vv[kDTile];
+  auto load_tile = [&](int tile) {
+    const int j0 = tile * kDTile;
+    const int j = j0 + key_l;
+    const int jc = j <= pos ? j : pos;          // clamped address (stays inside this tile: pos lies in it); masked below
+    const size_t toff = kv_tile_off(kvl, hk, j0);   // the tile's first row: one table lookup per tile when the cache is paged
+    const float* kr = kcache + toff + (size_t)(jc - j0) * kHeadDim + quarter * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
+#pragma unroll
+    for (int u = 0; u < kDTile; ++u) {
+      const int ju = j0 + u <= pos ? j0 + u : pos;
+      vv[u] = *reinterpret_cast<const float2*>(vcache + toff + (size_t)(ju - j0) * kHeadDim + lane * 2);
+    }
+  };
+  load_tile(slot);
+
+  {
+    const float c = p.cos_tab[(size_t)pos * 64 + lane], s = p.sin_tab[(size_t)pos * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; ++g) {
+      if (g < G) {
+        const float* src = qkv + (size_t)(hk * G + g) * kHeadDim;
+        float a = src[lane], b = src[lane + 64];
+        norm_rope(a, b, p.q_norm_w, p.eps, c, s, lane);
+        q_s[g * kHeadDim + lane] = a;
+        q_s[g * kHeadDim + lane + 64] = b;
+      }
+    }
+    if (owner) {                                // the new K/V row: to the cache and to LDS
+      const float* ks = qkv + (size_t)(p.n_q + hk) * kHeadDim;
+      float a = ks[lane], b = ks[lane + 64];
+      norm_rope(a, b, p.k_norm_w, p.eps, c, s, lane);
+      knew_s[lane] = a;
+      knew_s[lane + 64] = b;
+      const size_t noff = kv_tile_off(kvl, hk, pos);      // row of the new token
+      float* kd = kcache + noff;
+      kd[lane] = a;
+      kd[lane + 64] = b;
+      const float* vs = qkv + (size_t)(p.n_q + p.n_kv + hk) * kHeadDim;
+      const float va = vs[lane], vb = vs[lane + 64];
+      vnew_s[lane] = va;
+      vnew_s[lane + 64] = vb;
+      float* vd = vcache + noff;
+      vd[lane] = va;
+      vd[lane + 64] = vb;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // single wave: orders the LDS writes above (in-order LDS, no barrier needed)
+
+  float m_run[kMaxGroup], l_run[kMaxGroup], acc0[kMaxGroup], acc1[kMaxGroup];
+#pragma unroll
+  for (int g = 0; g < kMaxGroup; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.f; acc0[g] = 0.f; acc1[g] = 0.f; }
+
+  for (int tile = slot; tile < ntiles; tile += NS) {
+    if (tile != slot) load_tile(tile);
+    const int j0 = tile * kDTile;
+    const int j = j0 + key_l;
+    const int jc = j <= pos ? j : pos;
+    if (owner && jc == pos) {                   // the row just produced is not in the cache for this wave yet
+#pragma unroll
+      for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(knew_s + quarter * 4 + i * 16);
+    }
+    if (owner) {
+      const float2 vn = *reinterpret_cast<const float2*>(vnew_s + lane * 2);
+#pragma unroll
+      for (int u = 0; u < kDTile; ++u)
+        if (j0 + u >= pos) vv[u] = vn;
+    }
+    float dot[kMaxGroup];
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; ++g) dot[g] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int g = 0; g < kMaxGroup; ++g) {
+        if (g < G) {
+          const f32x4 qv = *reinterpret_cast<const f32x4*>(q_s + g * kHeadDim + quarter * 4 + i * 16);
+          dot[g] = fmaf(kv[i].x, qv.x, dot[g]);
+          dot[g] = fmaf(kv[i].y, qv.y, dot[g]);
+          dot[g] = fmaf(kv[i].z, qv.z, dot[g]);
+          dot[g] = fmaf(kv[i].w, qv.w, dot[g]);
+        }
+      }
+    }
+    float pr[kMaxGroup];
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; ++g) {
+      pr[g] = 0.f;
+      if (g < G) {
+        float sc = dot[g];
+        sc += lane_xor1(sc);
+        sc += lane_xor2(sc);                    // all 4 lanes of a key now hold its score (DPP, no LDS round trip)
+        sc = j <= pos ? sc * scale : -INFINITY;
+        // max / sum over the 16 keys: keys of one 16-lane row with row_ror (DPP), the four rows with v_readlane
+        const float mt = rows4_max(fmaxf(fmaxf(sc, row_ror4(sc)), row_ror8(fmaxf(sc, row_ror4(sc)))));
+        const float m_new = fmaxf(m_run[g], mt);  // finite: key j0 <= pos is always valid
+        const float e = __builtin_amdgcn_exp2f(sc - m_new);
+        float es = e + row_ror4(e);
+        es = rows4_sum(es + row_ror8(es));
+        const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
+        l_run[g] = l_run[g] * alpha + es;
+        m_run[g] = m_new;
+        acc0[g] *= alpha;
+        acc1[g] *= alpha;
+        pr[g] = e;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kDTile; ++u) {
+#pragma unroll
+      for (int g = 0; g < kMaxGroup; ++g) {
+        if (g < G) {
+          const float pu = readlane_f(pr[g], u * 4);   // p of key u, wave-uniform (0 for masked keys)
+          acc0[g] = fmaf(pu, vv[u].x, acc0[g]);
+          acc1[g] = fmaf(pu, vv[u].y, acc1[g]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < kMaxGroup; ++g) {
+    if (g < G) {
+      const size_t pi = ((size_t)seq * p.n_q + hk * G + g) * NS + slot;
+      const float mn = m_run[g] * 0.6931471805599453f;       // m back to nats for the combine
+      if (WT) {
+        wt_store2(p.part_o + pi * kHeadDim + lane * 2, acc0[g], acc1[g]);
+        if (lane == 0) wt_store2(p.part_ml + pi * 2, mn, l_run[g]);
+      } else {
+        *reinterpret_cast<float2*>(p.part_o + pi * kHeadDim + lane * 2) = make_float2(acc0[g], acc1[g]);
+        if (lane == 0) { p.part_ml[pi * 2] = mn; p.part_ml[pi * 2 + 1] = l_run[g]; }
+      }
+    }
+  }
+}
+
+
+// out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots).  One workgroup
+// (2 waves) per head; lane s of each wave holds (m_s, l_s), weights are broadcast by shuffle, and 16 independent
+// o_s[d] loads are in flight per thread: no LDS, no barrier.
+// One wave's half of a head: d = half * 64 + lane (the stand-alone kernel runs two waves per head).
+template <bool WT>
+__device__ __forceinline__ void attn_combine_wave(const AttnParams& p, const int hq, const int seq, const int d, const int lane) {
+  const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;
+  const int ntiles = pos < 0 ? 0 : pos / kDTile + 1;         // parked slot: no partials exist, the row is written as zeros
+  const int ns = ntiles < p.n_splits ? ntiles : p.n_splits;
+  const size_t base = ((size_t)seq * p.n_q + hq) * p.n_splits;
+  float m = -INFINITY, l = 0.f;
+  if (lane < ns) { m = p.part_ml[(base + lane) * 2]; l = p.part_ml[(base + lane) * 2 + 1]; }
+  const float M = wave_max(m);
+  const float w = lane < ns ? expf(m - M) : 0.f;
+  const float den = wave_sum(w * l);
+  float num = 0.f;
+  for (int s0 = 0; s0 < ns; s0 += 16) {
+    float o[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int s = s0 + u < ns ? s0 + u : ns - 1;
+      o[u] = p.part_o[(base + s) * kHeadDim + d];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float ws = __shfl(w, (s0 + u) & 63, 64);     // 0 for slots >= ns
+      num = fmaf(ws, o[u], num);
+    }
+  }
+  const size_t oi = ((size_t)seq * p.n_q + hq) * kHeadDim + d;
+  const float v = ns > 0 ? num / den : 0.f;
+  if (p.out_hi) {
+    const __bf16 h = (__bf16)v;
+    p.out_hi[oi] = __builtin_bit_cast(uint16_t, h);
+    p.out_lo[oi] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+  } else if (WT) {
+    wt_store1(p.out + oi, v);
+  } else {
+    p.out[oi] = v;
+  }
+}
+
+
+}  // namespace chatts

@@ -49,9 +49,7 @@ extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) 
   if (a->m == 0) return CHATTS_OK;
   const bool planes = a->a_hi || a->a_lo;
   const bool cplanes = a->c_hi || a->c_lo;
-  const bool attn_x = a->attn_part_o != nullptr;
-  if (attn_x) CHATTS_REQUIRE(a->m == 1 && !planes, CHATTS_E_BADARG, "linear: attention parts as the input need M == 1");
-  CHATTS_REQUIRE((a->a || planes || attn_x) && a->w && (a->c || cplanes), CHATTS_E_BADARG, "linear: null pointer");
+  CHATTS_REQUIRE((a->a || planes) && a->w && (a->c || cplanes), CHATTS_E_BADARG, "linear: null pointer");
   if (cplanes)
     CHATTS_REQUIRE(a->c_hi && a->c_lo && a->m > 1 && a->ld_cplanes >= (a->epilogue == CHATTS_EPI_SWIGLU ? a->n / 2 : a->n),
                    CHATTS_E_SHAPE, "linear: plane output needs both planes, M > 1 and ld_cplanes >= the output width");
@@ -292,23 +290,8 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, d->cur_seq);
     bool attn_out_planes = false;
-    int attn_parts = 0;
     if (t == 1) {   // decode: RoPE + cache write fused into the attention kernel
-      // "parts" form (CHATTS_ATTN_PARTS=n, 1..8; -1 = as many as max_ctx needs): 16 tile slots merge inside a workgroup, <= 8
-      // partials per head, the final merge happens while o_proj stages its input - one launch less per layer than kernel +
-      // combine.  Built, verified (tests) and measured in round 2: 172.8 tok/s against 178.2 for the two-kernel form - every
-      // one of o_proj's 256 workgroups pays the merge's dependent L2 round trips, which costs more than the 4.9 us combine
-      // launch it removes - so it stays OFF by default.
-      static const int env_parts = getenv("CHATTS_ATTN_PARTS") ? atoi(getenv("CHATTS_ATTN_PARTS")) : 0;
-      const int max_tiles = (c.max_ctx + 15) / 16;
-      attn_parts = env_parts >= 0 ? env_parts : (max_tiles + 15) / 16;
-      if (attn_parts > 8) attn_parts = 8;
-      if (attn_parts >= 1 && chatts_attn_workspace(1, c.n_q, attn_parts) > d->b.workspace_bytes) attn_parts = 0;
-      if (attn_parts >= 1) {
-        if ((rc = chatts_attention_decode_parts(d->b.qkv, 1, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab,
-                                                pos0, pos0_dev, &kc, 0, attn_parts, d->b.workspace, d->b.workspace_bytes, stream)) != 0)
-          return rc;
-      } else if ((rc = chatts_attention_decode_fused(d->b.qkv, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
+      if ((rc = chatts_attention_decode_fused(d->b.qkv, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
                                                      d->w.sin_tab, pos0, pos0_dev, &kc, d->b.attn, n_splits, d->b.workspace,
                                                      d->b.workspace_bytes, stream)) != 0) {
         return rc;
@@ -338,11 +321,6 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     if (t == 1) {
       la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k;
       la.w4 = lw.o4; la.w4_sz = lw.o4_sz; la.ldw4 = la.k / 2; la.w4_group = lw.w4_group;
-      if (attn_parts >= 1) {                   // x = merge of the attention parts, done in the GEMV's staging prologue
-        float* po = reinterpret_cast<float*>(d->b.workspace);
-        la.a = nullptr; la.attn_part_o = po; la.attn_part_ml = po + (size_t)c.n_q * attn_parts * kHeadDim;
-        la.attn_pos_dev = pos0_dev; la.attn_pos = pos0; la.attn_parts = attn_parts;
-      }
     } else if (attn_out_planes) {              // written by the attention kernel
       la.a = nullptr; la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k;
     } else if (planes_path(d, t, la.k)) {      // the VALU attention kernel writes float32: split it

@@ -14,6 +14,7 @@
 // only the summation order differs from the CPU oracle (parity budget: 1e-3 relative on logits).
 // Fusions: RMSNorm of x in the prologue (Qwen2RMSNorm.forward), bias, residual add, SwiGLU.
 #include "common.h"
+#include "gemv_common.h"
 
 namespace chatts {
 
@@ -37,60 +38,7 @@ struct GemvParams {
   const uint8_t* w4;
   const float* w4_sz;     // [N, K / w4_group, 2]
   int ldw4, w4_group;
-  // optional: x is not read from memory but merged from the decode attention's per-part partials while it is staged
-  // (attention.hip attn_decode_parts_kernel): x[h * 128 + d] = sum_p 2^(m_p - M) o_p[d] / sum_p 2^(m_p - M) l_p
-  const float* apo;       // part_o  [heads, aparts, 128]
-  const float* aml;       // part_ml [heads, aparts, 2]   (m in the log2 domain, l)
-  const int32_t* apos_dev;
-  int apos, aparts;
 };
-
-// four consecutive elements k4..k4+3 of the attention output (same head: 128 % 4 == 0) from the live parts
-__device__ __forceinline__ f32x4 attn_parts_x4(const GemvParams& p, int k4, int nact) {
-  const int h = k4 >> 7, d = k4 & 127;
-  const float* ml = p.aml + (size_t)h * p.aparts * 2;
-  float M = -INFINITY;
-  for (int q = 0; q < nact; ++q) M = fmaxf(M, ml[2 * q]);
-  float den = 0.f;
-  f32x4 num = {0.f, 0.f, 0.f, 0.f};
-  for (int q = 0; q < nact; ++q) {
-    const float w = __builtin_amdgcn_exp2f(ml[2 * q] - M);
-    den = fmaf(w, ml[2 * q + 1], den);
-    const f32x4 o = *reinterpret_cast<const f32x4*>(p.apo + ((size_t)h * p.aparts + q) * kHeadDim + d);
-    num.x = fmaf(w, o.x, num.x); num.y = fmaf(w, o.y, num.y); num.z = fmaf(w, o.z, num.z); num.w = fmaf(w, o.w, num.w);
-  }
-  const float inv = 1.0f / den;
-  return (f32x4){num.x * inv, num.y * inv, num.z * inv, num.w * inv};
-}
-__device__ __forceinline__ int attn_parts_live(const GemvParams& p) {
-  const int pos = p.apos_dev ? p.apos_dev[0] : p.apos;
-  const int ntiles = pos / 16 + 1;
-  const int nact = (ntiles + 15) / 16;            // parts of 16 tile slots each (attention.hip kPartWaves)
-  return nact < p.aparts ? nact : p.aparts;
-}
-
-__device__ __forceinline__ float dot8(const u32x4 wv, const f32x4 xa, const f32x4 xb, float acc) {
-  acc = fmaf(bf16_lo(wv.x), xa.x, acc);
-  acc = fmaf(bf16_hi(wv.x), xa.y, acc);
-  acc = fmaf(bf16_lo(wv.y), xa.z, acc);
-  acc = fmaf(bf16_hi(wv.y), xa.w, acc);
-  acc = fmaf(bf16_lo(wv.z), xb.x, acc);
-  acc = fmaf(bf16_hi(wv.z), xb.y, acc);
-  acc = fmaf(bf16_lo(wv.w), xb.z, acc);
-  acc = fmaf(bf16_hi(wv.w), xb.w, acc);
-  return acc;
-}
-
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
-
-template <int ROWS, int EPI>
-__device__ __forceinline__ int task_row(int task, int r) {
-  if (EPI == CHATTS_EPI_SWIGLU) {   // gate/up interleaved in blocks of 16 rows: unit u -> rows g(u), g(u)+16
-    const int unit = task * (ROWS / 2) + (r >> 1);
-    return (unit >> 4) * 32 + (unit & 15) + (r & 1) * 16;
-  }
-  return task * ROWS + r;
-}
 
 // lane r (< ROWS, or < ROWS/2 for SwiGLU) of the finishing wave writes row r
 template <int ROWS, int EPI>
@@ -138,7 +86,7 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(GemvParams p) {
     float ss = 0.f;
     for (int k4 = tid * 4; k4 < K; k4 += nthreads * 4) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + k4);
-      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      ss = sumsq4(ss, v);
     }
     ss = wave_sum(ss);
     if (lane == 0) red[wave] = ss;
@@ -147,18 +95,13 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(GemvParams p) {
     for (int i = 0; i < nw; ++i) t += red[i];
     rstd = rsqrtf(t / (float)K + p.eps);
   }
-  const int nact = (!NORM && p.apo) ? attn_parts_live(p) : 0;
   for (int k4 = tid * 4; k4 < nchunks * 512; k4 += nthreads * 4) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (k4 < K) {
-      if (!NORM && p.apo) {
-        v = attn_parts_x4(p, k4, nact);
-      } else {
-        v = *reinterpret_cast<const f32x4*>(p.x + k4);
-        if (NORM) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
-          v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
-        }
+      v = *reinterpret_cast<const f32x4*>(p.x + k4);
+      if (NORM) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
+        v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
       }
     }
     const int chunk = k4 >> 9, within = k4 & 511;
@@ -240,7 +183,7 @@ __global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
     float ss = 0.f;
     for (int k4 = tid * 4; k4 < K; k4 += nthreads * 4) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + k4);
-      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      ss = sumsq4(ss, v);
     }
     ss = wave_sum(ss);
     if (lane == 0) red[wave] = ss;
@@ -249,18 +192,13 @@ __global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
     for (int i = 0; i < nw; ++i) t += red[i];
     rstd = rsqrtf(t / (float)K + p.eps);
   }
-  const int nact = (!NORM && p.apo) ? attn_parts_live(p) : 0;
   for (int k4 = tid * 4; k4 < nchunks * 1024; k4 += nthreads * 4) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (k4 < K) {
-      if (!NORM && p.apo) {
-        v = attn_parts_x4(p, k4, nact);
-      } else {
-        v = *reinterpret_cast<const f32x4*>(p.x + k4);
-        if (NORM) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
-          v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
-        }
+      v = *reinterpret_cast<const f32x4*>(p.x + k4);
+      if (NORM) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
+        v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
       }
     }
     const int chunk = k4 >> 10, within = k4 & 1023;
@@ -365,7 +303,7 @@ __global__ __launch_bounds__(1024) void gemv4_ldsx_kernel(GemvParams p) {
     float ss = 0.f;
     for (int k4 = tid * 4; k4 < K; k4 += nthreads * 4) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + k4);
-      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      ss = sumsq4(ss, v);
     }
     ss = wave_sum(ss);
     if (lane == 0) red[wave] = ss;
@@ -374,19 +312,14 @@ __global__ __launch_bounds__(1024) void gemv4_ldsx_kernel(GemvParams p) {
     for (int i = 0; i < nw; ++i) t += red[i];
     rstd = rsqrtf(t / (float)K + p.eps);
   }
-  const int nact = (!NORM && p.apo) ? attn_parts_live(p) : 0;
   uint32_t* xs1 = reinterpret_cast<uint32_t*>(smem);
   for (int k4 = tid * 4; k4 < nchunks * 1024; k4 += nthreads * 4) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (k4 < K) {
-      if (!NORM && p.apo) {
-        v = attn_parts_x4(p, k4, nact);
-      } else {
-        v = *reinterpret_cast<const f32x4*>(p.x + k4);
-        if (NORM) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
-          v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
-        }
+      v = *reinterpret_cast<const f32x4*>(p.x + k4);
+      if (NORM) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
+        v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
       }
     }
     uint16_t h[4], l[4];
@@ -481,16 +414,38 @@ static int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
+// Waves per workgroup (and workgroups per CU, 0 = whatever fits) of the bf16 GEMV for a shape: the sweep results of
+// tools/gemv_sweep.py.  Also read by decode_mega.hip, whose fused RMSNorm reproduces this kernel's summation order.
+void gemv_default_geometry(int n, int k, int epilogue, int cus, int* nw_out, int* occ_out) {
+  const int swiglu = epilogue == CHATTS_EPI_SWIGLU;
+  const int units = swiglu ? n / 2 : n;
+  int nw_auto, occ_auto = 0;
+  if (k > 8192) nw_auto = 16;                       // down_proj: 55 KB of x per workgroup -> amortise over 16 waves
+  else if (units >= 65536) { nw_auto = 4; occ_auto = 2; }   // lm_head
+  else if (n >= 16384) { nw_auto = 8; occ_auto = 2; }    // gate_up
+  else if (n > 6000) nw_auto = 16;                  // qkv
+  else nw_auto = 4;                                    // o_proj
+  // Balanced layout (profiles/r2_gemv_sweep_balanced.txt): when the CUs divide the row-group tasks, one workgroup per CU whose
+  // wave count divides the tasks per CU gives every wave the same number of tasks (no ragged last round): o_proj 11.5 ->
+  // 11.2 us, gate_up 44.5 -> 44.1, down_proj 24.9 -> 24.5; lm_head (297 tasks per CU) keeps the 2-workgroup layout.
+  const int tasks_r2 = (units + (swiglu ? 0 : 1)) / (swiglu ? 1 : 2);
+  int balanced_nw = 0;
+  if (units < 65536 && tasks_r2 % cus == 0) {
+    const int per_cu = tasks_r2 / cus;
+    for (int w = 16; w >= 5 && !balanced_nw; --w)
+      if (per_cu % w == 0) balanced_nw = w;
+  }
+  if (balanced_nw) { nw_auto = balanced_nw; occ_auto = 1; }
+  *nw_out = nw_auto;
+  *occ_out = occ_auto;
+}
+
 int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   GemvParams p;
   p.w = a->w; p.x = a->a; p.bias = a->bias; p.resid = a->resid; p.out = a->c;
   p.norm_w = a->norm_w; p.eps = a->norm_eps; p.n = a->n; p.k = a->k; p.ldw = a->ldw;
   p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8;
   p.w4 = a->w4; p.w4_sz = a->w4_sz; p.ldw4 = a->ldw4; p.w4_group = a->w4_group;
-  p.apo = a->attn_part_o; p.aml = a->attn_part_ml; p.apos_dev = a->attn_pos_dev; p.apos = a->attn_pos; p.aparts = a->attn_parts;
-  if (p.apo)
-    CHATTS_REQUIRE(p.aml && a->attn_parts >= 1 && a->attn_parts <= 8 && a->k % kHeadDim == 0 && !a->norm_w, CHATTS_E_BADARG,
-                   "gemv: attention parts need part_ml, 1..8 parts, K a multiple of 128 and no fused RMSNorm");
   const bool norm = a->norm_w != nullptr;
   const int cus = device_cus();
   const int swiglu = a->epilogue == CHATTS_EPI_SWIGLU;
@@ -505,23 +460,8 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   if (rows != 4) rows = 2;
   int unr = env_int("CHATTS_GEMV_UNR", 2);
   if (unr != 4) unr = 2;
-  int nw_auto, occ_auto = 0;
-  if (a->k > 8192) nw_auto = 16;                       // down_proj: 55 KB of x per workgroup -> amortise over 16 waves
-  else if (units >= 65536) { nw_auto = 4; occ_auto = 2; }   // lm_head
-  else if (a->n >= 16384) { nw_auto = 8; occ_auto = 2; }    // gate_up
-  else if (a->n > 6000) nw_auto = 16;                  // qkv
-  else nw_auto = 4;                                    // o_proj
-  // Balanced layout (profiles/r2_gemv_sweep_balanced.txt): when the CUs divide the row-group tasks, one workgroup per CU whose
-  // wave count divides the tasks per CU gives every wave the same number of tasks (no ragged last round): o_proj 11.5 ->
-  // 11.2 us, gate_up 44.5 -> 44.1, down_proj 24.9 -> 24.5; lm_head (297 tasks per CU) keeps the 2-workgroup layout.
-  const int tasks_r2 = (units + (swiglu ? 0 : 1)) / (swiglu ? 1 : 2);
-  int balanced_nw = 0;
-  if (units < 65536 && tasks_r2 % cus == 0) {
-    const int per_cu = tasks_r2 / cus;
-    for (int w = 16; w >= 5 && !balanced_nw; --w)
-      if (per_cu % w == 0) balanced_nw = w;
-  }
-  if (balanced_nw) { nw_auto = balanced_nw; occ_auto = 1; }
+  int nw_auto, occ_auto;
+  gemv_default_geometry(a->n, a->k, a->epilogue, cus, &nw_auto, &occ_auto);
   int nw = env_int("CHATTS_GEMV_NW", nw_auto);
   if (nw < 1 || nw > 16) nw = 4;
   int occ = (int)((150 * 1024) / lds);          // workgroups per CU that fit in LDS

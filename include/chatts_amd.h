@@ -170,14 +170,6 @@ typedef struct ChattsLinearArgs {
   const uint8_t* w4;
   const float* w4_sz;
   int ldw4, w4_group;
-  /* optional (M == 1, no norm_w, K = heads * 128): the input row is not read from `a` (may be NULL) but merged from the
-   * partials chatts_attention_decode_parts left - x[h*128 + d] = sum_p 2^(m_p - M) o_p[d] / sum_p 2^(m_p - M) l_p over the live
-   * parts of the position (attn_pos, or *attn_pos_dev) - while the GEMV stages it: the decode step's o_proj absorbs the
-   * attention's final combine.  attn_part_o [K/128, attn_parts, 128], attn_part_ml [K/128, attn_parts, 2]. */
-  const float* attn_part_o;
-  const float* attn_part_ml;
-  const int32_t* attn_pos_dev;
-  int attn_pos, attn_parts;
 } ChattsLinearArgs;
 size_t chatts_linear_workspace(int m, int n, int k);
 /* hi = bf16(x) (RNE), lo = bf16(x - hi): the operand split of the bf16x2 GEMM, done once per activation matrix. */
@@ -256,16 +248,6 @@ int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int n_kv, const
                                   const float* sin_tab, int pos, const int32_t* pos_dev,
                                   const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
                                   size_t workspace_bytes, chatts_stream_t stream);
-
-/* The same attention in "parts" form for the batch-1 decode step: 16 tile slots per workgroup are merged through LDS, so a head
- * leaves at most n_parts (1..8) UNNORMALISED partials in the workspace - part_o [batch, n_q, n_parts, 128] followed by part_ml
- * [batch, n_q, n_parts, 2] (running max in the log2 domain, denominator); part p covers tile slots 16p..16p+15 of 16*n_parts,
- * parts beyond the context are not written.  The consumer is chatts_linear with ChattsLinearArgs.attn_part_o (o_proj).
- * workspace >= chatts_attn_workspace(batch, n_q, n_parts). */
-int chatts_attention_decode_parts(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w,
-                                  const float* k_norm_w, float norm_eps, const float* cos_tab, const float* sin_tab, int pos,
-                                  const int32_t* pos_dev, const ChattsKvCache* cache, size_t seq_stride, int n_parts,
-                                  void* workspace, size_t workspace_bytes, chatts_stream_t stream);
 
 /* Batched form of the above: `batch` sequences, one decode token each; row b of qkv_raw / out and pos_dev[b] belong
  * to sequence b, whose cache is `cache` advanced by b * seq_stride floats (same layer). */

@@ -566,63 +566,6 @@ def test_attention_decode_fused_equals_unfused(lib, qk_norm, pos, splits):
     assert rel_err(out_b.cpu().numpy(), out_a.cpu().numpy()) < 1e-6
 
 
-@pytest.mark.parametrize("fp8", [False, True])
-@pytest.mark.parametrize("qk_norm", [False, True])
-@pytest.mark.parametrize("pos,parts", [(0, 1), (5, 2), (15, 8), (16, 2), (255, 1), (256, 2), (300, 4), (511, 2), (1000, 8), (2047, 8), (1500, 3)])
-def test_attention_decode_parts_plus_oproj_equals_fused_plus_linear(lib, qk_norm, pos, parts, fp8):
-    """The batch-1 decode step's form: chatts_attention_decode_parts (16 tile slots merged per workgroup, <= 8 unnormalised
-    partials per head) + o_proj GEMV that merges the parts while staging its input  ==  fused attention + combine + GEMV.
-    Also: same cache row written, no NaN from rows beyond the context, position read from the device."""
-    nq, nkv, max_ctx, H = 10, 2, 2048, 1280
-    g = torch.Generator().manual_seed(pos * 7 + parts)
-    raw = torch.randn((1, (nq + 2 * nkv) * 128), generator=g).to(DEV)
-    kc0 = torch.randn((nkv, max_ctx, 128), generator=g).to(DEV)
-    vc0 = torch.randn((nkv, max_ctx, 128), generator=g).to(DEV)
-    kc0[:, pos:] = float("nan")
-    vc0[:, pos:] = float("nan")
-    qn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV) if qk_norm else None
-    kn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV) if qk_norm else None
-    cos, sin = _rope_tables(max_ctx)
-    w = (torch.randn((H, nq * 128), generator=g) * 0.05).to(torch.bfloat16).to(DEV)
-    resid = torch.randn((1, H), generator=g).to(DEV)
-    w8 = scale = None
-    if fp8:
-        from chatts_amd.modeling import quantize_fp8_rows
-        w8, scale, w = quantize_fp8_rows(w)
-    pos_dev = torch.tensor([pos], dtype=torch.int32, device=DEV)
-    wsb = int(lib.chatts_attn_workspace(1, nq, 64))
-    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
-
-    def linear(out, **kw):
-        la = _lib.LinearArgs(w=w.data_ptr(), bias=None, resid=resid.data_ptr(), c=out.data_ptr(), norm_w=None, norm_eps=0.0, m=1, n=H,
-                             k=nq * 128, lda=nq * 128, ldw=nq * 128, ldc=H, epilogue=_lib.EPI_RESID, workspace=None, workspace_bytes=0,
-                             w8=_lib.ptr(w8), w8_scale=_lib.ptr(scale), ldw8=nq * 128, **kw)
-        _lib.check(lib.chatts_linear(la, st()))
-    # reference: fused attention + combine -> float32 row -> GEMV
-    kc_a, vc_a = kc0.clone(), vc0.clone()
-    ca = _lib.KvCache(k=kc_a.data_ptr(), v=vc_a.data_ptr(), max_ctx=max_ctx)
-    attn = torch.empty((1, nq * 128), device=DEV)
-    _lib.check(lib.chatts_attention_decode_fused(raw.data_ptr(), nq, nkv, _lib.ptr(qn), _lib.ptr(kn), 1e-6, cos.data_ptr(), sin.data_ptr(),
-                                                 0, pos_dev.data_ptr(), C.byref(ca), attn.data_ptr(), 64, ws.data_ptr(), wsb, st()))
-    out_a = torch.empty((1, H), device=DEV)
-    linear(out_a, a=attn.data_ptr())
-    torch.cuda.synchronize()
-    # parts form
-    kc_b, vc_b = kc0.clone(), vc0.clone()
-    cb = _lib.KvCache(k=kc_b.data_ptr(), v=vc_b.data_ptr(), max_ctx=max_ctx)
-    ws.fill_(255)                                             # NaN patterns: parts beyond the context must not be read
-    _lib.check(lib.chatts_attention_decode_parts(raw.data_ptr(), 1, nq, nkv, _lib.ptr(qn), _lib.ptr(kn), 1e-6, cos.data_ptr(),
-                                                 sin.data_ptr(), 0, pos_dev.data_ptr(), C.byref(cb), 0, parts, ws.data_ptr(), wsb, st()))
-    out_b = torch.full((1, H), float("nan"), device=DEV)
-    po = ws.data_ptr()
-    linear(out_b, a=None, attn_part_o=po, attn_part_ml=po + nq * parts * 128 * 4, attn_pos_dev=pos_dev.data_ptr(), attn_pos=0,
-           attn_parts=parts)
-    torch.cuda.synchronize()
-    assert not torch.isnan(out_b).any()
-    assert torch.equal(kc_b[:, pos], kc_a[:, pos]) and torch.equal(vc_b[:, pos], vc_a[:, pos]) and torch.equal(kc_b[:, :pos], kc0[:, :pos])
-    assert rel_err(out_b.cpu().numpy(), out_a.cpu().numpy()) < 2e-6
-
-
 def test_embed_merge_and_argmax(lib):
     V, H, T = 1000, 256, 50
     table = torch.randn((V, H)).to(torch.bfloat16).to(DEV)
@@ -1105,20 +1048,3 @@ def test_attention_decode_batched_paged_equals_contiguous(lib, block):
     assert torch.equal(out_a[live], out_b[live])
     for b in range(B):
         assert torch.equal(_from_pool(pk, table[b], block), ka[b]) and torch.equal(_from_pool(pv, table[b], block), va[b])
-    # the "parts" form of the same kernel (its consumer is o_proj; compare the raw partials)
-    for parts in (1, 2):
-        wsp = int(lib.chatts_attn_workspace(1, nq, parts))
-        w_a = torch.zeros(wsp, dtype=torch.uint8, device=DEV)
-        w_b = torch.zeros(wsp, dtype=torch.uint8, device=DEV)
-        b = 3
-        ka1, va1 = kc0[b].clone(), vc0[b].clone()
-        c1 = _lib.KvCache(k=ka1.data_ptr(), v=va1.data_ptr(), max_ctx=max_ctx)
-        pk2, pv2 = pk.clone(), pv.clone()
-        c2 = _lib.KvCache(k=pk2.data_ptr(), v=pv2.data_ptr(), max_ctx=max_ctx, block_table=table[b].contiguous().data_ptr(),
-                          block_size=block, table_stride=nb)
-        for cch, wbuf in ((c1, w_a), (c2, w_b)):
-            _lib.check(lib.chatts_attention_decode_parts(raw[b:b + 1].contiguous().data_ptr(), 1, nq, nkv, qn.data_ptr(), kn.data_ptr(), 1e-6,
-                                                         cos.data_ptr(), sin.data_ptr(), pos[b], None, C.byref(cch), 0, parts,
-                                                         wbuf.data_ptr(), wsp, st()))
-        torch.cuda.synchronize()
-        assert torch.equal(w_a, w_b)
