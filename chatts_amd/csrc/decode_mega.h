@@ -45,7 +45,7 @@ struct MegaHost {           // host-side plan
 
 struct MegaParams {
   const MegaLayer* layers;
-  const MegaGeom* geom;
+  MegaGeom geom[5];          // qkv, o, gate_up, down, lm_head (by value: read with scalar loads from the kernarg segment)
   MegaSync* sync;
   unsigned long long* argmax_pairs;     // [nwg] (float bits << 32 | row): each workgroup's best lm_head row
   float* x;                 // [H] residual stream (input embedding at entry)

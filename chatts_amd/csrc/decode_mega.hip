@@ -69,6 +69,35 @@ __device__ __forceinline__ bool grid_barrier(MegaSync* s, unsigned epoch, int gr
   return spin_until(&s->grp_gen[grp * 32], epoch, &s->status[0]);
 }
 
+// Pointers read from the device-side layer table are generic to the compiler: a load through them would be a FLAT load, which
+// counts on lgkmcnt as well as vmcnt - every LDS wait would then drain the whole weight stream.  Device code therefore reads
+// the table through this view of MegaLayer (same layout) whose members are global-address-space pointers.
+#define MEGA_G __attribute__((address_space(1)))
+struct MegaLayerDev {
+  const MEGA_G float* input_norm;
+  const MEGA_G uint16_t* qkv;
+  const MEGA_G float* qkv_bias;
+  const MEGA_G float* q_norm;
+  const MEGA_G float* k_norm;
+  const MEGA_G uint16_t* o;
+  const MEGA_G float* post_norm;
+  const MEGA_G uint16_t* gate_up;
+  const MEGA_G uint16_t* down;
+  MEGA_G float* kc;
+  MEGA_G float* vc;
+};
+static_assert(sizeof(MegaLayerDev) == sizeof(MegaLayer), "device view of the layer table");
+typedef const __attribute__((address_space(1))) u32x4* gw_ptr;
+
+// One 8-byte field of the layer table by SCALAR load (a vector load + s_waitcnt vmcnt(0) here would stall the compute wave
+// behind its own 16 outstanding weight loads at every phase change).
+__device__ __forceinline__ const uint16_t* sload_weight_ptr(const MegaLayer* layers, int layer, int field_off) {
+  unsigned long long r;
+  const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(layer * (int)sizeof(MegaLayer) + field_off);
+  asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(layers), "s"(off) : "memory");
+  return reinterpret_cast<const uint16_t*>(r);
+}
+
 // ---- the weight stream of a compute wave ------------------------------------------------------------------------------
 struct WDesc {             // one weight phase as seen by one compute wave (all wave-uniform)
   const uint16_t* w;
@@ -86,8 +115,9 @@ __device__ __forceinline__ WDesc weight_desc(const MegaParams& p, int wph, int b
   const MegaGeom g = p.geom[kind];
   const uint16_t* w = p.lm_head;
   if (wph < last) {
-    const MegaLayer* L = p.layers + (wph >> 2);
-    w = kind == G_QKV ? L->qkv : kind == G_O ? L->o : kind == G_GATE_UP ? L->gate_up : L->down;
+    const int foff = kind == G_QKV ? (int)offsetof(MegaLayer, qkv) : kind == G_O ? (int)offsetof(MegaLayer, o) :
+                     kind == G_GATE_UP ? (int)offsetof(MegaLayer, gate_up) : (int)offsetof(MegaLayer, down);
+    w = sload_weight_ptr(p.layers, wph >> 2, foff);
   }
   d.w = w; d.k = g.k; d.nchunks = (g.k + 511) >> 9; d.n = g.n; d.swiglu = g.swiglu; d.nact = g.nact;
   int nt = g.tasks - b * g.tpw;
@@ -149,32 +179,24 @@ __device__ __forceinline__ void stage_write(const float* src, const float* norm_
     asm volatile("" ::: "memory");                          \
   } while (0)
 
-__global__ __launch_bounds__(kMegaThreads) void decode_mega_kernel(MegaParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  f32x4* xs4 = reinterpret_cast<f32x4*>(smem);                                   // staged activation vector / attention scratch
-  float* out_s = reinterpret_cast<float*>(smem + p.xs_bytes);                    // this workgroup's results of the phase
-  float* red = out_s + kOutSlots;                                                // RMSNorm partial sums (<= 16 virtual waves)
-  long long* tok_s = reinterpret_cast<long long*>(red + 32);                     // greedy tail: the token, for the embedding
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x;
-  const bool compute = wave < kCompute;
-  const int hw = wave - kCompute, htid = tid - kCompute * 64;
-  MegaSync* sync = p.sync;
-  if (__hip_atomic_load(&sync->status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;     // a previous step hung
-  const int grp = b & 7;
-  const unsigned n_groups = p.nwg < 8 ? p.nwg : 8;
-  const unsigned grp_size = (p.nwg - grp + 7) >> 3;
+// geometry index of the phase after `ph` if it needs a staged activation vector, else -1
+__device__ __forceinline__ int stage_kind_after(int ph, int n_ph, int L) {
+  if (ph + 1 >= n_ph) return -1;
+  const int nk = ph + 1 < 6 * L ? (ph + 1) % 6 : PH_LM_HEAD;
+  return nk == PH_QKV ? G_QKV : nk == PH_O ? G_O : nk == PH_GATE_UP ? G_GATE_UP : nk == PH_DOWN ? G_DOWN : nk == PH_LM_HEAD ? G_LM_HEAD : -1;
+}
+
+// ---- compute waves: nothing but the weight stream, the FMAs and s_barriers -------------------------------------------------
+// Barrier schedule (must match helper_main exactly): 2 at entry; per phase A, B and - when the next phase stages a vector - 2
+// more; 1 in the greedy tail of workgroup 0.
+__device__ __forceinline__ void compute_main(const MegaParams& p, const int b, const int wave, const int lane, const f32x4* xs4,
+                                             float* out_s) {
   const int L = p.n_layers;
   const int n_ph = 6 * L + 1;
-  unsigned epoch = 0;
-  bool alive = true;
-
-  // ---- compute-wave stream state ----
   u32x4 buf[kDepth][2];
   WDesc dn = weight_desc(p, 0, b, wave);        // the phase being ISSUED (at most one weight phase ahead of the FMAs)
   int it = 0, ic = 0, ie = 0;                   // its cursor: task ordinal, chunk, element
-  int wph = 0;                                  // weight phase being consumed next
+  int wph = 0;
   auto issue = [&](int j) __attribute__((always_inline)) {
     const bool valid = ie < dn.n_elems;
     const int task = dn.task0 + it * dn.nact;
@@ -183,55 +205,40 @@ __global__ __launch_bounds__(kMegaThreads) void decode_mega_kernel(MegaParams p)
     if (!valid || r1 >= dn.n) r1 = 0;
     const int col = ic * 512 + lane * 8;
     const int off = (valid && col < dn.k) ? col : 0;
-    buf[j][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dn.w + (size_t)r0 * dn.k + off));
-    buf[j][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dn.w + (size_t)r1 * dn.k + off));
+    buf[j][0] = __builtin_nontemporal_load((gw_ptr)(dn.w + (size_t)r0 * dn.k + off));
+    buf[j][1] = __builtin_nontemporal_load((gw_ptr)(dn.w + (size_t)r1 * dn.k + off));
     ++ie;
     if (++ic == dn.nchunks) { ic = 0; ++it; }
   };
-  if (compute) {
 #pragma unroll
-    for (int j = 0; j < kDepth; ++j) issue(j);
-  }
-
-  // ---- stage the first projection's input: RMSNorm(x) for layer 0's qkv ----
-  {
-    const MegaGeom g = p.geom[G_QKV];
-    if (!compute) stage_sumsq(p.x, g.k, g.vthreads, hw, lane, red);
-    MEGA_LDS_SYNC();
-    if (!compute) stage_write(p.x, p.layers[0].input_norm, g.k, (g.k + 511) >> 9, g.vthreads, p.eps, htid, red, xs4);
-    MEGA_LDS_SYNC();
-  }
-
+  for (int j = 0; j < kDepth; ++j) issue(j);
+  MEGA_LDS_SYNC();
+  MEGA_LDS_SYNC();                              // layer 0's normalised input is staged
   for (int ph = 0; ph < n_ph; ++ph) {
-    const int layer = ph < 6 * L ? ph / 6 : L - 1;
-    const int kind = ph < 6 * L ? ph - layer * 6 : PH_LM_HEAD;
-    const MegaLayer* ML = p.layers + layer;
-    const bool weight_phase = kind != PH_ATTN && kind != PH_COMBINE;
-
-    // ================= work =================
-    if (weight_phase && compute) {
-      const WDesc dc = dn;                     // by construction the issue side is exactly at this phase
+    const int kind = ph < 6 * L ? ph % 6 : PH_LM_HEAD;
+    if (kind != PH_ATTN && kind != PH_COMBINE) {
+      const int nchunks = dn.nchunks, n_elems = dn.n_elems, swiglu = dn.swiglu, lt0 = dn.lt0, nact = dn.nact;
       int ct = 0, cc = 0, ce = 0;
       float acc0 = 0.f, acc1 = 0.f;
-      const int nblk = dc.n_elems > 0 ? (dc.n_elems + kDepth - 1) / kDepth : 1;
+      const int nblk = n_elems > 0 ? (n_elems + kDepth - 1) / kDepth : 1;
       for (int blk = 0; blk < nblk; ++blk) {
-        if (blk == nblk - 1) {                 // everything of this phase has been issued: run ahead into the next weight phase
+        if (blk == nblk - 1) {                  // everything of this phase has been issued: run ahead into the next weight phase
           ++wph;
           dn = weight_desc(p, wph, b, wave);
           it = 0; ic = 0; ie = 0;
         }
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) {
-          if (ce < dc.n_elems) {
+          if (ce < n_elems) {
             const f32x4 xa = xs4[cc * 128 + lane], xb = xs4[cc * 128 + 64 + lane];
             acc0 = dot8(buf[j][0], xa, xb, acc0);
             acc1 = dot8(buf[j][1], xa, xb, acc1);
             ++ce;
-            if (++cc == dc.nchunks) {          // a row pair is complete
+            if (++cc == nchunks) {              // a row pair is complete
               const float r0 = wave_sum(acc0), r1 = wave_sum(acc1);
-              const int lt = dc.lt0 + ct * dc.nact;
+              const int lt = lt0 + ct * nact;
               if (lane == 0) {
-                if (dc.swiglu) out_s[lt] = silu_f(r0) * r1;
+                if (swiglu) out_s[lt] = silu_f(r0) * r1;
                 else { out_s[2 * lt] = r0; out_s[2 * lt + 1] = r1; }
               }
               acc0 = 0.f; acc1 = 0.f; cc = 0; ++ct;
@@ -240,11 +247,46 @@ __global__ __launch_bounds__(kMegaThreads) void decode_mega_kernel(MegaParams p)
           issue(j);
         }
       }
-    } else if (!weight_phase && !compute) {
+    }
+    MEGA_LDS_SYNC();                            // A
+    MEGA_LDS_SYNC();                            // B
+    if (stage_kind_after(ph, n_ph, L) >= 0) {
+      MEGA_LDS_SYNC();
+      MEGA_LDS_SYNC();                          // C: xs4 holds this phase's successor's input
+    }
+  }
+  if (p.greedy_tail && b == 0) MEGA_LDS_SYNC();
+}
+
+// ---- helper waves: staging, attention, publishing, the grid barrier ------------------------------------------------------
+__device__ __forceinline__ void helper_main(const MegaParams& p, const int b, const int wave, const int lane, const int htid, char* smem,
+                                            f32x4* xs4, float* out_s, float* red, long long* tok_s) {
+  const int hw = wave - kCompute;
+  MegaSync* sync = p.sync;
+  const int grp = b & 7;
+  const unsigned n_groups = p.nwg < 8 ? p.nwg : 8;
+  const unsigned grp_size = (p.nwg - grp + 7) >> 3;
+  const int L = p.n_layers;
+  const int n_ph = 6 * L + 1;
+  unsigned epoch = 0;
+  bool alive = true;
+  {
+    const MegaGeom g = p.geom[G_QKV];
+    stage_sumsq(p.x, g.k, g.vthreads, hw, lane, red);
+    MEGA_LDS_SYNC();
+    stage_write(p.x, (const float*)reinterpret_cast<const MegaLayerDev*>(p.layers)[0].input_norm, g.k, (g.k + 511) >> 9, g.vthreads, p.eps, htid, red, xs4);
+    MEGA_LDS_SYNC();
+  }
+  for (int ph = 0; ph < n_ph; ++ph) {
+    const int layer = ph < 6 * L ? ph / 6 : L - 1;
+    const int kind = ph < 6 * L ? ph - layer * 6 : PH_LM_HEAD;
+    const MegaLayerDev* ML = reinterpret_cast<const MegaLayerDev*>(p.layers) + layer;
+    const bool weight_phase = kind != PH_ATTN && kind != PH_COMBINE;
+    if (!weight_phase) {
       AttnParams ap;
-      ap.qkv = p.qkv; ap.kc = ML->kc; ap.vc = ML->vc; ap.out = p.attn; ap.part_ml = p.part_ml; ap.part_o = p.part_o;
+      ap.qkv = p.qkv; ap.kc = (float*)ML->kc; ap.vc = (float*)ML->vc; ap.out = p.attn; ap.part_ml = p.part_ml; ap.part_o = p.part_o;
       ap.pos0_dev = p.pos_dev; ap.pos0 = 0; ap.t = 1; ap.n_q = p.n_q; ap.n_kv = p.n_kv; ap.max_ctx = p.max_ctx;
-      ap.n_splits = p.n_splits; ap.q_norm_w = ML->q_norm; ap.k_norm_w = ML->k_norm; ap.cos_tab = p.cos_tab; ap.sin_tab = p.sin_tab;
+      ap.n_splits = p.n_splits; ap.q_norm_w = (const float*)ML->q_norm; ap.k_norm_w = (const float*)ML->k_norm; ap.cos_tab = p.cos_tab; ap.sin_tab = p.sin_tab;
       ap.eps = p.eps; ap.seq_stride = 0; ap.table = p.kv_table; ap.log_block = p.kv_log_block; ap.table_stride = 0;
       ap.out_hi = nullptr; ap.out_lo = nullptr;
       if (kind == PH_ATTN) {
@@ -262,8 +304,7 @@ __global__ __launch_bounds__(kMegaThreads) void decode_mega_kernel(MegaParams p)
     }
     MEGA_LDS_SYNC();                                          // A: the workgroup's part of the phase is done
 
-    // ================= publish + grid barrier (master wave) =================
-    if (wave == kMaster) {
+    if (wave == kMaster) {                                    // publish + grid barrier
       if (weight_phase) {
         const int gk = kind == PH_QKV ? G_QKV : kind == PH_O ? G_O : kind == PH_GATE_UP ? G_GATE_UP : kind == PH_DOWN ? G_DOWN : G_LM_HEAD;
         const MegaGeom g = p.geom[gk];
@@ -272,7 +313,7 @@ __global__ __launch_bounds__(kMegaThreads) void decode_mega_kernel(MegaParams p)
         if (g.swiglu) {                                       // gate_up: one value per task
           for (int i = lane; i < nt; i += 64) wt_store1(p.act + (size_t)b * g.tpw + i, out_s[i]);
         } else {
-          const float* bias = kind == PH_QKV ? ML->qkv_bias : nullptr;
+          const float* bias = kind == PH_QKV ? (const float*)ML->qkv_bias : nullptr;
           float* dst = kind == PH_QKV ? p.qkv : kind == PH_LM_HEAD ? p.logits : p.x;
           const bool resid = kind == PH_O || kind == PH_DOWN;
           float best = -INFINITY;
@@ -308,22 +349,20 @@ __global__ __launch_bounds__(kMegaThreads) void decode_mega_kernel(MegaParams p)
     }
     MEGA_LDS_SYNC();                                          // B: everybody's results of this phase are visible
 
-    // ================= stage the next weight phase's input =================
-    const int nkind = ph + 1 >= n_ph ? -1 : (ph + 1 < 6 * L ? (ph + 1) % 6 : PH_LM_HEAD);
-    if (nkind == PH_QKV || nkind == PH_O || nkind == PH_GATE_UP || nkind == PH_DOWN || nkind == PH_LM_HEAD) {
-      const int gk = nkind == PH_QKV ? G_QKV : nkind == PH_O ? G_O : nkind == PH_GATE_UP ? G_GATE_UP : nkind == PH_DOWN ? G_DOWN : G_LM_HEAD;
+    const int gk = stage_kind_after(ph, n_ph, L);
+    if (gk >= 0) {                                            // stage the next weight phase's input
       const MegaGeom g = p.geom[gk];
-      const MegaLayer* NL = p.layers + (ph + 1 < 6 * L ? (ph + 1) / 6 : L - 1);
-      const float* src = nkind == PH_O ? p.attn : nkind == PH_DOWN ? p.act : p.x;
-      const float* nw = nkind == PH_QKV ? NL->input_norm : nkind == PH_GATE_UP ? NL->post_norm : nkind == PH_LM_HEAD ? p.final_norm : nullptr;
-      if (!compute && nw) stage_sumsq(src, g.k, g.vthreads, hw, lane, red);
+      const MegaLayerDev* NL = reinterpret_cast<const MegaLayerDev*>(p.layers) + (ph + 1 < 6 * L ? (ph + 1) / 6 : L - 1);
+      const float* src = gk == G_O ? p.attn : gk == G_DOWN ? p.act : p.x;
+      const float* nw = gk == G_QKV ? (const float*)NL->input_norm : gk == G_GATE_UP ? (const float*)NL->post_norm : gk == G_LM_HEAD ? p.final_norm : nullptr;
+      if (nw) stage_sumsq(src, g.k, g.vthreads, hw, lane, red);
       MEGA_LDS_SYNC();
-      if (!compute) stage_write(src, nw, g.k, (g.k + 511) >> 9, g.vthreads, p.eps, htid, red, xs4);
+      stage_write(src, nw, g.k, (g.k + 511) >> 9, g.vthreads, p.eps, htid, red, xs4);
       MEGA_LDS_SYNC();                                        // C: the compute waves may read xs4
     }
   }
 
-  // ================= greedy tail: token, decode-loop state, next input embedding (workgroup 0) =================
+  // greedy tail: token, decode-loop state, next input embedding (workgroup 0)
   if (p.greedy_tail && b == 0) {
     if (wave == kMaster) {
       float best = -INFINITY;
@@ -351,18 +390,29 @@ __global__ __launch_bounds__(kMegaThreads) void decode_mega_kernel(MegaParams p)
       }
     }
     MEGA_LDS_SYNC();
-    if (!compute) {
-      const long long id = tok_s[0] - p.embed_offset;
-      for (int k = htid * 4; k < p.hidden; k += kHelpers * 64 * 4) {
-        f32x4 f = {0.f, 0.f, 0.f, 0.f};
-        if (id >= 0 && id < p.embed_rows) {
-          const u32x2 v = *reinterpret_cast<const u32x2*>(p.embed + (size_t)id * p.hidden + k);
-          f = (f32x4){bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y)};
-        }
-        *reinterpret_cast<f32x4*>(p.x + k) = f;
+    const long long id = tok_s[0] - p.embed_offset;
+    for (int k = htid * 4; k < p.hidden; k += kHelpers * 64 * 4) {
+      f32x4 f = {0.f, 0.f, 0.f, 0.f};
+      if (id >= 0 && id < p.embed_rows) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(p.embed + (size_t)id * p.hidden + k);
+        f = (f32x4){bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y)};
       }
+      *reinterpret_cast<f32x4*>(p.x + k) = f;
     }
   }
+}
+
+__global__ __launch_bounds__(kMegaThreads) void decode_mega_kernel(MegaParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* xs4 = reinterpret_cast<f32x4*>(smem);                                   // staged activation vector / attention scratch
+  float* out_s = reinterpret_cast<float*>(smem + p.xs_bytes);                    // this workgroup's results of the phase
+  float* red = out_s + kOutSlots;                                                // RMSNorm partial sums (<= 16 virtual waves)
+  long long* tok_s = reinterpret_cast<long long*>(red + 32);                     // greedy tail: the token, for the embedding
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (__hip_atomic_load(&p.sync->status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;     // a previous step hung
+  if (wave < kCompute) compute_main(p, blockIdx.x, wave, lane, xs4, out_s);
+  else helper_main(p, blockIdx.x, wave, lane, tid - kCompute * 64, smem, xs4, out_s, red, tok_s);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------
@@ -372,8 +422,8 @@ static int pick_nact(int tpw) {
   return tpw < kCompute ? (tpw > 0 ? tpw : 1) : kCompute;
 }
 
-size_t mega_state_bytes(int n_layers, int nwg) {
-  return sizeof(MegaSync) + 5 * sizeof(MegaGeom) + 64 + (size_t)nwg * 8 + 64 + (size_t)n_layers * sizeof(MegaLayer) + 256;
+size_t mega_state_bytes(int n_layers, int nwg) {        // MegaSync | argmax pairs [nwg] (64-byte padded) | MegaLayer [n_layers]
+  return sizeof(MegaSync) + (((size_t)nwg * 8 + 63) / 64) * 64 + (size_t)n_layers * sizeof(MegaLayer) + 256;
 }
 
 int mega_lds_bytes(const MegaHost& h) {

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "common.h"
+#include "decode_mega.h"
 
 namespace chatts {
 int launch_gemv(const ChattsLinearArgs* a, hipStream_t s);
@@ -36,6 +37,11 @@ struct ChattsDecoder {
   bool sampling = false;    // token selection of the decode steps: greedy argmax, or the sampler with `sa`
   ChattsSamplingArgs sa{};
   ChattsTpComm* tp = nullptr;   // tensor-parallel exchange (borrowed); required by the whole-step entry points when tp_world > 1
+  // persistent decode step (decode_mega.hip): plan + caller-owned device state (tables, barrier counters); null = not attached
+  MegaHost mega{};
+  bool mega_planned = false;
+  void* mega_state = nullptr;
+  int mega_n_splits = 0;
 };
 
 static int64_t embed_rows(const ChattsDecoder* d) { return d->cfg.embed_rows > 0 ? d->cfg.embed_rows : d->cfg.vocab_local; }
@@ -626,6 +632,94 @@ extern "C" int chatts_decoder_logits(ChattsDecoder* d, int row, chatts_stream_t 
   return chatts_linear(&la, stream);
 }
 
+// ---- persistent decode step (decode_mega.hip) -----------------------------------------------------------------------------
+static bool mega_eligible(const ChattsDecoder* d) {
+  if (d->cfg.tp_world != 1) return false;                     // the partial sums of a TP rank leave the GPU between the halves
+  for (const ChattsLayerWeights& lw : d->layers)
+    if (lw.qkv8 || lw.o8 || lw.gate_up8 || lw.down8 || lw.qkv4 || lw.o4 || lw.gate_up4 || lw.down4) return false;   // bf16 stream only
+  return d->w.lm_head8 == nullptr;
+}
+
+extern "C" size_t chatts_decoder_mega_state_bytes(ChattsDecoder* d) {
+  if (!d || !mega_eligible(d)) return 0;
+  if (!d->mega_planned) {
+    const int cus = device_cus();
+    if (cus < 8 || !mega_plan(&d->mega, d->cfg.hidden, d->cfg.n_q, d->cfg.n_kv, d->cfg.inter, d->cfg.vocab_local, cus)) return 0;
+    d->mega_planned = true;
+  }
+  return mega_state_bytes(d->cfg.n_layers, d->mega.nwg);
+}
+
+// state layout: MegaSync | argmax pairs [nwg] | MegaLayer [n_layers]
+static unsigned long long* mega_pairs(const ChattsDecoder* d) {
+  return reinterpret_cast<unsigned long long*>(static_cast<char*>(d->mega_state) + sizeof(MegaSync));
+}
+static MegaLayer* mega_layers(const ChattsDecoder* d) {
+  return reinterpret_cast<MegaLayer*>(static_cast<char*>(d->mega_state) + sizeof(MegaSync) + (((size_t)d->mega.nwg * 8 + 63) / 64) * 64);
+}
+
+extern "C" int chatts_decoder_mega_attach(ChattsDecoder* d, void* state, size_t bytes, int n_splits) {
+  CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_mega_attach: null decoder");
+  if (!state) { d->mega_state = nullptr; return CHATTS_OK; }
+  const size_t need = chatts_decoder_mega_state_bytes(d);
+  CHATTS_REQUIRE(need > 0, CHATTS_E_SHAPE, "decoder_mega_attach: this decoder cannot run the persistent step (tensor parallel, fp8 / int4 "
+                 "weights or an unsupported shape)");
+  CHATTS_REQUIRE(bytes >= need && ((uintptr_t)state % 256) == 0, CHATTS_E_WORKSPACE, "decoder_mega_attach: needs %zu bytes, 256-byte aligned", need);
+  CHATTS_REQUIRE(n_splits >= 1 && n_splits <= 64 && chatts_attn_workspace(1, d->cfg.n_q, n_splits) <= d->b.workspace_bytes, CHATTS_E_WORKSPACE,
+                 "decoder_mega_attach: attention workspace too small for %d key slots", n_splits);
+  d->mega_state = state;
+  d->mega_n_splits = n_splits;
+  std::vector<MegaLayer> tab(d->cfg.n_layers);
+  for (int l = 0; l < d->cfg.n_layers; ++l) {
+    const ChattsLayerWeights& lw = d->layers[l];
+    const ChattsKvCache kc = layer_cache(d, l, 0);          // cache slot 0: the single-sequence decode path
+    tab[l] = MegaLayer{lw.input_norm, lw.qkv, lw.qkv_bias, lw.q_norm, lw.k_norm, lw.o, lw.post_norm, lw.gate_up, lw.down, kc.k, kc.v};
+  }
+  // set-up call (like the exchange buffers of chatts_tp_*): zero the state, upload the layer table, synchronously
+  hipError_t e = hipMemset(state, 0, need);
+  if (e == hipSuccess) e = hipMemcpy(mega_layers(d), tab.data(), tab.size() * sizeof(MegaLayer), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { d->mega_state = nullptr; }
+  CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "decoder_mega_attach: %s", hipGetErrorString(e));
+  return CHATTS_OK;
+}
+
+extern "C" int chatts_decoder_mega_status(ChattsDecoder* d) {
+  CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_mega_status: null decoder");
+  if (!d->mega_state) return 0;
+  unsigned st = 0;
+  const hipError_t e = hipMemcpy(&st, static_cast<char*>(d->mega_state) + offsetof(MegaSync, status), sizeof(st), hipMemcpyDeviceToHost);
+  CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "decoder_mega_status: %s", hipGetErrorString(e));
+  return (int)st;
+}
+
+static int decode_step_mega(ChattsDecoder* d, int32_t* pos_dev, int32_t* step_dev, int64_t* token_dev, float* token_logit_dev,
+                            int64_t* out_tokens, chatts_stream_t stream) {
+  const ChattsDecoderConfig& c = d->cfg;
+  MegaParams p{};
+  p.layers = mega_layers(d);
+  for (int i = 0; i < 5; ++i) p.geom[i] = d->mega.geom[i];
+  p.sync = static_cast<MegaSync*>(d->mega_state);
+  p.argmax_pairs = mega_pairs(d);
+  p.x = d->b.x; p.qkv = d->b.qkv; p.attn = d->b.attn; p.act = d->b.act; p.logits = d->b.logits;
+  p.part_o = reinterpret_cast<float*>(d->b.workspace);
+  p.part_ml = p.part_o + (size_t)c.n_q * d->mega_n_splits * kHeadDim;
+  p.final_norm = d->w.final_norm; p.lm_head = d->w.lm_head; p.embed = d->w.embed; p.cos_tab = d->w.cos_tab; p.sin_tab = d->w.sin_tab;
+  p.kv_table = d->b.kv_block_table;                         // row of cache slot 0
+  p.kv_log_block = d->b.kv_block_table ? kv_log_block(d->b.kv_block_size) : 0;
+  p.pos_dev = pos_dev; p.step_dev = step_dev; p.token_dev = token_dev; p.token_logit_dev = token_logit_dev; p.out_tokens = out_tokens;
+  p.vocab_offset = c.vocab_offset; p.embed_rows = embed_rows(d); p.embed_offset = embed_offset(d);
+  p.eps = c.rms_eps; p.n_layers = c.n_layers; p.hidden = c.hidden; p.n_q = c.n_q; p.n_kv = c.n_kv; p.max_ctx = c.max_ctx;
+  p.n_splits = d->mega_n_splits;
+  p.greedy_tail = d->sampling ? 0 : 1;
+  p.nwg = d->mega.nwg; p.xs_bytes = mega_lds_bytes(d->mega);
+  int rc = mega_launch(p, d->mega, as_stream(stream));
+  if (rc || !d->sampling) return rc;
+  // sampling: the launch ends with the logits; selection and the next embedding are the ordinary kernels
+  if ((rc = chatts_decoder_select_tokens(d, d->b.logits, 1, c.vocab_local, token_dev, token_logit_dev, out_tokens, 0, step_dev, pos_dev, 0,
+                                         nullptr, stream)) != 0) return rc;
+  return chatts_embed_token(token_dev, d->w.embed, embed_offset(d), embed_rows(d), c.hidden, d->b.x, stream);
+}
+
 extern "C" int chatts_decoder_decode_step(ChattsDecoder* d, int32_t* pos_dev, int32_t* step_dev, int64_t* token_dev,
                                           float* token_logit_dev, int64_t* out_tokens, int n_splits,
                                           chatts_stream_t stream) {
@@ -634,6 +728,10 @@ extern "C" int chatts_decoder_decode_step(ChattsDecoder* d, int32_t* pos_dev, in
   CHATTS_REQUIRE(!tp || d->tp, CHATTS_E_BADARG, "decode_step: tp_world = %d but no exchange attached (chatts_decoder_set_tp)", d->cfg.tp_world);
   int rc;
   const int H = d->cfg.hidden;
+  if (d->mega_state && d->cur_seq == 0 && n_splits == d->mega_n_splits && mega_eligible(d)) {
+    static const bool off = getenv("CHATTS_DECODE_MEGA") && atoi(getenv("CHATTS_DECODE_MEGA")) == 0;
+    if (!off) return decode_step_mega(d, pos_dev, step_dev, token_dev, token_logit_dev, out_tokens, stream);
+  }
   for (int l = 0; l < d->cfg.n_layers; ++l) {
     if ((rc = chatts_decoder_layer_part(d, l, 0, 1, 0, pos_dev, n_splits, stream)) != 0) return rc;
     if (tp && (rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, H, stream)) != 0) return rc;    // x += sum of the partial o_proj

@@ -412,6 +412,12 @@ class ChatTSForCausalLM:
         self._decoder = C.c_void_p(h)
         self._graph = None
         self._graph_batched = None
+        # persistent decode step (csrc/decode_mega.hip): one launch per token instead of 6 per layer; available for TP = 1 on bf16
+        # weights (state bytes 0 otherwise); CHATTS_DECODE_MEGA=0 keeps the multi-kernel schedule
+        self._mega_state = None
+        import os
+        if os.environ.get("CHATTS_DECODE_MEGA", "1") != "0":
+            self.enable_persistent_decode(True)
         if plan.world > 1 and self.use_p2p and getattr(self.comm, "dist", None) is not None and self._tp is None:
             from .tp import P2PExchange
             ex, err = None, None
@@ -434,6 +440,34 @@ class ChatTSForCausalLM:
                 warnings.warn(f"peer-to-peer exchange unavailable on ranks {[r for r, ok in enumerate(oks) if not ok]} ({err}): "
                               "decode-sized sums go through RCCL from the host (slower, no hipGraph)")
                 self.use_p2p = False
+
+    def enable_persistent_decode(self, on=True):
+        """Attach / detach the persistent decode step.  -> True when decode_step() will run as one launch per token."""
+        lib = self.lib
+        self._graph = None                        # a captured step has the old schedule baked in
+        if not on:
+            _lib.check(lib.chatts_decoder_mega_attach(self._decoder, None, 0, 0))
+            self._mega_state = None
+            return False
+        nb = int(lib.chatts_decoder_mega_state_bytes(self._decoder))
+        if nb <= 0:
+            self._mega_state = None
+            return False
+        st = torch.zeros(nb + 256, dtype=torch.uint8, device=self.device)
+        off = (-st.data_ptr()) % 256
+        _lib.check(lib.chatts_decoder_mega_attach(self._decoder, st.data_ptr() + off, nb, self.n_splits))
+        self._mega_state = st
+        return True
+
+    def persistent_decode_status(self):
+        """0 = healthy (or not attached); != 0 = a grid barrier of a persistent step timed out: tokens since then are invalid.
+        Synchronises (one word read)."""
+        if self._mega_state is None:
+            return 0
+        rc = int(self.lib.chatts_decoder_mega_status(self._decoder))
+        if rc < 0:
+            _lib.check(rc)
+        return rc
 
     def exchange_elems(self):
         """float32 elements per rank the largest in-step collective moves: [max_batch, H] partial sums, or the logits gather."""
@@ -1239,6 +1273,8 @@ class ChatTSForCausalLM:
         toks = self.buf["out_tokens"][:produced].tolist()
         if self._tp is not None and self._tp.status():
             raise RuntimeError("tensor-parallel exchange timed out (a peer rank did not reach the collective): tokens are invalid")
+        if self._mega_state is not None and self.persistent_decode_status():
+            raise RuntimeError("persistent decode step: a grid barrier timed out (status word set): tokens are invalid")
         if eos:
             for i, t in enumerate(toks):
                 if t in eos:

@@ -35,8 +35,9 @@ typedef uint16_t chatts_bf16;  /* raw bfloat16 bits */
 const char* chatts_last_error(void);
 /* ABI version of this header: bumped whenever a struct grows or a signature changes
  * (2: plane operands, sampler, decoder plane buffers; 3: post-norm planes of chatts_linear;
- *  4: tensor-parallel exchange chatts_tp_* / chatts_allreduce, decoder embed_rows + TP buffers, chatts_decoder_select_tokens). */
-#define CHATTS_ABI_VERSION 5
+ *  4: tensor-parallel exchange chatts_tp_* / chatts_allreduce, decoder embed_rows + TP buffers, chatts_decoder_select_tokens;
+ *  6: persistent decode step chatts_decoder_mega_*; the attention 'parts' form and its ChattsLinearArgs fields removed). */
+#define CHATTS_ABI_VERSION 6
 int chatts_abi_version(void);
 /* Number of CUs of the current device (grid sizing), or <0. */
 int chatts_device_cus(void);
@@ -499,6 +500,20 @@ int chatts_decoder_logits(ChattsDecoder*, int row, chatts_stream_t stream);
 int chatts_decoder_decode_step(ChattsDecoder*, int32_t* pos_dev, int32_t* step_dev,
                                int64_t* token_dev, float* token_logit_dev, int64_t* out_tokens,
                                int n_splits, chatts_stream_t stream);
+
+/* Persistent decode step (csrc/decode_mega.hip): with a state buffer attached, chatts_decoder_decode_step runs a whole token -
+ * every layer's projections, attention, lm_head, greedy token, decode-loop state, next input embedding - as ONE launch whose
+ * weight stream never stops at a projection boundary (the replacement for the 291 dependent launches of the multi-kernel
+ * schedule; bit-identical results).  Available for tensor_parallel_size 1, bf16 weights, cache slot 0; otherwise, or with
+ * CHATTS_DECODE_MEGA=0 in the environment, decode_step keeps the multi-kernel schedule.
+ *   chatts_decoder_mega_state_bytes: device bytes the caller must provide (0 = this decoder cannot use it);
+ *   chatts_decoder_mega_attach: binds the buffer (256-byte aligned) and uploads the layer table - a SET-UP call: it zero-fills
+ *     and copies synchronously; n_splits = the key-slot count decode_step will be called with; state == NULL detaches;
+ *   chatts_decoder_mega_status: synchronising diagnostic; != 0 = a grid barrier inside a step timed out (bounded spins): the
+ *     tokens since then are invalid and every later step returns immediately until the buffer is re-attached. */
+size_t chatts_decoder_mega_state_bytes(ChattsDecoder*);
+int chatts_decoder_mega_attach(ChattsDecoder*, void* state, size_t bytes, int n_splits);
+int chatts_decoder_mega_status(ChattsDecoder*);
 
 #ifdef __cplusplus
 }
