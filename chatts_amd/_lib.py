@@ -144,6 +144,7 @@ SIGNATURES = {
     "chatts_decoder_mega_state_bytes": (c_size_t, [c_void_p]),
     "chatts_decoder_mega_attach": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
     "chatts_decoder_mega_status": (c_int, [c_void_p]),
+    "chatts_decoder_mega_profile": (c_int, [c_void_p, c_void_p, c_size_t]),
     "chatts_decoder_select_tokens": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                              c_void_p, c_int, C.POINTER(SamplingArgs), c_void_p]),
     # tensor-parallel exchange (tp.hip)

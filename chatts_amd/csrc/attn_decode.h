@@ -65,18 +65,70 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 // ---------------------------------------------------------------------------------------------------
 // decode: grid (n_kv, n_slots), 64 threads.  Slot s walks tiles s, s + n_slots, ... of 16 keys.
 // ---------------------------------------------------------------------------------------------------
-// One wave's work: kv head hk, tile slot `slot` of sequence `seq`.  q_s [kMaxGroup * 128], knew_s / vnew_s [128] are this wave's
-// private LDS scratch (16-byte aligned).  WT: the partials are stored write-through (agent-scope relaxed atomics = `sc1` stores),
-// for consumers inside the SAME launch (decode_mega.hip); the stand-alone kernel uses plain stores.
-template <bool WT>
-__device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
-                                                 float* q_s, float* knew_s, float* vnew_s) {
+// One wave's work: kv head hk, tile slot `slot` of sequence `seq`, in two stages so that a caller which knows its task before
+// the projections are ready (decode_mega.hip) can have the cache rows in registers by then:
+//   attn_decode_preload: everything that does not depend on this step's qkv - the position, the slot's first K / V tile, cos / sin;
+//   attn_decode_finish : q prologue, new K / V row, scores, softmax, P.V, the partial.
+// q_s [kMaxGroup * 128], knew_s / vnew_s [128] are this wave's private LDS scratch (16-byte aligned).  WT: the partials are
+// stored write-through (agent-scope relaxed atomics = `sc1` stores) for consumers inside the SAME launch; the stand-alone kernel
+// uses plain stores.
+struct AttnTileRegs {       // what a wave keeps between the two stages: the slot's first K tile, cos / sin, the position
+  f32x4 kv[8];
+  float c, s;
+  int pos;
+};
+
+__device__ __forceinline__ void attn_load_k(const KvLayout& kvl, const float* kcache, const int hk, const int tile, const int pos,
+                                            const int lane, f32x4 (&kv)[8]) {
+  const int key_l = lane >> 2, quarter = lane & 3;
+  const int j0 = tile * kDTile;
+  const int j = j0 + key_l;
+  const int jc = j <= pos ? j : pos;          // clamped address (stays inside this tile: pos lies in it); masked below
+  const size_t toff = kv_tile_off(kvl, hk, j0);   // the tile's first row: one table lookup per tile when the cache is paged
+  const float* kr = kcache + toff + (size_t)(jc - j0) * kHeadDim + quarter * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
+}
+__device__ __forceinline__ void attn_load_v(const KvLayout& kvl, const float* vcache, const int hk, const int tile, const int pos,
+                                            const int lane, float2 (&vv)[kDTile]) {
+  const int j0 = tile * kDTile;
+  const size_t toff = kv_tile_off(kvl, hk, j0);
+#pragma unroll
+  for (int u = 0; u < kDTile; ++u) {
+    const int ju = j0 + u <= pos ? j0 + u : pos;
+    vv[u] = *reinterpret_cast<const float2*>(vcache + toff + (size_t)(ju - j0) * kHeadDim + lane * 2);
+  }
+}
+
+// -> false: nothing to do for this slot (parked sequence, or the slot lies beyond the context)
+__device__ __forceinline__ bool attn_decode_preload(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
+                                                    AttnTileRegs& t) {
+  const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;     // batched decode: one position per sequence
+  t.pos = pos;
+  if (pos < 0) return false;                   // parked slot of a batched step: no cache write, no attention (its row is ignored)
+  const int ntiles = pos / kDTile + 1;
+  if (slot >= ntiles) return false;            // the combine only reads slots < min(ntiles, NS)
+  const float* kcache = p.kc + (p.table ? 0 : (size_t)seq * p.seq_stride);
+  const KvLayout kvl{p.table ? p.table + (size_t)seq * p.table_stride : nullptr, p.n_kv, p.max_ctx, p.log_block};
+  // K of the first tile only depends on `pos`: issued before the q prologue so that the cache rows, q, cos / sin all travel in
+  // the same memory round trip (or, preloaded, in an earlier one); V follows at the head of the second stage - it is not
+  // needed before the softmax is done
+  attn_load_k(kvl, kcache, hk, slot, pos, lane, t.kv);
+  t.c = p.cos_tab[(size_t)pos * 64 + lane];
+  t.s = p.sin_tab[(size_t)pos * 64 + lane];
+  return true;
+}
+
+// GMAX: query heads of the group this wave handles at most; it takes heads g0 .. g0 + gn - 1 of kv head hk's group (the stand-alone
+// kernel: all of them, GMAX = kMaxGroup; the persistent step splits a group over two waves).  Heads are independent of each
+// other, so the split does not change a single operation of any head.  The wave with g0 == 0 stores the new K / V row.
+template <bool WT, int GMAX>
+__device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
+                                                   AttnTileRegs& t, float* q_s, float* knew_s, float* vnew_s, const int g0, const int gn) {
   const int NS = p.n_splits;
   const int G = p.n_q / p.n_kv;
-  const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;     // batched decode: one position per sequence
-  if (pos < 0) return;                         // parked slot of a batched step: no cache write, no attention (its row is ignored)
+  const int pos = t.pos;
   const int ntiles = pos / kDTile + 1;
-  if (slot >= ntiles) return;                  // the combine only reads slots < min(ntiles, NS)
   const float* qkv = p.qkv + (size_t)seq * (p.n_q + 2 * p.n_kv) * kHeadDim;
   float* kcache = p.kc + (p.table ? 0 : (size_t)seq * p.seq_stride);
   float* vcache = p.vc + (p.table ? 0 : (size_t)seq * p.seq_stride);
@@ -84,33 +136,16 @@ __device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int 
   const bool owner = ((pos / kDTile) % NS) == slot;
   const float scale = 0.08838834764831845f * 1.4426950408889634f;    // 128^-1/2 * log2(e): the softmax runs on v_exp_f32 (exp2)
   const int key_l = lane >> 2, quarter = lane & 3;
-
-  // K and V of the first tile only depend on `pos`: issue them before the q prologue so that the cache rows,
-  // q, cos/sin all travel in the same memory round trip.
-  f32x4 kv[8];
+  f32x4 (&kv)[8] = t.kv;
   float2 vv[kDTile];
-  auto load_tile = [&](int tile) {
-    const int j0 = tile * kDTile;
-    const int j = j0 + key_l;
-    const int jc = j <= pos ? j : pos;          // clamped address (stays inside this tile: pos lies in it); masked below
-    const size_t toff = kv_tile_off(kvl, hk, j0);   // the tile's first row: one table lookup per tile when the cache is paged
-    const float* kr = kcache + toff + (size_t)(jc - j0) * kHeadDim + quarter * 4;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
-#pragma unroll
-    for (int u = 0; u < kDTile; ++u) {
-      const int ju = j0 + u <= pos ? j0 + u : pos;
-      vv[u] = *reinterpret_cast<const float2*>(vcache + toff + (size_t)(ju - j0) * kHeadDim + lane * 2);
-    }
-  };
-  load_tile(slot);
+  attn_load_v(kvl, vcache, hk, slot, pos, lane, vv);
 
   {
-    const float c = p.cos_tab[(size_t)pos * 64 + lane], s = p.sin_tab[(size_t)pos * 64 + lane];
+    const float c = t.c, s = t.s;
 #pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g) {
-      if (g < G) {
-        const float* src = qkv + (size_t)(hk * G + g) * kHeadDim;
+    for (int g = 0; g < GMAX; ++g) {
+      if (g < gn) {
+        const float* src = qkv + (size_t)(hk * G + g0 + g) * kHeadDim;
         float a = src[lane], b = src[lane + 64];
         norm_rope(a, b, p.q_norm_w, p.eps, c, s, lane);
         q_s[g * kHeadDim + lane] = a;
@@ -125,25 +160,26 @@ __device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int 
       knew_s[lane + 64] = b;
       const size_t noff = kv_tile_off(kvl, hk, pos);      // row of the new token
       float* kd = kcache + noff;
-      kd[lane] = a;
-      kd[lane + 64] = b;
+      if (g0 == 0) { kd[lane] = a; kd[lane + 64] = b; }
       const float* vs = qkv + (size_t)(p.n_q + p.n_kv + hk) * kHeadDim;
       const float va = vs[lane], vb = vs[lane + 64];
       vnew_s[lane] = va;
       vnew_s[lane + 64] = vb;
       float* vd = vcache + noff;
-      vd[lane] = va;
-      vd[lane + 64] = vb;
+      if (g0 == 0) { vd[lane] = va; vd[lane + 64] = vb; }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // single wave: orders the LDS writes above (in-order LDS, no barrier needed)
 
-  float m_run[kMaxGroup], l_run[kMaxGroup], acc0[kMaxGroup], acc1[kMaxGroup];
+  float m_run[GMAX], l_run[GMAX], acc0[GMAX], acc1[GMAX];
 #pragma unroll
-  for (int g = 0; g < kMaxGroup; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.f; acc0[g] = 0.f; acc1[g] = 0.f; }
+  for (int g = 0; g < GMAX; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.f; acc0[g] = 0.f; acc1[g] = 0.f; }
 
   for (int tile = slot; tile < ntiles; tile += NS) {
-    if (tile != slot) load_tile(tile);
+    if (tile != slot) {
+      attn_load_k(kvl, kcache, hk, tile, pos, lane, kv);
+      attn_load_v(kvl, vcache, hk, tile, pos, lane, vv);
+    }
     const int j0 = tile * kDTile;
     const int j = j0 + key_l;
     const int jc = j <= pos ? j : pos;
@@ -157,14 +193,14 @@ __device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int 
       for (int u = 0; u < kDTile; ++u)
         if (j0 + u >= pos) vv[u] = vn;
     }
-    float dot[kMaxGroup];
+    float dot[GMAX];
 #pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g) dot[g] = 0.f;
+    for (int g = 0; g < GMAX; ++g) dot[g] = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
-      for (int g = 0; g < kMaxGroup; ++g) {
-        if (g < G) {
+      for (int g = 0; g < GMAX; ++g) {
+        if (g < gn) {
           const f32x4 qv = *reinterpret_cast<const f32x4*>(q_s + g * kHeadDim + quarter * 4 + i * 16);
           dot[g] = fmaf(kv[i].x, qv.x, dot[g]);
           dot[g] = fmaf(kv[i].y, qv.y, dot[g]);
@@ -173,11 +209,11 @@ __device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int 
         }
       }
     }
-    float pr[kMaxGroup];
+    float pr[GMAX];
 #pragma unroll
-    for (int g = 0; g < kMaxGroup; ++g) {
+    for (int g = 0; g < GMAX; ++g) {
       pr[g] = 0.f;
-      if (g < G) {
+      if (g < gn) {
         float sc = dot[g];
         sc += lane_xor1(sc);
         sc += lane_xor2(sc);                    // all 4 lanes of a key now hold its score (DPP, no LDS round trip)
@@ -199,8 +235,8 @@ __device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int 
 #pragma unroll
     for (int u = 0; u < kDTile; ++u) {
 #pragma unroll
-      for (int g = 0; g < kMaxGroup; ++g) {
-        if (g < G) {
+      for (int g = 0; g < GMAX; ++g) {
+        if (g < gn) {
           const float pu = readlane_f(pr[g], u * 4);   // p of key u, wave-uniform (0 for masked keys)
           acc0[g] = fmaf(pu, vv[u].x, acc0[g]);
           acc1[g] = fmaf(pu, vv[u].y, acc1[g]);
@@ -209,9 +245,9 @@ __device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int 
     }
   }
 #pragma unroll
-  for (int g = 0; g < kMaxGroup; ++g) {
-    if (g < G) {
-      const size_t pi = ((size_t)seq * p.n_q + hk * G + g) * NS + slot;
+  for (int g = 0; g < GMAX; ++g) {
+    if (g < gn) {
+      const size_t pi = ((size_t)seq * p.n_q + hk * G + g0 + g) * NS + slot;
       const float mn = m_run[g] * 0.6931471805599453f;       // m back to nats for the combine
       if (WT) {
         wt_store2(p.part_o + pi * kHeadDim + lane * 2, acc0[g], acc1[g]);
@@ -224,6 +260,14 @@ __device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int 
   }
 }
 
+
+template <bool WT>
+__device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
+                                                 float* q_s, float* knew_s, float* vnew_s) {
+  AttnTileRegs t;
+  if (!attn_decode_preload(p, hk, slot, seq, lane, t)) return;
+  attn_decode_finish<WT, kMaxGroup>(p, hk, slot, seq, lane, t, q_s, knew_s, vnew_s, 0, p.n_q / p.n_kv);
+}
 
 // out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots).  One workgroup
 // (2 waves) per head; lane s of each wave holds (m_s, l_s), weights are broadcast by shuffle, and 16 independent
@@ -241,15 +285,15 @@ __device__ __forceinline__ void attn_combine_wave(const AttnParams& p, const int
   const float w = lane < ns ? expf(m - M) : 0.f;
   const float den = wave_sum(w * l);
   float num = 0.f;
-  for (int s0 = 0; s0 < ns; s0 += 16) {
-    float o[16];
+  for (int s0 = 0; s0 < ns; s0 += 32) {       // 32 independent loads in flight per lane: at most two dependent rounds for 64 slots
+    float o[32];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 32; ++u) {
       const int s = s0 + u < ns ? s0 + u : ns - 1;
       o[u] = p.part_o[(base + s) * kHeadDim + d];
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 32; ++u) {
       const float ws = __shfl(w, (s0 + u) & 63, 64);     // 0 for slots >= ns
       num = fmaf(ws, o[u], num);
     }

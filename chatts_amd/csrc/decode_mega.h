@@ -71,6 +71,10 @@ struct MegaParams {
   int n_layers, hidden, n_q, n_kv, max_ctx, n_splits, kv_log_block;
   int greedy_tail;          // 1: argmax + decode-loop state + next input embedding inside the launch
   int nwg, xs_bytes;
+  // optional profiling (chatts_decoder_mega_profile): s_memtime stamps of two workgroups, [2][n_phases][16] uint64:
+  //   0 phase start (master), 1 after A, 2 published + drained, 3 grid barrier passed, 4 after B, 5 after C (staged),
+  //   6 / 7 compute wave 0: first / last cycle of its block loop, 8..15: start of its first eight blocks
+  unsigned long long* prof;
 };
 
 size_t mega_state_bytes(int n_layers, int nwg);

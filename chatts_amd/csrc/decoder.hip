@@ -42,6 +42,7 @@ struct ChattsDecoder {
   bool mega_planned = false;
   void* mega_state = nullptr;
   int mega_n_splits = 0;
+  unsigned long long* mega_prof = nullptr;
 };
 
 static int64_t embed_rows(const ChattsDecoder* d) { return d->cfg.embed_rows > 0 ? d->cfg.embed_rows : d->cfg.vocab_local; }
@@ -683,6 +684,14 @@ extern "C" int chatts_decoder_mega_attach(ChattsDecoder* d, void* state, size_t 
   return CHATTS_OK;
 }
 
+extern "C" int chatts_decoder_mega_profile(ChattsDecoder* d, void* buf, size_t bytes) {
+  CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_mega_profile: null decoder");
+  const size_t need = ((size_t)2 * (6 * d->cfg.n_layers + 1) * 16 + (size_t)12 * 1024) * sizeof(unsigned long long);
+  CHATTS_REQUIRE(!buf || bytes >= need, CHATTS_E_WORKSPACE, "decoder_mega_profile: needs %zu bytes", need);
+  d->mega_prof = static_cast<unsigned long long*>(buf);
+  return CHATTS_OK;
+}
+
 extern "C" int chatts_decoder_mega_status(ChattsDecoder* d) {
   CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_mega_status: null decoder");
   if (!d->mega_state) return 0;
@@ -712,6 +721,7 @@ static int decode_step_mega(ChattsDecoder* d, int32_t* pos_dev, int32_t* step_de
   p.n_splits = d->mega_n_splits;
   p.greedy_tail = d->sampling ? 0 : 1;
   p.nwg = d->mega.nwg; p.xs_bytes = mega_lds_bytes(d->mega);
+  p.prof = d->mega_prof;
   int rc = mega_launch(p, d->mega, as_stream(stream));
   if (rc || !d->sampling) return rc;
   // sampling: the launch ends with the logits; selection and the next embedding are the ordinary kernels

@@ -514,6 +514,9 @@ int chatts_decoder_decode_step(ChattsDecoder*, int32_t* pos_dev, int32_t* step_d
 size_t chatts_decoder_mega_state_bytes(ChattsDecoder*);
 int chatts_decoder_mega_attach(ChattsDecoder*, void* state, size_t bytes, int n_splits);
 int chatts_decoder_mega_status(ChattsDecoder*);
+/* diagnostics: when buf != NULL ([2][6 * n_layers + 1][16] uint64 device memory) the following steps record s_memtime stamps of two
+ * workgroups at every phase edge (tools/mega_profile.py prints the breakdown); NULL switches it off again. */
+int chatts_decoder_mega_profile(ChattsDecoder*, void* buf, size_t bytes);
 
 #ifdef __cplusplus
 }
