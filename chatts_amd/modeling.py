@@ -413,10 +413,11 @@ class ChatTSForCausalLM:
         self._graph = None
         self._graph_batched = None
         # persistent decode step (csrc/decode_mega.hip): one launch per token instead of 6 per layer; available for TP = 1 on bf16
-        # weights (state bytes 0 otherwise); CHATTS_DECODE_MEGA=0 keeps the multi-kernel schedule
+        # weights.  OFF by default: bit-identical to the multi-kernel schedule but measured slower on MI355X (6.5 against 5.56 ms per
+        # ChatTS-14B token, profiles/r3_mega_*); CHATTS_DECODE_MEGA=1 or enable_persistent_decode() turns it on
         self._mega_state = None
         import os
-        if os.environ.get("CHATTS_DECODE_MEGA", "1") != "0":
+        if os.environ.get("CHATTS_DECODE_MEGA", "0") == "1":
             self.enable_persistent_decode(True)
         if plan.world > 1 and self.use_p2p and getattr(self.comm, "dist", None) is not None and self._tp is None:
             from .tp import P2PExchange

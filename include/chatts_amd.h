@@ -504,8 +504,9 @@ int chatts_decoder_decode_step(ChattsDecoder*, int32_t* pos_dev, int32_t* step_d
 /* Persistent decode step (csrc/decode_mega.hip): with a state buffer attached, chatts_decoder_decode_step runs a whole token -
  * every layer's projections, attention, lm_head, greedy token, decode-loop state, next input embedding - as ONE launch whose
  * weight stream never stops at a projection boundary (the replacement for the 291 dependent launches of the multi-kernel
- * schedule; bit-identical results).  Available for tensor_parallel_size 1, bf16 weights, cache slot 0; otherwise, or with
- * CHATTS_DECODE_MEGA=0 in the environment, decode_step keeps the multi-kernel schedule.
+ * schedule; bit-identical results; measured SLOWER than that schedule on MI355X - DESIGN.md section 5 - so callers attach it only on
+ * request).  Available for tensor_parallel_size 1, bf16 weights, cache slot 0; otherwise, or with CHATTS_DECODE_MEGA=0 in the
+ * environment, decode_step keeps the multi-kernel schedule.
  *   chatts_decoder_mega_state_bytes: device bytes the caller must provide (0 = this decoder cannot use it);
  *   chatts_decoder_mega_attach: binds the buffer (256-byte aligned) and uploads the layer table - a SET-UP call: it zero-fills
  *     and copies synchronously; n_splits = the key-slot count decode_step will be called with; state == NULL detaches;

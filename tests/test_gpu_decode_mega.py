@@ -45,7 +45,7 @@ def test_persistent_step_is_bit_identical_to_the_multi_kernel_schedule(preset, k
     ser = inputs["timeseries"].cuda()
     model = ChatTSForCausalLM.from_synthetic(cfg, seed=9, max_ctx=512, max_prefill_tokens=512, kv_block_size=kv_block,
                                              enable_prefix_caching=False)
-    assert model._mega_state is not None, "the persistent step should be available for a TP = 1 bf16 model"
+    assert model.enable_persistent_decode(True), "the persistent step should be available for a TP = 1 bf16 model"
     new = 12
     runs = {}
     for mega in (True, False):
@@ -91,15 +91,15 @@ def test_persistent_step_with_sampling_and_across_requests():
 
 def test_persistent_step_full_width_14b_4_layers():
     """ChatTS-14B widths (the shapes the plan is tuned for: 14 / 10 / 54 / 10 / 297 row-pair tasks per workgroup), 4 layers, the
-    bench prompt: bit-identical to the multi-kernel schedule, graph replay included; oracle parity of this very path is
-    tests/test_gpu_parity_real_size.py (the default decode path IS the persistent step)."""
+    bench prompt: bit-identical to the multi-kernel schedule, graph replay included; the multi-kernel schedule's oracle parity at this size is
+    tests/test_gpu_parity_real_size.py."""
     cfg = cfgmod.preset("chatts-14b", num_hidden_layers=4)
     proc, prompt, series, lengths = bench.build_inputs(cfg, 8, 256)
     inputs = proc(text=[prompt], timeseries=series, padding=True, return_tensors="pt")
     ids = inputs["input_ids"][0].tolist()
     ser = inputs["timeseries"].cuda()
     model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, max_ctx=2048, max_prefill_tokens=1024, enable_prefix_caching=False)
-    assert model._mega_state is not None
+    assert model.enable_persistent_decode(True)
     runs = {}
     for mega in (True, False):
         model.enable_persistent_decode(mega)

@@ -29,7 +29,7 @@ def main():
     ids = inputs["input_ids"][0].tolist()
     ser = inputs["timeseries"].cuda()
     model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, max_ctx=2048, max_prefill_tokens=1024, enable_prefix_caching=False)
-    res = {"model": args.model, "layers": cfg.num_hidden_layers, "attached": model._mega_state is not None}
+    res = {"model": args.model, "layers": cfg.num_hidden_layers, "available": bool(model.enable_persistent_decode(True))}
     out = {}
     for mega in (True, False):
         model.enable_persistent_decode(mega)

@@ -27,6 +27,7 @@ def main():
     ids = inputs["input_ids"][0].tolist()
     model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, max_ctx=2048, max_prefill_tokens=1024, enable_prefix_caching=False)
     model.use_graph = False
+    assert model.enable_persistent_decode(True), "persistent decode step not available for this model"
     model.generate_one(ids, inputs["timeseries"].cuda(), proc.last_lengths, 4, eos_token_id=None)
     L = cfg.num_hidden_layers
     n_ph = 6 * L + 1
