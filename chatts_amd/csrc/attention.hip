@@ -2,7 +2,7 @@
 // Math per transformers eager_attention_forward (oracle/qwen_decoder.py): scores = q.k^T * d^-1/2,
 // float32 softmax, out = P.V; GQA: the n_q/n_kv query heads of a group share one K/V head (repeat_kv).
 //
-// Two kernels:
+// Kernels:
 //  * attn_decode_kernel (T = 1, the per-token path): ONE WAVE per (kv head, 16-key tile).  A wave has no
 //    barriers to wait for, issues all of its K (8 x 16 B) and V (16 x 8 B) loads at once and finishes in about
 //    one memory round trip; hundreds of such waves spread the cache read over all CUs.  It also fuses what
@@ -10,8 +10,9 @@
 //    the new K/V row into the cache (done by the single wave whose tile contains `pos`, which then uses the row
 //    from LDS).  Softmax statistics are wave shuffles; P is broadcast lane->wave with v_readlane.
 //    Each wave emits an (m, l, o[G][128]) partial; attn_decode_combine_kernel merges the partials of a head.
-//  * attn_rows_kernel (prefill, T > 1): one workgroup per (kv head, query row), 64-key tiles, online softmax,
-//    float32 VALU.  Correct and simple; an MFMA flash kernel is the planned replacement.
+//  * attn_rows_kernel (short prefill chunks, T < 16, and the last-row path): one workgroup per (kv head, query row), 64-key
+//    tiles, online softmax, float32 VALU.  Longer chunks run the flash kernels further down: attn_prefill_bf16x3_kernel (bf16
+//    matrix pipe on hi / lo planes, the default) and attn_prefill_mfma_kernel (exact-f32 MFMA).
 // The KV cache is float32 on purpose: the parity target is the float32 reference path and the cache
 // is ~1% of decode traffic at the benchmark context.
 #include <math.h>
