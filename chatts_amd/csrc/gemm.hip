@@ -146,6 +146,73 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, const f32x4 (&ac
     }
 }
 
+// The same epilogue for accumulators of the 32x32 MFMA (gemm_dma_kernel<.., W32 = true>): FM x FN blocks of 32 x 32, 16 values per
+// lane; C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  A SwiGLU pair (gate rows 32q .. 32q+15, up
+// rows 32q+16 .. 32q+31 of W) lies inside ONE block: lane c < 16 holds the gate, lane c + 16 the up value of unit c.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int FM, int FN, int TM, int TN>
+__device__ __forceinline__ void gemm_store32(const GemmParams& p, const f32x16 (&acc)[FM][FN], int m0, int n0, int wm, int wn,
+                                             int lane, int split) {
+  const int ccol = lane & 31, rbase = 4 * (lane >> 5);
+  if (!p.direct) {
+    float* ws = p.c + (size_t)split * p.m * p.n;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wn * TN + j * 32 + ccol;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+          if (row < p.m && col < p.n) ws[(size_t)row * p.n + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  if (p.epilogue == CHATTS_EPI_SWIGLU) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int unit = ccol & 15;
+        const int prow = n0 + wn * TN + j * 32 + unit;   // packed gate row; up row = prow + 16
+        const int ocol = (prow >> 5) * 16 + unit;
+        const bool live = ccol < 16 && prow + 16 < p.n;
+        const float bg = (live && p.bias) ? p.bias[prow] : 0.f, bu = (live && p.bias) ? p.bias[prow + 16] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float g = acc[i][j][r];
+          const float u = __shfl_xor(g, 16, 64);            // every lane takes part: lane c < 16 receives the up value of its unit
+          const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+          if (live && row < p.m) {
+            const float v = silu_g(g + bg) * (u + bu);
+            if (p.c_hi) store_planes(p.c_hi, p.c_lo, (size_t)row * p.ldcp + ocol, v);
+            else p.c[(size_t)row * p.ldc + ocol] = v;
+          }
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * TN + j * 32 + ccol;
+      if (col >= p.n) continue;
+      const float b = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        if (row >= p.m) continue;
+        float v = acc[i][j][r] + b;
+        if (p.epilogue == CHATTS_EPI_GELU) v = gelu_erf_f(v);
+        if (p.epilogue == CHATTS_EPI_RESID) v = p.resid[(size_t)row * p.ldc + col] + v;
+        if (p.c_hi) store_planes(p.c_hi, p.c_lo, (size_t)row * p.ldcp + col, v);
+        else p.c[(size_t)row * p.ldc + col] = v;
+      }
+    }
+}
+
 // W8: W is streamed from its fp8 copy (compile-time switch: a runtime branch in the K-loop cost 18 % on the bf16 path)
 template <int BM, int WM, int WN, bool W8>
 __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
@@ -337,11 +404,19 @@ constexpr int kDmaBN = 256, kDmaBK = 64, kDmaLds = 2 * (2 * 128 * 128 + kDmaBN *
 // neither read nor multiplied - activations rounded to bf16, one MFMA pass, half the matrix work; logits then sit at ~1e-2 of
 // the float32 oracle instead of 5e-5, so this is never the parity-grade / headline path.  SINGLE = false is the kernel as it was
 // (same instruction stream: the flag only removes code).
-template <bool SINGLE>
-__global__ __launch_bounds__(kDmaThreads) void gemm_dma_kernel(GemmParams p, const uint16_t* __restrict__ a_hi,
-                                                               const uint16_t* __restrict__ a_lo, int ldp) {
-  constexpr int BM = 128, BN = kDmaBN, BK = kDmaBK, WN = 4, NCOMPUTE = 8, NLOAD = 4;
-  constexpr int TM = 64, TN = 64, FM = 4, FN = 4;
+//
+// W32 (round 3, opt-in - measured slower, see launch_dma): FOUR compute waves, one per SIMD, as 2 x 2 with 64 x 128 wave tiles on v_mfma_f32_32x32x16_bf16.  The speed-mode
+// measurement of round 2 (half the MFMAs: -7 %) had shown the K loop to be paced by LDS operand delivery, not by the matrix pipe:
+// eight waves x 24 ds_read_b128 = 192 KB of fragment reads per K-step next to the 64 KB of DMA writes.  A wave tile twice as wide
+// reads A 8 + 8 and W 16 fragments for 64 MFMAs of twice the size: 128 KB per K-step and workgroup for the same matrix work (2048
+// MFMA cycles per SIMD and K-step either way); accumulators 2 x 4 x 16 = 128 registers per wave, fragments double-buffered per
+// 16-deep K sub-step.  Loader waves, LDS layout and swizzle are unchanged - the swizzle is conflict-free for the 32-row fragment
+// reads as well (a 16-lane group of ds_read_b128 covers row pairs with all eight values of (r >> 1) & 7, in both K chunks).
+template <bool SINGLE, bool W32>
+__global__ __launch_bounds__(W32 ? 512 : kDmaThreads) void gemm_dma_kernel(GemmParams p, const uint16_t* __restrict__ a_hi,
+                                                                           const uint16_t* __restrict__ a_lo, int ldp) {
+  constexpr int BM = 128, BN = kDmaBN, BK = kDmaBK, WN = W32 ? 2 : 4, NCOMPUTE = W32 ? 4 : 8, NLOAD = 4;
+  constexpr int TM = 64, TN = W32 ? 128 : 64, FM = 4, FN = 4;
   constexpr int A_PLANE = BM * 128, STAGE = 2 * A_PLANE + BN * 128;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -464,6 +539,71 @@ __global__ __launch_bounds__(kDmaThreads) void gemm_dma_kernel(GemmParams p, con
 
   // ---- compute wave
   const int wm = wave / WN, wn = wave % WN;
+  if constexpr (W32) {
+    constexpr int GM = 2, GN = 4;                 // 32 x 32 blocks of the 64 x 128 wave tile
+    f32x16 acc[GM][GN];
+#pragma unroll
+    for (int i = 0; i < GM; ++i)
+#pragma unroll
+      for (int j = 0; j < GN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // ragged last M-tile: 32-row blocks of this wave wholly past M are neither read nor multiplied
+    const int rows_left = p.m - (m0 + wm * TM);
+    const int gm_live = rows_left <= 0 ? 0 : (rows_left > 32 ? 2 : 1);
+    if (gm_live == 0) {
+      for (int kt = 0; kt < nk; ++kt) __builtin_amdgcn_s_barrier();    // nk barriers, like the live waves
+      return;
+    }
+    const int frow = lane & 31, fhalf = lane >> 5;                      // fragment row (A) / column (W), 8-wide K chunk of the 16
+    auto k_loop32 = [&](auto gml_c) {
+      constexpr int GML = decltype(gml_c)::value;
+      bf16x8_t bfrag[2][GN], alo[2][GML], ahi[2][GML];
+      auto read_sub = [&](int kt, int sub, int buf) {                   // fragments of K sub-step `sub` (16 deep) of stage kt
+        const char* base = smem + (kt & 1) * STAGE;
+        const int chunk = sub * 2 + fhalf;
+#pragma unroll
+        for (int j = 0; j < GN; ++j)
+          bfrag[buf][j] = *reinterpret_cast<const bf16x8_t*>(base + 2 * A_PLANE + lds_off128(wn * TN + j * 32 + frow, chunk));
+#pragma unroll
+        for (int i = 0; i < GML; ++i) {
+          if constexpr (!SINGLE) alo[buf][i] = *reinterpret_cast<const bf16x8_t*>(base + A_PLANE + lds_off128(wm * TM + i * 32 + frow, chunk));
+          ahi[buf][i] = *reinterpret_cast<const bf16x8_t*>(base + lds_off128(wm * TM + i * 32 + frow, chunk));
+        }
+      };
+      auto sweep = [&](const bf16x8_t (&af)[GML], const bf16x8_t (&bf)[GN]) {
+#pragma unroll
+        for (int i = 0; i < GML; ++i)
+#pragma unroll
+          for (int j = 0; j < GN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      };
+      __builtin_amdgcn_s_barrier();                // stage 0 published
+      read_sub(0, 0, 0);
+      auto step = [&](int kt, bool more) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int cur = sub & 1, nxt = cur ^ 1;
+          __builtin_amdgcn_sched_barrier(0);
+          if (sub < 3) {
+            read_sub(kt, sub + 1, nxt);            // the next sub-step's fragments land under this one's MFMAs
+          } else if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of slot kt has returned
+            __builtin_amdgcn_s_barrier();          // stage kt + 1 is published; the loaders refill slot kt behind this
+            read_sub(kt + 1, 0, nxt);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!SINGLE) sweep(alo[cur], bfrag[cur]);
+          sweep(ahi[cur], bfrag[cur]);
+        }
+      };
+      for (int kt = 0; kt + 1 < nk; ++kt) step(kt, true);
+      step(nk - 1, false);
+    };
+    if (gm_live == 1) k_loop32(std::integral_constant<int, 1>{});
+    else k_loop32(std::integral_constant<int, 2>{});
+    gemm_store32<GM, GN, TM, TN>(p, acc, m0, n0, wm, wn, lane, slab);
+    return;
+  }
   f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -976,23 +1116,30 @@ static bool dma_single_pass() {
   return v && strcmp(v, "bf16") == 0;
 }
 
-template <bool SINGLE>
+template <bool SINGLE, bool W32>
 static int launch_dma_t(const GemmParams& p, const ChattsLinearArgs* a, int sk, hipStream_t s) {
   static bool configured = false;     // > 64 KB of dynamic LDS must be opted into once
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<SINGLE>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<SINGLE, W32>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds);
     CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "gemm_dma: cannot reserve %d bytes of LDS: %s", kDmaLds, hipGetErrorString(e));
     configured = true;
   }
   const int tiles = ((a->n + kDmaBN - 1) / kDmaBN) * ((a->m + 127) / 128);
-  dim3 grid(p.sk_T > 0 ? 8 * 64 : 8 * ((tiles + 7) / 8), 1, p.sk_T > 0 ? 1 : sk), block(kDmaThreads);
-  hipLaunchKernelGGL(gemm_dma_kernel<SINGLE>, grid, block, kDmaLds, s, p, a->a_hi, a->a_lo, a->ld_planes);
+  dim3 grid(p.sk_T > 0 ? 8 * 64 : 8 * ((tiles + 7) / 8), 1, p.sk_T > 0 ? 1 : sk), block(W32 ? 512 : kDmaThreads);
+  hipLaunchKernelGGL((gemm_dma_kernel<SINGLE, W32>), grid, block, kDmaLds, s, p, a->a_hi, a->a_lo, a->ld_planes);
   return CHATTS_OK;
 }
 
+// CHATTS_GEMM_DMA32=1: the 4 x (64 x 128) compute waves on the 32x32x16 MFMA instead of the 8 x (64 x 64) ones on 16x16x32.
+// MEASURED (round 3, profiles/r3_gemm_dma32_sweep.txt, M = 798): correct (every GEMM test passes with it) and a third fewer LDS
+// fragment bytes per K-step, but SLOWER - gate_up 537 against 363 us, down 272 / 212, qkv 168 / 112: with ONE compute wave per SIMD
+// every s_waitcnt and every barrier idles that SIMD's matrix pipe (two co-resident waves cover each other's stalls), which costs
+// more than the LDS traffic it saves.  Hence OFF by default; kept for the tests and as the starting point of a hand-scheduled version.
 static int launch_dma(const GemmParams& p, const ChattsLinearArgs* a, int sk, hipStream_t s) {
-  return dma_single_pass() ? launch_dma_t<true>(p, a, sk, s) : launch_dma_t<false>(p, a, sk, s);
+  const bool w32 = gemm_env_int("CHATTS_GEMM_DMA32", 0) != 0;
+  if (dma_single_pass()) return w32 ? launch_dma_t<true, true>(p, a, sk, s) : launch_dma_t<true, false>(p, a, sk, s);
+  return w32 ? launch_dma_t<false, true>(p, a, sk, s) : launch_dma_t<false, false>(p, a, sk, s);
 }
 
 int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {

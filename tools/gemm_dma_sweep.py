@@ -70,7 +70,9 @@ for name, (n, k, epi) in SHAPES.items():
     ref = out.clone()
     t_ref = timed(lambda: [run(False, w) for w in ws]) / len(ws)
     print(f"   {t_ref:8.1f} us  {2.0 * M * n * k / t_ref / 1e6:6.0f} TF  register-staged (split {t_split:.1f} us)")
-    envs = [{}, {"CHATTS_GEMM_SK": 1}, {"CHATTS_GEMM_SK": 2}, {"CHATTS_GEMM_SK": 3}, {"CHATTS_GEMM_SK": 4}]
+    envs = [{"CHATTS_GEMM_DMA32": 0}, {"CHATTS_GEMM_DMA32": 1}, {"CHATTS_GEMM_DMA32": 1, "CHATTS_GEMM_SK": 1},
+            {"CHATTS_GEMM_DMA32": 1, "CHATTS_GEMM_SK": 2}, {"CHATTS_GEMM_DMA32": 1, "CHATTS_GEMM_SK": 3},
+            {"CHATTS_GEMM_DMA32": 0, "CHATTS_GEMM_SK": 1}, {"CHATTS_GEMM_DMA32": 0, "CHATTS_GEMM_SK": 2}]
     for env in envs:
         setenv(env)
         out.zero_()
