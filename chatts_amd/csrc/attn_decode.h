@@ -122,7 +122,7 @@ __device__ __forceinline__ bool attn_decode_preload(const AttnParams& p, const i
 // GMAX: query heads of the group this wave handles at most; it takes heads g0 .. g0 + gn - 1 of kv head hk's group (the stand-alone
 // kernel: all of them, GMAX = kMaxGroup; the persistent step splits a group over two waves).  Heads are independent of each
 // other, so the split does not change a single operation of any head.  The wave with g0 == 0 stores the new K / V row.
-template <bool WT, int GMAX>
+template <bool WT, int GMAX, bool PF>
 __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
                                                    AttnTileRegs& t, float* q_s, float* knew_s, float* vnew_s, const int g0, const int gn) {
   const int NS = p.n_splits;
@@ -175,23 +175,20 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
 #pragma unroll
   for (int g = 0; g < GMAX; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.f; acc0[g] = 0.f; acc1[g] = 0.f; }
 
-  for (int tile = slot; tile < ntiles; tile += NS) {
-    if (tile != slot) {
-      attn_load_k(kvl, kcache, hk, tile, pos, lane, kv);
-      attn_load_v(kvl, vcache, hk, tile, pos, lane, vv);
-    }
+  // one 16-key tile: scores, online softmax, P.V - on the K / V rows held in (kvb, vvb)
+  auto tile_body = [&](const int tile, f32x4 (&kvb)[8], float2 (&vvb)[kDTile]) __attribute__((always_inline)) {
     const int j0 = tile * kDTile;
     const int j = j0 + key_l;
     const int jc = j <= pos ? j : pos;
     if (owner && jc == pos) {                   // the row just produced is not in the cache for this wave yet
 #pragma unroll
-      for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(knew_s + quarter * 4 + i * 16);
+      for (int i = 0; i < 8; ++i) kvb[i] = *reinterpret_cast<const f32x4*>(knew_s + quarter * 4 + i * 16);
     }
     if (owner) {
       const float2 vn = *reinterpret_cast<const float2*>(vnew_s + lane * 2);
 #pragma unroll
       for (int u = 0; u < kDTile; ++u)
-        if (j0 + u >= pos) vv[u] = vn;
+        if (j0 + u >= pos) vvb[u] = vn;
     }
     float dot[GMAX];
 #pragma unroll
@@ -202,10 +199,10 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
       for (int g = 0; g < GMAX; ++g) {
         if (g < gn) {
           const f32x4 qv = *reinterpret_cast<const f32x4*>(q_s + g * kHeadDim + quarter * 4 + i * 16);
-          dot[g] = fmaf(kv[i].x, qv.x, dot[g]);
-          dot[g] = fmaf(kv[i].y, qv.y, dot[g]);
-          dot[g] = fmaf(kv[i].z, qv.z, dot[g]);
-          dot[g] = fmaf(kv[i].w, qv.w, dot[g]);
+          dot[g] = fmaf(kvb[i].x, qv.x, dot[g]);
+          dot[g] = fmaf(kvb[i].y, qv.y, dot[g]);
+          dot[g] = fmaf(kvb[i].z, qv.z, dot[g]);
+          dot[g] = fmaf(kvb[i].w, qv.w, dot[g]);
         }
       }
     }
@@ -238,10 +235,38 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
       for (int g = 0; g < GMAX; ++g) {
         if (g < gn) {
           const float pu = readlane_f(pr[g], u * 4);   // p of key u, wave-uniform (0 for masked keys)
-          acc0[g] = fmaf(pu, vv[u].x, acc0[g]);
-          acc1[g] = fmaf(pu, vv[u].y, acc1[g]);
+          acc0[g] = fmaf(pu, vvb[u].x, acc0[g]);
+          acc1[g] = fmaf(pu, vvb[u].y, acc1[g]);
         }
       }
+    }
+  };
+  if constexpr (PF) {
+    // a slot that walks several tiles (long contexts, batched decode with few slots per sequence) fetches tile t + NS while it
+    // works on tile t: two register sets in ping-pong, one memory round trip per PAIR of steps instead of one per tile
+    f32x4 kv2[8];
+    float2 vv2[kDTile];
+    int tile = slot;
+    while (true) {
+      const int n1 = tile + NS;
+      const bool h1 = n1 < ntiles;
+      if (h1) { attn_load_k(kvl, kcache, hk, n1, pos, lane, kv2); attn_load_v(kvl, vcache, hk, n1, pos, lane, vv2); }
+      tile_body(tile, kv, vv);
+      if (!h1) break;
+      const int n2 = n1 + NS;
+      const bool h2 = n2 < ntiles;
+      if (h2) { attn_load_k(kvl, kcache, hk, n2, pos, lane, kv); attn_load_v(kvl, vcache, hk, n2, pos, lane, vv); }
+      tile_body(n1, kv2, vv2);
+      if (!h2) break;
+      tile = n2;
+    }
+  } else {
+    for (int tile = slot; tile < ntiles; tile += NS) {
+      if (tile != slot) {
+        attn_load_k(kvl, kcache, hk, tile, pos, lane, kv);
+        attn_load_v(kvl, vcache, hk, tile, pos, lane, vv);
+      }
+      tile_body(tile, kv, vv);
     }
   }
 #pragma unroll
@@ -266,7 +291,7 @@ __device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int 
                                                  float* q_s, float* knew_s, float* vnew_s) {
   AttnTileRegs t;
   if (!attn_decode_preload(p, hk, slot, seq, lane, t)) return;
-  attn_decode_finish<WT, kMaxGroup>(p, hk, slot, seq, lane, t, q_s, knew_s, vnew_s, 0, p.n_q / p.n_kv);
+  attn_decode_finish<WT, kMaxGroup, true>(p, hk, slot, seq, lane, t, q_s, knew_s, vnew_s, 0, p.n_q / p.n_kv);
 }
 
 // out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots).  One workgroup

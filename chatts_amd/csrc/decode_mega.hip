@@ -505,7 +505,7 @@ __device__ __forceinline__ void helper_main(const MegaParams& p, const int b, co
     const int sub = i & 1, hs = i >> 1;
     const int g0 = sub ? gsplit : 0, gn = sub ? G - gsplit : gsplit;
     if (gn > 0)
-      attn_decode_finish<true, (kMaxGroup + 1) / 2>(ap, hs % p.n_kv, hs / p.n_kv, 0, lane, t, scratch, scratch + kMaxGroup * kHeadDim,
+      attn_decode_finish<true, (kMaxGroup + 1) / 2, false>(ap, hs % p.n_kv, hs / p.n_kv, 0, lane, t, scratch, scratch + kMaxGroup * kHeadDim,
                                                     scratch + kMaxGroup * kHeadDim + kHeadDim, g0, gn);
   };
   for (int layer = 0; layer < L; ++layer) {

@@ -813,10 +813,15 @@ class ChatTSForCausalLM:
 
     def _n_splits_batched(self):
         """16-key slots per sequence of the batched decode attention: with many sequences in flight the grid is full anyway and
-        fewer, longer slots save partials traffic (B = 16: 64 -> 8 slots, 7.10 -> 6.91 ms per step)."""
+        fewer, longer slots save partials traffic (round 2, B = 16 at ctx 0.8k: 64 -> 8 slots, 7.10 -> 6.91 ms per step; round 3, with
+        the next tile prefetched under the current one and ctx 1.2k: 16 slots, profiles/r3_cfg5_nsplits_sweep.txt)."""
+        import os
+        forced = int(os.environ.get("CHATTS_BATCH_NSPLITS", "0") or 0)          # tuning only
+        if forced > 0:
+            return max(1, min(self.n_splits, forced))
         if self.max_batch <= 4:
             return self.n_splits
-        return max(1, min(self.n_splits, max(8, 128 // self.max_batch)))
+        return max(1, min(self.n_splits, max(16, 256 // self.max_batch)))      # (B = 16 at ctx 1.2k: 8 -> 16 slots, 7.83 -> 7.01 ms per step)
 
     def _batched_step_eager(self):
         B = self.buf
