@@ -698,17 +698,19 @@ constexpr int stream_stage(bool w8, int mb = 1) { return 2 * mb * 16 * stream_bk
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  else static_assert(N == 0, "add the vmcnt literal");
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Wait until at most min(later, CAP) x PIECES of this wave's loads are outstanding (later = stages issued after the one about to be read).
+template <int PIECES, int CAP>
+__device__ __forceinline__ void wait_stages(int later) {
+  if constexpr (CAP >= 1) {
+    if (later >= CAP) { wait_vmcnt<PIECES * CAP>(); return; }
+    wait_stages<PIECES, CAP - 1>(later);
+  } else {
+    wait_vmcnt<0>();
+  }
 }
 
 // W8: W is the fp8 (e4m3fn) copy: a 128-byte line of a row holds 128 K-values, so a stage is 128 deep; the 8-byte B fragments
@@ -719,16 +721,23 @@ __device__ __forceinline__ void wait_vmcnt() {
 // partials and 8 K-steps per workgroup, mostly pipeline fill (33.7 us per TS layer at P = 128, profiles/r2_ts_gemm_sweep.txt).
 // Here the tile is (16 MB) x 128: 40 N-tiles x ~6 K-splits = one workgroup per CU, W streamed in whole lines exactly once per
 // split, the MB A blocks of a K-step (MB x 4 KB) staged next to the W tile (16 KB), 8 MB MFMAs per wave and K-step.
-template <int NSTAGE, bool W8, int MB>
-__global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const uint16_t* __restrict__ a_hi,
-                                                          const uint16_t* __restrict__ a_lo, int ldp) {
+// NW = waves per workgroup.  4: each wave owns 32 columns (two B fragments).  8 [fp8 W]: each owns 16 - the per-stage chain of a
+// wave (LDS reads -> fp8 widening -> MFMAs) is what paces a workgroup when it is alone on its CU (a deeper ring changes nothing,
+// profiles/r3_stream_sweep_fp8.txt), and two waves per SIMD overlap their chains.  Every output column still sees its K-steps in
+// the same order with the same operands: bit-identical to NW = 4.
+template <int NSTAGE, bool W8, int MB, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_stream_kernel(GemmParams p, const uint16_t* __restrict__ a_hi,
+                                                              const uint16_t* __restrict__ a_lo, int ldp) {
   static_assert(!W8 || MB == 1, "the fp8 weight stream is a batched-decode format (M <= 16)");
+  static_assert(NW == 4 || (NW == 8 && W8), "8 waves: fp8 W only (8 A pieces per stage, one per wave)");
   constexpr int BN = kStreamBN, BK = stream_bk(W8), STAGE = stream_stage(W8, MB);
   constexpr int A_SUB = 16 * 128;                  // one A sub-block: 16 token rows x 64 K-values (128 B)
   constexpr int NSUB = BK / 64;                    // K sub-blocks per plane and stage (2 for fp8 W)
   constexpr int A_PLANE = MB * NSUB * A_SUB, W_OFF = 2 * A_PLANE;
-  constexpr int NAP = W8 ? NSUB : MB;              // A pieces per wave and stage
-  constexpr int NPIECE = 4 + NAP;                  // DMA pieces per wave and stage
+  constexpr int NWP = 16 / NW;                     // W pieces per wave and stage
+  constexpr int NAP = NW == 8 ? 1 : (W8 ? NSUB : MB);   // A pieces per wave and stage
+  constexpr int NPIECE = NWP + NAP;                // DMA pieces per wave and stage
+  constexpr int FN = 8 / NW;                       // 16-column B fragments per wave
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -738,24 +747,26 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const ui
   if (kend > p.k) kend = p.k;
   const int nk = (kend - kbeg) / BK;
 
-  // 1 KB DMA pieces (8 rows x 128 B): W pieces {wave, wave+4, wave+8, wave+12}; of the A pieces (plane, block / K sub-block,
-  // token-row half) this wave takes row half wave & 1 of plane wave >> 1 of EVERY block [bf16 W], or of both planes for K
-  // sub-block wave >> 1 [fp8 W, MB = 1].  Every piece index this wave touches has parity wave & 1.
+  // 1 KB DMA pieces (8 rows x 128 B): W pieces {wave + NW h}; of the A pieces (plane, block / K sub-block, token-row half) this
+  // wave takes row half wave & 1 of plane wave >> 1 of EVERY block [bf16 W], or of both planes for K sub-block wave >> 1 [fp8 W,
+  // 4 waves], or the one piece (plane wave >> 2, sub-block (wave >> 1) & 1) [fp8 W, 8 waves].  Every piece index this wave
+  // touches has parity wave & 1.
   const int lrow = lane >> 3;
   const int lchunk = (lane & 7) ^ (((wave & 1) << 2) | (lrow >> 1));
-  const char* wsrc[4];
+  const char* wsrc[NWP];
   const uint16_t* asrc[NAP];
   int adst[NAP];
 #pragma unroll
-  for (int h = 0; h < 4; ++h) {
-    int wr = n0 + (wave + 4 * h) * 8 + lrow;
+  for (int h = 0; h < NWP; ++h) {
+    int wr = n0 + (wave + NW * h) * 8 + lrow;
     if (wr > p.n - 1) wr = p.n - 1;
     wsrc[h] = W8 ? reinterpret_cast<const char*>(p.w8) + (size_t)wr * p.ldw8 + kbeg + lchunk * 16
                  : reinterpret_cast<const char*>(p.w + (size_t)wr * p.ldw + kbeg + lchunk * 8);
   }
 #pragma unroll
   for (int q = 0; q < NAP; ++q) {
-    const int plane = W8 ? q : (wave >> 1), sub = W8 ? (wave >> 1) : 0, blk = W8 ? 0 : q;
+    const int plane = NW == 8 ? (wave >> 2) : (W8 ? q : (wave >> 1));
+    const int sub = NW == 8 ? ((wave >> 1) & 1) : (W8 ? (wave >> 1) : 0), blk = W8 ? 0 : q;
     int am = blk * 16 + (wave & 1) * 8 + lrow;
     if (am > p.m - 1) am = p.m - 1;
     asrc[q] = (plane ? a_lo : a_hi) + (size_t)am * ldp + kbeg + sub * 64 + lchunk * 8;
@@ -764,17 +775,19 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const ui
   auto issue = [&](int kt) {
     char* base = smem + (kt % NSTAGE) * STAGE;
 #pragma unroll
-    for (int h = 0; h < 4; ++h)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[h] + (size_t)kt * 128), (lptr_t)(base + W_OFF + (wave + 4 * h) * 1024), 16, 0,
+    for (int h = 0; h < NWP; ++h)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[h] + (size_t)kt * 128), (lptr_t)(base + W_OFF + (wave + NW * h) * 1024), 16, 0,
                                        2 /* nt: streamed once */);
 #pragma unroll
     for (int q = 0; q < NAP; ++q)
       __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + (size_t)kt * BK), (lptr_t)(base + adst[q]), 16, 0, 0);
   };
 
-  f32x4 acc[MB][2];
+  f32x4 acc[MB][FN];
 #pragma unroll
-  for (int b = 0; b < MB; ++b) { acc[b][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[b][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s);
@@ -782,20 +795,17 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const ui
   const int frow = lane & 15, fchunk = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int later = nk - 1 - kt;               // stages issued after kt that may still be in flight
-    if (NSTAGE >= 4 && later >= NSTAGE - 2) wait_vmcnt<NPIECE * (NSTAGE - 2)>();
-    else if (NSTAGE >= 5 && later == 2) wait_vmcnt<2 * NPIECE>();
-    else if (later >= 1) wait_vmcnt<NPIECE>();
-    else wait_vmcnt<0>();
+    wait_stages<NPIECE, NSTAGE - 2>(later);
     __builtin_amdgcn_s_barrier();
     if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);
     const char* base = smem + (kt % NSTAGE) * STAGE;
     constexpr int NH = BK / 32;                  // MFMA K-steps per stage
-    bf16x8_t bfrag[NH][2];
+    bf16x8_t bfrag[NH][FN];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int r = wave * 32 + j * 16 + frow;
+      for (int j = 0; j < FN; ++j) {
+        const int r = wave * (16 * FN) + j * 16 + frow;
         if (W8) {   // 8 fp8 = 8 bytes at byte 32 h + 8 q of the row: 16-byte chunk 2 h + (q >> 1), half q & 1
           const u32x2 q8 = *reinterpret_cast<const u32x2*>(base + W_OFF + lds_off128(r, 2 * h + (fchunk >> 1)) + (fchunk & 1) * 8);
           typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -822,13 +832,30 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p, const ui
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[h], bfrag[h][j], acc[b][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[h], bfrag[h][j], acc[b][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[h], bfrag[h][j], acc[b][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[h], bfrag[h][j], acc[b][j], 0, 0, 0);
       }
     }
   }
-  gemm_store<MB, 2, 16 * MB, 32, W8>(p, acc, 0, n0, 0, wave, lane, blockIdx.z);
+  if constexpr (FN == 1) {
+    if (p.direct && p.epilogue == CHATTS_EPI_SWIGLU) {
+      // a (gate, up) pair of 16-column fragments sits in waves (2 q, 2 q + 1): the odd wave hands its accumulator over through LDS
+      // and the even one runs the two-fragment epilogue
+      __syncthreads();                           // every wave is done reading the last stage
+      f32x4* xch = reinterpret_cast<f32x4*>(smem);
+      if (wave & 1) xch[(wave >> 1) * 64 + lane] = acc[0][0];
+      __syncthreads();
+      if (!(wave & 1)) {
+        f32x4 pair[1][2] = {{acc[0][0], xch[(wave >> 1) * 64 + lane]}};
+        gemm_store<1, 2, 16, 32, W8>(p, pair, 0, n0, 0, wave >> 1, lane, blockIdx.z);
+      }
+      return;
+    }
+    gemm_store<MB, 1, 16 * MB, 16, W8>(p, acc, 0, n0, 0, wave, lane, blockIdx.z);
+  } else {
+    gemm_store<MB, 2, 16 * MB, 32, W8>(p, acc, 0, n0, 0, wave, lane, blockIdx.z);
+  }
 }
 
 // x = hi + lo (to 16 mantissa bits): one thread per 8 consecutive elements.
@@ -1040,6 +1067,9 @@ static int pick_stream_sk(int n, int k, bool w8) {
   // partials round trip and the epilogue launch
   const int cus = device_cus();
   int sk = 4 * tiles >= 3 * cus ? 1 : (cus + tiles / 2) / tiles;
+  // fp8 W: a workgroup's 4 x 24 KB ring leaves room for ONE per CU, so a grid beyond the CU count runs a second, nearly empty round
+  // (qkv, 56 tiles: 5 splits = 280 workgroups 19.3 us, 4 = 224 workgroups 13.9 us - profiles/r3_stream_sweep_fp8.txt)
+  if (w8 && sk > 1 && tiles * sk > cus) sk = cus / tiles;
   if (sk > nk / 4) sk = nk / 4;
   if (sk < 1) sk = 1;
   const int force_sk = gemm_env_int("CHATTS_GEMM_SK", 0);
@@ -1047,18 +1077,18 @@ static int pick_stream_sk(int n, int k, bool w8) {
   return sk;
 }
 
-template <int NSTAGE, bool W8, int MB = 1>
+template <int NSTAGE, bool W8, int MB = 1, int NW = 4>
 static int launch_stream_t(const GemmParams& p, const ChattsLinearArgs* a, int sk, hipStream_t s) {
   constexpr int LDS = NSTAGE * stream_stage(W8, MB);
   static bool configured = false;
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NSTAGE, W8, MB>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NSTAGE, W8, MB, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "gemm_stream: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
     configured = true;
   }
-  dim3 grid((a->n + kStreamBN - 1) / kStreamBN, 1, sk), block(256);
-  hipLaunchKernelGGL((gemm_stream_kernel<NSTAGE, W8, MB>), grid, block, LDS, s, p, a->a_hi, a->a_lo, a->ld_planes);
+  dim3 grid((a->n + kStreamBN - 1) / kStreamBN, 1, sk), block(64 * NW);
+  hipLaunchKernelGGL((gemm_stream_kernel<NSTAGE, W8, MB, NW>), grid, block, LDS, s, p, a->a_hi, a->a_lo, a->ld_planes);
   return CHATTS_OK;
 }
 
@@ -1191,6 +1221,8 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
     if (a->m > 64) rc = launch_stream_t<3, false, 8>(p, a, sk, s);          // 3 x 48 KB stages: one workgroup per CU
     else if (a->m > 32) rc = launch_stream_t<4, false, 4>(p, a, sk, s);     // 4 x 32 KB
     else if (a->m > 16) rc = launch_stream_t<4, false, 2>(p, a, sk, s);     // 4 x 24 KB
+    else if (a->w8 && gemm_env_int("CHATTS_GEMM_STREAM_WAVES", 4) == 8)
+      rc = stages == 3 ? launch_stream_t<3, true, 1, 8>(p, a, sk, s) : launch_stream_t<4, true, 1, 8>(p, a, sk, s);
     else if (a->w8) rc = stages == 3 ? launch_stream_t<3, true>(p, a, sk, s) : launch_stream_t<4, true>(p, a, sk, s);
     else if (stages == 3) rc = launch_stream_t<3, false>(p, a, sk, s);
     else if (stages == 5) rc = launch_stream_t<5, false>(p, a, sk, s);

@@ -715,12 +715,13 @@ def test_gemm_fp8_weights_parity(lib, epi, m, n, k):
 
 @pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
 @pytest.mark.parametrize("m,n,k", [(2, 128, 128), (5, 160, 384), (16, 5120, 5120), (16, 1024, 13824), (9, 7168, 5120)])
-@pytest.mark.parametrize("stages", [3, 4])
-def test_gemm_stream_fp8_weights_parity(lib, epi, m, n, k, stages, monkeypatch):
+@pytest.mark.parametrize("stages,waves", [(3, 4), (4, 4), (3, 8), (4, 8)])
+def test_gemm_stream_fp8_weights_parity(lib, epi, m, n, k, stages, waves, monkeypatch):
     """Batched decode on the fp8 copy of W (BASELINE config 5): the streaming kernel's 128-deep stages, 8-byte fragments
-    widened in registers, row scale in the epilogue - against float64 on the dequantised matrix."""
+    widened in registers, row scale in the epilogue - against float64 on the dequantised matrix.  (4 or 8 waves per workgroup.)"""
     from chatts_amd.modeling import quantize_fp8_rows
     monkeypatch.setenv("CHATTS_GEMM_STREAM_STAGES", str(stages))
+    monkeypatch.setenv("CHATTS_GEMM_STREAM_WAVES", str(waves))
     a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
     w[5] *= 50.0
     q, scale, deq = quantize_fp8_rows(w)
@@ -738,6 +739,34 @@ def test_gemm_stream_fp8_weights_parity(lib, epi, m, n, k, stages, monkeypatch):
     want = _ref_linear(a, deq, bias, resid, epi)
     assert not torch.isnan(out).any()
     assert rel_err(out.cpu().numpy(), want) < 2e-5
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k,sk", [(16, 27648, 5120, 1), (16, 5120, 13824, 6), (11, 7168, 5120, 4), (3, 160, 384, 1)])
+def test_gemm_stream_fp8_eight_waves_equal_four_bitwise(lib, epi, m, n, k, sk, monkeypatch):
+    """gemm_stream_kernel<., true, 1, 8> (16 columns per wave, the SwiGLU pair exchanged through LDS) == the 4-wave form, bit for
+    bit: every column sees the same operands in the same K order."""
+    from chatts_amd.modeling import quantize_fp8_rows
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
+    q, scale, deq = quantize_fp8_rows(w)
+    hi, lo = _split_planes(lib, a)
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    wsb = max(int(lib.chatts_linear_workspace(m, n, k)), 8 * m * n * 4)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    monkeypatch.setenv("CHATTS_GEMM_SK", str(sk))
+    outs = []
+    for waves in (4, 8):
+        monkeypatch.setenv("CHATTS_GEMM_STREAM_WAVES", str(waves))
+        out = torch.full((m, ncols), float("nan"), device=DEV)
+        la = _lib.LinearArgs(a=None, w=deq.data_ptr(), bias=bias.data_ptr(), resid=resid.data_ptr() if epi == _lib.EPI_RESID else None,
+                             c=out.data_ptr(), norm_w=None, norm_eps=0.0, m=m, n=n, k=k, lda=k, ldw=k, ldc=ncols, epilogue=epi,
+                             workspace=ws.data_ptr(), workspace_bytes=wsb, w8=q.data_ptr(), w8_scale=scale.data_ptr(), ldw8=k,
+                             a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=k)
+        _lib.check(lib.chatts_linear(la, st()))
+        torch.cuda.synchronize()
+        assert not torch.isnan(out).any()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("m,n,k", [(16, 5120, 5120), (300, 5120, 1536), (16, 5120, 64), (7, 256, 512)])
