@@ -29,6 +29,9 @@ class TsWeights(C.Structure):
                 ("b", c_void_p * 8)]
 
 
+TILE_COUNTERS = 4096      # CHATTS_TILE_COUNTERS
+
+
 class LinearArgs(C.Structure):
     _fields_ = [("a", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("resid", c_void_p), ("c", c_void_p),
                 ("norm_w", c_void_p), ("norm_eps", c_float), ("m", c_int), ("n", c_int), ("k", c_int),
@@ -37,7 +40,7 @@ class LinearArgs(C.Structure):
                 ("a_hi", c_void_p), ("a_lo", c_void_p), ("ld_planes", c_int),
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("ld_cplanes", c_int),
                 ("post_norm_w", c_void_p), ("post_norm_eps", c_float), ("post_hi", c_void_p), ("post_lo", c_void_p), ("ld_post", c_int),
-                ("w4", c_void_p), ("w4_sz", c_void_p), ("ldw4", c_int), ("w4_group", c_int)]
+                ("w4", c_void_p), ("w4_sz", c_void_p), ("ldw4", c_int), ("w4_group", c_int), ("tile_counters", c_void_p)]
 
 
 class KvCache(C.Structure):
@@ -82,7 +85,8 @@ class DecoderBuffers(C.Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("t_max", c_int), ("max_batch", c_int),
                 ("planes_hi", c_void_p), ("planes_lo", c_void_p), ("planes2_hi", c_void_p), ("planes2_lo", c_void_p),
                 ("tp_pair_logit", c_void_p), ("tp_pair_token", c_void_p), ("logits_full", c_void_p),
-                ("kv_block_table", c_void_p), ("kv_block_size", c_int), ("kv_table_stride", c_int), ("kv_pool_blocks", c_int)]
+                ("kv_block_table", c_void_p), ("kv_block_size", c_int), ("kv_table_stride", c_int), ("kv_pool_blocks", c_int),
+                ("tile_counters", c_void_p)]
 
 
 # name -> (restype, argtypes); this table IS the list of symbols include/chatts_amd.h declares

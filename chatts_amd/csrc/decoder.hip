@@ -402,7 +402,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = batch; la.n = qkv_n; la.k = H;
     la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
     la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H;
-    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
     if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, 0);
@@ -415,7 +415,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     la.a = d->b.attn; la.w = lw.o; la.m = batch; la.n = H; la.k = c.n_q * kHeadDim;
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
     la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k;
-    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
     if (attn_planes) { la.a = nullptr; la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k; }
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
@@ -426,7 +426,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   la.w = lw.gate_up; la.c = d->b.act; la.m = batch; la.n = 2 * c.inter; la.k = H;
   la.lda = H; la.ldw = H; la.ldc = c.inter; la.epilogue = CHATTS_EPI_SWIGLU;
   la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H;
-  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
   if ((rc = norm_into(d, lw.post_norm, &la, stream)) != 0) return rc;
   const bool act_planes = planes_path(d, batch, c.inter, lw.down8 != nullptr) && planes_path(d, batch, H, lw.gate_up8 != nullptr);
   if (act_planes) { la.c = nullptr; la.c_hi = d->b.planes2_hi; la.c_lo = d->b.planes2_lo; la.ld_cplanes = c.inter; }
@@ -435,7 +435,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   la.a = d->b.act; la.w = lw.down; la.m = batch; la.n = H; la.k = c.inter;
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
   la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter;
-  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
   if (act_planes) { la.a = nullptr; la.a_hi = d->b.planes2_hi; la.a_lo = d->b.planes2_lo; la.ld_planes = c.inter; }
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }

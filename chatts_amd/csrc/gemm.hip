@@ -45,6 +45,8 @@ struct GemmParams {
   uint16_t* c_lo;        // format) instead of float32 c
   int ldcp;
   int sk_T, sk_nk;       // stream-K (gemm_dma_kernel only): T = tiles * K-steps per tile, sk_nk = K-steps per tile; 0 = off
+  int32_t* fix_cnt;      // gemm_stream_kernel, split-K: per-tile arrival counters -> the last workgroup of a tile runs the epilogue
+  float* c_out;          // ... into the real output (c holds the partial slabs)
 };
 
 // ---- stream-K decomposition (gemm_dma_kernel) -------------------------------------------------------------------
@@ -721,6 +723,88 @@ __device__ __forceinline__ void wait_stages(int later) {
 // partials and 8 K-steps per workgroup, mostly pipeline fill (33.7 us per TS layer at P = 128, profiles/r2_ts_gemm_sweep.txt).
 // Here the tile is (16 MB) x 128: 40 N-tiles x ~6 K-splits = one workgroup per CU, W streamed in whole lines exactly once per
 // split, the MB A blocks of a K-step (MB x 4 KB) staged next to the W tile (16 KB), 8 MB MFMAs per wave and K-step.
+// Split-K without the epilogue launch (2 <= M <= 16): every workgroup of a tile writes its partial slab with write-through
+// stores, drains them and bumps the tile's arrival counter; the one that arrives LAST (whichever it is) acquires, sums the slabs
+// in split order 0 .. sk-1 and applies the epilogue - the arithmetic of splitk_epilogue_kernel, element for element - then
+// re-arms the counter.  The cross-workgroup hand-off is the guide's recipe (sc1 stores + vmcnt(0) + relaxed atomic / acquire
+// fence + plain loads).
+template <int FN, int NW, bool W8>
+__device__ __forceinline__ void stream_fixup(const GemmParams& p, const f32x4 (&acc)[1][FN], int n0, int wave, int lane, char* smem) {
+  const int sk = gridDim.z;
+  const size_t plane = (size_t)p.m * p.n;
+  float* ws = p.c + blockIdx.z * plane;
+  const int ccol = lane & 15, crow0 = (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int col = n0 + wave * (16 * FN) + j * 16 + ccol;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = crow0 + r;
+      if (row < p.m && col < p.n)      // write-through (sc1): read by another workgroup inside this launch
+        __hip_atomic_store(reinterpret_cast<unsigned int*>(ws + (size_t)row * p.n + col), __float_as_uint(acc[0][j][r]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                               // the slab is out; nobody reads the ring any more
+  int* flag = reinterpret_cast<int*>(smem);
+  if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(p.fix_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*flag != sk - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (threadIdx.x == 0) __hip_atomic_store(p.fix_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float* __restrict__ all = p.c;
+  const float* scale = W8 ? p.w8_scale : nullptr;
+  // all loads of a thread first (8 elements x up to kMaxSk slabs in flight: one memory round trip, not one per element), sums in
+  // split order afterwards
+  constexpr int kMaxSk = 8, NE = 16 * 128 / (64 * NW);
+  const bool swiglu = p.epilogue == CHATTS_EPI_SWIGLU;
+  float part[NE][kMaxSk];
+  size_t off[NE];
+  bool live[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = threadIdx.x + i * 64 * NW;
+    // SwiGLU: element (row, packed row n0 + c) of the slab, c = 0 .. 127 (gate and up rows alike: summed here, paired below)
+    const int row = e >> 7, col = n0 + (e & 127);
+    live[i] = row < p.m && col < p.n;
+    off[i] = (size_t)row * p.n + col;
+#pragma unroll
+    for (int sp = 0; sp < kMaxSk; ++sp) part[i][sp] = (live[i] && sp < sk) ? all[sp * plane + off[i]] : 0.f;
+  }
+  float* xch = reinterpret_cast<float*>(smem) + 64;      // SwiGLU: the summed tile goes through LDS to pair gate with up
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = threadIdx.x + i * 64 * NW;
+    const int row = e >> 7, col = n0 + (e & 127);
+    float v = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < kMaxSk; ++sp)
+      if (sp < sk) v += part[i][sp];
+    if (swiglu) { xch[e] = v; continue; }
+    if (!live[i]) continue;
+    if (scale) v *= scale[col];
+    if (p.bias) v += p.bias[col];
+    if (p.epilogue == CHATTS_EPI_GELU) v = gelu_erf_f(v);
+    if (p.epilogue == CHATTS_EPI_RESID) v = p.resid[(size_t)row * p.ldc + col] + v;
+    if (p.c_hi) store_planes(p.c_hi, p.c_lo, (size_t)row * p.ldcp + col, v);
+    else p.c_out[(size_t)row * p.ldc + col] = v;
+  }
+  if (!swiglu) return;
+  __syncthreads();
+  for (int e = threadIdx.x; e < 16 * 64; e += 64 * NW) {
+    const int row = e >> 6, cc = e & 63;
+    const int loc = (cc >> 4) * 32 + (cc & 15), prow = n0 + loc;
+    if (row >= p.m || prow + 16 >= p.n) continue;
+    float g = xch[row * 128 + loc], u = xch[row * 128 + loc + 16];
+    if (scale) { g *= scale[prow]; u *= scale[prow + 16]; }
+    if (p.bias) { g += p.bias[prow]; u += p.bias[prow + 16]; }
+    const int col = (prow >> 5) * 16 + (prow & 15);
+    if (p.c_hi) store_planes(p.c_hi, p.c_lo, (size_t)row * p.ldcp + col, silu_g(g) * u);
+    else p.c_out[(size_t)row * p.ldc + col] = silu_g(g) * u;
+  }
+}
+
 // NW = waves per workgroup.  4: each wave owns 32 columns (two B fragments).  8 [fp8 W]: each owns 16 - the per-stage chain of a
 // wave (LDS reads -> fp8 widening -> MFMAs) is what paces a workgroup when it is alone on its CU (a deeper ring changes nothing,
 // profiles/r3_stream_sweep_fp8.txt), and two waves per SIMD overlap their chains.  Every output column still sees its K-steps in
@@ -837,6 +921,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_stream_kernel(GemmParams p, cons
         for (int j = 0; j < FN; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[h], bfrag[h][j], acc[b][j], 0, 0, 0);
       }
     }
+  }
+  if constexpr (MB == 1) {
+    if (!p.direct && p.fix_cnt) { stream_fixup<FN, NW, W8>(p, acc, n0, wave, lane, smem); return; }
   }
   if constexpr (FN == 1) {
     if (p.direct && p.epilogue == CHATTS_EPI_SWIGLU) {
@@ -1205,6 +1292,13 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   p.epilogue = a->epilogue; p.k_per_split = kps; p.direct = sk == 1;
   p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8;
   p.c_hi = a->c_hi; p.c_lo = a->c_lo; p.ldcp = a->ld_cplanes;
+  p.fix_cnt = nullptr; p.c_out = a->c;
+  if (stream && sk > 1 && sk <= 8 && a->m <= 16 && a->tile_counters && !a->post_norm_w && (a->n + kStreamBN - 1) / kStreamBN <= CHATTS_TILE_COUNTERS &&
+      gemm_env_int("CHATTS_GEMM_FIXUP", 0) != 0)      // MEASURED slower than the epilogue launch (config 5: 7.32 against 6.78 ms per
+                                                       // step, profiles/r3_cfg5_split_k_fixup_ab.txt): a captured launch costs ~2 us,
+                                                       // the serial tail of the last workgroup + write-through slabs cost more
+
+    p.fix_cnt = a->tile_counters;
   if (sk > 1) {
     const size_t need = (size_t)sk * a->m * a->n * sizeof(float);
     CHATTS_REQUIRE(a->workspace && a->workspace_bytes >= need, CHATTS_E_WORKSPACE,
@@ -1247,6 +1341,7 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
     }
   }
   CHATTS_CHECK_LAUNCH("gemm_bf16x2");
+  if (p.fix_cnt) return CHATTS_OK;        // the epilogue ran inside the launch
   const bool post_norm = a->post_norm_w != nullptr;
   if (sk > 1 && post_norm) {        // epilogue + the consumer's RMSNorm in one row-wise launch
     hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(a->m), dim3(256), 0, s, reinterpret_cast<const float*>(a->workspace), sk,

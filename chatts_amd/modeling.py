@@ -364,6 +364,7 @@ class ChatTSForCausalLM:
             # tensor parallel: scratch of the token agreement (chatts_decoder_select_tokens)
             "tp_pair_logit": torch.zeros(MB, **f32) if plan.world > 1 else None,
             "tp_pair_token": torch.zeros(MB, dtype=torch.int64, device=dev) if plan.world > 1 else None,
+            "tile_counters": torch.zeros(_lib.TILE_COUNTERS, dtype=torch.int32, device=dev),     # arrival counters of the split-K tiles
             "logits_full": torch.zeros((MB, plan.vocab * plan.world), **f32) if plan.world > 1 else None,
         }
         # single-sequence views (slot 0): the batch-1 fast path and its hipGraph use these
@@ -405,7 +406,8 @@ class ChatTSForCausalLM:
                                  tp_pair_token=_lib.ptr(B["tp_pair_token"]), logits_full=_lib.ptr(B["logits_full"]),
                                  kv_block_table=_lib.ptr(B["kv_table"]), kv_block_size=self.kv_block_size,
                                  kv_table_stride=(self.max_ctx // self.kv_block_size) if self.kv_block_size else 0,
-                                 kv_pool_blocks=self._kv.n_blocks if self._kv is not None else 0)
+                                 kv_pool_blocks=self._kv.n_blocks if self._kv is not None else 0,
+                                 tile_counters=_lib.ptr(B["tile_counters"]))
         h = lib.chatts_decoder_create(C.byref(dc), C.byref(dw), C.byref(db))
         if not h:
             raise _lib.ChattsError(-1, lib.chatts_last_error().decode())

@@ -171,7 +171,14 @@ typedef struct ChattsLinearArgs {
   const uint8_t* w4;
   const float* w4_sz;
   int ldw4, w4_group;
+  /* optional (2 <= M <= 16 on planes, split-K): CHATTS_TILE_COUNTERS int32 in device memory, ZERO before the first use and not
+   * shared between streams.  When set, the workgroup that finishes a 128-column tile LAST (a per-tile arrival counter, reset by
+   * that workgroup) sums the tile's partial slabs in the fixed split order and applies the epilogue inside the GEMM launch:
+   * the same arithmetic as the separate epilogue launch it replaces (bit-identical), one launch less per projection.  Honoured only
+   * under CHATTS_GEMM_FIXUP=1: measured SLOWER than the launch it saves on MI355X (profiles/r3_cfg5_split_k_fixup_ab.txt). */
+  int32_t* tile_counters;
 } ChattsLinearArgs;
+#define CHATTS_TILE_COUNTERS 4096
 size_t chatts_linear_workspace(int m, int n, int k);
 /* hi = bf16(x) (RNE), lo = bf16(x - hi): the operand split of the bf16x2 GEMM, done once per activation matrix. */
 int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, chatts_bf16* lo, int ld_planes,
@@ -431,6 +438,7 @@ typedef struct ChattsDecoderBuffers {
   int kv_block_size;
   int kv_table_stride;
   int kv_pool_blocks;
+  int32_t* tile_counters;  /* optional: CHATTS_TILE_COUNTERS zeroed int32 (ChattsLinearArgs.tile_counters) for the batched-decode projections */
 } ChattsDecoderBuffers;
 
 typedef struct ChattsDecoder ChattsDecoder;  /* opaque; host memory only */

@@ -769,6 +769,45 @@ def test_gemm_stream_fp8_eight_waves_equal_four_bitwise(lib, epi, m, n, k, sk, m
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k,sk", [(16, 5120, 13824, 6), (16, 7168, 5120, 4), (11, 5120, 5120, 6), (16, 27648, 5120, 2)])
+def test_gemm_stream_in_launch_split_k_epilogue_bitwise(lib, epi, m, n, k, sk, fp8, monkeypatch):
+    """ChattsLinearArgs.tile_counters: the last workgroup of a tile sums the split-K slabs and applies the epilogue inside the GEMM
+    launch == the separate epilogue launch, bit for bit; repeated launches (the counters re-arm themselves) stay identical."""
+    from chatts_amd.modeling import quantize_fp8_rows
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
+    q, scale, deq = quantize_fp8_rows(w)
+    hi, lo = _split_planes(lib, a)
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    wsb = max(int(lib.chatts_linear_workspace(m, n, k)), 8 * m * n * 4)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    cnt = torch.zeros(_lib.TILE_COUNTERS, dtype=torch.int32, device=DEV)
+    monkeypatch.setenv("CHATTS_GEMM_SK", str(sk))
+    monkeypatch.setenv("CHATTS_GEMM_FIXUP", "1")         # opt-in (measured slower than the launch it saves)
+
+    def run(counters):
+        out = torch.full((m, ncols), float("nan"), device=DEV)
+        r = resid.clone()
+        la = _lib.LinearArgs(a=None, w=deq.data_ptr(), bias=bias.data_ptr(), resid=r.data_ptr() if epi == _lib.EPI_RESID else None,
+                             c=out.data_ptr(), norm_w=None, norm_eps=0.0, m=m, n=n, k=k, lda=k, ldw=k, ldc=ncols, epilogue=epi,
+                             workspace=ws.data_ptr(), workspace_bytes=wsb, a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=k,
+                             tile_counters=cnt.data_ptr() if counters else None)
+        if fp8:
+            la.w8, la.w8_scale, la.ldw8 = q.data_ptr(), scale.data_ptr(), k
+        _lib.check(lib.chatts_linear(la, st()))
+        torch.cuda.synchronize()
+        return out
+
+    want = run(False)
+    assert not torch.isnan(want).any()
+    for _ in range(3):
+        ws.fill_(0xFF)                                   # stale slabs from the previous launch must not matter
+        got = run(True)
+        assert torch.equal(got, want)
+        assert int(cnt.abs().sum()) == 0                 # every counter re-armed
+
+
 @pytest.mark.parametrize("m,n,k", [(16, 5120, 5120), (300, 5120, 1536), (16, 5120, 64), (7, 256, 512)])
 @pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID])
 def test_linear_post_norm_planes_equal_separate_rmsnorm(lib, m, n, k, epi):
