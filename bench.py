@@ -244,7 +244,36 @@ def ts_encoder_roofline(model, ser, lengths, reps=20):
     return res
 
 
-def cpu_baseline(model, prompt_tokens, depth=8):
+def cpu_ts_encode(model, ser, reps=5):
+    """SURVEY.md section 8(d) "report TS-encoder ms": TimeSeriesEmbedding.forward on the host cores of THIS box, beside
+    ts_encoder_roofline - the oracle's patch-feature restatement (numpy, chatts_vllm.py:94-183) followed by the reference's module
+    stack itself (nn.Linear / nn.GELU, :83-91) as float32 torch calls with the thread count the decoder leg picked, weights copied
+    back from the GPU.  Median of `reps` calls after one warm-up, same series as the GPU line."""
+    import torch
+    from oracle import from_device, ts_embedding
+    tsw = {k[len("ts_encoder."):]: v for k, v in from_device.ts_encoder_state_dict(model).items()}
+    x = ser.float().cpu().numpy()
+    cfg = model.config.ts
+    n_layers = int(cfg["num_layers"])
+    lin = [(torch.from_numpy(tsw[f"mlp.{2 * l}.weight"]), torch.from_numpy(tsw[f"mlp.{2 * l}.bias"])) for l in range(n_layers)]
+
+    def once():
+        t0 = time.perf_counter()
+        feat, _ = ts_embedding.patch_features(x, cfg, tsw.get("position_embedding.weight"))
+        h = torch.from_numpy(feat)
+        with torch.no_grad():
+            for l, (w, b) in enumerate(lin):
+                h = torch.nn.functional.linear(h, w, b)
+                if l < n_layers - 1:
+                    h = torch.nn.functional.gelu(h)
+        return time.perf_counter() - t0, int(h.shape[0])
+
+    once()
+    runs = [once() for _ in range(reps)]
+    return median([r[0] for r in runs]) * 1e3, runs[0][1]
+
+
+def cpu_baseline(model, prompt_tokens, depth=8, ser=None):
     """The reference's own decoder dependency - stock `transformers` Qwen2ForCausalLM / Qwen3ForCausalLM, float32, eager
     attention (oracle/hf_reference.py) - timed on the host cores of THIS box.  Bounded sample: the model's real widths at
     `depth` layers (weights copied back from the GPU, so both arms hold identical values), prefill of the real prompt length +
@@ -289,7 +318,13 @@ def cpu_baseline(model, prompt_tokens, depth=8):
     dec_s = fixed_dec + Lfull * per_layer_dec
     pre_s = fixed_pre + Lfull * per_layer_pre
     import transformers
-    return dict(value=1.0 / dec_s, unit="tokens/s", cores=ncores, kind="reference", host_cores=ncores_box,
+    ts_ms, ts_patches = (None, None)
+    if ser is not None:
+        try:
+            ts_ms, ts_patches = cpu_ts_encode(model, ser)
+        except Exception as e:      # reported, never fatal
+            ts_ms, ts_patches = f"failed: {type(e).__name__}: {e}", None
+    return dict(value=1.0 / dec_s, ts_encode_ms=ts_ms, ts_encode_patches=ts_patches, unit="tokens/s", cores=ncores, kind="reference", host_cores=ncores_box,
                 sample=(f"stock transformers {transformers.__version__} {type(m).__name__} (the reference's decoder dependency), float32, eager "
                         f"attention, on {ncores} of {ncores_box} host threads (fastest of a decode probe); {cfg.name} widths, depths {depth} and {half} "
                         f"of {Lfull} layers measured (prefill {prompt_tokens} tok + 4 decode tok each), linearly extrapolated to {Lfull} "
@@ -670,7 +705,7 @@ def main():
         result["prefill_roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(model, T)
+            result["cpu_baseline"] = cpu_baseline(model, T, ser=ser)
         except Exception as e:          # the baseline must never take the GPU number down with it
             result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                       "sample": f"failed: {type(e).__name__}: {e}"}

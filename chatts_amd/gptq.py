@@ -68,6 +68,17 @@ def dequantized_pairs(pairs, quant_cfg):
     gs = int(quant_cfg.get("group_size", 128))
     v2 = quant_cfg.get("checkpoint_format", "gptq") == "gptq_v2"
     pending = {}
+
+    def emit(base, d):
+        g = gs if gs > 0 else d["qweight"].shape[0] * 8
+        w = dequantize(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), g, v2)
+        yield base + ".weight", w.to(torch.bfloat16)
+        # the int4 decode GEMV takes ONE group size for all projections of the model (a power of two >= 16): a per-column
+        # checkpoint (group_size = -1: g = K, different per module) keeps streaming the dequantised bf16 weights instead
+        cz = codes(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), g, v2) if gs >= 16 and gs & (gs - 1) == 0 else None
+        if cz is not None:                  # (None: act-order channel -> group map)
+            yield base + ".gptq_codes", cz  # consumed by ChatTSForCausalLM.load_weights (int4 decode GEMV)
+
     for name, t in pairs:
         base, _, suffix = name.rpartition(".")
         if suffix not in SUFFIXES:
@@ -75,27 +86,15 @@ def dequantized_pairs(pairs, quant_cfg):
             continue
         d = pending.setdefault(base, {})
         d[suffix] = t
-        need = ("qweight", "qzeros", "scales") + (("g_idx",) if quant_cfg.get("desc_act") else ())
-        if all(k in d for k in need) and ("g_idx" in d or not _expects_g_idx(pending, base)):
-            g = gs if gs > 0 else d["qweight"].shape[0] * 8
-            w = dequantize(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), g, v2)
-            cz = codes(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), g, v2) if g % 16 == 0 else None
-            pending.pop(base)
-            yield base + ".weight", w.to(torch.bfloat16)
-            if cz is not None:
-                yield base + ".gptq_codes", cz          # consumed by ChatTSForCausalLM.load_weights (int4 decode GEMV)
-    # checkpoints always store g_idx; modules still pending only miss it because of iteration order -> flush them
+        # AutoGPTQ checkpoints store g_idx for every module (trivial when desc_act is false) and it may arrive after the other
+        # three tensors: a module is complete when all four are there; one that never gets a g_idx is emitted by the flush below
+        if all(k in d for k in ("qweight", "qzeros", "scales", "g_idx")):
+            yield from emit(base, pending.pop(base))
     for base, d in list(pending.items()):
-        if all(k in d for k in ("qweight", "qzeros", "scales")):
-            w = dequantize(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), gs if gs > 0 else d["qweight"].shape[0] * 8, v2)
-            yield base + ".weight", w.to(torch.bfloat16)
+        if all(k in d for k in ("qweight", "qzeros", "scales")) and not quant_cfg.get("desc_act"):
+            yield from emit(base, d)        # no g_idx in the checkpoint: groups are consecutive (desc_act = false)
         else:
             raise ValueError(f"incomplete GPTQ module {base}: has {sorted(d)}")
-
-
-def _expects_g_idx(pending, base):
-    """g_idx may arrive after the other three tensors: wait for it unless the stream is exhausted (handled by the flush)."""
-    return True
 
 
 def quantize_rows(w, group_size=128):

@@ -64,6 +64,20 @@ def test_quantize_then_dequantize_and_pair_stream():
     shuffled["g_idx"] = t["g_idx"].flip(0)
     pairs2 = [(f"m.{k}", v) for k, v in shuffled.items()]
     assert set(dict(gptq.dequantized_pairs(iter(pairs2), {"bits": 4, "group_size": 128, "desc_act": True}))) == {"m.weight"}
+    # a checkpoint WITHOUT g_idx tensors (desc_act = false) is emitted by the final flush - with its codes, like the others
+    no_gidx = [(f"m.{k}", v) for k, v in t.items() if k != "g_idx"]
+    out3 = dict(gptq.dequantized_pairs(iter(no_gidx), {"bits": 4, "group_size": 128, "desc_act": False}))
+    assert set(out3) == {"m.weight", "m.gptq_codes"} and torch.equal(out3["m.weight"], deq.to(torch.bfloat16))
+    assert all(torch.equal(a, b) for a, b in zip(out3["m.gptq_codes"], out["model.layers.0.mlp.up_proj.gptq_codes"]))
+    # ... while an act-order checkpoint that misses a g_idx is an error, not a guess
+    with pytest.raises(ValueError, match="incomplete"):
+        list(gptq.dequantized_pairs(iter(no_gidx), {"bits": 4, "group_size": 128, "desc_act": True}))
+    # per-column groups (group_size = -1: one group of K per row, K differs per module): no codes, the bf16 matrix is streamed
+    K = 256
+    tc = gptq.quantize_rows(w, K)
+    outc = dict(gptq.dequantized_pairs(iter([(f"m.{k}", v) for k, v in tc.items()]), {"bits": 4, "group_size": -1}))
+    assert set(outc) == {"m.weight"}
+    assert torch.equal(outc["m.weight"], gptq.dequantize(tc["qweight"], tc["qzeros"], tc["scales"], tc["g_idx"], K).to(torch.bfloat16))
     with pytest.raises(ValueError, match="bits"):
         list(gptq.dequantized_pairs(iter(pairs), {"bits": 8}))
 
