@@ -457,6 +457,27 @@ def bench_batched(args, model, cfg, comm, world, device):
     }
     res["parity_checked"], res["parity"] = parity_check(args, toks)
     res["config"]["rccl_world_size"] = dist.get_world_size() if world > 1 else 1
+    # the step also reads every sequence's KV cache (float32 K and V rows of all layers): at 16 sequences x ctx 1.2k that is a
+    # third of the step's bytes, so the weight-only rate above understates the HBM stream
+    ctx_mid = T + 1 + args.warmup + args.steps / 2.0
+    kv_bytes = B * ctx_mid * model.plan.nkv * 128 * 4 * 2 * cfg.num_hidden_layers
+    res["decode_kv_bytes_per_step"] = kv_bytes
+    res["decode_hbm_gbs_incl_kv"] = (step_bytes + kv_bytes) / (dt / args.steps) / 1e9
+    res["decode_hbm_frac_of_8TBs_incl_kv"] = res["decode_hbm_gbs_incl_kv"] / HBM_PEAK_GBS
+    try:        # HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc FETCH_SIZE pass of THIS workload
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f).get("batched", {}).get(workload_key(args))
+        if pmc and world == 1:
+            res["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+            res["roofline"]["traffic_source"] = pmc["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+    try:        # the TS encoder at the patch count of the WHOLE batch (config 5: 16 x 8 x 1024 points = 8192 patches: MFMA-bound)
+        sers = [proc(text=[prompt], timeseries=r, padding=True, return_tensors="pt")["timeseries"] for r in reqs]
+        ser_all = torch.cat(sers, dim=0).to(device)
+        res["ts_encoder_roofline"] = ts_encoder_roofline(model, ser_all, list(lengths) * B, reps=5)
+    except Exception as e:
+        res["ts_encoder_roofline"] = {"error": f"{type(e).__name__}: {e}"}
     return res
 
 
