@@ -818,7 +818,7 @@ int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int 
   p.t = batch; p.n_q = n_q; p.n_kv = n_kv; p.n_splits = n_splits;
   if (const int rc = bind_cache(p, cache)) return rc;
   p.q_norm_w = q_norm_w; p.k_norm_w = k_norm_w; p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.eps = norm_eps;
-  p.seq_stride = seq_stride; p.out_hi = out_hi; p.out_lo = out_lo;
+  p.seq_stride = seq_stride; p.out_hi = out_hi; p.out_lo = out_lo; p.kv_round = kv_round_mode();
   const int rc = bind_workspace(p, workspace, workspace_bytes);
   if (rc) return rc;
   hipLaunchKernelGGL(attn_decode_kernel, dim3(n_kv, n_splits, batch), dim3(64), 0, as_stream(stream), p);

@@ -43,6 +43,7 @@ struct AttnParams {
   int log_block, table_stride;
   uint16_t* out_hi;    // decode combine, optional: the output as bf16 hi / lo planes [T, n_q * 128] (the o_proj operand of the
   uint16_t* out_lo;    // weight-streaming kernel) instead of float32 `out`
+  int kv_round;        // experiment knob, see kv_round_f (0 = off)
 };
 
 // rotate one 128-wide head held as (a = x[lane], b = x[lane+64]) by the wave; optional RMSNorm first
@@ -156,13 +157,14 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
       const float* ks = qkv + (size_t)(p.n_q + hk) * kHeadDim;
       float a = ks[lane], b = ks[lane + 64];
       norm_rope(a, b, p.k_norm_w, p.eps, c, s, lane);
+      a = kv_round_f(a, p.kv_round); b = kv_round_f(b, p.kv_round);
       knew_s[lane] = a;
       knew_s[lane + 64] = b;
       const size_t noff = kv_tile_off(kvl, hk, pos);      // row of the new token
       float* kd = kcache + noff;
       if (g0 == 0) { kd[lane] = a; kd[lane + 64] = b; }
       const float* vs = qkv + (size_t)(p.n_q + p.n_kv + hk) * kHeadDim;
-      const float va = vs[lane], vb = vs[lane + 64];
+      const float va = kv_round_f(vs[lane], p.kv_round), vb = kv_round_f(vs[lane + 64], p.kv_round);
       vnew_s[lane] = va;
       vnew_s[lane + 64] = vb;
       float* vd = vcache + noff;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/chatts_amd.h"
 
@@ -134,5 +135,16 @@ inline int kv_log_block(int block_size) {
 inline hipStream_t as_stream(chatts_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 int device_cus();
+
+// EXPERIMENT knob (CHATTS_KV_ROUND, default 0 = off): K / V rows are rounded to a narrower format's VALUES as they enter the float32
+// cache - 1 = bf16, 2 = bf16 hi + lo (16 mantissa bits), 3 = fp16 - to measure what such a cache would cost in logits error against
+// the 1e-3 bar before any kernel is rewritten for it.  The cache layout and every kernel stay float32.
+__device__ __forceinline__ float kv_round_f(float v, int mode) {
+  if (mode == 1) return (float)(__bf16)v;
+  if (mode == 2) { const __bf16 h = (__bf16)v; return (float)h + (float)(__bf16)(v - (float)h); }
+  if (mode == 3) return (float)(_Float16)v;
+  return v;
+}
+inline int kv_round_mode() { const char* e = getenv("CHATTS_KV_ROUND"); return e ? atoi(e) : 0; }
 
 }  // namespace chatts

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(float* __restrict__ qkv, i
                                                      const float* __restrict__ cos_tab,
                                                      const float* __restrict__ sin_tab, int pos0,
                                                      const int32_t* __restrict__ pos0_dev, float* __restrict__ kc,
-                                                     float* __restrict__ vc, KvLayout kvl) {
+                                                     float* __restrict__ vc, KvLayout kvl, int kv_round) {
   const int heads = n_q + 2 * n_kv;
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(float* __restrict__ qkv, i
   float a = row[lane], b = row[lane + 64];
   if (h >= n_q + n_kv) {   // v head: straight copy into the cache
     float* dst = vc + kv_tile_off(kvl, h - n_q - n_kv, pos);
-    dst[lane] = a;
-    dst[lane + 64] = b;
+    dst[lane] = kv_round_f(a, kv_round);
+    dst[lane + 64] = kv_round_f(b, kv_round);
     return;
   }
   const float* nw = h < n_q ? q_norm_w : k_norm_w;
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(float* __restrict__ qkv, i
     row[lane + 64] = ob;
   } else {
     float* dst = kc + kv_tile_off(kvl, h - n_q, pos);
-    dst[lane] = oa;
-    dst[lane + 64] = ob;
+    dst[lane] = kv_round_f(oa, kv_round);
+    dst[lane + 64] = kv_round_f(ob, kv_round);
   }
 }
 
@@ -278,7 +278,7 @@ extern "C" int chatts_rope_kv_write(float* qkv, int t, int n_q, int n_kv, const 
   }
   const int waves = t * (n_q + 2 * n_kv);
   hipLaunchKernelGGL(rope_kv_kernel, dim3((waves + 3) / 4), dim3(256), 0, as_stream(stream), qkv, t, n_q, n_kv,
-                     q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos0, pos0_dev, cache->k, cache->v, kvl);
+                     q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos0, pos0_dev, cache->k, cache->v, kvl, kv_round_mode());
   CHATTS_CHECK_LAUNCH("rope_kv_write");
   return CHATTS_OK;
 }
