@@ -121,6 +121,9 @@ SIGNATURES = {
                                                 c_void_p, c_size_t, c_void_p]),
     "chatts_argmax_batched": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_int, c_void_p]),
+    "chatts_argmax_workspace": (c_size_t, [c_int]),
+    "chatts_argmax_batched_ws": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                         c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "chatts_sample_batched": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, C.POINTER(SamplingArgs), c_void_p, c_void_p,
                                       c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     "chatts_embed_token_batched": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),

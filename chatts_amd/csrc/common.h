@@ -136,6 +136,12 @@ inline hipStream_t as_stream(chatts_stream_t s) { return reinterpret_cast<hipStr
 
 int device_cus();
 
+// greedy selection with scratch for the two-launch form (elementwise.hip); falls back to chatts_argmax_batched without it
+size_t argmax_scratch_bytes(int batch);
+int argmax_batched_scratch(const float* logits, int batch, int64_t logits_stride, int64_t vocab, int64_t vocab_offset, int64_t* token,
+                           float* token_logit, int64_t* out_tokens, int64_t out_stride, int32_t* step_dev, int32_t* pos_dev,
+                           int pos_limit, void* scratch, size_t scratch_bytes, hipStream_t s);
+
 // EXPERIMENT knob (CHATTS_KV_ROUND, default 0 = off): K / V rows are rounded to a narrower format's VALUES as they enter the float32
 // cache - 1 = bf16, 2 = bf16 hi + lo (16 mantissa bits), 3 = fp16 - to measure what such a cache would cost in logits error against
 // the 1e-3 bar before any kernel is rewritten for it.  The cache layout and every kernel stay float32.

@@ -240,8 +240,10 @@ extern "C" int chatts_decoder_select_tokens(ChattsDecoder* d, const float* logit
     if (sa)
       return chatts_sample_batched(logits, batch, logits_stride, c.vocab_local, c.vocab_offset, sa, token, token_logit, out_tokens,
                                    out_stride, step_dev, pos_dev, pos_limit, stream);
-    return chatts_argmax_batched(logits, batch, logits_stride, c.vocab_local, c.vocab_offset, token, token_logit, out_tokens, out_stride,
-                                 step_dev, pos_dev, pos_limit, stream);
+    // (the split-K / attention workspace is idle here: every kernel that used it is ahead of this call on the stream)
+    return chatts::argmax_batched_scratch(logits, batch, logits_stride, c.vocab_local, c.vocab_offset, token, token_logit, out_tokens,
+                                          out_stride, step_dev, pos_dev, pos_limit, d->b.workspace, d->b.workspace_bytes,
+                                          reinterpret_cast<hipStream_t>(stream));
   }
   CHATTS_REQUIRE(d->tp, CHATTS_E_BADARG, "decoder_select_tokens: tp_world = %d but no exchange attached (chatts_decoder_set_tp)", c.tp_world);
   const int mb = d->b.max_batch > 0 ? d->b.max_batch : 1;

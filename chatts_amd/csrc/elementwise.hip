@@ -219,6 +219,99 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   }
 }
 
+// ---- the same selection in two launches: 64 workgroups per sequence scan 1/64 of the row each (one workgroup needs 24 us for the
+// 152 k logits of a row - the tail of every decode step), one wave per sequence merges the 64 (value, first index) pairs and applies
+// the side effects.  Maximum and first-index tie rule are order-free: the token is the one argmax_kernel picks.
+constexpr int kArgmaxParts = 64;
+__global__ __launch_bounds__(256) void argmax_part_kernel(const float* __restrict__ logits_all, int64_t logits_stride, int64_t vocab,
+                                                         float* __restrict__ part_v, int64_t* __restrict__ part_i) {
+  __shared__ float sv[4];
+  __shared__ int64_t si[4];
+  const int seq = blockIdx.y, blk = blockIdx.x;
+  const float* logits = logits_all + (size_t)seq * logits_stride;
+  const int64_t chunk = ((vocab + kArgmaxParts - 1) / kArgmaxParts + 3) / 4 * 4;
+  const int64_t lo = blk * chunk, hi = lo + chunk < vocab ? lo + chunk : vocab;
+  float best = -INFINITY;
+  int64_t bi = 0x7fffffffffffffffLL;
+  const bool vec = (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
+  const int64_t body_end = vec ? lo + (hi > lo ? (hi - lo) / 4 * 4 : 0) : lo;
+  for (int64_t i = lo + threadIdx.x * 4; i < body_end; i += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(logits + i);
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (e[j] > best) { best = e[j]; bi = i + j; }        // ascending i within a thread: '>' keeps the first
+  }
+  for (int64_t i = body_end + threadIdx.x; i < hi; i += 256) {
+    const float v = logits[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int64_t oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    part_v[seq * kArgmaxParts + blk] = best;
+    part_i[seq * kArgmaxParts + blk] = bi;
+  }
+}
+
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ part_v, const int64_t* __restrict__ part_i,
+                                                         int64_t vocab_offset, int64_t* __restrict__ token_all,
+                                                         float* __restrict__ token_logit_all, int64_t* __restrict__ out_tokens_all,
+                                                         int64_t out_stride, int32_t* __restrict__ step_all,
+                                                         int32_t* __restrict__ pos_all, int pos_limit) {
+  const int seq = blockIdx.x, lane = threadIdx.x;
+  float best = part_v[seq * kArgmaxParts + lane];
+  int64_t bi = part_i[seq * kArgmaxParts + lane];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int64_t oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) {
+    int64_t* token = token_all ? token_all + seq : nullptr;
+    float* token_logit = token_logit_all ? token_logit_all + seq : nullptr;
+    int64_t* out_tokens = out_tokens_all ? out_tokens_all + (size_t)seq * out_stride : nullptr;
+    int32_t* step_dev = step_all ? step_all + seq : nullptr;
+    int32_t* pos_dev = pos_all ? pos_all + seq : nullptr;
+    const int64_t tok = bi + vocab_offset;
+    if (token) *token = tok;
+    if (token_logit) *token_logit = best;
+    if (out_tokens && step_dev && (out_stride == 0 || *step_dev < out_stride)) out_tokens[*step_dev] = tok;
+    if (step_dev) *step_dev += 1;
+    if (pos_dev && *pos_dev >= 0 && (pos_limit <= 0 || *pos_dev < pos_limit)) *pos_dev += 1;
+  }
+}
+
+// chatts_argmax_batched with `scratch` (>= argmax_scratch_bytes(batch)): the two-launch form; without: the single workgroup per row.
+size_t argmax_scratch_bytes(int batch) { return (size_t)batch * kArgmaxParts * (sizeof(float) + sizeof(int64_t)) + 16; }
+int argmax_batched_scratch(const float* logits, int batch, int64_t logits_stride, int64_t vocab, int64_t vocab_offset, int64_t* token,
+                           float* token_logit, int64_t* out_tokens, int64_t out_stride, int32_t* step_dev, int32_t* pos_dev,
+                           int pos_limit, void* scratch, size_t scratch_bytes, hipStream_t s) {
+  static const bool off = getenv("CHATTS_ARGMAX_2STAGE") && atoi(getenv("CHATTS_ARGMAX_2STAGE")) == 0;
+  if (!scratch || scratch_bytes < argmax_scratch_bytes(batch) || vocab < 4096 || off)
+    return chatts_argmax_batched(logits, batch, logits_stride, vocab, vocab_offset, token, token_logit, out_tokens, out_stride, step_dev,
+                                 pos_dev, pos_limit, reinterpret_cast<chatts_stream_t>(s));
+  CHATTS_REQUIRE(logits && vocab > 0 && batch >= 1 && logits_stride >= vocab, CHATTS_E_BADARG, "argmax: bad arguments");
+  int64_t* part_i = reinterpret_cast<int64_t*>((reinterpret_cast<uintptr_t>(scratch) + 15) & ~(uintptr_t)15);
+  float* part_v = reinterpret_cast<float*>(part_i + (size_t)batch * kArgmaxParts);
+  hipLaunchKernelGGL(argmax_part_kernel, dim3(kArgmaxParts, batch), dim3(256), 0, s, logits, logits_stride, vocab, part_v, part_i);
+  CHATTS_CHECK_LAUNCH("argmax_part");
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(batch), dim3(64), 0, s, part_v, part_i, vocab_offset, token, token_logit, out_tokens,
+                     out_stride, step_dev, pos_dev, pos_limit);
+  CHATTS_CHECK_LAUNCH("argmax_final");
+  return CHATTS_OK;
+}
+
 __global__ __launch_bounds__(256) void residual_add_kernel(float* __restrict__ x, const float* __restrict__ d, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     f32x4 a = reinterpret_cast<f32x4*>(x)[i];
@@ -320,6 +413,14 @@ extern "C" int chatts_argmax_batched(const float* logits, int batch, int64_t log
                      vocab_offset, token, token_logit, out_tokens, out_stride, step_dev, pos_dev, pos_limit);
   CHATTS_CHECK_LAUNCH("argmax");
   return CHATTS_OK;
+}
+
+extern "C" size_t chatts_argmax_workspace(int batch) { return chatts::argmax_scratch_bytes(batch); }
+extern "C" int chatts_argmax_batched_ws(const float* logits, int batch, int64_t logits_stride, int64_t vocab, int64_t vocab_offset,
+                                        int64_t* token, float* token_logit, int64_t* out_tokens, int64_t out_stride, int32_t* step_dev,
+                                        int32_t* pos_dev, int pos_limit, void* workspace, size_t workspace_bytes, chatts_stream_t stream) {
+  return chatts::argmax_batched_scratch(logits, batch, logits_stride, vocab, vocab_offset, token, token_logit, out_tokens, out_stride,
+                                        step_dev, pos_dev, pos_limit, workspace, workspace_bytes, as_stream(stream));
 }
 
 extern "C" int chatts_argmax(const float* logits, int64_t vocab, int64_t vocab_offset, int64_t* token,

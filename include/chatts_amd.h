@@ -278,6 +278,15 @@ int chatts_argmax_batched(const float* logits, int batch, int64_t logits_stride,
                           int64_t* token, float* token_logit, int64_t* out_tokens, int64_t out_stride,
                           int32_t* step_dev, int32_t* pos_dev, int pos_limit /* pos saturates here; 0 = none */,
                           chatts_stream_t stream);
+/* The same selection and side effects in two launches when the caller lends scratch (>= chatts_argmax_workspace(batch) bytes of device
+ * memory): 64 workgroups per row + one merging wave per row instead of one workgroup per row (24 us for 152 k logits - the tail of
+ * every decode step; the decoder passes its idle split-K workspace).  Same token: maximum, first index on ties.  Without scratch (NULL
+ * / too small) it IS chatts_argmax_batched. */
+size_t chatts_argmax_workspace(int batch);
+int chatts_argmax_batched_ws(const float* logits, int batch, int64_t logits_stride, int64_t vocab, int64_t vocab_offset,
+                             int64_t* token, float* token_logit, int64_t* out_tokens, int64_t out_stride,
+                             int32_t* step_dev, int32_t* pos_dev, int pos_limit, void* workspace, size_t workspace_bytes,
+                             chatts_stream_t stream);
 int chatts_embed_token_batched(const int64_t* token_dev, int batch, const chatts_bf16* table, int64_t vocab_offset,
                                int64_t vocab_rows, int hidden, float* out /* [batch, hidden] */, chatts_stream_t stream);
 

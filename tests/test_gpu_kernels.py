@@ -574,6 +574,39 @@ def test_attention_decode_fused_equals_unfused(lib, qk_norm, pos, splits):
     assert rel_err(out_b.cpu().numpy(), out_a.cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("vocab,stride", [(152064, 152064), (151936, 152064), (19008, 19010), (4099, 4100)])
+def test_argmax_two_launch_form_picks_the_same_token(lib, vocab, stride):
+    """chatts_argmax_batched_ws (64 partial workgroups per row + a merging wave) == chatts_argmax_batched == torch.argmax: maxima at
+    block edges, exact ties (first index wins), a row of equal values, unaligned rows (odd stride), parked / saturating positions."""
+    B = 5
+    g = torch.Generator().manual_seed(vocab)
+    logits = torch.randn((B, stride), generator=g).to(DEV)
+    chunk = ((vocab + 63) // 64 + 3) // 4 * 4
+    logits[0, chunk - 1] = 50.0; logits[0, chunk] = 50.0; logits[0, vocab - 1] = 50.0       # tie across a block edge and at the end
+    logits[1, vocab - 1] = 60.0                                                            # last element
+    logits[2, :vocab] = 1.25                                                               # all equal -> index 0
+    logits[3, 7 * chunk + 3] = 70.0; logits[3, vocab:] = 99.0                               # padding beyond vocab must not win
+    ws = torch.empty(int(lib.chatts_argmax_workspace(B)), dtype=torch.uint8, device=DEV)
+    outs = []
+    for use_ws in (False, True):
+        tok = torch.zeros(B, dtype=torch.int64, device=DEV)
+        val = torch.zeros(B, device=DEV)
+        outt = torch.full((B, 4), -1, dtype=torch.int64, device=DEV)
+        step = torch.tensor([0, 1, 2, 3, 0], dtype=torch.int32, device=DEV)
+        pos = torch.tensor([5, -1, 9, 10, 3], dtype=torch.int32, device=DEV)
+        _lib.check(lib.chatts_argmax_batched_ws(logits.data_ptr(), B, stride, vocab, 1000, tok.data_ptr(), val.data_ptr(), outt.data_ptr(), 4,
+                                                step.data_ptr(), pos.data_ptr(), 10, ws.data_ptr() if use_ws else None,
+                                                ws.numel() if use_ws else 0, st()))
+        torch.cuda.synchronize()
+        outs.append((tok.cpu(), val.cpu(), outt.cpu(), step.cpu(), pos.cpu()))
+    want = torch.argmax(logits[:, :vocab], dim=1).cpu() + 1000
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[1][0], want)
+    assert outs[1][0][0] == 1000 + chunk - 1 and outs[1][0][2] == 1000
+    assert outs[1][4].tolist() == [6, -1, 10, 10, 4] and outs[1][3].tolist() == [1, 2, 3, 4, 1]
+
+
 def test_embed_merge_and_argmax(lib):
     V, H, T = 1000, 256, 50
     table = torch.randn((V, H)).to(torch.bfloat16).to(DEV)
