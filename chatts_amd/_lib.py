@@ -64,7 +64,8 @@ class PrefillSegment(C.Structure):
 
 class SamplingArgs(C.Structure):
     _fields_ = [("temperature", c_float), ("top_k", c_int), ("top_p", c_float), ("seed", c_uint32), ("n_kept", c_void_p),
-                ("kept_mass", c_void_p)]
+                ("kept_mass", c_void_p), ("temperature_rows", c_void_p), ("top_k_rows", c_void_p), ("top_p_rows", c_void_p),
+                ("seed_rows", c_void_p)]
 
 
 class DecoderConfig(C.Structure):

@@ -136,6 +136,40 @@ inline hipStream_t as_stream(chatts_stream_t s) { return reinterpret_cast<hipStr
 
 int device_cus();
 
+// Maximum of a row with torch.argmax's tie rule (first index), by a workgroup of 1024 threads; sv / si: 16-entry shared scratch.
+// The result is valid in thread 0 (argmax_kernel, and the greedy rows of sample_kernel's per-row mode).
+__device__ __forceinline__ void block_argmax_first(const float* __restrict__ logits, int64_t vocab, float* sv, int64_t* si, float& best,
+                                                   int64_t& bi) {
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  best = -INFINITY;
+  bi = 0x7fffffffffffffffLL;
+  const int64_t v4 = ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) ? vocab / 4 : 0;   // float4 body, scalar tail
+  for (int64_t q = threadIdx.x; q < v4; q += 1024) {
+    const f32x4_t v = reinterpret_cast<const f32x4_t*>(logits)[q];
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (e[j] > best) { best = e[j]; bi = q * 4 + j; }      // ascending i within a thread: '>' keeps the first
+  }
+  for (int64_t i = v4 * 4 + threadIdx.x; i < vocab; i += 1024) {
+    const float v = logits[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int64_t oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+  }
+}
+
 // greedy selection with scratch for the two-launch form (elementwise.hip); falls back to chatts_argmax_batched without it
 size_t argmax_scratch_bytes(int batch);
 int argmax_batched_scratch(const float* logits, int batch, int64_t logits_stride, int64_t vocab, int64_t vocab_offset, int64_t* token,

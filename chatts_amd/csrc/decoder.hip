@@ -204,7 +204,7 @@ static void request_post_norm(ChattsDecoder* d, ChattsLinearArgs* la, const floa
 
 extern "C" int chatts_decoder_set_sampling(ChattsDecoder* d, const ChattsSamplingArgs* sa) {
   CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_set_sampling: null decoder");
-  if (sa) CHATTS_REQUIRE(sa->temperature > 0.f && sa->top_p > 0.f, CHATTS_E_BADARG,
+  if (sa) CHATTS_REQUIRE(sa->temperature_rows || (sa->temperature > 0.f && sa->top_p > 0.f), CHATTS_E_BADARG,
                          "decoder_set_sampling: temperature %g / top_p %g must be positive (pass NULL for greedy)",
                          (double)sa->temperature, (double)sa->top_p);
   d->sampling = sa != nullptr;

@@ -183,32 +183,10 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   int64_t* out_tokens = out_tokens_all ? out_tokens_all + (size_t)seq * out_stride : nullptr;
   int32_t* step_dev = step_all ? step_all + seq : nullptr;
   int32_t* pos_dev = pos_all ? pos_all + seq : nullptr;
-  float best = -INFINITY;
-  int64_t bi = 0x7fffffffffffffffLL;
-  const int64_t v4 = ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) ? vocab / 4 : 0;   // float4 body, scalar tail
-  for (int64_t q = threadIdx.x; q < v4; q += 1024) {
-    const f32x4 v = reinterpret_cast<const f32x4*>(logits)[q];
-    const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (e[j] > best) { best = e[j]; bi = q * 4 + j; }      // ascending i within a thread: '>' keeps the first
-  }
-  for (int64_t i = v4 * 4 + threadIdx.x; i < vocab; i += 1024) {
-    const float v = logits[i];
-    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int64_t oi = __shfl_xor(bi, o, 64);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { sv[wave] = best; si[wave] = bi; }
-  __syncthreads();
+  float best;
+  int64_t bi;
+  block_argmax_first(logits, vocab, sv, si, best, bi);
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; ++w)
-      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
     const int64_t tok = bi + vocab_offset;
     if (token) *token = tok;
     if (token_logit) *token_logit = best;

@@ -33,6 +33,12 @@ struct SampleParams {
   int pos_limit;
   int32_t* n_kept;
   float* kept_mass;
+  // per-row mode (ChattsSamplingArgs.temperature_rows != NULL): row b draws with (temperature, top_k, top_p, seed)[b], read on the
+  // device at run time; temperature 0 = that row decodes greedily
+  const float* temp_rows;
+  const int32_t* topk_rows;
+  const float* topp_rows;
+  const uint32_t* seed_rows;
 };
 
 __device__ __forceinline__ uint32_t smix32(uint32_t x) {
@@ -85,6 +91,36 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
   const float* logits = p.logits + (size_t)seq * p.stride;
   const int64_t V = p.vocab;
   const int32_t step = p.step ? p.step[seq] : 0;     // draw counter; read before the first barrier, rewritten at the very end
+  float inv_temp = p.inv_temp, top_p = p.top_p;
+  int top_k = p.top_k;
+  uint32_t seed = p.seed, seq_salt = (uint32_t)seq;
+  if (p.temp_rows) {
+    const float tr = p.temp_rows[seq];
+    if (!(tr > 0.f)) {                               // a greedy row among sampling ones: torch.argmax's token, same side effects
+      __shared__ float gsv[16];
+      __shared__ int64_t gsi[16];
+      float best;
+      int64_t bi;
+      block_argmax_first(logits, V, gsv, gsi, best, bi);
+      if (t == 0) {
+        const int64_t tok = bi + p.vocab_offset;
+        if (p.token) p.token[seq] = tok;
+        if (p.token_logit) p.token_logit[seq] = best;
+        if (p.out_tokens && p.step && (p.out_stride == 0 || step < p.out_stride)) p.out_tokens[(size_t)seq * p.out_stride + step] = tok;
+        if (p.step) p.step[seq] = step + 1;
+        if (p.pos && p.pos[seq] >= 0 && (p.pos_limit <= 0 || p.pos[seq] < p.pos_limit)) p.pos[seq] += 1;
+        if (p.n_kept) p.n_kept[seq] = 1;
+        if (p.kept_mass) p.kept_mass[seq] = 0.f;
+      }
+      return;
+    }
+    inv_temp = 1.0f / tr;
+    top_p = p.topp_rows ? p.topp_rows[seq] : 1.0f;
+    if (!(top_p > 0.f) || top_p > 1.0f) top_p = 1.0f;
+    top_k = p.topk_rows ? p.topk_rows[seq] : 0;
+    seed = p.seed_rows ? p.seed_rows[seq] : 0u;
+    seq_salt = 0u;                                   // the row's own seed identifies the request: its tokens do not depend on the slot
+  }
 
   // ---- max
   float m = -INFINITY;
@@ -99,8 +135,8 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
 
   // ---- top-k: the k-th largest logit by count (key of the cut; everything >= it is kept)
   uint32_t k_cut = 0;                                   // order_key >= 0 keeps everything
-  if (p.top_k > 0 && (int64_t)p.top_k < V) {
-    unsigned long long want = (unsigned long long)p.top_k;
+  if (top_k > 0 && (int64_t)top_k < V) {
+    unsigned long long want = (unsigned long long)top_k;
     uint32_t prefix = 0;
     const int shifts[3] = {21, 10, 0};
     const int widths[3] = {11, 11, 10};
@@ -124,7 +160,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
   }
 
   // ---- Z over the top-k set, as fixed point
-  const float it = p.inv_temp;
+  const float it = inv_temp;
   unsigned long long zq = 0;
   for (int64_t i = t; i < V; i += 1024) {
     const float l = logits[i];
@@ -141,8 +177,8 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
 
   // ---- top-p: the cut e* by mass
   uint32_t e_cut = 0;                                   // float bits of e* (e >= 0: bit order == value order)
-  if (p.top_p < 1.0f && zq > 0) {
-    unsigned long long want = (unsigned long long)((double)p.top_p * (double)zq);
+  if (top_p < 1.0f && zq > 0) {
+    unsigned long long want = (unsigned long long)((double)top_p * (double)zq);
     if (want < 1) want = 1;
     if (want > zq) want = zq;
     uint32_t prefix = 0;
@@ -193,7 +229,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
   int kept = 0;
 #pragma unroll
   for (int w = 0; w < 16; ++w) { total += wave_tot[w]; kept += cnt_red[w]; }
-  const uint32_t r = smix32(p.seed ^ smix32((uint32_t)seq * 0x9e3779b9u + (uint32_t)step * 0x85ebca6bu + 0x68bc21ebu)) >> 8;
+  const uint32_t r = smix32(seed ^ smix32(seq_salt * 0x9e3779b9u + (uint32_t)step * 0x85ebca6bu + 0x68bc21ebu)) >> 8;
   // target in [0, total): (total * r) >> 24
   const unsigned long long target = __umul64hi(total, (unsigned long long)r << 40);
   int my_wave = -1;
@@ -255,13 +291,14 @@ extern "C" int chatts_sample_batched(const float* logits, int batch, int64_t log
                                      int64_t out_stride, int32_t* step_dev, int32_t* pos_dev, int pos_limit,
                                      chatts_stream_t stream) {
   CHATTS_REQUIRE(logits && sa && vocab > 0 && batch >= 1 && logits_stride >= vocab, CHATTS_E_BADARG, "sample: bad arguments");
-  CHATTS_REQUIRE(sa->temperature > 0.f && sa->top_p > 0.f, CHATTS_E_BADARG,
+  CHATTS_REQUIRE(sa->temperature_rows || (sa->temperature > 0.f && sa->top_p > 0.f), CHATTS_E_BADARG,
                  "sample: temperature %g and top_p %g must be positive (temperature 0 = greedy: call chatts_argmax)",
                  (double)sa->temperature, (double)sa->top_p);
   CHATTS_REQUIRE(batch == 1 || out_tokens == nullptr || out_stride > 0, CHATTS_E_BADARG, "sample: out_stride missing");
   SampleParams p;
   p.logits = logits; p.stride = logits_stride; p.vocab = vocab; p.vocab_offset = vocab_offset;
-  p.inv_temp = 1.0f / sa->temperature; p.top_p = sa->top_p; p.top_k = sa->top_k; p.seed = sa->seed;
+  p.inv_temp = sa->temperature > 0.f ? 1.0f / sa->temperature : 1.0f; p.top_p = sa->top_p; p.top_k = sa->top_k; p.seed = sa->seed;
+  p.temp_rows = sa->temperature_rows; p.topk_rows = sa->top_k_rows; p.topp_rows = sa->top_p_rows; p.seed_rows = sa->seed_rows;
   p.token = token; p.token_logit = token_logit; p.out_tokens = out_tokens; p.out_stride = out_stride;
   p.step = step_dev; p.pos = pos_dev; p.pos_limit = pos_limit; p.n_kept = sa->n_kept; p.kept_mass = sa->kept_mass;
   hipLaunchKernelGGL(sample_kernel, dim3(batch), dim3(1024), 0, as_stream(stream), p);

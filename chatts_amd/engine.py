@@ -6,8 +6,10 @@ into free cache slots between decode steps, advance together in one batched step
 they are produced.  One engine owns one model (= one GPU, or one TP rank group); it is driven by a single thread
 (`EngineThread`) because the HIP stream, the captured graphs and the slot state are not re-entrant.
 
-Sampling parameters are baked into the captured decode step, so the requests decoded together share one sampling
-configuration: a request with a different one waits until the running batch has drained.
+Sampling: with a model that keeps per-slot sampling settings on the device (`set_slot_sampling`, ChattsSamplingArgs.*_rows) requests
+with DIFFERENT temperature / top-k / top-p / seed decode together in one captured step - each slot's settings are written when the
+request is admitted; the step selects greedily as long as nobody samples.  With a model that only has one baked-in configuration
+(`set_sampling`) the requests decoded together share it: a request with a different one waits until the running batch has drained.
 """
 import queue
 import threading
@@ -62,21 +64,30 @@ class Engine:
         self.slots = [None] * self.nslots
         self.produced = [0] * self.nslots
         self.active_key = None
+        self.mixed = hasattr(model, "set_slot_sampling")   # per-slot sampling settings on the device: no sampling groups
         self._since_sync = 0
         self._rid = 0
         if self.nslots > 1:
             model.buf["pos_all"].fill_(-1)            # every slot starts parked
 
     # ---- requests ---------------------------------------------------------------------------------
-    def add_request(self, prompt, timeseries=None, max_tokens=64, temperature=0.0, top_p=1.0, top_k=0, seed=0,
+    def add_request(self, prompt, timeseries=None, max_tokens=64, temperature=0.0, top_p=1.0, top_k=0, seed=None,
                     stop_token_ids=None, ignore_eos=False, on_tokens=None):
+        """seed None: per-slot mode gives every request its own stream (a hash of its arrival number - vLLM's seed=None means "not
+        reproducible across requests"; here two identical prompts still differ, and a rerun of the same arrival order repeats);
+        grouped mode uses 0 (requests that decode together must share ONE configuration there)."""
         validate_sampling(max_tokens, temperature, top_p, top_k)
+        if seed is None:
+            seed = ((self._rid + 1) * 2654435761) & 0xFFFFFFFF if self.mixed else 0
         e = self.model.config.eos_token_id
         eos = [] if ignore_eos else (list(e) if isinstance(e, (list, tuple)) else [e])
         eos += list(stop_token_ids or [])
         key = None if not temperature else (float(temperature), max(int(top_k or 0), 0), float(top_p), int(seed))
         self._rid += 1
         r = Request(self._rid, prompt, list(timeseries or []), max_tokens, key, eos, on_tokens)
+        r.sampling = (0.0, 0, 1.0, 0) if key is None else key
+        if self.mixed:
+            r.sampling_key = "rows" if key is not None else None     # one group: who samples is a per-slot matter
         self.waiting.append(r)
         return r
 
@@ -93,9 +104,20 @@ class Engine:
     def _apply_sampling(self, key):
         if key is None:
             self.model.set_sampling(0.0)
+        elif key == "rows":
+            self.model.set_sampling_rows()
         else:
             self.model.set_sampling(key[0], key[1], key[2], key[3])
         self.active_key = key
+
+    def _mixed_mode(self):
+        """Per-slot mode: the step draws per row (greedy rows included) while any running or waiting request samples, and goes back
+        to the plain argmax tail when nobody does.  Every slot's settings are current at all times, so the switch is safe whenever."""
+        want = "rows" if (any(r is not None and r.sampling_key for r in self.slots) or
+                          (self.prefilling is not None and self.prefilling[0].sampling_key) or
+                          any(q.sampling_key for q in self.waiting)) else None
+        if want != self.active_key:
+            self._apply_sampling(want)
 
     def _emit(self, r, finished, reason=None):
         new = r.tokens[r.sent:]
@@ -113,7 +135,9 @@ class Engine:
         done = []
         # (a prompt that is being prefilled in chunks draws its first token with the CURRENT configuration: it counts as running)
         running = any(s is not None for s in self.slots) or self.prefilling is not None
-        while not running and self.waiting and self.waiting[0].sampling_key != self.active_key:
+        if self.mixed:
+            self._mixed_mode()
+        while not self.mixed and not running and self.waiting and self.waiting[0].sampling_key != self.active_key:
             try:
                 self._apply_sampling(self.waiting[0].sampling_key)
             except Exception as e:                       # a configuration the library refuses fails THAT request, not the engine
@@ -140,13 +164,16 @@ class Engine:
             # one (it joins when the batch has drained) - but only `max_bypass` times, or a steady stream of same-key arrivals
             # would starve it
             head = self.waiting[0]
-            if head.sampling_key != self.active_key and head.bypassed >= self.max_bypass:
-                break
-            cands = [q for q in self.waiting if q.sampling_key == self.active_key][:len(free)]
-            if not cands:
-                break
-            if head.sampling_key != self.active_key:
-                head.bypassed += len(cands)
+            if self.mixed:
+                cands = list(self.waiting)[:len(free)]
+            else:
+                if head.sampling_key != self.active_key and head.bypassed >= self.max_bypass:
+                    break
+                cands = [q for q in self.waiting if q.sampling_key == self.active_key][:len(free)]
+                if not cands:
+                    break
+                if head.sampling_key != self.active_key:
+                    head.bypassed += len(cands)
             ready = []
             for r in cands:                              # tokenise / sp-encode once per request
                 if getattr(r, "_enc", None) is None:
@@ -185,6 +212,8 @@ class Engine:
                 free.remove(s)
                 items.append((s, ids, ser, lens, r.max_tokens))
                 self.waiting.remove(r)
+                if self.mixed:                           # the slot's settings, before its first token is drawn
+                    m.set_slot_sampling(s, *r.sampling)
             try:
                 if len(items) > 1:
                     m._admit_packed(items)               # several short prompts: one packed prefill pass

@@ -722,6 +722,46 @@ class ChatTSForCausalLM:
         self._graph = None               # the captured steps have the old selection kernel baked in
         self._graph_batched = None
 
+    def _sampling_arrays(self):
+        if "samp_temp" not in self.buf:
+            dev, n = self.device, max(1, self.max_batch)
+            self.buf["samp_temp"] = torch.zeros(n, dtype=torch.float32, device=dev)     # 0 = the slot decodes greedily
+            self.buf["samp_topk"] = torch.zeros(n, dtype=torch.int32, device=dev)
+            self.buf["samp_topp"] = torch.ones(n, dtype=torch.float32, device=dev)
+            self.buf["samp_seed"] = torch.zeros(n, dtype=torch.int32, device=dev)       # (bit pattern of the uint32 seed)
+        return self.buf
+
+    def _rows_args(self, slot):
+        B = self._sampling_arrays()
+        return _lib.SamplingArgs(temperature=1.0, top_k=0, top_p=1.0, seed=0, n_kept=None, kept_mass=None,
+                                 temperature_rows=B["samp_temp"][slot:].data_ptr(), top_k_rows=B["samp_topk"][slot:].data_ptr(),
+                                 top_p_rows=B["samp_topp"][slot:].data_ptr(), seed_rows=B["samp_seed"][slot:].data_ptr())
+
+    def set_sampling_rows(self):
+        """Per-slot sampling (ChattsSamplingArgs.*_rows): every cache slot draws with its own (temperature, top_k, top_p, seed), read on
+        the device at run time from four small arrays - requests with different settings share one captured step, and
+        set_slot_sampling() changes a slot without re-capturing.  Slots start greedy (temperature 0)."""
+        if getattr(self, "_sampling_key", None) == "rows":
+            return
+        args = self._rows_args(0)
+        _lib.check(self.lib.chatts_decoder_set_sampling(self._decoder, C.byref(args)))
+        self._sampling, self._sampling_key = args, "rows"
+        self._graph = None
+        self._graph_batched = None
+
+    def set_slot_sampling(self, slot, temperature=0.0, top_k=0, top_p=1.0, seed=0):
+        """Sampling settings of the sequence in cache slot `slot`: used by every step in per-slot mode (set_sampling_rows), inert in
+        the other modes.  A plain device write - no re-capture."""
+        temperature = 0.0 if temperature is None else float(temperature)
+        if temperature < 0 or not (0.0 < top_p <= 1.0):
+            raise ValueError(f"temperature={temperature} must be >= 0 and top_p={top_p} in (0, 1]")
+        B = self._sampling_arrays()
+        B["samp_temp"][slot] = temperature
+        B["samp_topk"][slot] = max(int(top_k or 0), 0)
+        B["samp_topp"][slot] = float(top_p)
+        s32 = int(seed) & 0xFFFFFFFF
+        B["samp_seed"][slot] = s32 - (1 << 32) if s32 >= (1 << 31) else s32
+
     def _select_token(self):
         """logits of this rank -> next token in B['token'] (appended to out_tokens, step bumped) on every rank: greedy or the
         configured sampler, agreed across TP ranks by chatts_decoder_select_tokens ((max, idx) pairs / gathered logits)."""
@@ -1031,7 +1071,9 @@ class ChatTSForCausalLM:
         B["step_all"][slot] = 0
         sa = getattr(self, "_sampling", None)
         sa1 = None
-        if sa is not None:   # the batched steps draw with (seed, slot, step); this single-row call would see slot 0: fold the slot into the seed
+        if getattr(self, "_sampling_key", None) == "rows":
+            sa1 = self._rows_args(slot)          # this single-row call sees row 0: hand it the slot's entries
+        elif sa is not None:   # the batched steps draw with (seed, slot, step); this single-row call would see slot 0: fold the slot into the seed
             sa1 = _lib.SamplingArgs(temperature=sa.temperature, top_k=sa.top_k, top_p=sa.top_p,
                                     seed=(sa.seed ^ (0x51ED27 * (slot + 1))) & 0xFFFFFFFF, n_kept=None, kept_mass=None)
         _lib.check(self.lib.chatts_decoder_select_tokens(

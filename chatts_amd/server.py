@@ -80,7 +80,7 @@ def sampling_from_body(body, default_max_tokens=512):
     top_p = body.get("top_p")
     try:
         out = dict(max_tokens=int(mt), temperature=0.0 if temp is None else float(temp), top_p=1.0 if top_p is None else float(top_p),
-                   top_k=int(body.get("top_k") or 0), seed=int(body.get("seed") or 0),
+                   top_k=int(body.get("top_k") or 0), seed=None if body.get("seed") is None else int(body["seed"]),
                    stop_token_ids=[int(t) for t in (body.get("stop_token_ids") or [])], ignore_eos=bool(body.get("ignore_eos", False)))
     except (TypeError, ValueError) as e:
         raise ValueError(f"malformed sampling parameter: {e}")

@@ -307,6 +307,15 @@ typedef struct ChattsSamplingArgs {
   uint32_t seed;
   int32_t* n_kept;     /* optional diagnostics [batch]: size of the renormalised set ...            */
   float* kept_mass;    /* ... and its share of the (top-k) probability mass                          */
+  /* Per-row mode (optional): device arrays [batch], read by the kernel at run time - a captured decode step serves requests with
+   * DIFFERENT sampling settings, and a setting changes without re-capturing.  temperature_rows != NULL switches it on (the scalars
+   * above are then ignored): row b uses (temperature_rows[b], top_k_rows[b], top_p_rows[b], seed_rows[b]); temperature 0 = that row
+   * decodes greedily (torch.argmax's token); top_k_rows / top_p_rows / seed_rows may be NULL (off / off / 0).  The variate of a row
+   * is a hash of (seed_rows[b], step_dev[b]) only - not of b - so a request's tokens do not depend on the cache slot it landed in. */
+  const float* temperature_rows;
+  const int32_t* top_k_rows;
+  const float* top_p_rows;
+  const uint32_t* seed_rows;
 } ChattsSamplingArgs;
 int chatts_sample_batched(const float* logits, int batch, int64_t logits_stride, int64_t vocab, int64_t vocab_offset,
                           const ChattsSamplingArgs* args, int64_t* token, float* token_logit, int64_t* out_tokens,

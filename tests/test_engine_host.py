@@ -180,6 +180,44 @@ def test_sampling_groups_do_not_mix():
     assert m.sampling[-1][0] == 0.5 and len(out[66]) == 3
 
 
+def test_per_slot_sampling_lets_different_settings_decode_together():
+    """A model with per-slot sampling arrays (set_slot_sampling / set_sampling_rows): no sampling groups - requests with different
+    temperatures are admitted into one batch, every slot gets its request's settings before its first token, the step runs in per-row
+    mode only while somebody samples, and seed=None gives every request its own stream."""
+    class RowsModel(StubModel):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.slot_sampling, self.modes = {}, []
+
+        def set_slot_sampling(self, slot, *a):
+            self.slot_sampling[slot] = a
+
+        def set_sampling_rows(self):
+            self.modes.append("rows")
+
+        def set_sampling(self, *a):
+            self.modes.append("greedy" if not a[0] else a)
+
+    m = RowsModel(3, pack=False)
+    eng = Engine(m, _Proc(), sync_every=1)
+    assert eng.mixed
+    got = {}
+    cb = lambda r, new, fin: got.setdefault(r.rid, []).extend(new)
+    a = eng.add_request("A" * 10, max_tokens=4, on_tokens=cb)                                           # greedy
+    b = eng.add_request("B" * 10, max_tokens=4, temperature=0.7, top_p=0.9, seed=5, on_tokens=cb)
+    c = eng.add_request("C" * 10, max_tokens=4, temperature=0.2, top_k=40, on_tokens=cb)               # seed None
+    eng.step()
+    assert [r.rid for r in eng.slots] == [a.rid, b.rid, c.rid]                  # all three admitted together
+    assert m.slot_sampling[0] == (0.0, 0, 1.0, 0) and m.slot_sampling[1] == (0.7, 0, 0.9, 5)
+    assert m.slot_sampling[2][:3] == (0.2, 40, 1.0) and m.slot_sampling[2][3] not in (0, 5)
+    assert m.modes == ["rows"]
+    eng.run_until_done()
+    assert all(len(got[r.rid]) == 4 for r in (a, b, c))
+    d = eng.add_request("D" * 10, max_tokens=2, on_tokens=cb)      # nobody samples any more: back to the argmax tail
+    eng.run_until_done()
+    assert m.modes == ["rows", "greedy"] and len(got[d.rid]) == 2
+
+
 def test_block_pool_gate_defers_then_admits():
     pool = BlockPool(n_blocks=3, block_size=64, n_slots=3, blocks_per_slot=4)
     m = StubModel(max_batch=3, pool=pool, pack=True, t_max=64)

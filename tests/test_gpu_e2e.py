@@ -803,3 +803,42 @@ def test_engine_chunked_prefill_keeps_the_running_batch_decoding(kv_block):
                 produced_meanwhile += 1
     assert chunked_iterations >= 3 and produced_meanwhile >= 2            # > 250 prompt rows in 64-row chunks, decode went on
     assert out[0] == cases[0][3] and out[1] == cases[1][3]
+
+
+def test_engine_per_slot_sampling_mixed_requests_share_a_step():
+    """Requests with DIFFERENT sampling settings decode together (per-slot settings on the device, one captured step): the greedy
+    request still produces the oracle's tokens, and a sampled request produces exactly the tokens it produces ALONE with the same
+    seed - whatever slot it lands in and whoever decodes beside it."""
+    from chatts_amd.engine import Engine
+    cfg = cfgmod.preset("tiny-qwen2")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(5)
+    sd = osynth.state_dict(synth.all_specs(cfg), 21)
+    shapes = [[64], [100, 40], [30]]
+    reqs = []
+    for lengths in shapes:
+        series = [random_walk_series(rng, L) for L in lengths]
+        reqs.append((chat_prompt(lengths), series))
+    settings = [dict(), dict(temperature=0.8, top_p=0.9, seed=42), dict(temperature=0.3, top_k=30, seed=7)]
+
+    def run(order, max_batch):
+        m = ChatTSForCausalLM.from_synthetic(cfg, seed=21, max_ctx=512, max_prefill_tokens=512, max_batch=max_batch)
+        eng = Engine(m, proc, sync_every=3)
+        out = {}
+        for k in order:
+            eng.add_request(reqs[k][0], reqs[k][1], max_tokens=10, ignore_eos=True,
+                            on_tokens=lambda r, new, fin, k=k: out.setdefault(k, []).extend(new), **settings[k])
+        eng.run_until_done()
+        return out, m
+
+    together, m = run([0, 1, 2], 4)
+    assert m._sampling_key == "rows"                    # (the mode is revisited at the next step: a greedy-only batch drops it)
+    inp = proc(text=[reqs[0][0]], timeseries=reqs[0][1], return_tensors="pt")
+    want0 = pipeline.generate(cfg, sd, inp["input_ids"][0].tolist(), inp["timeseries"].numpy(), 10)["tokens"]
+    assert together[0] == want0                         # the greedy request among sampling neighbours
+    for k in (1, 2):
+        alone, _ = run([k], 2)                          # slot 0 of another engine, nobody beside it
+        assert alone[k] == together[k], k
+    other_order, _ = run([2, 0, 1], 4)                  # other slots, other neighbours
+    assert other_order == together
+    assert together[1] != together[2] and len(set(together[1])) > 1

@@ -137,3 +137,49 @@ def test_sampler_argument_errors(lib):
         tok = torch.zeros(1, dtype=torch.int64, device=DEV)
         rc = lib.chatts_sample_batched(logits.data_ptr(), 1, 64, 64, 0, C.byref(sa), tok.data_ptr(), None, None, 0, None, None, 0, st())
         assert rc == _lib.E_BADARG
+
+
+def test_per_row_sampling_parameters(lib):
+    """ChattsSamplingArgs.*_rows: every row draws with its own (temperature, top_k, top_p, seed) read from device arrays; a row with
+    temperature 0 decodes greedily (torch.argmax's token, ties -> first index); the variate of a row depends on (seed, step) only, so
+    the same settings give the same token in ANY row - and equal the scalar call's row 0."""
+    v = 152064
+    g = torch.Generator().manual_seed(11)
+    base = (torch.randn((1, v), generator=g) * 2.5)
+    logits = base.repeat(5, 1).to(DEV)
+    logits[3, 500] = 40.0; logits[3, 499] = 40.0                # greedy row with a tie
+    rows = [(0.7, 20, 0.9, 1234), (1.0, 0, 1.0, 77), (0.7, 20, 0.9, 1234), (0.0, 0, 1.0, 5), (0.2, 0, 0.5, 9)]
+    temp = torch.tensor([r[0] for r in rows], dtype=torch.float32, device=DEV)
+    topk = torch.tensor([r[1] for r in rows], dtype=torch.int32, device=DEV)
+    topp = torch.tensor([r[2] for r in rows], dtype=torch.float32, device=DEV)
+    seed = torch.tensor([r[3] for r in rows], dtype=torch.int32, device=DEV)
+    steps = [3, 3, 3, 0, 7]
+    b = len(rows)
+    tok = torch.full((b,), -1, dtype=torch.int64, device=DEV)
+    tl = torch.zeros(b, dtype=torch.float32, device=DEV)
+    step = torch.tensor(steps, dtype=torch.int32, device=DEV)
+    pos = torch.tensor([4, 4, -1, 4, 4], dtype=torch.int32, device=DEV)
+    out = torch.full((b, 8), -1, dtype=torch.int64, device=DEV)
+    sa = _lib.SamplingArgs(temperature=0.0, top_k=0, top_p=0.0, seed=0, n_kept=None, kept_mass=None, temperature_rows=temp.data_ptr(),
+                           top_k_rows=topk.data_ptr(), top_p_rows=topp.data_ptr(), seed_rows=seed.data_ptr())
+    _lib.check(lib.chatts_sample_batched(logits.data_ptr(), b, v, v, 0, C.byref(sa), tok.data_ptr(), tl.data_ptr(), out.data_ptr(), 8,
+                                         step.data_ptr(), pos.data_ptr(), 0, st()))
+    torch.cuda.synchronize()
+    tok = tok.cpu().numpy()
+    assert tok[0] == tok[2]                                      # same settings, same step, another row: the same token
+    assert tok[3] == 499 and float(tl[3]) == 40.0                # greedy row: first index of the maximum
+    assert step.tolist() == [4, 4, 4, 1, 8] and pos.tolist() == [5, 5, -1, 5, 5]
+    assert all(int(out[i, steps[i]]) == int(tok[i]) for i in range(b))
+    ln = logits.cpu().numpy()
+    for i in (0, 1, 4):                                          # each row valid under ITS settings (row salt 0 in per-row mode)
+        nk, km = _sample_rows_diag(lib, logits[i:i + 1], rows[i], steps[i])
+        _check_draw(ln[i], tok[i], rows[i][0], rows[i][1], rows[i][2], rows[i][3], 0, steps[i], nk, km)
+    # the scalar call draws row 0 with salt 0 too: identical token
+    t0 = _sample(lib, logits[:1], rows[0][0], rows[0][1], rows[0][2], rows[0][3], steps=[3])[0][0]
+    assert t0 == tok[0]
+
+
+def _sample_rows_diag(lib, logits1, row, step):
+    """kept-set diagnostics of one row through the scalar interface (same cuts as the per-row call)."""
+    _, _, nk, km = _sample(lib, logits1, row[0], row[1], row[2], row[3], steps=[step])
+    return nk[0], km[0]
