@@ -48,6 +48,9 @@ struct AttnParams {
 
 // rotate one 128-wide head held as (a = x[lane], b = x[lane+64]) by the wave; optional RMSNorm first
 __device__ __forceinline__ void norm_rope(float& a, float& b, const float* nw, float eps, float c, float s, int lane) {
+  // every instantiation of the decode attention (stand-alone, persistent step) must produce the SAME bits here: no contraction
+  // decisions left to the optimiser (seen: an unrelated statement after this call flipped one instantiation's a * c - b * s to an fma)
+#pragma clang fp contract(off)
   if (nw) {
     const float ss = wave_sum(a * a + b * b);
     const float rstd = rsqrtf(ss / (float)kHeadDim + eps);

@@ -520,7 +520,7 @@ __device__ __forceinline__ void helper_main(const MegaParams& p, const int b, co
     ap.pos0_dev = p.pos_dev; ap.pos0 = 0; ap.t = 1; ap.n_q = p.n_q; ap.n_kv = p.n_kv; ap.max_ctx = p.max_ctx;
     ap.n_splits = p.n_splits; ap.q_norm_w = (const float*)ML->q_norm; ap.k_norm_w = (const float*)ML->k_norm; ap.cos_tab = p.cos_tab; ap.sin_tab = p.sin_tab;
     ap.eps = p.eps; ap.seq_stride = 0; ap.table = p.kv_table; ap.log_block = p.kv_log_block; ap.table_stride = 0;
-    ap.out_hi = nullptr; ap.out_lo = nullptr;
+    ap.out_hi = nullptr; ap.out_lo = nullptr; ap.kv_round = 0;
     const int ph0 = layer * 6;
     unsigned long long* pr;
     {
