@@ -32,6 +32,7 @@ struct ChattsDecoder {
   int cur_seq = 0;          // sequence (KV-cache slot) the single-sequence entry points operate on
   bool chain = false;       // set by the entry points that run the layers back to back themselves (chatts_decoder_prefill,
                             // decode_step_batched): only then may a projection write the NEXT projection's normed operand
+  bool x_in_xn = false;     // batched step: o_proj left the residual stream in b.xn (ping-pong, see layer_part_batched); down_proj brings it back
   bool normed = false;      // planes 0 already hold RMSNorm(x) for the projection that comes next (written by the previous
                             // projection's fused epilogue): norm_into only binds them
   bool sampling = false;    // token selection of the decode steps: greedy argmax, or the sampler with `sa`
@@ -193,9 +194,15 @@ static int norm_into(ChattsDecoder* d, const float* norm_w, ChattsLinearArgs* la
 
 // The residual-updating projection (o_proj / down_proj, tp_world == 1) also produces the NEXT projection's operand:
 // RMSNorm(x) with `next_norm_w` as planes 0, when that projection will take the plane path for the same M.
+static bool gemm_post_norm_small_m() {
+  const char* e = getenv("CHATTS_POST_NORM_SMALL_M");
+  return !e || atoi(e) != 0;
+}
 static void request_post_norm(ChattsDecoder* d, ChattsLinearArgs* la, const float* next_norm_w, bool next_fp8) {
   if (!d->chain || d->cfg.tp_world > 1 || !next_norm_w || la->epilogue != CHATTS_EPI_RESID) return;
-  if (la->m < 64) return;     // the fused epilogue runs one workgroup per row: at batched-decode M it leaves the chip idle (measured slower)
+  // the fused epilogue runs one workgroup per row - fine for a prefill chunk; at batched-decode M it needs several workgroups per row,
+  // which re-read resid while others write c: only when the caller gave it a c that does not alias resid (layer_part_batched)
+  if (la->m < 64 && !(la->m <= 16 && la->c != la->resid && gemm_post_norm_small_m())) return;
   if (!planes_path(d, la->m, la->n, next_fp8)) return;
   la->post_norm_w = next_norm_w; la->post_norm_eps = d->cfg.rms_eps;
   la->post_hi = d->b.planes_hi; la->post_lo = d->b.planes_lo; la->ld_post = la->n;
@@ -421,7 +428,15 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     if (attn_planes) { la.a = nullptr; la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k; }
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
+    // The residual stream ping-pongs x -> xn (here) -> x (down_proj) inside a chained step, so that the post-norm epilogue may use
+    // several workgroups per row (they read resid columns other workgroups update: c must not alias resid).
+    d->x_in_xn = false;
+    if (!tp && d->chain && d->b.xn && batch <= 16 && planes_path(d, batch, H, lw.gate_up8 != nullptr)) {
+      la.c = d->b.xn;
+      d->x_in_xn = true;
+    }
     request_post_norm(d, &la, lw.post_norm, lw.gate_up8 != nullptr);
+    if (d->x_in_xn && !la.post_norm_w) { la.c = d->b.x; d->x_in_xn = false; }      // not fused after all: the norm launch reads x
     return chatts_linear(&la, stream);
   }
   la = ChattsLinearArgs{};
@@ -440,7 +455,8 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
   if (act_planes) { la.a = nullptr; la.a_hi = d->b.planes2_hi; la.a_lo = d->b.planes2_lo; la.ld_planes = c.inter; }
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
-  else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
+  else { la.c = d->b.x; la.resid = d->x_in_xn ? d->b.xn : d->b.x; la.epilogue = CHATTS_EPI_RESID; }
+  d->x_in_xn = false;
   request_post_norm(d, &la, layer + 1 < c.n_layers ? d->layers[layer + 1].input_norm : d->w.final_norm,
                     (layer + 1 < c.n_layers ? d->layers[layer + 1].qkv8 : d->w.lm_head8) != nullptr);
   return chatts_linear(&la, stream);

@@ -1064,6 +1064,74 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
   }
 }
 
+// The same kernel for FEW rows (batched decode, M <= 16): one workgroup per row leaves the chip idle (16 workgroups), so gridDim.y = Q
+// workgroups share a row.  Each of them sums the slabs of the WHOLE row - it needs the row's sum of squares, and forming it with the same
+// thread-to-column mapping as above keeps every bit - but stores c and the planes only for its own 256 / Q threads' columns.  The
+// re-read of the slabs by Q workgroups is L2 traffic (Q x sk x M x N x 4 bytes: 16 MB at Q = 8, sk = 6, 16 x 5120).  Because a
+// workgroup reads resid columns that another one updates, c must NOT alias resid here (the batched decoder ping-pongs x / xn).
+template <int kMaxIt>
+__global__ __launch_bounds__(256) void splitk_epilogue_norm_q_kernel(const float* __restrict__ ws, int sk, int m, int n,
+                                                                    const float* __restrict__ bias, const float* __restrict__ resid,
+                                                                    float* __restrict__ c, int ldc, int epilogue,
+                                                                    const float* __restrict__ scale, const float* __restrict__ norm_w,
+                                                                    float eps, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                                    int ldp) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const bool mine = (int)(threadIdx.x * gridDim.y / 256) == (int)blockIdx.y;
+  const size_t plane = (size_t)m * n;
+  f32x4 keep[kMaxIt];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < kMaxIt; ++it) {
+    const int col = threadIdx.x * 4 + it * 1024;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (col < n) {
+      // all slabs of this column group requested at once (sk <= 8, the clamp re-reads the last slab and the value is dropped): with
+      // 16 workgroups' worth of rows there is no other wave to hide a chain of sk dependent round trips behind
+      f32x4 t8[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        t8[s] = *reinterpret_cast<const f32x4*>(ws + (s < sk ? s : sk - 1) * plane + (size_t)row * n + col);
+      f32x4 tr = {0.f, 0.f, 0.f, 0.f};
+      if (epilogue == CHATTS_EPI_RESID) tr = *reinterpret_cast<const f32x4*>(resid + (size_t)row * ldc + col);
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        if (s < sk) { v.x += t8[s].x; v.y += t8[s].y; v.z += t8[s].z; v.w += t8[s].w; }
+      if (scale) { const f32x4 t = *reinterpret_cast<const f32x4*>(scale + col); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+      if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + col); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (epilogue == CHATTS_EPI_RESID) { v.x = tr.x + v.x; v.y = tr.y + v.y; v.z = tr.z + v.z; v.w = tr.w + v.w; }
+      if (mine) *reinterpret_cast<f32x4*>(c + (size_t)row * ldc + col) = v;
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;        // same accumulation pattern as rmsnorm_kernel
+    }
+    keep[it] = v;
+  }
+  ss = block_sum<4>(ss, red);
+  const float rstd = rsqrtf(ss / (float)n + eps);
+  if (!mine) return;
+#pragma unroll
+  for (int it = 0; it < kMaxIt; ++it) {
+    const int col = threadIdx.x * 4 + it * 1024;
+    if (col >= n) continue;
+    const f32x4 v = keep[it];
+    const f32x4 g = *reinterpret_cast<const f32x4*>(norm_w + col);
+    const float o[4] = {g.x * (v.x * rstd), g.y * (v.y * rstd), g.z * (v.z * rstd), g.w * (v.w * rstd)};
+    {
+#pragma clang fp contract(off)   // lo must be the split of the ROUNDED product, as in rmsnorm_kernel<true>
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      bf16x4_t hv, lv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const __bf16 h = (__bf16)o[j];
+        hv[j] = h;
+        lv[j] = (__bf16)(o[j] - (float)h);
+      }
+      *reinterpret_cast<bf16x4_t*>(hi + (size_t)row * ldp + col) = hv;
+      *reinterpret_cast<bf16x4_t*>(lo + (size_t)row * ldp + col) = lv;
+    }
+  }
+}
+
 static int gemm_env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -1344,6 +1412,15 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
   if (p.fix_cnt) return CHATTS_OK;        // the epilogue ran inside the launch
   const bool post_norm = a->post_norm_w != nullptr;
   if (sk > 1 && post_norm) {        // epilogue + the consumer's RMSNorm in one row-wise launch
+    const int qsplit = gemm_env_int("CHATTS_EPI_NORM_Q", 8);
+    if (a->m <= 16 && qsplit > 1 && qsplit <= 256 && p.sk_T == 0 && sk <= 8 && a->n <= 8192 && a->n % 4 == 0 &&
+        (a->epilogue != CHATTS_EPI_RESID || a->c != a->resid)) {          // few rows: Q workgroups per row (c must not alias resid)
+      hipLaunchKernelGGL((splitk_epilogue_norm_q_kernel<8>), dim3(a->m, qsplit), dim3(256), 0, s,
+                         reinterpret_cast<const float*>(a->workspace), sk, a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue,
+                         a->w8 ? a->w8_scale : nullptr, a->post_norm_w, a->post_norm_eps, a->post_hi, a->post_lo, a->ld_post);
+      CHATTS_CHECK_LAUNCH("splitk_epilogue_norm_q");
+      return CHATTS_OK;
+    }
     hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(a->m), dim3(256), 0, s, reinterpret_cast<const float*>(a->workspace), sk,
                        a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue, a->w8 ? a->w8_scale : nullptr, a->post_norm_w,
                        a->post_norm_eps, a->post_hi, a->post_lo, a->ld_post, p.sk_T, p.sk_nk);
