@@ -1029,9 +1029,18 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
   for (int col = threadIdx.x * 4; col < n; col += 1024) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (sk_T > 0) sk = sk_tile_nseg((col / 256) * ((m + 127) / 128) + row / 128, sk_T, sk_nk);    // stream-K: slabs of THIS tile
-    for (int s = 0; s < sk; ++s) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(ws + s * plane + (size_t)row * n + col);
-      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    if (sk <= 4) {          // the usual split counts: all slabs requested at once, summed in split order (same sums, one round trip)
+      f32x4 t4[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) t4[s] = *reinterpret_cast<const f32x4*>(ws + (s < sk ? s : sk - 1) * plane + (size_t)row * n + col);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (s < sk) { v.x += t4[s].x; v.y += t4[s].y; v.z += t4[s].z; v.w += t4[s].w; }
+    } else {
+      for (int s = 0; s < sk; ++s) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(ws + s * plane + (size_t)row * n + col);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
     }
     if (scale) { const f32x4 t = *reinterpret_cast<const f32x4*>(scale + col); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
     if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + col); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
