@@ -132,6 +132,27 @@ inline int kv_log_block(int block_size) {
   return -1;
 }
 
+// What rope_kv_kernel does to the raw qkv rows of a prefill chunk: per head optional RMSNorm (Qwen3 q_norm / k_norm), rotation by the
+// token's position, q back in place, K / V rows into the cache.  Also carried by the qkv projection's split-K epilogue
+// (splitk_epilogue_rope_kernel): ONE definition of the arithmetic, contraction off, so both forms write the same bits.
+struct RopeFuse {
+  int n_q, n_kv;
+  const float* q_norm_w;
+  const float* k_norm_w;
+  float eps;
+  const float* cos_tab;
+  const float* sin_tab;
+  int pos0;
+  const int32_t* pos0_dev;
+  float* kc;
+  float* vc;
+  KvLayout kvl;
+  int kv_round;
+};
+// one 128-wide head of one token, held by a wave as (a, b) = elements (lane, lane + 64); h = head index in [q | k | v] order;
+// `row` = this head's 128 floats of the qkv buffer (q is written back there)
+__device__ __forceinline__ void rope_kv_head(float a, float b, int h, int pos, int lane, float* row, const RopeFuse& r);
+
 inline hipStream_t as_stream(chatts_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 int device_cus();
@@ -186,5 +207,35 @@ __device__ __forceinline__ float kv_round_f(float v, int mode) {
   return v;
 }
 inline int kv_round_mode() { const char* e = getenv("CHATTS_KV_ROUND"); return e ? atoi(e) : 0; }
+
+__device__ __forceinline__ void rope_kv_head(float a, float b, int h, int pos, int lane, float* row, const RopeFuse& r) {
+#pragma clang fp contract(off)
+  if (h >= r.n_q + r.n_kv) {   // v head: straight copy into the cache
+    float* dst = r.vc + kv_tile_off(r.kvl, h - r.n_q - r.n_kv, pos);
+    dst[lane] = kv_round_f(a, r.kv_round);
+    dst[lane + 64] = kv_round_f(b, r.kv_round);
+    return;
+  }
+  const float* nw = h < r.n_q ? r.q_norm_w : r.k_norm_w;
+  if (nw) {
+    const float ss = wave_sum(a * a + b * b);
+    const float rstd = rsqrtf(ss / (float)kHeadDim + r.eps);
+    a = nw[lane] * (a * rstd);
+    b = nw[lane + 64] * (b * rstd);
+  }
+  const float c = r.cos_tab[(size_t)pos * 64 + lane], s = r.sin_tab[(size_t)pos * 64 + lane];
+  const float oa = a * c - b * s, ob = b * c + a * s;
+  if (h < r.n_q) {
+    row[lane] = oa;
+    row[lane + 64] = ob;
+  } else {
+    float* dst = r.kc + kv_tile_off(r.kvl, h - r.n_q, pos);
+    dst[lane] = kv_round_f(oa, r.kv_round);
+    dst[lane + 64] = kv_round_f(ob, r.kv_round);
+  }
+}
+// host: validate the arguments of chatts_rope_kv_write and fill a RopeFuse (elementwise.hip)
+int rope_fuse_prepare(int t, int n_q, int n_kv, const float* q_norm_w, const float* k_norm_w, float norm_eps, const float* cos_tab,
+                      const float* sin_tab, int pos0, const int32_t* pos0_dev, const ChattsKvCache* cache, RopeFuse* out);
 
 }  // namespace chatts

@@ -11,7 +11,7 @@
 
 namespace chatts {
 int launch_gemv(const ChattsLinearArgs* a, hipStream_t s);
-int launch_gemm(const ChattsLinearArgs* a, hipStream_t s);
+int launch_gemm(const ChattsLinearArgs* a, hipStream_t s, const RopeFuse* rope = nullptr, bool* rope_done = nullptr);
 int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w, const float* k_norm_w,
                                   float norm_eps, const float* cos_tab, const float* sin_tab, int pos, const int32_t* pos_dev,
                                   const ChattsKvCache* cache, size_t seq_stride, float* out, uint16_t* out_hi, uint16_t* out_lo,
@@ -51,7 +51,12 @@ static int64_t embed_offset(const ChattsDecoder* d) { return d->cfg.embed_rows >
 
 extern "C" size_t chatts_linear_workspace(int m, int n, int k) { return gemm_workspace(m, n, k); }
 
-extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) {
+static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const RopeFuse* rope, bool* rope_done);
+extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) { return linear_impl(a, stream, nullptr, nullptr); }
+
+// rope / rope_done: the qkv projection of a prefill chunk may carry rope_kv_kernel's work in its split-K epilogue (*rope_done says
+// whether it did; otherwise the caller launches chatts_rope_kv_write as before)
+static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const RopeFuse* rope, bool* rope_done) {
   CHATTS_REQUIRE(a != nullptr, CHATTS_E_BADARG, "linear: null args");
   CHATTS_REQUIRE(a->m >= 0 && a->n > 0 && a->k > 0, CHATTS_E_BADARG, "linear: bad sizes m=%d n=%d k=%d", a->m, a->n, a->k);
   if (a->m == 0) return CHATTS_OK;
@@ -90,7 +95,7 @@ extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) 
                    CHATTS_E_BADARG, "linear: post-norm planes need M > 1, float32 c, EPI_NONE / EPI_RESID, both planes, ld_post >= N");
   if (a->m == 1 && a->epilogue != CHATTS_EPI_GELU) return launch_gemv(a, as_stream(stream));
   CHATTS_REQUIRE(a->norm_w == nullptr, CHATTS_E_BADARG, "linear: fused RMSNorm is only available for M == 1");
-  return launch_gemm(a, as_stream(stream));
+  return launch_gemm(a, as_stream(stream), rope, rope_done);
 }
 
 extern "C" int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, chatts_bf16* lo, int ld_planes,
@@ -303,8 +308,17 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     } else {
       if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
     }
-    if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, d->cur_seq);
+    bool rope_done = false;
+    const bool rope_fuse = !(getenv("CHATTS_ROPE_FUSE") && atoi(getenv("CHATTS_ROPE_FUSE")) == 0);
+    if (t > 1 && rope_fuse) {   // prefill: the projection's split-K epilogue (when it has one) also rotates q / k and fills the cache
+      RopeFuse rf;
+      if ((rc = rope_fuse_prepare(t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, pos0, pos0_dev, &kc,
+                                  &rf)) != 0) return rc;
+      if ((rc = linear_impl(&la, stream, &rf, &rope_done)) != 0) return rc;
+    } else if ((rc = chatts_linear(&la, stream)) != 0) {
+      return rc;
+    }
     bool attn_out_planes = false;
     if (t == 1) {   // decode: RoPE + cache write fused into the attention kernel
       if ((rc = chatts_attention_decode_fused(d->b.qkv, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
@@ -313,8 +327,8 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
         return rc;
       }
     } else {
-      if ((rc = chatts_rope_kv_write(d->b.qkv, t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
-                                     d->w.sin_tab, pos0, pos0_dev, &kc, stream)) != 0) return rc;
+      if (!rope_done && (rc = chatts_rope_kv_write(d->b.qkv, t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
+                                                   d->w.sin_tab, pos0, pos0_dev, &kc, stream)) != 0) return rc;
       // long chunks: split the keys over 2 workgroups per (query tile, head) - one sequence has too few waves otherwise
       static const int env_ks = getenv("CHATTS_ATTN_KSPLIT") ? atoi(getenv("CHATTS_ATTN_KSPLIT")) : 0;
       // (the bf16x3 kernel is fast enough per tile that the second key split + its combine launch no longer pay: 73.3 us

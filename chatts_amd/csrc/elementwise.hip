@@ -51,44 +51,15 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 //   out[l]    = x[l]    * cos[l] - x[l+64] * sin[l]
 //   out[l+64] = x[l+64] * cos[l] + x[l]    * sin[l]      (rotate_half / apply_rotary_pos_emb)
 // k (rotated) and v rows go to the cache at position pos; q is rotated in place.
-__global__ __launch_bounds__(256) void rope_kv_kernel(float* __restrict__ qkv, int t, int n_q, int n_kv,
-                                                     const float* __restrict__ q_norm_w,
-                                                     const float* __restrict__ k_norm_w, float eps,
-                                                     const float* __restrict__ cos_tab,
-                                                     const float* __restrict__ sin_tab, int pos0,
-                                                     const int32_t* __restrict__ pos0_dev, float* __restrict__ kc,
-                                                     float* __restrict__ vc, KvLayout kvl, int kv_round) {
-  const int heads = n_q + 2 * n_kv;
+__global__ __launch_bounds__(256) void rope_kv_kernel(float* __restrict__ qkv, int t, RopeFuse r) {
+  const int heads = r.n_q + 2 * r.n_kv;
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (gw >= t * heads) return;
   const int tok = gw / heads, h = gw - tok * heads;
-  const int pos = (pos0_dev ? *pos0_dev : pos0) + tok;
+  const int pos = (r.pos0_dev ? *r.pos0_dev : r.pos0) + tok;
   float* row = qkv + ((size_t)tok * heads + h) * kHeadDim;
-  float a = row[lane], b = row[lane + 64];
-  if (h >= n_q + n_kv) {   // v head: straight copy into the cache
-    float* dst = vc + kv_tile_off(kvl, h - n_q - n_kv, pos);
-    dst[lane] = kv_round_f(a, kv_round);
-    dst[lane + 64] = kv_round_f(b, kv_round);
-    return;
-  }
-  const float* nw = h < n_q ? q_norm_w : k_norm_w;
-  if (nw) {
-    const float ss = wave_sum(a * a + b * b);
-    const float rstd = rsqrtf(ss / (float)kHeadDim + eps);
-    a = nw[lane] * (a * rstd);
-    b = nw[lane + 64] * (b * rstd);
-  }
-  const float c = cos_tab[(size_t)pos * 64 + lane], s = sin_tab[(size_t)pos * 64 + lane];
-  const float oa = a * c - b * s, ob = b * c + a * s;
-  if (h < n_q) {
-    row[lane] = oa;
-    row[lane + 64] = ob;
-  } else {
-    float* dst = kc + kv_tile_off(kvl, h - n_q, pos);
-    dst[lane] = kv_round_f(oa, kv_round);
-    dst[lane + 64] = kv_round_f(ob, kv_round);
-  }
+  rope_kv_head(row[lane], row[lane + 64], h, pos, lane, row, r);
 }
 
 // ---- embedding gather + TS merge -------------------------------------------------------------------
@@ -327,14 +298,11 @@ extern "C" int chatts_rmsnorm_planes(const float* x, const float* w, chatts_bf16
   return CHATTS_OK;
 }
 
-extern "C" int chatts_rope_kv_write(float* qkv, int t, int n_q, int n_kv, const float* q_norm_w,
-                                    const float* k_norm_w, float norm_eps, const float* cos_tab,
-                                    const float* sin_tab, int pos0, const int32_t* pos0_dev,
-                                    const ChattsKvCache* cache, chatts_stream_t stream) {
+namespace chatts {
+int rope_fuse_prepare(int t, int n_q, int n_kv, const float* q_norm_w, const float* k_norm_w, float norm_eps, const float* cos_tab,
+                      const float* sin_tab, int pos0, const int32_t* pos0_dev, const ChattsKvCache* cache, RopeFuse* out) {
   CHATTS_REQUIRE(t >= 0 && n_q > 0 && n_kv > 0, CHATTS_E_BADARG, "rope_kv_write: bad sizes");
-  if (t == 0) return CHATTS_OK;
-  CHATTS_REQUIRE(qkv && cos_tab && sin_tab && cache && cache->k && cache->v, CHATTS_E_BADARG,
-                 "rope_kv_write: null pointer");
+  CHATTS_REQUIRE(cos_tab && sin_tab && cache && cache->k && cache->v, CHATTS_E_BADARG, "rope_kv_write: null pointer");
   CHATTS_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), CHATTS_E_BADARG,
                  "rope_kv_write: q_norm and k_norm must both be set or both be null");
   if (!pos0_dev)
@@ -347,9 +315,22 @@ extern "C" int chatts_rope_kv_write(float* qkv, int t, int n_q, int n_kv, const 
                    "rope_kv_write: block_size %d must be a power of two in 64..32768 that divides max_ctx %d", cache->block_size,
                    cache->max_ctx);
   }
+  *out = RopeFuse{n_q, n_kv, q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos0, pos0_dev, cache->k, cache->v, kvl, kv_round_mode()};
+  return CHATTS_OK;
+}
+}  // namespace chatts
+
+extern "C" int chatts_rope_kv_write(float* qkv, int t, int n_q, int n_kv, const float* q_norm_w,
+                                    const float* k_norm_w, float norm_eps, const float* cos_tab,
+                                    const float* sin_tab, int pos0, const int32_t* pos0_dev,
+                                    const ChattsKvCache* cache, chatts_stream_t stream) {
+  CHATTS_REQUIRE(t >= 0 && n_q > 0 && n_kv > 0, CHATTS_E_BADARG, "rope_kv_write: bad sizes");
+  if (t == 0) return CHATTS_OK;
+  CHATTS_REQUIRE(qkv != nullptr, CHATTS_E_BADARG, "rope_kv_write: null pointer");
+  RopeFuse r;
+  if (const int rc = rope_fuse_prepare(t, n_q, n_kv, q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos0, pos0_dev, cache, &r)) return rc;
   const int waves = t * (n_q + 2 * n_kv);
-  hipLaunchKernelGGL(rope_kv_kernel, dim3((waves + 3) / 4), dim3(256), 0, as_stream(stream), qkv, t, n_q, n_kv,
-                     q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos0, pos0_dev, cache->k, cache->v, kvl, kv_round_mode());
+  hipLaunchKernelGGL(rope_kv_kernel, dim3((waves + 3) / 4), dim3(256), 0, as_stream(stream), qkv, t, r);
   CHATTS_CHECK_LAUNCH("rope_kv_write");
   return CHATTS_OK;
 }

@@ -1141,6 +1141,33 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_q_kernel(const float
   }
 }
 
+// The qkv projection's split-K epilogue that also does rope_kv_kernel's work (prefill): one wave per (token, head) sums the head's
+// 128 columns over the slabs in split order, adds the bias - splitk_epilogue_kernel's arithmetic - and hands the two values per lane
+// to rope_kv_head: q rotated into c, K / V rows into the cache.  One pass over the [T, 7168] rows less per layer.
+__global__ __launch_bounds__(256) void splitk_epilogue_rope_kernel(const float* __restrict__ ws, int sk, int m, int n,
+                                                                  const float* __restrict__ bias, float* __restrict__ c, int ldc,
+                                                                  RopeFuse r) {
+  const int heads = r.n_q + 2 * r.n_kv;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (gw >= m * heads) return;
+  const int tok = gw / heads, h = gw - tok * heads;
+  const size_t plane = (size_t)m * n, at = (size_t)tok * n + h * kHeadDim + lane;
+  float a = 0.f, b = 0.f;
+  int s = 0;
+  for (; s + 4 <= sk; s += 4) {                  // four slabs in flight, summed in split order
+    float ta[4], tb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ta[u] = ws[(s + u) * plane + at]; tb[u] = ws[(s + u) * plane + at + 64]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a += ta[u]; b += tb[u]; }
+  }
+  for (; s < sk; ++s) { a += ws[s * plane + at]; b += ws[s * plane + at + 64]; }
+  if (bias) { a += bias[h * kHeadDim + lane]; b += bias[h * kHeadDim + lane + 64]; }
+  const int pos = (r.pos0_dev ? *r.pos0_dev : r.pos0) + tok;
+  rope_kv_head(a, b, h, pos, lane, c + (size_t)tok * ldc + h * kHeadDim, r);
+}
+
 static int gemm_env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -1336,7 +1363,7 @@ static int launch_dma(const GemmParams& p, const ChattsLinearArgs* a, int sk, hi
   return w32 ? launch_dma_t<false, true>(p, a, sk, s) : launch_dma_t<false, false>(p, a, sk, s);
 }
 
-int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
+int launch_gemm(const ChattsLinearArgs* a, hipStream_t s, const RopeFuse* rope, bool* rope_done) {
   int bm, sk;
   const bool stream = use_stream(a);
   const bool dma = !stream && use_dma(a);
@@ -1434,6 +1461,15 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s) {
                        a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue, a->w8 ? a->w8_scale : nullptr, a->post_norm_w,
                        a->post_norm_eps, a->post_hi, a->post_lo, a->ld_post, p.sk_T, p.sk_nk);
     CHATTS_CHECK_LAUNCH("splitk_epilogue_norm");
+    return CHATTS_OK;
+  }
+  if (sk > 1 && rope && rope_done && !post_norm && a->epilogue == CHATTS_EPI_NONE && !a->c_hi && !a->w8 && p.sk_T == 0 &&
+      a->n == (rope->n_q + 2 * rope->n_kv) * kHeadDim) {
+    const int waves = a->m * (rope->n_q + 2 * rope->n_kv);
+    hipLaunchKernelGGL(splitk_epilogue_rope_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, reinterpret_cast<const float*>(a->workspace),
+                       sk, a->m, a->n, a->bias, a->c, a->ldc, *rope);
+    CHATTS_CHECK_LAUNCH("splitk_epilogue_rope");
+    *rope_done = true;
     return CHATTS_OK;
   }
   if (sk > 1) {

@@ -140,3 +140,28 @@ def test_config5_fp8_batch16_full_width_4_layers_vs_oracle():
             assert e < LOGIT_TOL and _max_abs_over_max(g, w) < LOGIT_TOL, (s, i, e)
     assert len({tuple(t) for t in toks}) > 1          # the prompts really differ
     assert worst < 2e-4, worst
+
+
+@pytest.mark.parametrize("preset", ["chatts-14b", "chatts-8b"])
+def test_rope_in_the_qkv_epilogue_writes_the_same_bits(preset, monkeypatch):
+    """The qkv projection's split-K epilogue that also rotates q / k and fills the cache (splitk_epilogue_rope_kernel, prefill) ==
+    the separate epilogue + rope_kv_kernel launches: same K / V cache rows, same first-token logits, bit for bit (Qwen2 with
+    bias, Qwen3 with q_norm / k_norm; 14B / 8B widths so that the projection really splits K)."""
+    cfg = cfgmod.preset(preset, num_hidden_layers=2)
+    proc, prompt, series, lengths = bench.build_inputs(cfg, 8, 256)
+    inputs = proc(text=[prompt], timeseries=series, padding=True, return_tensors="pt")
+    ids = inputs["input_ids"][0].tolist()
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=3, max_ctx=1024, max_prefill_tokens=1024, enable_prefix_caching=False)
+    ser = inputs["timeseries"].cuda()
+    runs = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("CHATTS_ROPE_FUSE", fuse)
+        model.buf["kv_k"].fill_(float("nan")); model.buf["kv_v"].fill_(float("nan"))
+        toks, logits0 = model.generate_one(ids, ser, proc.last_lengths, 3, eos_token_id=None, return_logits=True)
+        torch.cuda.synchronize()
+        runs.append((toks, logits0.clone(), model.buf["kv_k"].clone(), model.buf["kv_v"].clone()))
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1])
+    for a, b in ((runs[0][2], runs[1][2]), (runs[0][3], runs[1][3])):
+        assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+    assert not torch.isnan(runs[1][2][..., :700, :]).all()
