@@ -35,9 +35,12 @@ def sp_stats(series):
 def sp_normalise(series):
     """-> (scaled float64 [L], mean, factor); scaled = (x-mean)/factor only when some |x-mean| >= 3."""
     x = np.asarray(series, dtype=np.float64)
-    mean, factor = sp_stats(x)
+    mean = np.mean(x)
     scaled = x - mean
-    if np.any(np.abs(scaled) >= 3.0):
+    peak = np.max(np.abs(scaled)) if x.size else 0.0      # one pass: any(|dev| >= 3) <=> max|dev| >= 3 (NaN compares false both ways)
+    factor = 1.0
+    if peak >= 3.0:
+        factor = peak / 3.0
         scaled = scaled / factor
     return scaled, mean, factor
 
