@@ -133,13 +133,15 @@ def roofline_gate_up(model, reps=2, m=1):
                                      ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU, workspace=None, workspace_bytes=0,
                                      w8=_lib.ptr(lw.get("gate_up8")), w8_scale=_lib.ptr(lw.get("gate_up8_scale")), ldw8=H,
                                      w4=_lib.ptr(lw.get("gate_up4")), w4_sz=_lib.ptr(lw.get("gate_up4_sz")), ldw4=H // 2,
-                                     w4_group=model.int4_group)
+                                     w4_group=model.int4_group,
+                                     w8_format=_lib.W8_INT8 if model.weight_format == "int8" else _lib.W8_FP8)
             else:
                 la = _lib.LinearArgs(a=None, w=lw["gate_up"].data_ptr(), bias=None, resid=None, c=None, norm_w=None, norm_eps=0.0,
                                      m=m, n=n, k=H, lda=H, ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU, workspace=ws.data_ptr(),
                                      workspace_bytes=wsb, w8=_lib.ptr(lw.get("gate_up8")), w8_scale=_lib.ptr(lw.get("gate_up8_scale")),
                                      ldw8=H, a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=H, c_hi=chi.data_ptr(),
-                                     c_lo=clo.data_ptr(), ld_cplanes=plan.inter)
+                                     c_lo=clo.data_ptr(), ld_cplanes=plan.inter,
+                                     w8_format=_lib.W8_INT8 if model.weight_format == "int8" else _lib.W8_FP8)
             _lib.check(lib.chatts_linear(la, stream.cuda_stream))
 
     sweep()
@@ -438,7 +440,7 @@ def bench_batched(args, model, cfg, comm, world, device):
                   f"{args.series}x{args.length}-step TS prompts, TP=N",
         "value": B * args.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16" if args.weights == "bf16" else "fp8-e4m3 weights (pow2 row scales, exactly representable in bf16), bf16x2 MFMA / f32 accumulate",
+        "dtype": "bf16" if args.weights == "bf16" else f"{'int8' if args.weights == 'int8' else 'fp8-e4m3'} weights (pow2 row scales, exactly representable in bf16), bf16x2 MFMA / f32 accumulate",
         "data": "synthetic",
         "config": {"workload": label, "model": args.model, "batch": B, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
                    "parallelism": f"tp{world}", "decode_graph": model.graph_capturable(), "kv_block": model.kv_block_size or None,
@@ -547,7 +549,7 @@ def main():
     ap.add_argument("--kv-block", type=int, default=0, help="block-paged KV cache with this many positions per block (0 = one "
                     "contiguous cache per slot, the default)")
     ap.add_argument("--no-pack", action="store_true", help="--batch: admit the prompts one by one instead of packed prefill passes")
-    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "int4"],
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "int8", "int4"],
                     help="fp8 = BASELINE.json config 5 weight format, int4 = the GPTQ-Int4 checkpoint's (NOT the headline: separate workloads)")
     ap.add_argument("--launch-check", action="store_true", help="only prove the N-rank launch path (no model): rank 0 prints the world it saw")
     args = ap.parse_args()
@@ -695,6 +697,7 @@ def main():
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": {"bf16": "bf16", "fp8": "fp8-e4m3 weights (pow2 row scales), f32 math",
+                  "int8": "int8 weights (pow2 row scales: a lossless encoding of the bf16 matrix), f32 math",
                   "int4": "int4 codes + fp16 group scales (round-to-nearest, groups of 128) = a bf16 matrix, f32 math"}[args.weights], "data": "synthetic",
         "config": {"workload": workload_name(args, world),
                    "model": args.model, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),

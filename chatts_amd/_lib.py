@@ -30,6 +30,7 @@ class TsWeights(C.Structure):
 
 
 TILE_COUNTERS = 4096      # CHATTS_TILE_COUNTERS
+W8_FP8, W8_INT8 = 0, 1     # ChattsLinearArgs.w8_format
 
 
 class LinearArgs(C.Structure):
@@ -40,7 +41,8 @@ class LinearArgs(C.Structure):
                 ("a_hi", c_void_p), ("a_lo", c_void_p), ("ld_planes", c_int),
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("ld_cplanes", c_int),
                 ("post_norm_w", c_void_p), ("post_norm_eps", c_float), ("post_hi", c_void_p), ("post_lo", c_void_p), ("ld_post", c_int),
-                ("w4", c_void_p), ("w4_sz", c_void_p), ("ldw4", c_int), ("w4_group", c_int), ("tile_counters", c_void_p)]
+                ("w4", c_void_p), ("w4_sz", c_void_p), ("ldw4", c_int), ("w4_group", c_int), ("tile_counters", c_void_p),
+                ("w8_format", c_int)]
 
 
 class KvCache(C.Structure):
@@ -71,7 +73,7 @@ class SamplingArgs(C.Structure):
 class DecoderConfig(C.Structure):
     _fields_ = [("hidden", c_int), ("n_layers", c_int), ("n_q", c_int), ("n_kv", c_int), ("head_dim", c_int),
                 ("inter", c_int), ("vocab_local", c_int64), ("vocab_offset", c_int64), ("rms_eps", c_float),
-                ("max_ctx", c_int), ("max_pos", c_int), ("tp_world", c_int), ("embed_rows", c_int64), ("embed_offset", c_int64)]
+                ("max_ctx", c_int), ("max_pos", c_int), ("tp_world", c_int), ("embed_rows", c_int64), ("embed_offset", c_int64), ("w8_format", c_int)]
 
 
 class DecoderWeights(C.Structure):

@@ -303,7 +303,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if (t == 1) {
       la.a = d->b.x; la.norm_w = lw.input_norm; la.norm_eps = c.rms_eps;
-      la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H;
+      la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H; la.w8_format = d->cfg.w8_format;
       la.w4 = lw.qkv4; la.w4_sz = lw.qkv4_sz; la.ldw4 = H / 2; la.w4_group = lw.w4_group;
     } else {
       if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
@@ -349,7 +349,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if (t == 1) {
-      la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k;
+      la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k; la.w8_format = d->cfg.w8_format;
       la.w4 = lw.o4; la.w4_sz = lw.o4_sz; la.ldw4 = la.k / 2; la.w4_group = lw.w4_group;
     } else if (attn_out_planes) {              // written by the attention kernel
       la.a = nullptr; la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k;
@@ -369,7 +369,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if (t == 1) {
     la.a = d->b.x; la.norm_w = lw.post_norm; la.norm_eps = c.rms_eps;
-    la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H;
+    la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H; la.w8_format = d->cfg.w8_format;
     la.w4 = lw.gate_up4; la.w4_sz = lw.gate_up4_sz; la.ldw4 = H / 2; la.w4_group = lw.w4_group;
   } else {
     if ((rc = norm_into(d, lw.post_norm, &la, stream)) != 0) return rc;
@@ -382,7 +382,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if (t == 1) {
-    la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter;
+    la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter; la.w8_format = d->cfg.w8_format;
     la.w4 = lw.down4; la.w4_sz = lw.down4_sz; la.ldw4 = c.inter / 2; la.w4_group = lw.w4_group;
   }
   if (act_planes) { la.a = nullptr; la.a_hi = d->b.planes2_hi; la.a_lo = d->b.planes2_lo; la.ld_planes = c.inter; }
@@ -424,7 +424,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     la = ChattsLinearArgs{};
     la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = batch; la.n = qkv_n; la.k = H;
     la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
-    la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H;
+    la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H; la.w8_format = d->cfg.w8_format;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
     if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
     if ((rc = chatts_linear(&la, stream)) != 0) return rc;
@@ -437,7 +437,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     la = ChattsLinearArgs{};
     la.a = d->b.attn; la.w = lw.o; la.m = batch; la.n = H; la.k = c.n_q * kHeadDim;
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
-    la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k;
+    la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k; la.w8_format = d->cfg.w8_format;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
     if (attn_planes) { la.a = nullptr; la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k; }
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
@@ -456,7 +456,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   la = ChattsLinearArgs{};
   la.w = lw.gate_up; la.c = d->b.act; la.m = batch; la.n = 2 * c.inter; la.k = H;
   la.lda = H; la.ldw = H; la.ldc = c.inter; la.epilogue = CHATTS_EPI_SWIGLU;
-  la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H;
+  la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H; la.w8_format = d->cfg.w8_format;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
   if ((rc = norm_into(d, lw.post_norm, &la, stream)) != 0) return rc;
   const bool act_planes = planes_path(d, batch, c.inter, lw.down8 != nullptr) && planes_path(d, batch, H, lw.gate_up8 != nullptr);
@@ -465,7 +465,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   la = ChattsLinearArgs{};
   la.a = d->b.act; la.w = lw.down; la.m = batch; la.n = H; la.k = c.inter;
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
-  la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter;
+  la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter; la.w8_format = d->cfg.w8_format;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
   if (act_planes) { la.a = nullptr; la.a_hi = d->b.planes2_hi; la.a_lo = d->b.planes2_lo; la.ld_planes = c.inter; }
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
@@ -506,7 +506,7 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
   la.w = d->w.lm_head; la.c = logits_all; la.m = batch; la.n = (int)c.vocab_local; la.k = c.hidden;
   la.lda = c.hidden; la.ldw = c.hidden; la.ldc = (int)c.vocab_local; la.epilogue = CHATTS_EPI_NONE;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
-  la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden;
+  la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden; la.w8_format = d->cfg.w8_format;
   if (rc == CHATTS_OK) rc = norm_into(d, d->w.final_norm, &la, stream);
   d->chain = false;
   d->normed = false;
@@ -564,7 +564,7 @@ static int layer_last_row(ChattsDecoder* d, int layer, int t, int pos0, chatts_s
   }
   la = ChattsLinearArgs{};
   la.a = d->b.attn; la.w = lw.o; la.m = 1; la.n = H; la.k = c.n_q * kHeadDim; la.lda = la.k; la.ldw = la.k; la.ldc = H;
-  la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k;
+  la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k; la.w8_format = d->cfg.w8_format;
   la.w4 = lw.o4; la.w4_sz = lw.o4_sz; la.ldw4 = la.k / 2; la.w4_group = lw.w4_group;
   la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID;
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
@@ -661,7 +661,7 @@ extern "C" int chatts_decoder_logits(ChattsDecoder* d, int row, chatts_stream_t 
   la.a = d->b.x + (size_t)row * c.hidden; la.w = d->w.lm_head; la.c = d->b.logits;
   la.m = 1; la.n = (int)c.vocab_local; la.k = c.hidden; la.lda = c.hidden; la.ldw = c.hidden; la.ldc = (int)c.vocab_local;
   la.epilogue = CHATTS_EPI_NONE; la.norm_w = d->w.final_norm; la.norm_eps = c.rms_eps;
-  la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden;
+  la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden; la.w8_format = d->cfg.w8_format;
   return chatts_linear(&la, stream);
 }
 

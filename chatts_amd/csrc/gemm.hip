@@ -41,6 +41,7 @@ struct GemmParams {
   const uint8_t* w8;     // optional fp8 (e4m3fn) copy of W: streamed instead of the bf16 copy, widened (exactly) to
   const float* w8_scale; // bf16 while it is staged to LDS; the per-row power-of-two scale is applied in the epilogue
   int ldw8;
+  int w8_format;         // CHATTS_W8_FP8 / CHATTS_W8_INT8 (gemm_stream_kernel only; the other kernels never see an int8 copy)
   uint16_t* c_hi;        // optional: the output goes out as bf16 hi / lo planes [M, ldcp] (the next GEMM's operand
   uint16_t* c_lo;        // format) instead of float32 c
   int ldcp;
@@ -809,7 +810,7 @@ __device__ __forceinline__ void stream_fixup(const GemmParams& p, const f32x4 (&
 // wave (LDS reads -> fp8 widening -> MFMAs) is what paces a workgroup when it is alone on its CU (a deeper ring changes nothing,
 // profiles/r3_stream_sweep_fp8.txt), and two waves per SIMD overlap their chains.  Every output column still sees its K-steps in
 // the same order with the same operands: bit-identical to NW = 4.
-template <int NSTAGE, bool W8, int MB, int NW = 4>
+template <int NSTAGE, bool W8, int MB, int NW = 4, bool I8 = false>
 __global__ __launch_bounds__(64 * NW) void gemm_stream_kernel(GemmParams p, const uint16_t* __restrict__ a_hi,
                                                               const uint16_t* __restrict__ a_lo, int ldp) {
   static_assert(!W8 || MB == 1, "the fp8 weight stream is a batched-decode format (M <= 16)");
@@ -896,8 +897,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_stream_kernel(GemmParams p, cons
           const f32x2_t f0 = __builtin_amdgcn_cvt_pk_f32_fp8(q8.x, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(q8.x, true);
           const f32x2_t f2 = __builtin_amdgcn_cvt_pk_f32_fp8(q8.y, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(q8.y, true);
           bf16x8_t bv;
-          bv[0] = (__bf16)f0.x; bv[1] = (__bf16)f0.y; bv[2] = (__bf16)f1.x; bv[3] = (__bf16)f1.y;
-          bv[4] = (__bf16)f2.x; bv[5] = (__bf16)f2.y; bv[6] = (__bf16)f3.x; bv[7] = (__bf16)f3.y;
+          if (I8) {   // int8 copy: eight sign-extended bytes, exactly representable in bf16 (|q| <= 127)
+            const int a0 = (int)q8.x, a1 = (int)q8.y;
+            bv[0] = (__bf16)(float)((a0 << 24) >> 24); bv[1] = (__bf16)(float)((a0 << 16) >> 24);
+            bv[2] = (__bf16)(float)((a0 << 8) >> 24);  bv[3] = (__bf16)(float)(a0 >> 24);
+            bv[4] = (__bf16)(float)((a1 << 24) >> 24); bv[5] = (__bf16)(float)((a1 << 16) >> 24);
+            bv[6] = (__bf16)(float)((a1 << 8) >> 24);  bv[7] = (__bf16)(float)(a1 >> 24);
+          } else {
+            bv[0] = (__bf16)f0.x; bv[1] = (__bf16)f0.y; bv[2] = (__bf16)f1.x; bv[3] = (__bf16)f1.y;
+            bv[4] = (__bf16)f2.x; bv[5] = (__bf16)f2.y; bv[6] = (__bf16)f3.x; bv[7] = (__bf16)f3.y;
+          }
           bfrag[h][j] = bv;
         } else {
           bfrag[h][j] = *reinterpret_cast<const bf16x8_t*>(base + W_OFF + lds_off128(r, h * 4 + fchunk));
@@ -1268,18 +1277,18 @@ static int pick_stream_sk(int n, int k, bool w8) {
   return sk;
 }
 
-template <int NSTAGE, bool W8, int MB = 1, int NW = 4>
+template <int NSTAGE, bool W8, int MB = 1, int NW = 4, bool I8 = false>
 static int launch_stream_t(const GemmParams& p, const ChattsLinearArgs* a, int sk, hipStream_t s) {
   constexpr int LDS = NSTAGE * stream_stage(W8, MB);
   static bool configured = false;
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NSTAGE, W8, MB, NW>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NSTAGE, W8, MB, NW, I8>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "gemm_stream: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
     configured = true;
   }
   dim3 grid((a->n + kStreamBN - 1) / kStreamBN, 1, sk), block(64 * NW);
-  hipLaunchKernelGGL((gemm_stream_kernel<NSTAGE, W8, MB, NW>), grid, block, LDS, s, p, a->a_hi, a->a_lo, a->ld_planes);
+  hipLaunchKernelGGL((gemm_stream_kernel<NSTAGE, W8, MB, NW, I8>), grid, block, LDS, s, p, a->a_hi, a->a_lo, a->ld_planes);
   return CHATTS_OK;
 }
 
@@ -1363,8 +1372,15 @@ static int launch_dma(const GemmParams& p, const ChattsLinearArgs* a, int sk, hi
   return w32 ? launch_dma_t<false, true>(p, a, sk, s) : launch_dma_t<false, false>(p, a, sk, s);
 }
 
-int launch_gemm(const ChattsLinearArgs* a, hipStream_t s, const RopeFuse* rope, bool* rope_done) {
+int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rope, bool* rope_done) {
   int bm, sk;
+  ChattsLinearArgs a_copy;
+  const ChattsLinearArgs* a = a_in;
+  if (a_in->w8 && a_in->w8_format == CHATTS_W8_INT8 && !use_stream(a_in)) {      // int8 copies: the weight-streaming kernel only
+    a_copy = *a_in;
+    a_copy.w8 = nullptr; a_copy.w8_scale = nullptr;
+    a = &a_copy;
+  }
   const bool stream = use_stream(a);
   const bool dma = !stream && use_dma(a);
   if (stream) {
@@ -1394,7 +1410,7 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s, const RopeFuse* rope, 
   p.a = a->a; p.w = a->w; p.bias = a->bias; p.resid = a->resid;
   p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
   p.epilogue = a->epilogue; p.k_per_split = kps; p.direct = sk == 1;
-  p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8;
+  p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8; p.w8_format = a->w8_format;
   p.c_hi = a->c_hi; p.c_lo = a->c_lo; p.ldcp = a->ld_cplanes;
   p.fix_cnt = nullptr; p.c_out = a->c;
   if (stream && sk > 1 && sk <= 8 && a->m <= 16 && a->tile_counters && !a->post_norm_w && (a->n + kStreamBN - 1) / kStreamBN <= CHATTS_TILE_COUNTERS &&
@@ -1419,6 +1435,8 @@ int launch_gemm(const ChattsLinearArgs* a, hipStream_t s, const RopeFuse* rope, 
     if (a->m > 64) rc = launch_stream_t<3, false, 8>(p, a, sk, s);          // 3 x 48 KB stages: one workgroup per CU
     else if (a->m > 32) rc = launch_stream_t<4, false, 4>(p, a, sk, s);     // 4 x 32 KB
     else if (a->m > 16) rc = launch_stream_t<4, false, 2>(p, a, sk, s);     // 4 x 24 KB
+    else if (a->w8 && a->w8_format == CHATTS_W8_INT8)
+      rc = stages == 3 ? launch_stream_t<3, true, 1, 4, true>(p, a, sk, s) : launch_stream_t<4, true, 1, 4, true>(p, a, sk, s);
     else if (a->w8 && gemm_env_int("CHATTS_GEMM_STREAM_WAVES", 4) == 8)
       rc = stages == 3 ? launch_stream_t<3, true, 1, 8>(p, a, sk, s) : launch_stream_t<4, true, 1, 8>(p, a, sk, s);
     else if (a->w8) rc = stages == 3 ? launch_stream_t<3, true>(p, a, sk, s) : launch_stream_t<4, true>(p, a, sk, s);

@@ -33,6 +33,7 @@ struct GemvParams {
   const uint8_t* w8;      // fp8 (OCP e4m3fn) weights [N, ldw8] or NULL
   const float* w8_scale;  // per-row power-of-two scale: w = scale[row] * float(w8)
   int ldw8;
+  int w8_format;          // CHATTS_W8_FP8 / CHATTS_W8_INT8
   // optional 4-bit copy of W (GPTQ codes, row-major: byte j of a row = codes 2j | 2j+1 << 4) with one (scale, scale * zero) pair
   // per `w4_group` weights of a row: w = bf16_rne(q * scale - scale_zero) - exactly the bf16 matrix the other kernels stream
   const uint8_t* w4;
@@ -168,7 +169,20 @@ __device__ __forceinline__ float dot16_fp8(const u32x4 wv, const f32x4 x0, const
   return acc;
 }
 
-template <int ROWS, int UNR, int EPI, bool NORM>
+// int8 form of the same 16 weights: four sign-extended bytes per dword (v_cvt_f32_i32 with an SDWA byte select, or a bit-field extract
+// before it - the compiler's choice), the same float32 FMAs.  |q| <= 127: the products are exact as in the fp8 form.
+__device__ __forceinline__ float dot16_i8(const u32x4 wv, const f32x4 x0, const f32x4 x1, const f32x4 x2, const f32x4 x3, float acc) {
+  auto four = [&](uint32_t d, const f32x4 x) {
+    acc = fmaf((float)(int)(int8_t)(d & 0xffu), x.x, acc);
+    acc = fmaf((float)(int)(int8_t)((d >> 8) & 0xffu), x.y, acc);
+    acc = fmaf((float)(int)(int8_t)((d >> 16) & 0xffu), x.z, acc);
+    acc = fmaf((float)((int)d >> 24), x.w, acc);
+  };
+  four(wv.x, x0); four(wv.y, x1); four(wv.z, x2); four(wv.w, x3);
+  return acc;
+}
+
+template <int ROWS, int UNR, int EPI, bool NORM, bool I8 = false>
 __global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* xs4 = reinterpret_cast<f32x4*>(smem);            // permuted x: [chunk][quarter][lane] float4
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
           const f32x4* xb = xs4 + (c + u) * 256 + lane;
           const f32x4 x0 = xb[0], x1 = xb[64], x2 = xb[128], x3 = xb[192];
 #pragma unroll
-          for (int r = 0; r < ROWS; ++r) acc[r] = dot16_fp8(wv[u][r], x0, x1, x2, x3, acc[r]);
+          for (int r = 0; r < ROWS; ++r) acc[r] = I8 ? dot16_i8(wv[u][r], x0, x1, x2, x3, acc[r]) : dot16_fp8(wv[u][r], x0, x1, x2, x3, acc[r]);
         }
       }
     }
@@ -405,6 +419,11 @@ static void launch4_norm(const GemvParams& p, bool norm, int blocks, int threads
 
 template <int EPI>
 static void launch8_norm(const GemvParams& p, bool norm, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (p.w8_format == CHATTS_W8_INT8) {
+    if (norm) hipLaunchKernelGGL((gemv8_ldsx_kernel<2, 2, EPI, true, true>), dim3(blocks), dim3(threads), lds, s, p);
+    else hipLaunchKernelGGL((gemv8_ldsx_kernel<2, 2, EPI, false, true>), dim3(blocks), dim3(threads), lds, s, p);
+    return;
+  }
   if (norm) hipLaunchKernelGGL((gemv8_ldsx_kernel<2, 2, EPI, true>), dim3(blocks), dim3(threads), lds, s, p);
   else hipLaunchKernelGGL((gemv8_ldsx_kernel<2, 2, EPI, false>), dim3(blocks), dim3(threads), lds, s, p);
 }
@@ -444,7 +463,7 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   GemvParams p;
   p.w = a->w; p.x = a->a; p.bias = a->bias; p.resid = a->resid; p.out = a->c;
   p.norm_w = a->norm_w; p.eps = a->norm_eps; p.n = a->n; p.k = a->k; p.ldw = a->ldw;
-  p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8;
+  p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8; p.w8_format = a->w8_format;
   p.w4 = a->w4; p.w4_sz = a->w4_sz; p.ldw4 = a->ldw4; p.w4_group = a->w4_group;
   const bool norm = a->norm_w != nullptr;
   const int cus = device_cus();

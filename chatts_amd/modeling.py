@@ -34,6 +34,21 @@ def interleave_gate_up(gate, up):
     return out
 
 
+def quantize_int8_rows(w):
+    """[N,K] bf16 -> (q uint8 view of int8 [N,K], scale f32 [N] (powers of two), deq bf16 [N,K]).
+
+    w ~= scale[n] * q[n,k], q in [-127, 127], scale a power of two: the dequantised value has <= 7 significant bits and is EXACTLY
+    representable in bf16 - the same lossless-re-encoding argument as quantize_fp8_rows, on a uniform grid (the weight-only 8-bit
+    format in the role of the HF demo's `load_in_8bit`, demo/demo_hf.ipynb:78-80)."""
+    wf = w.float()
+    amax = wf.abs().amax(dim=1).clamp_min(1e-30)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / 127.0)))
+    scale = torch.where(amax / scale > 127.0, scale * 2.0, scale)          # guard log2 rounding: never overflow int8
+    q = torch.clamp(torch.round(wf / scale[:, None]), -127, 127).to(torch.int8)
+    deq = (q.float() * scale[:, None]).to(torch.bfloat16)
+    return q.view(torch.uint8).contiguous(), scale.contiguous(), deq.contiguous()
+
+
 def quantize_fp8_rows(w):
     """[N,K] bf16 -> (q uint8 view of float8_e4m3fn [N,K], scale f32 [N] (powers of two), deq bf16 [N,K]).
 
@@ -118,8 +133,8 @@ class ChatTSForCausalLM:
         self._kv_replaced = {}                   # slot -> logical blocks swapped for private ones since its last prefix decision
         self._kv_dynamic = False
         self._cur_slot = 0
-        if weight_format not in ("bf16", "fp8", "int4"):
-            raise ValueError("weight_format must be 'bf16', 'fp8' or 'int4'")
+        if weight_format not in ("bf16", "fp8", "int8", "int4"):
+            raise ValueError("weight_format must be 'bf16', 'fp8', 'int8' or 'int4'")
         # "fp8": decode GEMVs stream an e4m3 copy (BASELINE.json config 5); "int4": they stream 4-bit codes + group scales (what a
         # GPTQ-Int4 checkpoint brings along; a bf16 checkpoint is quantised round-to-nearest at load)
         self.weight_format = weight_format
@@ -300,14 +315,15 @@ class ChatTSForCausalLM:
         H, d = cfg.hidden_size, cfg.head_dim
         max_pos = max(self.max_ctx, 64)
         T["cos"], T["sin"] = rope_tables(cfg, max_pos, dev)
-        if self.weight_format == "fp8" and "lm_head8" not in T:
+        if self.weight_format in ("fp8", "int8") and "lm_head8" not in T:
             # quantise every decoder projection once; the bf16 tensors are REPLACED by the (bf16-exact) dequantised
-            # values so prefill (bf16 MFMA GEMM), batched decode and the fp8 decode GEMV all see the same weights
+            # values so prefill (bf16 MFMA GEMM), batched decode and the 8-bit decode GEMV all see the same weights
+            quant = quantize_fp8_rows if self.weight_format == "fp8" else quantize_int8_rows
             for lw in self.layers:
                 for name in ("qkv", "o", "gate_up", "down"):
-                    lw[name + "8"], lw[name + "8_scale"], lw[name] = quantize_fp8_rows(lw[name])
+                    lw[name + "8"], lw[name + "8_scale"], lw[name] = quant(lw[name])
             tied = T["lm_head"].data_ptr() == T["embed"].data_ptr()
-            T["lm_head8"], T["lm_head8_scale"], deq = quantize_fp8_rows(T["lm_head"])
+            T["lm_head8"], T["lm_head8_scale"], deq = quant(T["lm_head"])
             T["lm_head"] = deq
             if tied:
                 T["embed"] = deq
@@ -322,7 +338,8 @@ class ChatTSForCausalLM:
         dc = _lib.DecoderConfig(hidden=H, n_layers=cfg.num_hidden_layers, n_q=plan.nq, n_kv=plan.nkv, head_dim=d,
                                 inter=plan.inter, vocab_local=plan.vocab, vocab_offset=plan.v0,
                                 rms_eps=cfg.rms_norm_eps, max_ctx=self.max_ctx, max_pos=max_pos, tp_world=plan.world,
-                                embed_rows=cfg.vocab_size, embed_offset=0)       # the embedding table is replicated
+                                embed_rows=cfg.vocab_size, embed_offset=0,       # the embedding table is replicated
+                                w8_format=_lib.W8_INT8 if self.weight_format == "int8" else _lib.W8_FP8)
         ws_bytes = int(lib.chatts_decoder_workspace(C.byref(dc), self.t_max, self.n_splits))
         ws_bytes = max(ws_bytes, int(lib.chatts_linear_workspace(self.t_max, plan.vocab, H)))
         for m in range(2, self.max_batch + 1):     # batched lm_head

@@ -177,7 +177,15 @@ typedef struct ChattsLinearArgs {
    * the same arithmetic as the separate epilogue launch it replaces (bit-identical), one launch less per projection.  Honoured only
    * under CHATTS_GEMM_FIXUP=1: measured SLOWER than the launch it saves on MI355X (profiles/r3_cfg5_split_k_fixup_ab.txt). */
   int32_t* tile_counters;
+  /* encoding of `w8`: 0 = OCP fp8 e4m3fn (above); 1 = int8 (two's complement), w = w8_scale[n] * int8 with the same per-row
+   * power-of-two scale - |int8| <= 127 has 7 significant bits, so the dequantised weight is again exactly a bf16 number and the
+   * int8 tensor is a lossless encoding of the bf16 matrix the other kernels stream (the weight-only 8-bit format in the role of
+   * the HF demo's `load_in_8bit`, demo/demo_hf.ipynb:78-80; bitsandbytes' own outlier decomposition is not reproduced).  Streamed by
+   * the M == 1 GEMV and the M <= 16 weight-streaming GEMM; every other kernel keeps streaming `w`. */
+  int w8_format;
 } ChattsLinearArgs;
+#define CHATTS_W8_FP8 0
+#define CHATTS_W8_INT8 1
 #define CHATTS_TILE_COUNTERS 4096
 size_t chatts_linear_workspace(int m, int n, int k);
 /* hi = bf16(x) (RNE), lo = bf16(x - hi): the operand split of the bf16x2 GEMM, done once per activation matrix. */
@@ -409,6 +417,7 @@ typedef struct ChattsDecoderConfig {
   int tp_world;                                       /* > 1: o/down outputs are partial sums   */
   int64_t embed_rows, embed_offset;                   /* rows of `embed` this rank holds and the id of row 0; 0 rows = the lm_head
                                                          slice (vocab_local, vocab_offset).  Replicated table: (vocab, 0)          */
+  int w8_format;                                      /* encoding of the optional 8-bit weight copies (ChattsLinearArgs.w8_format)   */
 } ChattsDecoderConfig;
 
 typedef struct ChattsDecoderWeights {

@@ -395,6 +395,38 @@ def test_fp8_weight_format_matches_oracle_on_dequantised_weights():
     assert toks == want["tokens"]
 
 
+@pytest.mark.parametrize("max_batch", [1, 3])
+def test_int8_weight_format_matches_oracle_on_dequantised_weights(max_batch):
+    """weight_format='int8' (the weight-only 8-bit format in the role of the HF demo's load_in_8bit): decode - single sequence and
+    the batched step - streams int8 codes with power-of-two row scales; the oracle runs on the dequantised values (the int8 copy is a
+    lossless encoding of them), same tolerance as bf16."""
+    from chatts_amd.modeling import quantize_int8_rows
+    cfg = cfgmod.preset("tiny-qwen2")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    rng = np.random.default_rng(3)
+    sd = osynth.state_dict(synth.all_specs(cfg), 4)
+    for name in list(sd):
+        if name.endswith("_proj.weight") or name == "lm_head.weight":
+            sd[name] = quantize_int8_rows(sd[name].to(torch.bfloat16))[2].float()
+    model = ChatTSForCausalLM.from_synthetic(cfg, seed=4, max_ctx=512, max_prefill_tokens=512, weight_format="int8", max_batch=max_batch)
+    assert model.weight_bytes_local() < 0.62 * ChatTSForCausalLM.from_synthetic(cfg, seed=4, max_ctx=64, max_prefill_tokens=64).weight_bytes_local()
+    assert torch.equal(model.layers[1]["down"].float().cpu(), sd["model.layers.1.mlp.down_proj.weight"])
+    reqs, wants = [], []
+    for lengths in ([64, 21], [100], [30, 30, 30])[:max(1, max_batch)]:
+        series = [random_walk_series(rng, L) for L in lengths]
+        inputs = proc(text=[chat_prompt(lengths)], timeseries=series, return_tensors="pt")
+        ids = inputs["input_ids"][0].tolist()
+        wants.append(pipeline.generate(cfg, sd, ids, inputs["timeseries"].numpy(), 10))
+        reqs.append((ids, inputs["timeseries"].cuda(), list(proc.last_lengths)))
+    if max_batch == 1:
+        toks, lg = model.generate_one(*reqs[0], 10, return_logits=True)
+        assert rel_err(lg.cpu().numpy(), wants[0]["logits"][0].numpy()) < TIGHT_TOL
+        assert toks == wants[0]["tokens"]
+    else:
+        got = model.generate_batch(reqs, 10)
+        assert got == [w["tokens"] for w in wants]
+
+
 def test_sampled_generation_is_valid_reproducible_and_graph_safe():
     """do_sample: every drawn token is the one oracle/sampler.py's rule selects from THAT step's logits (teacher forcing
     through the CPU decoder oracle), the hipGraph replay draws the same tokens as the eager path, the seed matters."""

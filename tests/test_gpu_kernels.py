@@ -775,6 +775,37 @@ def test_gemm_stream_fp8_weights_parity(lib, epi, m, n, k, stages, waves, monkey
 
 
 @pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k,norm", [(1, 5120, 5120, True), (1, 1024, 13824, False), (1, 96, 1024, True), (16, 5120, 5120, False),
+                                        (9, 7168, 5120, False), (2, 128, 128, False), (40, 256, 512, False)])
+def test_linear_int8_weight_copy_parity(lib, epi, m, n, k, norm):
+    """ChattsLinearArgs.w8_format = int8 (per-row power-of-two scale, |q| <= 127: a lossless encoding of the bf16 matrix): the decode
+    GEMV (M = 1, with / without the fused RMSNorm) and the weight-streaming GEMM (2 <= M <= 16, on planes) stream the int8 copy -
+    against float64 math on the dequantised matrix; other shapes (M = 40 here) ignore the copy and stream `w` (same result)."""
+    from chatts_amd.modeling import quantize_int8_rows
+    a, w, bias, resid, nw = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
+    w[5] *= 50.0
+    q, scale, deq = quantize_int8_rows(w)
+    assert torch.equal((q.view(torch.int8).float() * scale[:, None]).to(torch.bfloat16).float(), deq.float())      # exactly bf16
+    assert int(q.view(torch.int8).abs().max()) <= 127 and float((deq.float() - w.float()).abs().max()) <= float(scale.max())
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    out = torch.full((m, ncols), float("nan"), device=DEV)
+    wsb = int(lib.chatts_linear_workspace(m, n, k))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    la = _lib.LinearArgs(a=a.data_ptr(), w=deq.data_ptr(), bias=bias.data_ptr(), resid=resid.data_ptr() if epi == _lib.EPI_RESID else None,
+                         c=out.data_ptr(), norm_w=nw.data_ptr() if (norm and m == 1) else None, norm_eps=1e-6, m=m, n=n, k=k, lda=k, ldw=k,
+                         ldc=ncols, epilogue=epi, workspace=ws.data_ptr(), workspace_bytes=wsb, w8=q.data_ptr(), w8_scale=scale.data_ptr(),
+                         ldw8=k, w8_format=_lib.W8_INT8)
+    if 2 <= m <= 16:
+        hi, lo = _split_planes(lib, a)
+        la.a, la.a_hi, la.a_lo, la.ld_planes = None, hi.data_ptr(), lo.data_ptr(), k
+    _lib.check(lib.chatts_linear(la, st()))
+    torch.cuda.synchronize()
+    want = _ref_linear(a, deq, bias, resid, epi, nw if (norm and m == 1) else None)
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu().numpy(), want) < 2e-5
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
 @pytest.mark.parametrize("m,n,k,sk", [(16, 27648, 5120, 1), (16, 5120, 13824, 6), (11, 7168, 5120, 4), (3, 160, 384, 1)])
 def test_gemm_stream_fp8_eight_waves_equal_four_bitwise(lib, epi, m, n, k, sk, monkeypatch):
     """gemm_stream_kernel<., true, 1, 8> (16 columns per wave, the SwiGLU pair exchanged through LDS) == the 4-wave form, bit for
