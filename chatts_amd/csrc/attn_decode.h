@@ -82,25 +82,34 @@ struct AttnTileRegs {       // what a wave keeps between the two stages: the slo
   int pos;
 };
 
+// Register layout of a 16-key tile (both loads ask for WHOLE 128-byte lines: a request of 16 rows x 64 bytes - the layout this
+// kernel had before, and the MFMA operand shape - streams at 4.1 TB/s on this part, whole lines at 6.2, profiles/r3_row_stream_probe.txt):
+//   K: lane = (kg = lane >> 3, c = lane & 7) holds dims c*4 + 32 i (i < 4) of key kg in kv[i] and of key 8 + kg in kv[4 + i]:
+//      one instruction = 8 key rows x 128 contiguous bytes;
+//   V: lane = (h = lane >> 5, c = lane & 31) holds dims c*4 .. c*4+3 of key 2 i + h in vv[i] (i < 8):
+//      one instruction = 2 key rows x 512 contiguous bytes.
 __device__ __forceinline__ void attn_load_k(const KvLayout& kvl, const float* kcache, const int hk, const int tile, const int pos,
                                             const int lane, f32x4 (&kv)[8]) {
-  const int key_l = lane >> 2, quarter = lane & 3;
+  const int kg = lane >> 3, c = lane & 7;
   const int j0 = tile * kDTile;
-  const int j = j0 + key_l;
-  const int jc = j <= pos ? j : pos;          // clamped address (stays inside this tile: pos lies in it); masked below
-  const size_t toff = kv_tile_off(kvl, hk, j0);   // the tile's first row: one table lookup per tile when the cache is paged
-  const float* kr = kcache + toff + (size_t)(jc - j0) * kHeadDim + quarter * 4;
+  const int ja = j0 + kg <= pos ? j0 + kg : pos;          // clamped addresses (stay inside this tile: pos lies in it); masked below
+  const int jb = j0 + 8 + kg <= pos ? j0 + 8 + kg : pos;
+  const size_t toff = kv_tile_off(kvl, hk, j0);           // the tile's first row: one table lookup per tile when the cache is paged
+  const float* ka = kcache + toff + (size_t)(ja - j0) * kHeadDim + c * 4;
+  const float* kb = kcache + toff + (size_t)(jb - j0) * kHeadDim + c * 4;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const f32x4*>(kr + i * 16);
+  for (int i = 0; i < 4; ++i) kv[i] = *reinterpret_cast<const f32x4*>(ka + i * 32);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) kv[4 + i] = *reinterpret_cast<const f32x4*>(kb + i * 32);
 }
 __device__ __forceinline__ void attn_load_v(const KvLayout& kvl, const float* vcache, const int hk, const int tile, const int pos,
-                                            const int lane, float2 (&vv)[kDTile]) {
-  const int j0 = tile * kDTile;
+                                            const int lane, f32x4 (&vv)[8]) {
+  const int j0 = tile * kDTile, h = lane >> 5, c = lane & 31;
   const size_t toff = kv_tile_off(kvl, hk, j0);
 #pragma unroll
-  for (int u = 0; u < kDTile; ++u) {
-    const int ju = j0 + u <= pos ? j0 + u : pos;
-    vv[u] = *reinterpret_cast<const float2*>(vcache + toff + (size_t)(ju - j0) * kHeadDim + lane * 2);
+  for (int i = 0; i < 8; ++i) {
+    const int ju = j0 + 2 * i + h <= pos ? j0 + 2 * i + h : pos;
+    vv[i] = *reinterpret_cast<const f32x4*>(vcache + toff + (size_t)(ju - j0) * kHeadDim + c * 4);
   }
 }
 
@@ -139,9 +148,9 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
   const KvLayout kvl{p.table ? p.table + (size_t)seq * p.table_stride : nullptr, p.n_kv, p.max_ctx, p.log_block};
   const bool owner = ((pos / kDTile) % NS) == slot;
   const float scale = 0.08838834764831845f * 1.4426950408889634f;    // 128^-1/2 * log2(e): the softmax runs on v_exp_f32 (exp2)
-  const int key_l = lane >> 2, quarter = lane & 3;
+  const int kg = lane >> 3, kc = lane & 7, vh = lane >> 5, vc = lane & 31;      // see attn_load_k / attn_load_v
   f32x4 (&kv)[8] = t.kv;
-  float2 vv[kDTile];
+  f32x4 vv[8];
   attn_load_v(kvl, vcache, hk, slot, pos, lane, vv);
 
   {
@@ -176,72 +185,87 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // single wave: orders the LDS writes above (in-order LDS, no barrier needed)
 
-  float m_run[GMAX], l_run[GMAX], acc0[GMAX], acc1[GMAX];
+  float m_run[GMAX], l_run[GMAX];
+  f32x4 acc[GMAX];                              // this lane's 4 dims, summed over the keys of its half (even / odd keys of a tile)
 #pragma unroll
-  for (int g = 0; g < GMAX; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.f; acc0[g] = 0.f; acc1[g] = 0.f; }
+  for (int g = 0; g < GMAX; ++g) { m_run[g] = -INFINITY; l_run[g] = 0.f; acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
   // one 16-key tile: scores, online softmax, P.V - on the K / V rows held in (kvb, vvb)
-  auto tile_body = [&](const int tile, f32x4 (&kvb)[8], float2 (&vvb)[kDTile]) __attribute__((always_inline)) {
+  auto tile_body = [&](const int tile, f32x4 (&kvb)[8], f32x4 (&vvb)[8]) __attribute__((always_inline)) {
     const int j0 = tile * kDTile;
-    const int j = j0 + key_l;
-    const int jc = j <= pos ? j : pos;
-    if (owner && jc == pos) {                   // the row just produced is not in the cache for this wave yet
+    const int ja = j0 + kg, jb = j0 + 8 + kg;
+    if (owner) {                                // the row just produced is not in the cache for this wave yet
+      if ((ja <= pos ? ja : pos) == pos) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) kvb[i] = *reinterpret_cast<const f32x4*>(knew_s + quarter * 4 + i * 16);
+        for (int i = 0; i < 4; ++i) kvb[i] = *reinterpret_cast<const f32x4*>(knew_s + kc * 4 + i * 32);
+      }
+      if ((jb <= pos ? jb : pos) == pos) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kvb[4 + i] = *reinterpret_cast<const f32x4*>(knew_s + kc * 4 + i * 32);
+      }
+      const f32x4 vn = *reinterpret_cast<const f32x4*>(vnew_s + vc * 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (j0 + 2 * i + vh >= pos) vvb[i] = vn;
     }
-    if (owner) {
-      const float2 vn = *reinterpret_cast<const float2*>(vnew_s + lane * 2);
+    float da[GMAX], db[GMAX];
 #pragma unroll
-      for (int u = 0; u < kDTile; ++u)
-        if (j0 + u >= pos) vvb[u] = vn;
-    }
-    float dot[GMAX];
+    for (int g = 0; g < GMAX; ++g) { da[g] = 0.f; db[g] = 0.f; }
 #pragma unroll
-    for (int g = 0; g < GMAX; ++g) dot[g] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int g = 0; g < GMAX; ++g) {
         if (g < gn) {
-          const f32x4 qv = *reinterpret_cast<const f32x4*>(q_s + g * kHeadDim + quarter * 4 + i * 16);
-          dot[g] = fmaf(kvb[i].x, qv.x, dot[g]);
-          dot[g] = fmaf(kvb[i].y, qv.y, dot[g]);
-          dot[g] = fmaf(kvb[i].z, qv.z, dot[g]);
-          dot[g] = fmaf(kvb[i].w, qv.w, dot[g]);
+          const f32x4 qv = *reinterpret_cast<const f32x4*>(q_s + g * kHeadDim + kc * 4 + i * 32);      // shared by both keys
+          da[g] = fmaf(kvb[i].x, qv.x, da[g]);
+          da[g] = fmaf(kvb[i].y, qv.y, da[g]);
+          da[g] = fmaf(kvb[i].z, qv.z, da[g]);
+          da[g] = fmaf(kvb[i].w, qv.w, da[g]);
+          db[g] = fmaf(kvb[4 + i].x, qv.x, db[g]);
+          db[g] = fmaf(kvb[4 + i].y, qv.y, db[g]);
+          db[g] = fmaf(kvb[4 + i].z, qv.z, db[g]);
+          db[g] = fmaf(kvb[4 + i].w, qv.w, db[g]);
         }
       }
     }
-    float pr[GMAX];
+    float pa[GMAX], pb[GMAX];
 #pragma unroll
     for (int g = 0; g < GMAX; ++g) {
-      pr[g] = 0.f;
+      pa[g] = 0.f; pb[g] = 0.f;
       if (g < gn) {
-        float sc = dot[g];
-        sc += lane_xor1(sc);
-        sc += lane_xor2(sc);                    // all 4 lanes of a key now hold its score (DPP, no LDS round trip)
-        sc = j <= pos ? sc * scale : -INFINITY;
-        // max / sum over the 16 keys: keys of one 16-lane row with row_ror (DPP), the four rows with v_readlane
-        const float mt = rows4_max(fmaxf(fmaxf(sc, row_ror4(sc)), row_ror8(fmaxf(sc, row_ror4(sc)))));
+        float sa = da[g], sb = db[g];
+        sa += lane_xor1(sa); sb += lane_xor1(sb);
+        sa += lane_xor2(sa); sb += lane_xor2(sb);
+        sa += half_mirror(sa); sb += half_mirror(sb);      // all 8 lanes of a key pair now hold both scores (DPP, no LDS round trip)
+        sa = ja <= pos ? sa * scale : -INFINITY;
+        sb = jb <= pos ? sb * scale : -INFINITY;
+        // max / sum over the 16 keys: a 16-lane row holds 4 of them (two lane groups x two keys), the four rows via v_readlane
+        const float m2 = fmaxf(sa, sb);
+        const float mt = rows4_max(fmaxf(m2, row_ror8(m2)));
         const float m_new = fmaxf(m_run[g], mt);  // finite: key j0 <= pos is always valid
-        const float e = __builtin_amdgcn_exp2f(sc - m_new);
-        float es = e + row_ror4(e);
-        es = rows4_sum(es + row_ror8(es));
+        const float ea = __builtin_amdgcn_exp2f(sa - m_new), eb = __builtin_amdgcn_exp2f(sb - m_new);
+        const float e2 = ea + eb;
+        const float es = rows4_sum(e2 + row_ror8(e2));
         const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
         l_run[g] = l_run[g] * alpha + es;
         m_run[g] = m_new;
-        acc0[g] *= alpha;
-        acc1[g] *= alpha;
-        pr[g] = e;
+        acc[g].x *= alpha; acc[g].y *= alpha; acc[g].z *= alpha; acc[g].w *= alpha;
+        pa[g] = ea; pb[g] = eb;
       }
     }
 #pragma unroll
-    for (int u = 0; u < kDTile; ++u) {
+    for (int i = 0; i < 8; ++i) {               // keys 2 i (lanes 0-31) and 2 i + 1 (lanes 32-63)
 #pragma unroll
       for (int g = 0; g < GMAX; ++g) {
         if (g < gn) {
-          const float pu = readlane_f(pr[g], u * 4);   // p of key u, wave-uniform (0 for masked keys)
-          acc0[g] = fmaf(pu, vvb[u].x, acc0[g]);
-          acc1[g] = fmaf(pu, vvb[u].y, acc1[g]);
+          // p of key u lives in lanes 8 u .. 8 u + 7 of pa (u < 8) / 8 (u - 8) .. of pb (u >= 8): wave-uniform reads (0 for masked keys)
+          const float pe = i < 4 ? readlane_f(pa[g], 16 * i) : readlane_f(pb[g], 16 * (i - 4));
+          const float po = i < 4 ? readlane_f(pa[g], 16 * i + 8) : readlane_f(pb[g], 16 * (i - 4) + 8);
+          const float pu = vh ? po : pe;
+          acc[g].x = fmaf(pu, vvb[i].x, acc[g].x);
+          acc[g].y = fmaf(pu, vvb[i].y, acc[g].y);
+          acc[g].z = fmaf(pu, vvb[i].z, acc[g].z);
+          acc[g].w = fmaf(pu, vvb[i].w, acc[g].w);
         }
       }
     }
@@ -250,7 +274,7 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
     // a slot that walks several tiles (long contexts, batched decode with few slots per sequence) fetches tile t + NS while it
     // works on tile t: two register sets in ping-pong, one memory round trip per PAIR of steps instead of one per tile
     f32x4 kv2[8];
-    float2 vv2[kDTile];
+    f32x4 vv2[8];
     int tile = slot;
     while (true) {
       const int n1 = tile + NS;
@@ -277,13 +301,16 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
 #pragma unroll
   for (int g = 0; g < GMAX; ++g) {
     if (g < gn) {
+      // even keys were summed by lanes 0-31, odd keys by lanes 32-63: one exchange gives the totals (written by the lower half)
+      f32x4 o = acc[g];
+      o.x += __shfl_xor(o.x, 32, 64); o.y += __shfl_xor(o.y, 32, 64); o.z += __shfl_xor(o.z, 32, 64); o.w += __shfl_xor(o.w, 32, 64);
       const size_t pi = ((size_t)seq * p.n_q + hk * G + g0 + g) * NS + slot;
       const float mn = m_run[g] * 0.6931471805599453f;       // m back to nats for the combine
       if (WT) {
-        wt_store2(p.part_o + pi * kHeadDim + lane * 2, acc0[g], acc1[g]);
+        if (lane < 32) { wt_store2(p.part_o + pi * kHeadDim + vc * 4, o.x, o.y); wt_store2(p.part_o + pi * kHeadDim + vc * 4 + 2, o.z, o.w); }
         if (lane == 0) wt_store2(p.part_ml + pi * 2, mn, l_run[g]);
       } else {
-        *reinterpret_cast<float2*>(p.part_o + pi * kHeadDim + lane * 2) = make_float2(acc0[g], acc1[g]);
+        if (lane < 32) *reinterpret_cast<f32x4*>(p.part_o + pi * kHeadDim + vc * 4) = o;
         if (lane == 0) { p.part_ml[pi * 2] = mn; p.part_ml[pi * 2 + 1] = l_run[g]; }
       }
     }

@@ -66,6 +66,7 @@ __device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v); }
 __device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v); }   // quad_perm [2,3,0,1]
 __device__ __forceinline__ float row_ror4(float v) { return dpp_mov<0x124>(v); }
 __device__ __forceinline__ float row_ror8(float v) { return dpp_mov<0x128>(v); }
+__device__ __forceinline__ float half_mirror(float v) { return dpp_mov<0x141>(v); }  // row_half_mirror: lane i <-> 7 - i within 8 lanes
 __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, lane_xor1(v)); v = fmaxf(v, lane_xor2(v)); v = fmaxf(v, row_ror4(v)); v = fmaxf(v, row_ror8(v));
   return v;
