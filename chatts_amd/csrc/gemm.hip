@@ -814,18 +814,24 @@ template <int NSTAGE, bool W8, int MB, int NW = 4, bool I8 = false>
 __global__ __launch_bounds__(64 * NW) void gemm_stream_kernel(GemmParams p, const uint16_t* __restrict__ a_hi,
                                                               const uint16_t* __restrict__ a_lo, int ldp) {
   static_assert(!W8 || MB == 1, "the fp8 weight stream is a batched-decode format (M <= 16)");
-  static_assert(NW == 4 || (NW == 8 && W8), "8 waves: fp8 W only (8 A pieces per stage, one per wave)");
+  static_assert(NW == 4 || (NW == 8 && (W8 || MB % 2 == 0)), "8 waves: fp8 W (one A piece per wave), or bf16 W with an even block count");
+  // wave grid inside the 16 MB x 128 tile: WM x WN.  4 waves: 1 x 4 (32 columns each).  8 waves, fp8 W (M <= 16): 1 x 8 (16 columns).
+  // 8 waves, bf16 W with several row blocks (the TS-encoder MLP, short prefill chunks): 2 x 4 - each wave MB / 2 row blocks x 32 columns:
+  // as many fragment reads and MFMAs per workgroup as with 4 waves, but the DMA pieces of a K-step (16 W + 4 MB A: 48 at MB = 8, ~150
+  // cycles of issue apiece) are spread over twice the waves and two waves per SIMD overlap issue with MFMAs.
+  constexpr int WM = (NW == 8 && !W8) ? 2 : 1, WN = NW / WM, MBW = MB / WM;
   constexpr int BN = kStreamBN, BK = stream_bk(W8), STAGE = stream_stage(W8, MB);
   constexpr int A_SUB = 16 * 128;                  // one A sub-block: 16 token rows x 64 K-values (128 B)
   constexpr int NSUB = BK / 64;                    // K sub-blocks per plane and stage (2 for fp8 W)
   constexpr int A_PLANE = MB * NSUB * A_SUB, W_OFF = 2 * A_PLANE;
   constexpr int NWP = 16 / NW;                     // W pieces per wave and stage
-  constexpr int NAP = NW == 8 ? 1 : (W8 ? NSUB : MB);   // A pieces per wave and stage
+  constexpr int NAP = W8 ? (NW == 8 ? 1 : NSUB) : (NW == 8 ? MB / 2 : MB);   // A pieces per wave and stage
   constexpr int NPIECE = NWP + NAP;                // DMA pieces per wave and stage
-  constexpr int FN = 8 / NW;                       // 16-column B fragments per wave
+  constexpr int FN = 8 / WN;                       // 16-column B fragments per wave
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
   const int n0 = blockIdx.x * BN;
   const int kbeg = blockIdx.z * p.k_per_split;
   int kend = kbeg + p.k_per_split;
@@ -850,8 +856,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_stream_kernel(GemmParams p, cons
   }
 #pragma unroll
   for (int q = 0; q < NAP; ++q) {
-    const int plane = NW == 8 ? (wave >> 2) : (W8 ? q : (wave >> 1));
-    const int sub = NW == 8 ? ((wave >> 1) & 1) : (W8 ? (wave >> 1) : 0), blk = W8 ? 0 : q;
+    // fp8 W: (plane, K sub-block) per wave as before.  bf16 W: 4 waves - plane wave >> 1 of EVERY block; 8 waves - plane (wave >> 1) & 1
+    // of the blocks 2 q + (wave >> 2).  The row half is wave & 1 in all forms (the piece parity the swizzle above assumes).
+    const int plane = W8 ? (NW == 8 ? (wave >> 2) : q) : ((wave >> 1) & 1);
+    const int sub = W8 ? (NW == 8 ? ((wave >> 1) & 1) : (wave >> 1)) : 0;
+    const int blk = W8 ? 0 : (NW == 8 ? 2 * q + (wave >> 2) : q);
     int am = blk * 16 + (wave & 1) * 8 + lrow;
     if (am > p.m - 1) am = p.m - 1;
     asrc[q] = (plane ? a_lo : a_hi) + (size_t)am * ldp + kbeg + sub * 64 + lchunk * 8;
@@ -868,9 +877,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_stream_kernel(GemmParams p, cons
       __builtin_amdgcn_global_load_lds((gptr_t)(asrc[q] + (size_t)kt * BK), (lptr_t)(base + adst[q]), 16, 0, 0);
   };
 
-  f32x4 acc[MB][FN];
+  f32x4 acc[MBW][FN];
 #pragma unroll
-  for (int b = 0; b < MB; ++b)
+  for (int b = 0; b < MBW; ++b)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_stream_kernel(GemmParams p, cons
     for (int h = 0; h < NH; ++h) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int r = wave * (16 * FN) + j * 16 + frow;
+        const int r = wn * (16 * FN) + j * 16 + frow;
         if (W8) {   // 8 fp8 = 8 bytes at byte 32 h + 8 q of the row: 16-byte chunk 2 h + (q >> 1), half q & 1
           const u32x2 q8 = *reinterpret_cast<const u32x2*>(base + W_OFF + lds_off128(r, 2 * h + (fchunk >> 1)) + (fchunk & 1) * 8);
           typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -914,11 +923,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_stream_kernel(GemmParams p, cons
       }
     }
 #pragma unroll
-    for (int b = 0; b < MB; ++b) {
+    for (int b = 0; b < MBW; ++b) {
       bf16x8_t alo[NH], ahi[NH];
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        const int aoff = (b * NSUB + (h >> 1)) * A_SUB + lds_off128(frow, (h & 1) * 4 + fchunk);
+        const int aoff = ((wm * MBW + b) * NSUB + (h >> 1)) * A_SUB + lds_off128(frow, (h & 1) * 4 + fchunk);
         alo[h] = *reinterpret_cast<const bf16x8_t*>(base + A_PLANE + aoff);
         ahi[h] = *reinterpret_cast<const bf16x8_t*>(base + aoff);
       }
@@ -948,9 +957,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_stream_kernel(GemmParams p, cons
       }
       return;
     }
-    gemm_store<MB, 1, 16 * MB, 16, W8>(p, acc, 0, n0, 0, wave, lane, blockIdx.z);
+    gemm_store<MBW, 1, 16 * MBW, 16, W8>(p, acc, 0, n0, wm, wn, lane, blockIdx.z);
   } else {
-    gemm_store<MB, 2, 16 * MB, 32, W8>(p, acc, 0, n0, 0, wave, lane, blockIdx.z);
+    gemm_store<MBW, 2, 16 * MBW, 32, W8>(p, acc, 0, n0, wm, wn, lane, blockIdx.z);
   }
 }
 
@@ -1251,7 +1260,9 @@ static void pick_dma_geometry(int m, int n, int k, int& sk) {
 // (~150 cycles apiece) in the same instruction stream as their 64 MFMAs, which is what the prefill kernel's loader waves exist
 // to avoid; and a short K (layer 0: 5 K-steps) is served better by the 2-way split of the 128 x 256 tiles.  Hence M <= 64, K >= 1024.
 static bool stream_multiblock(int m, int n, int k, bool w8) {
-  const int max_m = gemm_env_int("CHATTS_GEMM_STREAM_MB", 64);
+  // round 3: with 8 waves as 2 x 4 the streaming form also wins at 65 .. 128 rows on the 5120-column shapes (P = 128, one TS-MLP layer:
+  // 30.1 us against 33.2 for the LDS-DMA kernel and 35.0 for the 4-wave form, epilogue included - profiles/r3_ts_gemm_sweep.txt)
+  const int max_m = gemm_env_int("CHATTS_GEMM_STREAM_MB", n <= 8192 && gemm_env_int("CHATTS_GEMM_STREAM_MB_WAVES", 8) == 8 ? 128 : 64);
   return m > 16 && m <= max_m && m <= 128 && !w8 && k % 64 == 0 && k >= 1024 &&
          2 * 8 * (((n + kDmaBN - 1) / kDmaBN + 7) / 8) <= device_cus();
 }
@@ -1432,9 +1443,10 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
   if (stream) {
     int rc;
     const int stages = gemm_env_int("CHATTS_GEMM_STREAM_STAGES", 4);
-    if (a->m > 64) rc = launch_stream_t<3, false, 8>(p, a, sk, s);          // 3 x 48 KB stages: one workgroup per CU
-    else if (a->m > 32) rc = launch_stream_t<4, false, 4>(p, a, sk, s);     // 4 x 32 KB
-    else if (a->m > 16) rc = launch_stream_t<4, false, 2>(p, a, sk, s);     // 4 x 24 KB
+    const bool w8x = gemm_env_int("CHATTS_GEMM_STREAM_MB_WAVES", 8) == 8;   // 8 waves as 2 x 4 for the multi-block forms (bit-identical to 4)
+    if (a->m > 64) rc = w8x ? launch_stream_t<3, false, 8, 8>(p, a, sk, s) : launch_stream_t<3, false, 8>(p, a, sk, s);   // 3 x 48 KB stages: one workgroup per CU
+    else if (a->m > 32) rc = w8x ? launch_stream_t<4, false, 4, 8>(p, a, sk, s) : launch_stream_t<4, false, 4>(p, a, sk, s);     // 4 x 32 KB
+    else if (a->m > 16) rc = w8x ? launch_stream_t<4, false, 2, 8>(p, a, sk, s) : launch_stream_t<4, false, 2>(p, a, sk, s);     // 4 x 24 KB
     else if (a->w8 && a->w8_format == CHATTS_W8_INT8)
       rc = stages == 3 ? launch_stream_t<3, true, 1, 4, true>(p, a, sk, s) : launch_stream_t<4, true, 1, 4, true>(p, a, sk, s);
     else if (a->w8 && gemm_env_int("CHATTS_GEMM_STREAM_WAVES", 4) == 8)

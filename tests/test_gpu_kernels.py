@@ -1032,6 +1032,22 @@ def test_gemm_stream_multiblock_parity(lib, monkeypatch, epi, m, n, k):
     assert rel_err(out.cpu().numpy(), base.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID])
+@pytest.mark.parametrize("m,n,k", [(17, 5120, 5120), (33, 1024, 512), (64, 5120, 5120), (100, 384, 1024), (128, 5120, 5120), (23, 96, 64)])
+def test_gemm_stream_multiblock_eight_waves_equal_four_bitwise(lib, monkeypatch, epi, m, n, k):
+    """The multi-block streaming kernel with 8 waves as 2 x 4 (each wave half the row blocks x 32 columns: the K-step's DMA pieces are
+    spread over twice the waves) == the 4-wave form, bit for bit - every output element sees the same operands in the same K order."""
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
+    r = resid if epi == _lib.EPI_RESID else None
+    monkeypatch.setenv("CHATTS_GEMM_STREAM_MB", "128")
+    outs = []
+    for waves in ("4", "8"):
+        monkeypatch.setenv("CHATTS_GEMM_STREAM_MB_WAVES", waves)
+        outs.append(_linear_planes(lib, a, w, bias, r, epi, with_a=False, ld=k + 64))
+    assert not torch.isnan(outs[1]).any()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("nq,nkv", [(4, 2), (5, 1), (8, 8)])
 @pytest.mark.parametrize("T,pos0,splits", [(16, 0, 1), (64, 0, 1), (65, 31, 1), (130, 100, 1), (200, 0, 1), (300, 17, 2), (70, 0, 2), (33, 400, 4)])
 def test_attention_prefill_bf16x3_parity(lib, monkeypatch, nq, nkv, T, pos0, splits):

@@ -57,6 +57,12 @@ def main():  # noqa
             print(f"== P={P} K={K} N=5120 (weights {5120 * K * 2 / 1e6:.1f} MB)")
             res = [("f32 A, register-staged, auto", run(P, K, 5120, {}, planes=False))]
             res.append(("planes, auto", run(P, K, 5120, {})))
+            for mbw in (4, 8):
+                res.append((f"planes, stream up to 128 rows, {mbw} waves", run(P, K, 5120, {"CHATTS_GEMM_STREAM_MB": 128, "CHATTS_GEMM_STREAM_MB_WAVES": mbw})))
+                for sk in (4, 5, 6, 8):
+                    if K // sk >= 64:
+                        res.append((f"planes, stream up to 128 rows, {mbw} waves, SK={sk}",
+                                    run(P, K, 5120, {"CHATTS_GEMM_STREAM_MB": 128, "CHATTS_GEMM_STREAM_MB_WAVES": mbw, "CHATTS_GEMM_SK": sk})))
             for sk in (1, 2, 3, 4, 6, 8, 10, 12, 16, 20):
                 if K // sk < 64:
                     continue
