@@ -1030,6 +1030,57 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   else c[(size_t)row * ldc + col] = v;
 }
 
+// The same epilogue, four columns per thread (N % 4 == 0, sk <= 8, no SwiGLU pairing, no stream-K): 16-byte loads instead of 4-byte
+// ones and all slabs of a thread requested at once.  Same sums in the same order per element: bit-identical to the kernel above.
+__global__ __launch_bounds__(256) void splitk_epilogue_v4_kernel(const float* __restrict__ ws, int sk, int m, int n,
+                                                                const float* __restrict__ bias, const float* __restrict__ resid,
+                                                                float* __restrict__ c, int ldc, int epilogue,
+                                                                const float* __restrict__ scale, uint16_t* __restrict__ c_hi,
+                                                                uint16_t* __restrict__ c_lo, int ldcp) {
+  const int n4 = n >> 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)m * n4) return;
+  const int row = (int)(idx / n4), col = (int)(idx % n4) * 4;
+  const size_t plane = (size_t)m * n, at = (size_t)row * n + col;
+  f32x4 t8[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) t8[s] = *reinterpret_cast<const f32x4*>(ws + (s < sk ? s : sk - 1) * plane + at);
+  f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+  if (epilogue == CHATTS_EPI_RESID) r4 = *reinterpret_cast<const f32x4*>(resid + (size_t)row * ldc + col);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+    if (s < sk) { v[0] += t8[s].x; v[1] += t8[s].y; v[2] += t8[s].z; v[3] += t8[s].w; }
+  const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (scale) v[j] *= scale[col + j];
+    if (bias) v[j] += bias[col + j];
+    if (epilogue == CHATTS_EPI_GELU) v[j] = gelu_erf_f(v[j]);
+    if (epilogue == CHATTS_EPI_RESID) v[j] = rr[j] + v[j];
+  }
+  if (c_hi) {
+    if ((ldcp & 3) == 0) {      // both planes as one 8-byte store each (store_planes' arithmetic)
+#pragma clang fp contract(off)
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      bf16x4_t hv, lv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        hv[j] = h;
+        lv[j] = (__bf16)(v[j] - (float)h);
+      }
+      *reinterpret_cast<bf16x4_t*>(c_hi + (size_t)row * ldcp + col) = hv;
+      *reinterpret_cast<bf16x4_t*>(c_lo + (size_t)row * ldcp + col) = lv;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) store_planes(c_hi, c_lo, (size_t)row * ldcp + col + j, v[j]);
+    }
+  } else {
+    *reinterpret_cast<f32x4*>(c + (size_t)row * ldc + col) = (f32x4){v[0], v[1], v[2], v[3]};
+  }
+}
+
 // Split-K epilogue fused with the RMSNorm that consumes its result: one workgroup per output row sums the partials
 // (fixed order), applies bias / residual, writes the row, and - the row's sum of squares being at hand - writes
 // norm_w * (row * rsqrt(mean(row^2) + eps)) as bf16 hi / lo planes, the next projection's operand.  Replaces the
@@ -1502,7 +1553,14 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
     *rope_done = true;
     return CHATTS_OK;
   }
-  if (sk > 1) {
+  if (sk > 1 && sk <= 8 && a->epilogue != CHATTS_EPI_SWIGLU && p.sk_T == 0 && a->n % 4 == 0 && a->ldc % 4 == 0 &&
+      ((uintptr_t)a->c % 16) == 0 && ((uintptr_t)a->resid % 16) == 0 && gemm_env_int("CHATTS_EPI_V4", 1) != 0) {
+    const size_t total = (size_t)a->m * (a->n / 4);
+    hipLaunchKernelGGL(splitk_epilogue_v4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float*>(a->workspace), sk, a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue,
+                       a->w8 ? a->w8_scale : nullptr, a->c_hi, a->c_lo, a->ld_cplanes);
+    CHATTS_CHECK_LAUNCH("splitk_epilogue_v4");
+  } else if (sk > 1) {
     const int ncols = a->epilogue == CHATTS_EPI_SWIGLU ? a->n / 2 : a->n;
     const size_t total = (size_t)a->m * ncols;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
