@@ -185,7 +185,8 @@ class ChattsError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB
+    """the in-tree library; CHATTS_AMD_LIB points at another build of it (A/B runs of compile-time knobs) - still no fallback"""
+    return os.environ.get("CHATTS_AMD_LIB") or _build.LIB
 
 
 def load():
