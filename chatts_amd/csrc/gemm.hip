@@ -25,6 +25,14 @@
 
 #include "common.h"
 
+// cache-policy bits of the prefill GEMM's LDS-DMA loads (A/B knobs, compile time): 0 = default, 2 = non-temporal
+#ifndef CHATTS_DMA_A_AUX
+#define CHATTS_DMA_A_AUX 0
+#endif
+#ifndef CHATTS_DMA_W_AUX
+#define CHATTS_DMA_W_AUX 0
+#endif
+
 namespace chatts {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -505,14 +513,14 @@ __global__ __launch_bounds__(W32 ? 512 : kDmaThreads) void gemm_dma_kernel(GemmP
 #pragma unroll
       for (int h = 0; h < NA; ++h) {
         if (m0 + (L + NLOAD * h) * 8 >= p.m) continue;     // ragged last M-tile: these 8 rows lie past M, nobody reads them
-        __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + (size_t)kt * BK), (lptr_t)(base + h * NLOAD * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + (size_t)kt * BK), (lptr_t)(base + h * NLOAD * 1024), 16, 0, CHATTS_DMA_A_AUX);
         __builtin_amdgcn_global_load_lds((gptr_t)(src[NA + h] + (size_t)kt * BK), (lptr_t)(base + A_PLANE + h * NLOAD * 1024),
-                                         16, 0, 0);
+                                         16, 0, CHATTS_DMA_A_AUX);
       }
 #pragma unroll
       for (int h = 0; h < NW; ++h)
         __builtin_amdgcn_global_load_lds((gptr_t)(src[2 * NA + h] + (size_t)kt * BK),
-                                         (lptr_t)(base + 2 * A_PLANE + h * NLOAD * 1024), 16, 0, 0);
+                                         (lptr_t)(base + 2 * A_PLANE + h * NLOAD * 1024), 16, 0, CHATTS_DMA_W_AUX);
     };
     static_assert(NA == 4 && NW == 8, "the vmcnt literals below count NW + 2 * (live A piece pairs) pieces per stage");
     issue(0);
