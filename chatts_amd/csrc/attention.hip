@@ -28,11 +28,12 @@ namespace chatts {
 // ---------------------------------------------------------------------------------------------------
 // decode: grid (n_kv, n_slots), 64 threads.  Slot s walks tiles s, s + n_slots, ... of 16 keys.
 // ---------------------------------------------------------------------------------------------------
+template <int GMAX>
 __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) float q_s[kMaxGroup * kHeadDim];
+  __shared__ __attribute__((aligned(16))) float q_s[GMAX * kHeadDim];
   __shared__ __attribute__((aligned(16))) float knew_s[kHeadDim];
   __shared__ __attribute__((aligned(16))) float vnew_s[kHeadDim];
-  attn_decode_wave<false>(p, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, q_s, knew_s, vnew_s);
+  attn_decode_wave<false, GMAX>(p, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, q_s, knew_s, vnew_s);
 }
 
 // out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots): attn_combine_wave
@@ -821,7 +822,13 @@ int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int 
   p.seq_stride = seq_stride; p.out_hi = out_hi; p.out_lo = out_lo; p.kv_round = kv_round_mode();
   const int rc = bind_workspace(p, workspace, workspace_bytes);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(n_kv, n_splits, batch), dim3(64), 0, as_stream(stream), p);
+  const dim3 grid(n_kv, n_splits, batch);
+  switch (n_q / n_kv) {       // registers sized for the group (every head's arithmetic is the same in all instantiations)
+    case 1: case 2: case 3: case 4: hipLaunchKernelGGL(attn_decode_kernel<4>, grid, dim3(64), 0, as_stream(stream), p); break;
+    case 5: hipLaunchKernelGGL(attn_decode_kernel<5>, grid, dim3(64), 0, as_stream(stream), p); break;
+    case 6: hipLaunchKernelGGL(attn_decode_kernel<6>, grid, dim3(64), 0, as_stream(stream), p); break;
+    default: hipLaunchKernelGGL(attn_decode_kernel<kMaxGroup>, grid, dim3(64), 0, as_stream(stream), p); break;
+  }
   CHATTS_CHECK_LAUNCH("attn_decode");
   hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(n_q, batch), dim3(128), 0, as_stream(stream), p);
   CHATTS_CHECK_LAUNCH("attn_decode_combine");

@@ -331,12 +331,13 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
 }
 
 
-template <bool WT>
+// GMAX >= the group size: the per-head registers are sized by it (a Qwen2-14B group of 5 in registers for 8 costs the third wave per SIMD)
+template <bool WT, int GMAX = kMaxGroup>
 __device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
                                                  float* q_s, float* knew_s, float* vnew_s) {
   AttnTileRegs t;
   if (!attn_decode_preload(p, hk, slot, seq, lane, t)) return;
-  attn_decode_finish<WT, kMaxGroup, true>(p, hk, slot, seq, lane, t, q_s, knew_s, vnew_s, 0, p.n_q / p.n_kv);
+  attn_decode_finish<WT, GMAX, true>(p, hk, slot, seq, lane, t, q_s, knew_s, vnew_s, 0, p.n_q / p.n_kv);
 }
 
 // out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots).  One workgroup
