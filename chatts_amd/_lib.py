@@ -29,6 +29,7 @@ class TsWeights(C.Structure):
                 ("b", c_void_p * 8)]
 
 
+ABI_VERSION = 7            # CHATTS_ABI_VERSION of include/chatts_amd.h this binding was written against (checked by load())
 TILE_COUNTERS = 4096      # CHATTS_TILE_COUNTERS
 W8_FP8, W8_INT8 = 0, 1     # ChattsLinearArgs.w8_format
 
@@ -42,7 +43,7 @@ class LinearArgs(C.Structure):
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("ld_cplanes", c_int),
                 ("post_norm_w", c_void_p), ("post_norm_eps", c_float), ("post_hi", c_void_p), ("post_lo", c_void_p), ("ld_post", c_int),
                 ("w4", c_void_p), ("w4_sz", c_void_p), ("ldw4", c_int), ("w4_group", c_int), ("tile_counters", c_void_p),
-                ("w8_format", c_int)]
+                ("w8_format", c_int), ("tp_reduce", c_void_p)]
 
 
 class KvCache(C.Structure):
@@ -148,6 +149,7 @@ SIGNATURES = {
     "chatts_decoder_prefill_last": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "chatts_decoder_prefill_packed": (c_int, [c_void_p, C.POINTER(PrefillSegment), c_int, c_void_p]),
     "chatts_decoder_logits": (c_int, [c_void_p, c_int, c_void_p]),
+    "chatts_decoder_logits_batched": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "chatts_decoder_decode_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                            c_void_p]),
     "chatts_decoder_set_tp": (c_int, [c_void_p, c_void_p]),
@@ -163,6 +165,7 @@ SIGNATURES = {
     "chatts_tp_buffer_free": (c_int, [c_void_p]),
     "chatts_tp_init": (c_void_p, [c_int, c_int, c_void_p, c_void_p, c_size_t, c_int64]),
     "chatts_tp_init_local": (c_void_p, [c_int, c_int, C.POINTER(c_void_p), c_size_t, c_int64]),
+    "chatts_tp_init_loopback": (c_void_p, [c_int, c_int, c_void_p, c_size_t, c_int64]),
     "chatts_tp_destroy": (None, [c_void_p]),
     "chatts_tp_rank": (c_int, [c_void_p]),
     "chatts_tp_world": (c_int, [c_void_p]),
@@ -208,6 +211,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.chatts_abi_version() != ABI_VERSION:      # e.g. CHATTS_AMD_LIB pointing at a stale A/B build: struct layouts would not match
+        raise RuntimeError(f"{path} has ABI version {lib.chatts_abi_version()}, this package binds version {ABI_VERSION} "
+                           "(include/chatts_amd.h: CHATTS_ABI_VERSION): rebuild it with `python -m chatts_amd.build --force`")
     _LIB = lib
     return lib
 

@@ -38,6 +38,8 @@ struct ChattsDecoder {
   bool sampling = false;    // token selection of the decode steps: greedy argmax, or the sampler with `sa`
   ChattsSamplingArgs sa{};
   ChattsTpComm* tp = nullptr;   // tensor-parallel exchange (borrowed); required by the whole-step entry points when tp_world > 1
+  bool fuse_tp = false;     // set by chatts_decoder_decode_step: the M == 1 o_proj / down_proj GEMVs carry the exchange in their own launch
+  bool tp_fused = false;    // ... and whether the last layer part's projection did (otherwise the caller launches chatts_allreduce)
   // persistent decode step (decode_mega.hip): plan + caller-owned device state (tables, barrier counters); null = not attached
   MegaHost mega{};
   bool mega_planned = false;
@@ -93,6 +95,7 @@ static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const 
     CHATTS_REQUIRE(a->m > 1 && a->c && a->post_hi && a->post_lo && a->ld_post >= a->n && a->ld_post % 4 == 0 && a->n % 4 == 0 &&
                        (a->epilogue == CHATTS_EPI_NONE || a->epilogue == CHATTS_EPI_RESID) && !cplanes,
                    CHATTS_E_BADARG, "linear: post-norm planes need M > 1, float32 c, EPI_NONE / EPI_RESID, both planes, ld_post >= N");
+  if (a->tp_reduce) CHATTS_REQUIRE(a->m == 1, CHATTS_E_BADARG, "linear: tp_reduce is available for M == 1 (the decode GEMV) only");
   if (a->m == 1 && a->epilogue != CHATTS_EPI_GELU) return launch_gemv(a, as_stream(stream));
   CHATTS_REQUIRE(a->norm_w == nullptr, CHATTS_E_BADARG, "linear: fused RMSNorm is only available for M == 1");
   return launch_gemm(a, as_stream(stream), rope, rope_done);
@@ -357,7 +360,11 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
       if ((rc = chatts_split_bf16x2(d->b.attn, t, la.k, la.k, d->b.planes_hi, d->b.planes_lo, la.k, stream)) != 0) return rc;
       la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k;
     }
-    if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
+    d->tp_fused = false;
+    if (tp && t == 1 && d->fuse_tp && d->tp && !la.w4) {      // x += sum over the ranks, inside the GEMV launch (ChattsLinearArgs.tp_reduce)
+      la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; la.tp_reduce = d->tp;
+      d->tp_fused = true;
+    } else if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
     request_post_norm(d, &la, lw.post_norm, false);
     return chatts_linear(&la, stream);
@@ -386,7 +393,11 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     la.w4 = lw.down4; la.w4_sz = lw.down4_sz; la.ldw4 = c.inter / 2; la.w4_group = lw.w4_group;
   }
   if (act_planes) { la.a = nullptr; la.a_hi = d->b.planes2_hi; la.a_lo = d->b.planes2_lo; la.ld_planes = c.inter; }
-  if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
+  d->tp_fused = false;
+  if (tp && t == 1 && d->fuse_tp && d->tp && !la.w4) {
+    la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; la.tp_reduce = d->tp;
+    d->tp_fused = true;
+  } else if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
   request_post_norm(d, &la, layer + 1 < c.n_layers ? d->layers[layer + 1].input_norm : nullptr, false);
   return chatts_linear(&la, stream);
@@ -476,6 +487,25 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   return chatts_linear(&la, stream);
 }
 
+// final norm + lm_head for rows 0 .. batch-1 of x (cache slots 0 .. batch-1) -> logits_all [batch, vocab_local]: the tail of a
+// batched step (compute_logits for a batch, chatts_vllm.py:603-610).  M = batch weight-streaming GEMM on this rank's vocabulary slice.
+extern "C" int chatts_decoder_logits_batched(ChattsDecoder* d, int batch, float* logits_all, chatts_stream_t stream) {
+  CHATTS_REQUIRE(d && logits_all, CHATTS_E_BADARG, "decoder_logits_batched: null argument");
+  const int maxb = d->b.max_batch > 0 ? d->b.max_batch : 1;
+  CHATTS_REQUIRE(batch >= 1 && batch <= maxb && batch <= d->b.t_max, CHATTS_E_SHAPE, "decoder_logits_batched: batch %d exceeds max_batch %d",
+                 batch, maxb);
+  const ChattsDecoderConfig& c = d->cfg;
+  ChattsLinearArgs la{};
+  la.w = d->w.lm_head; la.c = logits_all; la.m = batch; la.n = (int)c.vocab_local; la.k = c.hidden;
+  la.lda = c.hidden; la.ldw = c.hidden; la.ldc = (int)c.vocab_local; la.epilogue = CHATTS_EPI_NONE;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+  la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden; la.w8_format = d->cfg.w8_format;
+  int rc = norm_into(d, d->w.final_norm, &la, stream);      // binds planes a fused epilogue already wrote (d->normed), or launches the norm
+  d->normed = false;
+  if (rc) return rc;
+  return chatts_linear(&la, stream);
+}
+
 // One greedy step for `batch` sequences (TP = 1): all layers, final norm + lm_head for every row, per-sequence
 // argmax (token / step / pos / out_tokens rows advance independently; pos saturates at max_ctx - 1).
 // logits_all: [batch, vocab_local] float32 scratch owned by the caller.
@@ -502,16 +532,9 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
     if (rc == CHATTS_OK) rc = chatts_decoder_layer_part_batched(d, l, 1, batch, pos_dev, n_splits, stream);
     if (tp && rc == CHATTS_OK) rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, nx, stream);     // ... and down_proj
   }
-  ChattsLinearArgs la{};
-  la.w = d->w.lm_head; la.c = logits_all; la.m = batch; la.n = (int)c.vocab_local; la.k = c.hidden;
-  la.lda = c.hidden; la.ldw = c.hidden; la.ldc = (int)c.vocab_local; la.epilogue = CHATTS_EPI_NONE;
-  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
-  la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden; la.w8_format = d->cfg.w8_format;
-  if (rc == CHATTS_OK) rc = norm_into(d, d->w.final_norm, &la, stream);
   d->chain = false;
-  d->normed = false;
-  if (rc) return rc;
-  if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+  if (rc) { d->normed = false; return rc; }
+  if ((rc = chatts_decoder_logits_batched(d, batch, logits_all, stream)) != 0) return rc;
   return chatts_decoder_select_tokens(d, logits_all, batch, c.vocab_local, token_dev, token_logit_dev, out_tokens, out_stride, step_dev,
                                       pos_dev, c.max_ctx - 1, nullptr, stream);
 }
@@ -774,12 +797,19 @@ extern "C" int chatts_decoder_decode_step(ChattsDecoder* d, int32_t* pos_dev, in
     static const bool off = getenv("CHATTS_DECODE_MEGA") && atoi(getenv("CHATTS_DECODE_MEGA")) == 0;
     if (!off) return decode_step_mega(d, pos_dev, step_dev, token_dev, token_logit_dev, out_tokens, stream);
   }
-  for (int l = 0; l < d->cfg.n_layers; ++l) {
-    if ((rc = chatts_decoder_layer_part(d, l, 0, 1, 0, pos_dev, n_splits, stream)) != 0) return rc;
-    if (tp && (rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, H, stream)) != 0) return rc;    // x += sum of the partial o_proj
-    if ((rc = chatts_decoder_layer_part(d, l, 1, 1, 0, pos_dev, n_splits, stream)) != 0) return rc;
-    if (tp && (rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, H, stream)) != 0) return rc;    // ... and down_proj
+  // Tensor parallel: the two exchanges of a layer ride in the o_proj / down_proj GEMV launches (6 launches per layer instead of 8;
+  // CHATTS_TP_FUSE=0 keeps the stand-alone chatts_allreduce kernels: same bits - tests/test_gpu_tp_p2p.py)
+  const bool fuse_off = getenv("CHATTS_TP_FUSE") && atoi(getenv("CHATTS_TP_FUSE")) == 0;     // (read per call: tests A/B it in one process)
+  d->fuse_tp = tp && !fuse_off;
+  rc = CHATTS_OK;
+  for (int l = 0; l < d->cfg.n_layers && rc == CHATTS_OK; ++l) {
+    rc = chatts_decoder_layer_part(d, l, 0, 1, 0, pos_dev, n_splits, stream);
+    if (rc == CHATTS_OK && tp && !d->tp_fused) rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, H, stream);    // x += sum of the partial o_proj
+    if (rc == CHATTS_OK) rc = chatts_decoder_layer_part(d, l, 1, 1, 0, pos_dev, n_splits, stream);
+    if (rc == CHATTS_OK && tp && !d->tp_fused) rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, H, stream);    // ... and down_proj
   }
+  d->fuse_tp = false;
+  if (rc) return rc;
   if ((rc = chatts_decoder_logits(d, 0, stream)) != 0) return rc;
   if ((rc = chatts_decoder_select_tokens(d, d->b.logits, 1, d->cfg.vocab_local, token_dev, token_logit_dev, out_tokens, 0, step_dev,
                                          pos_dev, 0, nullptr, stream)) != 0) return rc;

@@ -15,8 +15,13 @@
 // Fusions: RMSNorm of x in the prologue (Qwen2RMSNorm.forward), bias, residual add, SwiGLU.
 #include "common.h"
 #include "gemv_common.h"
+#include "tp_common.h"
 
 namespace chatts {
+
+// EPI_RESID of a row-parallel projection under tensor parallelism (ChattsLinearArgs.tp_reduce): the sum over the ranks is formed
+// inside the launch.  Internal template value, not part of the C-ABI's epilogue enum.
+constexpr int kEpiResidTp = 4;
 
 struct GemvParams {
   const uint16_t* w;
@@ -39,12 +44,64 @@ struct GemvParams {
   const uint8_t* w4;
   const float* w4_sz;     // [N, K / w4_group, 2]
   int ldw4, w4_group;
+  TpParams tp;            // kEpiResidTp only
 };
+
+// ---- the exchange inside the launch (kEpiResidTp) ---------------------------------------------------------------------------
+// A wave that has finished the ROWS rows of a task PUSHES them at once - lane l holds (row l % ROWS, destination l / ROWS): ROWS x W
+// independent 8-byte granule stores, one per xGMI link and row - and goes on streaming its next task.  After its last task it
+// POLLS the rows of each of its tasks from the local exchange buffer - lane l = (row l % ROWS, source rank l / ROWS), all W x ROWS
+// polls of a task in flight at once - adds them in RANK ORDER (v_readlane: every rank forms the same sum, bit for bit, so the
+// replicated residual stream cannot diverge) and writes out = resid + sum: the arithmetic of tp_allreduce_kernel.  Between a
+// wave's push and its poll lie the peers' pushes of the same rows, i.e. one link latency when the ranks run in step; the other waves
+// of the CU keep the weight stream going meanwhile.  Every rank launches the same geometry, so the workgroup that waits for a row
+// and the peer workgroup that produces it have the same index: no circular wait even if a grid were not fully resident.
+template <int ROWS>
+__device__ __forceinline__ void tp_push_task(const GemvParams& p, uint32_t epoch, int task, int lane, const float (&acc)[ROWS]) {
+  static_assert(ROWS * kMaxWorld <= 64, "one lane per (row, rank)");
+  const int r = lane % ROWS, k = lane / ROWS;
+  const int row = task * ROWS + r;
+  float v = acc[0];
+#pragma unroll
+  for (int i = 1; i < ROWS; ++i)
+    if (r == i) v = acc[i];
+  if (k < p.tp.world && row < p.n) {
+    const int q = (p.tp.rank + k) % p.tp.world;           // start with myself, then ring order: spreads the links
+    put(push_ptr(p.tp, q, epoch) + row, epoch, push_bits(p.tp, q, __float_as_uint(v)));
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void tp_take_task(const GemvParams& p, uint32_t epoch, int task, int lane) {
+  const int r = lane % ROWS, src = lane / ROWS;
+  const int row = task * ROWS + r;
+  uint32_t bits = 0;
+  if (src < p.tp.world && row < p.n) (void)take(slot_ptr(p.tp, p.tp.rank, epoch, src) + row, epoch, bits, &p.tp.ctr[2]);
+  float sum[ROWS];
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) sum[i] = 0.f;
+#pragma unroll
+  for (int s = 0; s < kMaxWorld; ++s) {
+    if (s < p.tp.world) {                                  // (wave-uniform)
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) {
+        const float v = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)bits, s * ROWS + i));
+        sum[i] = s == 0 ? v : sum[i] + v;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const int rw = task * ROWS + i;
+    if (lane == i && rw < p.n) p.out[rw] = p.resid[rw] + sum[i];
+  }
+}
 
 // lane r (< ROWS, or < ROWS/2 for SwiGLU) of the finishing wave writes row r
 template <int ROWS, int EPI>
-__device__ __forceinline__ void gemv_epilogue(const GemvParams& p, int task, int lane, const float (&acc)[ROWS]) {
-  if (EPI == CHATTS_EPI_SWIGLU) {
+__device__ __forceinline__ void gemv_epilogue(const GemvParams& p, int task, int lane, const float (&acc)[ROWS], uint32_t epoch = 0) {
+  if (EPI == kEpiResidTp) {
+    tp_push_task<ROWS>(p, epoch, task, lane, acc);
+  } else if (EPI == CHATTS_EPI_SWIGLU) {
 #pragma unroll
     for (int u = 0; u < ROWS / 2; ++u) {
       const int rg = task_row<ROWS, EPI>(task, 2 * u);
@@ -81,6 +138,8 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(GemvParams p) {
   const int nthreads = blockDim.x, nw = nthreads >> 6;
   const int K = p.k;
   const int nchunks = (K + 511) >> 9;
+  uint32_t epoch = 0;
+  if (EPI == kEpiResidTp) epoch = p.tp.ctr[0] + 1u;
 
   float rstd = 1.f;
   if (NORM) {
@@ -143,7 +202,11 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(GemvParams p) {
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
-    gemv_epilogue<ROWS, EPI>(p, task, lane, acc);
+    gemv_epilogue<ROWS, EPI>(p, task, lane, acc, epoch);
+  }
+  if (EPI == kEpiResidTp) {
+    for (int task = blockIdx.x * nw + wave; task < p.tasks; task += gridDim.x * nw) tp_take_task<ROWS>(p, epoch, task, lane);
+    finish_call(p.tp, epoch);
   }
 }
 
@@ -191,6 +254,8 @@ __global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
   float* red = reinterpret_cast<float*>(smem) + (size_t)nchunks * 1024;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x, nw = nthreads >> 6;
+  uint32_t epoch = 0;
+  if (EPI == kEpiResidTp) epoch = p.tp.ctr[0] + 1u;
 
   float rstd = 1.f;
   if (NORM) {
@@ -256,7 +321,11 @@ __global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]) * scale[r];     // power-of-two scale: exact
-    gemv_epilogue<ROWS, EPI>(p, task, lane, acc);
+    gemv_epilogue<ROWS, EPI>(p, task, lane, acc, epoch);
+  }
+  if (EPI == kEpiResidTp) {
+    for (int task = blockIdx.x * nw + wave; task < p.tasks; task += gridDim.x * nw) tp_take_task<ROWS>(p, epoch, task, lane);
+    finish_call(p.tp, epoch);
   }
 }
 
@@ -406,6 +475,7 @@ template <int ROWS, int UNR>
 static void launch_ldsx(const GemvParams& p, int epi, bool norm, int blocks, int threads, size_t lds, hipStream_t s) {
   switch (epi) {
     case CHATTS_EPI_RESID: launch_ldsx_norm<ROWS, UNR, CHATTS_EPI_RESID>(p, norm, blocks, threads, lds, s); break;
+    case kEpiResidTp: hipLaunchKernelGGL((gemv_ldsx_kernel<ROWS, UNR, kEpiResidTp, false>), dim3(blocks), dim3(threads), lds, s, p); break;
     case CHATTS_EPI_SWIGLU: launch_ldsx_norm<ROWS, UNR, CHATTS_EPI_SWIGLU>(p, norm, blocks, threads, lds, s); break;
     default: launch_ldsx_norm<ROWS, UNR, CHATTS_EPI_NONE>(p, norm, blocks, threads, lds, s); break;
   }
@@ -461,12 +531,23 @@ void gemv_default_geometry(int n, int k, int epilogue, int cus, int* nw_out, int
 
 int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   GemvParams p;
+  p.tp = TpParams{};
   p.w = a->w; p.x = a->a; p.bias = a->bias; p.resid = a->resid; p.out = a->c;
   p.norm_w = a->norm_w; p.eps = a->norm_eps; p.n = a->n; p.k = a->k; p.ldw = a->ldw;
   p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8; p.w8_format = a->w8_format;
   p.w4 = a->w4; p.w4_sz = a->w4_sz; p.ldw4 = a->ldw4; p.w4_group = a->w4_group;
   const bool norm = a->norm_w != nullptr;
   const int cus = device_cus();
+  int epilogue = a->epilogue;
+  if (a->tp_reduce) {       // row-parallel projection: the sum over the ranks is formed inside this launch (kEpiResidTp)
+    const TpParams* tp = tp_params(a->tp_reduce);
+    CHATTS_REQUIRE(a->epilogue == CHATTS_EPI_RESID && !a->bias && !a->norm_w && !a->w4, CHATTS_E_BADARG,
+                   "gemv: tp_reduce needs EPI_RESID without bias / fused norm / 4-bit codes");
+    CHATTS_REQUIRE(a->n <= tp->max_elems, CHATTS_E_SHAPE, "gemv: tp_reduce of %d rows exceeds the exchange buffer (%lld)", a->n,
+                   (long long)tp->max_elems);
+    p.tp = *tp;
+    epilogue = kEpiResidTp;
+  }
   const int swiglu = a->epilogue == CHATTS_EPI_SWIGLU;
   const int units = swiglu ? a->n / 2 : a->n;
   const int nchunks = (a->k + 511) / 512;
@@ -494,6 +575,9 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   int blocks = (p.tasks + nw - 1) / nw;
   if (blocks > cus * occ) blocks = cus * occ;
   blocks = env_int("CHATTS_GEMV_BLOCKS", blocks);
+  // several emulated ranks on ONE device (tests, tools/jobs): their exchange-carrying launches wait for each other, so all of them
+  // must be resident at once - cap the grid (results do not depend on it: a row is always summed by one wave in the same order)
+  if (a->tp_reduce) { const int cap = env_int("CHATTS_TP_FUSE_BLOCKS", 0); if (cap > 0 && blocks > cap) blocks = cap; }
   if (blocks < 1) blocks = 1;
   const int threads = nw * 64;
   // CHATTS_GEMV_LDSPAD = p: declare 1/p of a CU's LDS, so that exactly p workgroups fit per CU and a grid of
@@ -526,8 +610,10 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
     p.tasks = (units + (swiglu ? 1 : 2) - 1) / (swiglu ? 1 : 2);
     int blocks8 = (p.tasks + nw - 1) / nw;
     if (blocks8 > cus * occ) blocks8 = cus * occ;
+    if (a->tp_reduce) { const int cap = env_int("CHATTS_TP_FUSE_BLOCKS", 0); if (cap > 0 && blocks8 > cap) blocks8 = cap; }
     if (blocks8 < 1) blocks8 = 1;
-    switch (a->epilogue) {
+    switch (epilogue) {
+      case kEpiResidTp: launch8_norm<kEpiResidTp>(p, false, blocks8, threads, lds8, s); break;
       case CHATTS_EPI_RESID: launch8_norm<CHATTS_EPI_RESID>(p, norm, blocks8, threads, lds8, s); break;
       case CHATTS_EPI_SWIGLU: launch8_norm<CHATTS_EPI_SWIGLU>(p, norm, blocks8, threads, lds8, s); break;
       default: launch8_norm<CHATTS_EPI_NONE>(p, norm, blocks8, threads, lds8, s); break;
@@ -535,10 +621,10 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
     CHATTS_CHECK_LAUNCH("gemv8_ldsx");
     return CHATTS_OK;
   }
-  if (rows == 4 && unr == 2) launch_ldsx<4, 2>(p, a->epilogue, norm, blocks, threads, lds_launch, s);
-  else if (rows == 4) launch_ldsx<4, 4>(p, a->epilogue, norm, blocks, threads, lds_launch, s);
-  else if (unr == 2) launch_ldsx<2, 2>(p, a->epilogue, norm, blocks, threads, lds_launch, s);
-  else launch_ldsx<2, 4>(p, a->epilogue, norm, blocks, threads, lds_launch, s);
+  if (rows == 4 && unr == 2) launch_ldsx<4, 2>(p, epilogue, norm, blocks, threads, lds_launch, s);
+  else if (rows == 4) launch_ldsx<4, 4>(p, epilogue, norm, blocks, threads, lds_launch, s);
+  else if (unr == 2) launch_ldsx<2, 2>(p, epilogue, norm, blocks, threads, lds_launch, s);
+  else launch_ldsx<2, 4>(p, epilogue, norm, blocks, threads, lds_launch, s);
   CHATTS_CHECK_LAUNCH("gemv_ldsx");
   return CHATTS_OK;
 }

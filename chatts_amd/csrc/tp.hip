@@ -24,52 +24,9 @@
 #include <vector>
 
 #include "common.h"
+#include "tp_common.h"
 
 namespace chatts {
-
-constexpr int kMaxWorld = 8;
-constexpr uint64_t kSpinTicks = 200000000ull;      // wall_clock64 runs at 100 MHz: 2 s
-constexpr uint64_t kSpinTicksBroken = 2000ull;     // 20 us once a timeout has been recorded
-// A communicator that has timed out once is broken until chatts_tp_reset: a step holds ~100 collectives, and each of them
-// waiting its own 2 s would keep the GPU busy for minutes before the host reads the status at its next sync point.
-__device__ __forceinline__ uint64_t spin_limit(const uint32_t* status) { return *status ? kSpinTicksBroken : kSpinTicks; }
-
-struct TpParams {
-  uint64_t* peer[kMaxWorld];   // peer[p]: rank p's exchange buffer as mapped in this process (peer[rank] = local)
-  uint32_t* ctr;               // device words: [0] completed-call counter (epoch - 1), [1] arrivals, [2] status
-  int rank, world;
-  int64_t max_elems;           // granules per (slot, source rank)
-};
-
-__device__ __forceinline__ uint64_t* slot_ptr(const TpParams& p, int owner, uint32_t epoch, int src) {
-  return p.peer[owner] + ((int64_t)(epoch & 1u) * p.world + src) * p.max_elems;
-}
-__device__ __forceinline__ void put(uint64_t* g, uint32_t epoch, uint32_t bits) {
-  __hip_atomic_store(g, ((uint64_t)epoch << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// poll one granule of the LOCAL buffer until its tag is `epoch`; false on timeout
-__device__ __forceinline__ bool take(uint64_t* g, uint32_t epoch, uint32_t& bits, uint32_t* status) {
-  uint64_t v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if ((uint32_t)(v >> 32) != epoch) {
-    const uint64_t t0 = wall_clock64();
-    do {
-      __builtin_amdgcn_s_sleep(1);
-      v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if ((uint32_t)(v >> 32) == epoch) break;
-      if (wall_clock64() - t0 > spin_limit(status)) { atomicOr(status, 1u); bits = 0; return false; }
-    } while (true);
-  }
-  bits = (uint32_t)v;
-  return true;
-}
-// the last workgroup to finish publishes the new call count (every workgroup has read ctr[0] before it arrives)
-__device__ __forceinline__ void finish_call(const TpParams& p, uint32_t epoch) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t old = atomicAdd(&p.ctr[1], 1u);
-    if (old == gridDim.x - 1) { p.ctr[1] = 0; __hip_atomic_store(&p.ctr[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  }
-}
 
 // out[i] = (resid ? resid[i] : 0) + sum_r in_r[i], r = 0..W-1 in rank order.  out may alias resid (x += all-reduced delta).
 // E elements per thread.  The exchange is pure latency, so nothing is serialised: a thread first pushes its E values to all W
@@ -89,7 +46,7 @@ __global__ __launch_bounds__(1024) void tp_allreduce_kernel(TpParams p, const fl
         const uint32_t bits = __float_as_uint(in[i]);
         for (int k = 0; k < p.world; ++k) {                   // start with myself, then ring order: spreads the links
           const int q = (p.rank + k) % p.world;
-          put(slot_ptr(p, q, epoch, p.rank) + i, epoch, bits);
+          put(push_ptr(p, q, epoch) + i, epoch, push_bits(p, q, bits));
         }
       }
     }
@@ -150,7 +107,7 @@ __global__ __launch_bounds__(1024) void tp_allgather_kernel(TpParams p, const fl
     const uint32_t bits = __float_as_uint(in[i]);
     for (int k = 0; k < p.world; ++k) {
       const int q = (p.rank + k) % p.world;
-      put(slot_ptr(p, q, epoch, p.rank) + i, epoch, bits);
+      put(push_ptr(p, q, epoch) + i, epoch, push_bits(p, q, bits));
     }
   }
   bool ok = true;
@@ -174,8 +131,9 @@ __global__ __launch_bounds__(64) void tp_argmax_kernel(TpParams p, const float* 
   const uint32_t epoch = p.ctr[0] + 1u;
   const int lane = threadIdx.x, b = blockIdx.x;
   if (lane < p.world) {
-    uint64_t* g = slot_ptr(p, lane, epoch, p.rank) + 2 * b;
-    put(g, epoch, __float_as_uint(logit[b]));
+    uint64_t* g = push_ptr(p, lane, epoch) + 2 * b;
+    // (loop-back: the absent peers contribute -inf, so this rank's own pair wins)
+    put(g, epoch, (p.loopback && lane != p.rank) ? 0xff800000u : __float_as_uint(logit[b]));
     put(g + 1, epoch, (uint32_t)token_in[b]);
   }
   float best = -INFINITY;
@@ -345,6 +303,22 @@ extern "C" ChattsTpComm* chatts_tp_init_local(int rank, int world, void* const* 
   tp_bind_local(c, bufs[rank]);
   return c;
 }
+
+// ONE rank of a `world`-rank group alone on its device: every peer pointer is the local buffer and the kernels run in loop-back
+// mode (tp_common.h) - the same stores and polls per element as a real step, no partner needed.  For measuring a rank's step.
+extern "C" ChattsTpComm* chatts_tp_init_loopback(int rank, int world, void* local_buf, size_t bytes, int64_t max_elems) {
+  ChattsTpComm* c = tp_make(rank, world, max_elems, bytes);
+  if (!c) return nullptr;
+  if (!local_buf) { set_error("tp_init_loopback: null buffer"); delete c; return nullptr; }
+  for (int r = 0; r < world; ++r) c->p.peer[r] = reinterpret_cast<uint64_t*>(local_buf);
+  tp_bind_local(c, local_buf);
+  c->p.loopback = 1;
+  return c;
+}
+
+namespace chatts {
+const TpParams* tp_params(const ChattsTpComm* c) { return c ? &c->p : nullptr; }
+}  // namespace chatts
 
 extern "C" void chatts_tp_destroy(ChattsTpComm* c) {
   if (!c) return;

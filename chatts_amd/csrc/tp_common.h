@@ -1,0 +1,67 @@
+// tp_common.h - the device side of the tensor-parallel exchange protocol (csrc/tp.hip), shared with the kernels that carry an
+// exchange in their own epilogue (csrc/gemv.hip: o_proj / down_proj of a decode step push their partial rows to the peers and
+// reduce them inside the same launch).  Protocol: see the head of tp.hip.
+#pragma once
+#include "common.h"
+
+namespace chatts {
+
+constexpr int kMaxWorld = CHATTS_TP_MAX_WORLD;
+constexpr uint64_t kSpinTicks = 200000000ull;      // wall_clock64 runs at 100 MHz: 2 s
+constexpr uint64_t kSpinTicksBroken = 2000ull;     // 20 us once a timeout has been recorded
+// A communicator that has timed out once is broken until chatts_tp_reset: a step holds ~100 collectives, and each of them
+// waiting its own 2 s would keep the GPU busy for minutes before the host reads the status at its next sync point.
+__device__ __forceinline__ uint64_t spin_limit(const uint32_t* status) { return *status ? kSpinTicksBroken : kSpinTicks; }
+
+struct TpParams {
+  uint64_t* peer[kMaxWorld];   // peer[p]: rank p's exchange buffer as mapped in this process (peer[rank] = local)
+  uint32_t* ctr;               // device words: [0] completed-call counter (epoch - 1), [1] arrivals, [2] status
+  int rank, world;
+  int64_t max_elems;           // granules per (slot, source rank)
+  // Loop-back (chatts_tp_init_loopback, tools/tp_shard_step.py): ONE rank of a W-rank group alone on a device.  Every push lands in
+  // the LOCAL buffer, in the slot of the peer it would have gone to, carrying 0.0 for every peer but the rank itself: the same
+  // W stores per element and the same W polls as a real step, zero link latency - what one GPU can measure of a rank's step time.
+  int loopback;
+};
+
+__device__ __forceinline__ uint64_t* slot_ptr(const TpParams& p, int owner, uint32_t epoch, int src) {
+  return p.peer[owner] + ((int64_t)(epoch & 1u) * p.world + src) * p.max_elems;
+}
+// where this rank's contribution for destination rank q goes (element 0 of the vector)
+__device__ __forceinline__ uint64_t* push_ptr(const TpParams& p, int q, uint32_t epoch) {
+  return p.loopback ? slot_ptr(p, p.rank, epoch, q) : slot_ptr(p, q, epoch, p.rank);
+}
+__device__ __forceinline__ uint32_t push_bits(const TpParams& p, int q, uint32_t bits) {
+  return (p.loopback && q != p.rank) ? 0u : bits;
+}
+__device__ __forceinline__ void put(uint64_t* g, uint32_t epoch, uint32_t bits) {
+  __hip_atomic_store(g, ((uint64_t)epoch << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// poll one granule of the LOCAL buffer until its tag is `epoch`; false on timeout
+__device__ __forceinline__ bool take(uint64_t* g, uint32_t epoch, uint32_t& bits, uint32_t* status) {
+  uint64_t v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((uint32_t)(v >> 32) != epoch) {
+    const uint64_t t0 = wall_clock64();
+    do {
+      __builtin_amdgcn_s_sleep(1);
+      v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((uint32_t)(v >> 32) == epoch) break;
+      if (wall_clock64() - t0 > spin_limit(status)) { atomicOr(status, 1u); bits = 0; return false; }
+    } while (true);
+  }
+  bits = (uint32_t)v;
+  return true;
+}
+// the last workgroup to finish publishes the new call count (every workgroup has read ctr[0] before it arrives)
+__device__ __forceinline__ void finish_call(const TpParams& p, uint32_t epoch) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t old = atomicAdd(&p.ctr[1], 1u);
+    if (old == gridDim.x - 1) { p.ctr[1] = 0; __hip_atomic_store(&p.ctr[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  }
+}
+
+// host (tp.hip): the kernel-side view of a communicator
+const TpParams* tp_params(const ChattsTpComm* c);
+
+}  // namespace chatts

@@ -134,6 +134,22 @@ class P2PExchange:
             out.append(cls(lib, h, ptrs[r]))
         return out
 
+    @classmethod
+    def create_loopback(cls, rank, world, max_elems):
+        """ONE rank of a `world`-rank group alone on the current device (chatts_tp_init_loopback): its pushes land in its own
+        buffer, the absent peers contribute zeros.  Same stores and polls per element as a real step, zero link latency - what a
+        single GPU can MEASURE of a rank's step time at the shard shapes of TP = 2 / 4 / 8 (tools/tp_shard_step.py).  Timing only."""
+        from . import _lib
+        lib = _lib.load()
+        nbytes = int(lib.chatts_tp_buffer_bytes(world, int(max_elems)))
+        ptr = C.c_void_p()
+        _lib.check(lib.chatts_tp_buffer_alloc(nbytes, C.byref(ptr), None))
+        h = lib.chatts_tp_init_loopback(rank, world, ptr, nbytes, int(max_elems))
+        if not h:
+            lib.chatts_tp_buffer_free(ptr)
+            raise _lib.ChattsError(-1, lib.chatts_last_error().decode())
+        return cls(lib, h, ptr)
+
     def status(self):
         """0 = healthy; bit 0 = a peer's contribution timed out.  Synchronising diagnostic (hipMemcpy of one word)."""
         rc = int(self.lib.chatts_tp_status(self.handle))

@@ -31,13 +31,16 @@ extern "C" {
 
 typedef void* chatts_stream_t; /* hipStream_t */
 typedef uint16_t chatts_bf16;  /* raw bfloat16 bits */
+typedef struct ChattsTpComm ChattsTpComm;     /* tensor-parallel exchange (section below); opaque, host memory only */
 
 const char* chatts_last_error(void);
 /* ABI version of this header: bumped whenever a struct grows or a signature changes
  * (2: plane operands, sampler, decoder plane buffers; 3: post-norm planes of chatts_linear;
  *  4: tensor-parallel exchange chatts_tp_* / chatts_allreduce, decoder embed_rows + TP buffers, chatts_decoder_select_tokens;
- *  6: persistent decode step chatts_decoder_mega_*; the attention 'parts' form and its ChattsLinearArgs fields removed). */
-#define CHATTS_ABI_VERSION 6
+ *  6: persistent decode step chatts_decoder_mega_*; the attention 'parts' form and its ChattsLinearArgs fields removed;
+ *  7: ChattsLinearArgs.tp_reduce (exchange inside the projection's launch), chatts_tp_init_loopback, chatts_decoder_prefill under
+ *     tensor parallelism with chatts_allreduce_large). */
+#define CHATTS_ABI_VERSION 7
 int chatts_abi_version(void);
 /* Number of CUs of the current device (grid sizing), or <0. */
 int chatts_device_cus(void);
@@ -183,6 +186,13 @@ typedef struct ChattsLinearArgs {
    * the HF demo's `load_in_8bit`, demo/demo_hf.ipynb:78-80; bitsandbytes' own outlier decomposition is not reproduced).  Streamed by
    * the M == 1 GEMV and the M <= 16 weight-streaming GEMM; every other kernel keeps streaming `w`. */
   int w8_format;
+  /* optional (M == 1, EPI_RESID, no bias): W is this rank's K-slice of a row-parallel projection (o_proj / down_proj under tensor
+   * parallelism, vLLM's RowParallelLinear + all-reduce, demo/demo_vllm.py:30).  The GEMV launch then carries the exchange itself: a
+   * wave pushes its finished rows to every rank as tagged granules, polls the same rows of all ranks from the local exchange buffer
+   * and writes c = resid + (sum over ranks in rank order) - the arithmetic of chatts_allreduce(partial, c, resid), bit for bit,
+   * without the partial vector's round trip and without the stand-alone exchange launch.  n <= chatts_tp_max_elems(comm).  Every rank
+   * must issue the same call (same N, same launch geometry) - like any collective. */
+  ChattsTpComm* tp_reduce;
 } ChattsLinearArgs;
 #define CHATTS_W8_FP8 0
 #define CHATTS_W8_INT8 1
@@ -347,7 +357,6 @@ int chatts_embed_token(const int64_t* token_dev, const chatts_bf16* table, int64
  * ------------------------------------------------------------------------------------------- */
 #define CHATTS_TP_HANDLE_BYTES 64
 #define CHATTS_TP_MAX_WORLD 8
-typedef struct ChattsTpComm ChattsTpComm;     /* opaque; host memory only */
 /* bytes of one rank's exchange buffer for collectives of up to max_elems float32 per rank */
 size_t chatts_tp_buffer_bytes(int world, int64_t max_elems);
 /* hipExtMallocWithFlags(uncached) + zero fill + (handle != NULL) hipIpcGetMemHandle into handle[CHATTS_TP_HANDLE_BYTES] */
@@ -359,6 +368,11 @@ int chatts_tp_buffer_free(void* dev_ptr);
 ChattsTpComm* chatts_tp_init(int rank, int world, void* local_buf, const uint8_t* handles, size_t bytes, int64_t max_elems);
 /* the same for ranks that live in ONE process (bufs[r] = rank r's buffer, plain device pointers): single-GPU emulation, tests */
 ChattsTpComm* chatts_tp_init_local(int rank, int world, void* const* bufs, size_t bytes, int64_t max_elems);
+/* ONE rank of a `world`-rank group alone on its device (measurement aid: tools/tp_shard_step.py): every push lands in the LOCAL
+ * buffer, in the slot of the peer it would have gone to, carrying 0.0 for the absent peers - the same stores and polls per element
+ * as a real step at zero link latency, so a single GPU can time one rank's decode step at the shard shapes of TP = 2 / 4 / 8.  The
+ * sums are this rank's partials alone: timing only, never a result. */
+ChattsTpComm* chatts_tp_init_loopback(int rank, int world, void* local_buf, size_t bytes, int64_t max_elems);
 void chatts_tp_destroy(ChattsTpComm*);
 int chatts_tp_rank(const ChattsTpComm*);
 int chatts_tp_world(const ChattsTpComm*);
@@ -513,6 +527,10 @@ int chatts_decoder_decode_step_batched(ChattsDecoder*, int batch, int32_t* pos_d
                                        int64_t* token_dev, float* token_logit_dev, int64_t* out_tokens,
                                        int64_t out_stride, float* logits_all /* [batch, vocab_local] */, int n_splits,
                                        chatts_stream_t stream);
+
+/* final norm + lm_head for rows 0 .. batch-1 of x -> logits_all [batch, vocab_local] (this rank's vocabulary slice): the tail of
+ * chatts_decoder_decode_step_batched as a call of its own (compute_logits for a batch, chatts_vllm.py:603-610). */
+int chatts_decoder_logits_batched(ChattsDecoder*, int batch, float* logits_all, chatts_stream_t stream);
 
 /* TP=1 fast paths: all layers back to back on the stream (no host round trip, graph-capturable). */
 int chatts_decoder_prefill(ChattsDecoder*, int t, int pos0, chatts_stream_t stream);

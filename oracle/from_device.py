@@ -5,7 +5,10 @@ fill kernel; tests spot-check blocks of the device tensors against it).  Evaluat
 minutes, so the large-config parity runs copy the device tensors back instead and UN-PACK them into the HF checkpoint
 names oracle/qwen_decoder.py reads - which also exercises the packing conventions of load_weights
 (NetManAIOps/ChatTS chatts/vllm/chatts_vllm.py:454-470,612-625: q|k|v fused, gate/up fused).
-Works on a tensor_parallel_size=1 model only (a rank-local shard is not a checkpoint).
+layer_tensors / decoder_state_dict work on a tensor_parallel_size=1 model (a rank-local shard is not a checkpoint);
+sharded_state_dict re-assembles the checkpoint from ALL W rank-local shards of a tensor-parallel group (ShardPlan's contiguous head /
+intermediate / vocabulary ranges: chatts_amd/tp.py) - for 8-bit weight formats that is the only way to know the weights the shards
+hold, since every shard picks its row scales over its own K-slice.
 """
 import torch
 
@@ -48,6 +51,45 @@ def decoder_state_dict(model, num_layers=None, embed_rows=None):
     sd = head_tensors(model, embed_rows)
     for l in range(model.config.num_hidden_layers if num_layers is None else num_layers):
         sd.update(layer_tensors(model, l))
+    return sd
+
+
+def sharded_state_dict(models, num_layers=None):
+    """HF-named float32 tensors of the WHOLE decoder from the W rank-local shard models of one tensor-parallel group (rank order)."""
+    m0 = models[0]
+    cfg = m0.config
+    assert [m.plan.rank for m in models] == list(range(m0.plan.world)), "pass every rank's model, in rank order"
+    d = cfg.head_dim
+    sd = {"model.embed_tokens.weight": m0._tensors["embed"].float().cpu(),             # replicated
+          "lm_head.weight": torch.cat([m._tensors["lm_head"].float().cpu() for m in models], dim=0),      # vocab-parallel
+          "model.norm.weight": m0._tensors["final_norm"].float().cpu()}
+    for l in range(cfg.num_hidden_layers if num_layers is None else num_layers):
+        p = f"model.layers.{l}."
+        q, k, v, o, g, u, dn, bq, bk, bv = [], [], [], [], [], [], [], [], [], []
+        for m in models:
+            lw, nq, nkv, I = m.layers[l], m.plan.nq, m.plan.nkv, m.plan.inter
+            qkv = lw["qkv"].float().cpu()
+            q.append(qkv[:nq * d]); k.append(qkv[nq * d:(nq + nkv) * d]); v.append(qkv[(nq + nkv) * d:])
+            if "qkv_bias" in lw:
+                b = lw["qkv_bias"].float().cpu()
+                bq.append(b[:nq * d]); bk.append(b[nq * d:(nq + nkv) * d]); bv.append(b[(nq + nkv) * d:])
+            o.append(lw["o"].float().cpu())                                  # column (K) slice
+            gu = lw["gate_up"].float().cpu().view(I // 16, 2, 16, -1)
+            g.append(gu[:, 0].reshape(I, -1)); u.append(gu[:, 1].reshape(I, -1))
+            dn.append(lw["down"].float().cpu())                              # column (K) slice
+        sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"] = \
+            torch.cat(q), torch.cat(k), torch.cat(v)
+        if bq:
+            sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"] = \
+                torch.cat(bq), torch.cat(bk), torch.cat(bv)
+        lw0 = m0.layers[l]
+        if "q_norm" in lw0:
+            sd[p + "self_attn.q_norm.weight"], sd[p + "self_attn.k_norm.weight"] = lw0["q_norm"].float().cpu(), lw0["k_norm"].float().cpu()
+        sd[p + "self_attn.o_proj.weight"] = torch.cat(o, dim=1).contiguous()
+        sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = torch.cat(g).contiguous(), torch.cat(u).contiguous()
+        sd[p + "mlp.down_proj.weight"] = torch.cat(dn, dim=1).contiguous()
+        sd[p + "input_layernorm.weight"] = lw0["input_norm"].float().cpu()
+        sd[p + "post_attention_layernorm.weight"] = lw0["post_norm"].float().cpu()
     return sd
 
 

@@ -271,3 +271,63 @@ def test_tp2_decode_step_through_the_exchange_matches_oracle(use_graph):
         for m in ms:
             m._tp.close()
             m._tp = None
+
+
+@pytest.mark.parametrize("weights", ["bf16", "fp8"])
+@_retry_if_peer_stalled
+def test_exchange_inside_the_gemv_launch_equals_the_standalone_kernels_at_14b_widths(weights, monkeypatch):
+    """ChattsLinearArgs.tp_reduce: the o_proj / down_proj GEMVs of a TP decode step push their rows to the peers and reduce them
+    inside their own launch (6 launches per layer instead of 8).  TP=2 at ChatTS-14B widths, 4 layers, two concurrent in-process
+    ranks, the whole step as a replayed hipGraph: the oracle's tokens, logits within 1e-3 - and every bit of the residual stream
+    and of the logits equal to the stand-alone chatts_allreduce form (CHATTS_TP_FUSE=0) on both ranks."""
+    import bench
+    from oracle import from_device
+    world, seed, new = 2, 0, 6
+    cfg = cfgmod.preset("chatts-14b", num_hidden_layers=4)
+    proc, prompt, series, lengths = bench.build_inputs(cfg, 2, 128)
+    inputs = proc(text=[prompt], timeseries=series, padding=True, return_tensors="pt")
+    ids = inputs["input_ids"][0].tolist()
+    ms = _shards(cfg, world, seed, max_ctx=512, max_prefill_tokens=512, use_graph=True, weight_format=weights)
+    try:
+        sd = {**from_device.ts_encoder_state_dict(ms[0]), **from_device.sharded_state_dict(ms)}
+        want = pipeline.generate(cfg, sd, ids, inputs["timeseries"].numpy(), new)
+        mm = ms[0].get_multimodal_embeddings(timeseries=inputs["timeseries"].cuda(), valid_lengths=proc.last_lengths)
+        full = ms[0].expand_input_ids(ids, [(L + 15) // 16 for L in lengths])
+        emb = ms[0].get_input_embeddings(torch.tensor(full), mm)
+        T = len(full)
+        runs = {}
+        for fuse in ("0", "1"):
+            monkeypatch.setenv("CHATTS_TP_FUSE", fuse)
+            for m in ms:
+                m._graph = None                              # the captured step has the other schedule baked in
+            _emulated_prefill(ms, emb, T)
+            torch.cuda.synchronize()
+            _on_streams(world, lambda r: ms[r]._first_token(T))
+            _on_streams(world, lambda r: ms[r]._decode_step_eager())     # warms the host-side caches on both ranks, really exchanging
+            torch.cuda.synchronize()
+            if any(m._tp.status() for m in ms):
+                raise _PeerStalled()
+            for m in ms:
+                m._capture(warm=False)
+            xs, lgs = [], []
+            for _ in range(new - 2):
+                _on_streams(world, lambda r: ms[r].decode_step())
+                torch.cuda.synchronize()
+                if any(m._tp.status() for m in ms):
+                    raise _PeerStalled()
+                xs.append([m.buf["x"][:1].clone() for m in ms])
+                lgs.append(torch.cat([m.buf["logits"] for m in ms]).clone())
+            runs[fuse] = (ms[0].buf["out_tokens"][:new].tolist(), xs, lgs)
+            assert ms[1].buf["out_tokens"][:new].tolist() == runs[fuse][0]
+            for x0, x1 in xs:
+                assert torch.equal(x0, x1)                   # replicated residual stream: identical bits on both ranks
+        assert runs["0"][0] == runs["1"][0] == want["tokens"]
+        for a, b in zip(runs["0"][1], runs["1"][1]):
+            assert torch.equal(a[0], b[0])                   # fused == stand-alone, bit for bit
+        for i, (a, b) in enumerate(zip(runs["0"][2], runs["1"][2])):
+            assert torch.equal(a, b)
+            assert rel_err(b.cpu().numpy(), want["logits"][i + 2].numpy()) < 1e-3
+    finally:
+        for m in ms:
+            m._tp.close()
+            m._tp = None
