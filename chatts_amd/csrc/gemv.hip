@@ -45,6 +45,7 @@ struct GemvParams {
   const float* w4_sz;     // [N, K / w4_group, 2]
   int ldw4, w4_group;
   TpParams tp;            // kEpiResidTp only
+  int ks;                 // gemv_ksplit_kernel: waves per row group
 };
 
 // ---- the exchange inside the launch (kEpiResidTp) ---------------------------------------------------------------------------
@@ -207,6 +208,105 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(GemvParams p) {
   if (EPI == kEpiResidTp) {
     for (int task = blockIdx.x * nw + wave; task < p.tasks; task += gridDim.x * nw) tp_take_task<ROWS>(p, epoch, task, lane);
     finish_call(p.tp, epoch);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-split form for SHARD-sized projections (a rank of TP = 4 / 8: qkv is 896 x 5120 at TP = 8 - 448 row groups for 256 CUs).  A wave
+// that walks the whole K alone is a chain of K / 1024 dependent HBM round trips, and with one or two such waves per CU nothing
+// hides them: the launch sits at 9.6 us for 9 MB (profiles/r4_tp8_shard_kernel_trace.txt) where 3.3 us + bytes / 6.7 TB/s says 4.7.
+// Here p.ks waves share a row group: wave j of the group takes the chunk pairs j, j + ks, ... (all of its loads in flight at once when
+// ks = chunks / 2), the partial sums meet in LDS and wave 0 of the group adds them in wave order (fixed -> reproducible; NOT the
+// bits of the whole-K kernel, which stays the one every TP = 1 shape runs) and applies the epilogue.  Same x staging / fused RMSNorm.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, bool NORM>
+__global__ __launch_bounds__(1024) void gemv_ksplit_kernel(GemvParams p) {
+  constexpr int ROWS = 2, UNR = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* xs4 = reinterpret_cast<f32x4*>(smem);            // permuted x: [chunk][half][lane] float4
+  float* red = reinterpret_cast<float*>(smem) + (size_t)((p.k + 511) / 512) * 512;
+  float* part = red + 16;                                 // [nw][ROWS] partial sums of the K-slices
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthreads = blockDim.x, nw = nthreads >> 6;
+  const int K = p.k;
+  const int nchunks = (K + 511) >> 9;
+
+  float rstd = 1.f;
+  if (NORM) {
+    float ss = 0.f;
+    for (int k4 = tid * 4; k4 < K; k4 += nthreads * 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + k4);
+      ss = sumsq4(ss, v);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    rstd = rsqrtf(t / (float)K + p.eps);
+  }
+  for (int k4 = tid * 4; k4 < nchunks * 512; k4 += nthreads * 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k4 < K) {
+      v = *reinterpret_cast<const f32x4*>(p.x + k4);
+      if (NORM) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.norm_w + k4);
+        v.x = g.x * (v.x * rstd); v.y = g.y * (v.y * rstd); v.z = g.z * (v.z * rstd); v.w = g.w * (v.w * rstd);
+      }
+    }
+    const int chunk = k4 >> 9, within = k4 & 511;
+    xs4[chunk * 128 + ((within >> 2) & 1) * 64 + (within >> 3)] = v;
+  }
+  __syncthreads();
+
+  const int ks = p.ks, ngroups = nw / ks, grp = wave / ks, j = wave - grp * ks;
+  for (int t0 = blockIdx.x * ngroups; t0 < p.tasks; t0 += gridDim.x * ngroups) {      // (uniform trip count: barriers inside)
+    const int task = t0 + grp;
+    const bool valid = grp < ngroups && task < p.tasks;
+    float acc[ROWS] = {0.f, 0.f};
+    if (valid) {
+      const uint16_t* wrow[ROWS];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        int row = task_row<ROWS, EPI>(task, r);
+        if (row >= p.n) row = 0;
+        wrow[r] = p.w + (size_t)row * p.ldw + lane * 8;
+      }
+      for (int c = j * UNR; c < nchunks; c += ks * UNR) {
+        u32x4 wv[UNR][ROWS];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const bool ok = c + u < nchunks && ((c + u) << 9) + lane * 8 < K;
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            wv[u][r] = (u32x4){0u, 0u, 0u, 0u};
+            if (ok) wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + ((c + u) << 9)));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (c + u < nchunks) {
+            const f32x4 xa = xs4[(c + u) * 128 + lane], xb = xs4[(c + u) * 128 + 64 + lane];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[r] = dot8(wv[u][r], xa, xb, acc[r]);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
+      if (lane == 0) { part[wave * ROWS] = acc[0]; part[wave * ROWS + 1] = acc[1]; }
+    }
+    __syncthreads();
+    if (valid && j == 0) {
+      float tot[ROWS];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        tot[r] = part[wave * ROWS + r];
+        for (int i = 1; i < ks; ++i) tot[r] += part[(wave + i) * ROWS + r];          // wave order: fixed
+      }
+      gemv_epilogue<ROWS, EPI>(p, task, lane, tot);
+    }
+    __syncthreads();
   }
 }
 
@@ -620,6 +720,47 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
     }
     CHATTS_CHECK_LAUNCH("gemv8_ldsx");
     return CHATTS_OK;
+  }
+  // K-split form (see gemv_ksplit_kernel): when the row groups alone leave the chip nearly empty - fewer than ~6 waves per CU - and a
+  // row is long enough to split.  Every TP = 1 shape of the supported models has >= 10 waves per CU and keeps the whole-K kernel.
+  p.ks = 1;
+  if (!a->tp_reduce && rows == 2 && unr == 2 && nchunks >= 4) {
+    int ks = 1;
+    const double per_cu = (double)p.tasks / cus;
+    if (per_cu < 6.0) {
+      ks = (int)(12.0 / (per_cu > 0.25 ? per_cu : 0.25) + 0.999);
+      const int rounds = (nchunks + 1) / 2;                 // chunk pairs of a row: a wave should keep at least one
+      if (ks > rounds) ks = rounds;
+      if (ks > 8) ks = 8;
+    }
+    ks = env_int("CHATTS_GEMV_KS", ks);
+    if (ks > 16) ks = 16;
+    if (ks > 1) {
+      int groups = 16 / ks;
+      if (groups < 1) groups = 1;
+      const int nwk = groups * ks;
+      int blocksk = (p.tasks + groups - 1) / groups;
+      const int occk = (int)((150 * 1024) / lds) < 32 / nwk ? (int)((150 * 1024) / lds) : 32 / nwk;
+      if (blocksk > cus * (occk < 1 ? 1 : occk)) blocksk = cus * (occk < 1 ? 1 : occk);
+      p.ks = ks;
+      const dim3 g(blocksk), b(nwk * 64);
+      switch (epilogue) {
+        case CHATTS_EPI_RESID:
+          if (norm) hipLaunchKernelGGL((gemv_ksplit_kernel<CHATTS_EPI_RESID, true>), g, b, lds, s, p);
+          else hipLaunchKernelGGL((gemv_ksplit_kernel<CHATTS_EPI_RESID, false>), g, b, lds, s, p);
+          break;
+        case CHATTS_EPI_SWIGLU:
+          if (norm) hipLaunchKernelGGL((gemv_ksplit_kernel<CHATTS_EPI_SWIGLU, true>), g, b, lds, s, p);
+          else hipLaunchKernelGGL((gemv_ksplit_kernel<CHATTS_EPI_SWIGLU, false>), g, b, lds, s, p);
+          break;
+        default:
+          if (norm) hipLaunchKernelGGL((gemv_ksplit_kernel<CHATTS_EPI_NONE, true>), g, b, lds, s, p);
+          else hipLaunchKernelGGL((gemv_ksplit_kernel<CHATTS_EPI_NONE, false>), g, b, lds, s, p);
+          break;
+      }
+      CHATTS_CHECK_LAUNCH("gemv_ksplit");
+      return CHATTS_OK;
+    }
   }
   if (rows == 4 && unr == 2) launch_ldsx<4, 2>(p, epilogue, norm, blocks, threads, lds_launch, s);
   else if (rows == 4) launch_ldsx<4, 4>(p, epilogue, norm, blocks, threads, lds_launch, s);

@@ -36,6 +36,12 @@ def validate_sampling(max_tokens=64, temperature=0.0, top_p=1.0, top_k=0, **_):
         raise ValueError(f"max_tokens must be at least 1, got {max_tokens}")
 
 
+class ExchangeBroken(RuntimeError):
+    """The tensor-parallel exchange timed out on THIS rank.  Fatal for the whole rank group: the ranks can no longer be assumed to hold
+    the same engine state (a peer that arrived late saw no timeout and kept decoding), so the engine stops instead of serving
+    on - EngineThread fails every request, releases the followers, and a supervisor restarts all ranks."""
+
+
 class Request:
     def __init__(self, rid, prompt, timeseries, max_tokens, sampling_key, eos, on_tokens):
         self.rid, self.prompt, self.timeseries, self.max_tokens = rid, prompt, timeseries, int(max_tokens)
@@ -116,6 +122,9 @@ class Engine:
         want = "rows" if (any(r is not None and r.sampling_key for r in self.slots) or
                           (self.prefilling is not None and self.prefilling[0].sampling_key) or
                           any(q.sampling_key for q in self.waiting)) else None
+        if want is None and self.active_key == "rows":
+            return          # stay in per-row mode once entered: greedy rows already take the argmax token there, and every switch drops
+                            # both captured hipGraphs (re-capture + a warm eager step on all ranks) - alternating traffic would stall
         if want != self.active_key:
             self._apply_sampling(want)
 
@@ -281,8 +290,12 @@ class Engine:
                 r.error = err
                 self._emit(r, True, "error")
                 done.append(r)
-            return done                  # (the exchange stays broken - every later harvest fails the same way - until the ranks
-                                         # are restarted: a one-sided reset would let the ranks' engines diverge)
+            # Each rank reads only ITS OWN sticky status: a peer that arrived late saw no timeout and would keep decoding these
+            # slots while this rank hands them to other requests - slot choice and packing would differ between the ranks and every
+            # later collective would be mismatched.  So this is fatal for the rank group, not for the running requests only: raise
+            # out of step() (EngineThread._run fails everything, publishes stop to the followers; a follower's loop ends with the
+            # exception) and let the supervisor restart all ranks.
+            raise ExchangeBroken(str(err))
         for s in range(self.nslots):
             r = self.slots[s]
             if r is None:
@@ -431,6 +444,24 @@ class EngineThread:
                 r.finished = True
                 r.on_tokens(r, [], True)
 
+    def _reject_invalid(self, new):
+        """validate_sampling on every queued request; the offending ones are answered with an error here and never reach the engine
+        (nor, under tensor parallelism, the followers - add_request raising after control.publish would take every rank down)."""
+        ok = []
+        for kw in new:
+            try:
+                validate_sampling(**{k: kw[k] for k in ("max_tokens", "temperature", "top_p", "top_k") if k in kw})
+                ok.append(kw)
+            except (ValueError, TypeError) as e:
+                r = Request(-1, kw.get("prompt"), list(kw.get("timeseries") or []), 1, None, [], kw.get("on_tokens"))
+                r.error, r.finished, r.finish_reason = e, True, "error"
+                holder = kw.get("holder")
+                if holder is not None:
+                    holder.append(r)
+                if r.on_tokens is not None:
+                    r.on_tokens(r, [], True)
+        return ok
+
     def _loop(self):
         import torch
         idx = getattr(self.device, "index", self.device) if self.device is not None else None
@@ -446,6 +477,7 @@ class EngineThread:
                     block = False
             except queue.Empty:
                 pass
+            new = self._reject_invalid(new)        # BEFORE anything is announced: a bad value fails that request only, on no rank
             if self.control is not None:
                 if not new and not self.engine.has_work():
                     continue                       # idle: nothing to announce, the followers keep waiting

@@ -60,9 +60,12 @@ def is_gptq_config(cfg_extra):
     return qc.get("quant_method") == "gptq"
 
 
-def dequantized_pairs(pairs, quant_cfg):
+def dequantized_pairs(pairs, quant_cfg, has_g_idx=None):
     """(name, tensor) stream of a GPTQ checkpoint -> stream where every quantised Linear appears as `<module>.weight` (bf16);
-    other tensors pass through.  Also yields nothing for the consumed qweight / qzeros / scales / g_idx entries."""
+    other tensors pass through.  Also yields nothing for the consumed qweight / qzeros / scales / g_idx entries.
+    has_g_idx: whether the checkpoint stores `<module>.g_idx` tensors, when the caller knows (the safetensors key index does):
+    False = a module is emitted as soon as its three tensors are there; None = unknown - modules wait for a g_idx and those that
+    never get one are flushed at the end of the stream (which buffers the whole int4 checkpoint for g_idx-less files)."""
     if int(quant_cfg.get("bits", 4)) != 4:
         raise ValueError(f"GPTQ bits={quant_cfg.get('bits')} is not supported (4-bit checkpoints only)")
     gs = int(quant_cfg.get("group_size", 128))
@@ -88,7 +91,10 @@ def dequantized_pairs(pairs, quant_cfg):
         d[suffix] = t
         # AutoGPTQ checkpoints store g_idx for every module (trivial when desc_act is false) and it may arrive after the other
         # three tensors: a module is complete when all four are there; one that never gets a g_idx is emitted by the flush below
-        if all(k in d for k in ("qweight", "qzeros", "scales", "g_idx")):
+        need = ("qweight", "qzeros", "scales") if has_g_idx is False else ("qweight", "qzeros", "scales", "g_idx")
+        if all(k in d for k in need):
+            if has_g_idx is False and quant_cfg.get("desc_act"):
+                raise ValueError(f"GPTQ module {base}: desc_act checkpoints need their g_idx tensors")
             yield from emit(base, pending.pop(base))
     for base, d in list(pending.items()):
         if all(k in d for k in ("qweight", "qzeros", "scales")) and not quant_cfg.get("desc_act"):

@@ -219,7 +219,7 @@ class ChatTSForCausalLM:
         pairs = ((k, h.get_tensor(k)) for k, h in index.items())
         from . import gptq
         if gptq.is_gptq_config(cfg.extra):          # ChatTS-14B-GPTQ-Int4: unpack qweight / qzeros / scales / g_idx to bf16 weights
-            pairs = gptq.dequantized_pairs(pairs, cfg.extra["quantization_config"])
+            pairs = gptq.dequantized_pairs(pairs, cfg.extra["quantization_config"], has_g_idx=any(k.endswith(".g_idx") for k in index))
         if lora_adapter is not None:
             from . import lora
             pairs = lora.merged(pairs, lora_adapter)

@@ -24,6 +24,23 @@ def free_port():
         return s.getsockname()[1]
 
 
+_RENDEZVOUS_VARS = ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK")
+
+
+def _save_env():
+    return {k: os.environ.get(k) for k in _RENDEZVOUS_VARS}
+
+
+def _restore_env(saved):
+    """put the rendezvous variables back the way the caller's process had them (a stale WORLD_SIZE would make the next
+    LLM(tensor_parallel_size=k) of this process skip its spawn branch, and every child process would inherit it)"""
+    for k, v in (saved or {}).items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
 def init_rank(rank, world, port, use_cuda=True):
     """Join the process group as `rank` (env-style rendezvous on 127.0.0.1:port) -> the CPU control group (gloo)."""
     import torch
@@ -73,9 +90,10 @@ def _follower(rank, world, port, use_cuda, factory, factory_args, factory_kwargs
 class TpGroup:
     """Leader-side handle of the spawned ranks."""
 
-    def __init__(self, world, procs, control):
+    def __init__(self, world, procs, control, saved_env=None):
         self.world, self.procs, self.control = world, procs, control
         self.closed = False
+        self.saved_env = saved_env          # the leader process's rendezvous variables before launch(): restored by shutdown()
 
     @classmethod
     def launch(cls, world, factory, factory_args=(), factory_kwargs=None, use_cuda=True):
@@ -90,9 +108,14 @@ class TpGroup:
         kw = dict(factory_kwargs or {})
         procs = [ctx.Process(target=_follower, args=(r, world, port, use_cuda, factory, tuple(factory_args), kw), daemon=True)
                  for r in range(1, world)]
+        saved = _save_env()
         for p in procs:
             p.start()
-        control = init_rank(0, world, port, use_cuda)
+        try:
+            control = init_rank(0, world, port, use_cuda)
+        except BaseException:
+            _restore_env(saved)
+            raise
         obj, err = None, None
         try:
             obj = factory(*factory_args, **kw)
@@ -105,8 +128,9 @@ class TpGroup:
             for p in procs:
                 p.join(timeout=30)
             dist.destroy_process_group()
+            _restore_env(saved)
             raise RuntimeError(f"tensor-parallel start-up failed on ranks {bad}")
-        return cls(world, procs, control), obj
+        return cls(world, procs, control, saved), obj
 
     def call(self, name, *args, **kwargs):
         """announce a method call to the followers (they start executing it now); the leader then makes the same call itself"""
@@ -130,3 +154,4 @@ class TpGroup:
                 p.terminate()
         if dist.is_initialized():
             dist.destroy_process_group()
+        _restore_env(self.saved_env)

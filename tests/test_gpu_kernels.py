@@ -1204,3 +1204,21 @@ def test_attention_decode_batched_paged_equals_contiguous(lib, block):
     assert torch.equal(out_a[live], out_b[live])
     for b in range(B):
         assert torch.equal(_from_pool(pk, table[b], block), ka[b]) and torch.equal(_from_pool(pv, table[b], block), va[b])
+
+
+@pytest.mark.parametrize("ks", [0, 1, 2, 3, 5, 8, 16])
+def test_gemv_ksplit_at_tensor_parallel_shard_shapes(lib, ks, monkeypatch):
+    """gemv_ksplit_kernel (several waves share a row group, partial sums meet in LDS): the form a rank of TP = 4 / 8 runs for qkv
+    (896 / 1792 x 5120) - picked automatically when the row groups alone leave the chip nearly empty (ks = 0 here: the launcher's
+    own choice), forced to 1 .. 16 waves per group otherwise.  Same float64 bar as every GEMV; two calls give the same bits."""
+    if ks:
+        monkeypatch.setenv("CHATTS_GEMV_KS", str(ks))
+    for epi, n, k, norm in [(_lib.EPI_NONE, 896, 5120, True), (_lib.EPI_SWIGLU, 6912, 5120, True), (_lib.EPI_RESID, 5120, 1728, False),
+                            (_lib.EPI_NONE, 1792, 5120, True), (_lib.EPI_NONE, 96, 13824, False), (_lib.EPI_NONE, 19008, 5120, True)]:
+        a, w, bias, resid, nw = _rand_problem(1, n, k, seed=n + k + ks)
+        nob = epi == _lib.EPI_RESID
+        out = _linear(lib, a, w, None if nob else bias, resid if nob else None, epi, nw if norm else None)
+        want = _ref_linear(a, w, None if nob else bias, resid, epi, nw if norm else None)
+        assert rel_err(out.cpu().numpy(), want) < 2e-5, (epi, n, k)
+        again = _linear(lib, a, w, None if nob else bias, resid if nob else None, epi, nw if norm else None)
+        assert torch.equal(out, again)
