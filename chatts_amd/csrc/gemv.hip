@@ -140,7 +140,7 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(GemvParams p) {
   const int K = p.k;
   const int nchunks = (K + 511) >> 9;
   uint32_t epoch = 0;
-  if (EPI == kEpiResidTp) epoch = p.tp.ctr[0] + 1u;
+  if (EPI == kEpiResidTp) epoch = tp_epoch(p.tp);
 
   float rstd = 1.f;
   if (NORM) {
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(1024) void gemv_ldsx_kernel(GemvParams p) {
     gemv_epilogue<ROWS, EPI>(p, task, lane, acc, epoch);
   }
   if (EPI == kEpiResidTp) {
+    // (no counter bump: the launch's epoch is counted by the host, TpParams::idx - a later collective of the step bumps the counter)
     for (int task = blockIdx.x * nw + wave; task < p.tasks; task += gridDim.x * nw) tp_take_task<ROWS>(p, epoch, task, lane);
-    finish_call(p.tp, epoch);
   }
 }
 
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x, nw = nthreads >> 6;
   uint32_t epoch = 0;
-  if (EPI == kEpiResidTp) epoch = p.tp.ctr[0] + 1u;
+  if (EPI == kEpiResidTp) epoch = tp_epoch(p.tp);
 
   float rstd = 1.f;
   if (NORM) {
@@ -424,8 +424,8 @@ __global__ __launch_bounds__(1024) void gemv8_ldsx_kernel(GemvParams p) {
     gemv_epilogue<ROWS, EPI>(p, task, lane, acc, epoch);
   }
   if (EPI == kEpiResidTp) {
+    // (no counter bump: the launch's epoch is counted by the host, TpParams::idx - a later collective of the step bumps the counter)
     for (int task = blockIdx.x * nw + wave; task < p.tasks; task += gridDim.x * nw) tp_take_task<ROWS>(p, epoch, task, lane);
-    finish_call(p.tp, epoch);
   }
 }
 
@@ -640,12 +640,10 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   const int cus = device_cus();
   int epilogue = a->epilogue;
   if (a->tp_reduce) {       // row-parallel projection: the sum over the ranks is formed inside this launch (kEpiResidTp)
-    const TpParams* tp = tp_params(a->tp_reduce);
     CHATTS_REQUIRE(a->epilogue == CHATTS_EPI_RESID && !a->bias && !a->norm_w && !a->w4, CHATTS_E_BADARG,
                    "gemv: tp_reduce needs EPI_RESID without bias / fused norm / 4-bit codes");
-    CHATTS_REQUIRE(a->n <= tp->max_elems, CHATTS_E_SHAPE, "gemv: tp_reduce of %d rows exceeds the exchange buffer (%lld)", a->n,
-                   (long long)tp->max_elems);
-    p.tp = *tp;
+    CHATTS_REQUIRE(a->n <= tp_capacity(a->tp_reduce), CHATTS_E_SHAPE, "gemv: tp_reduce of %d rows exceeds the exchange buffer (%lld)", a->n,
+                   (long long)tp_capacity(a->tp_reduce));
     epilogue = kEpiResidTp;
   }
   const int swiglu = a->epilogue == CHATTS_EPI_SWIGLU;
@@ -712,6 +710,7 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
     if (blocks8 > cus * occ) blocks8 = cus * occ;
     if (a->tp_reduce) { const int cap = env_int("CHATTS_TP_FUSE_BLOCKS", 0); if (cap > 0 && blocks8 > cap) blocks8 = cap; }
     if (blocks8 < 1) blocks8 = 1;
+    if (a->tp_reduce) p.tp = tp_issue(a->tp_reduce, false);      // (after the last check that can refuse the call: one issue per launch)
     switch (epilogue) {
       case kEpiResidTp: launch8_norm<kEpiResidTp>(p, false, blocks8, threads, lds8, s); break;
       case CHATTS_EPI_RESID: launch8_norm<CHATTS_EPI_RESID>(p, norm, blocks8, threads, lds8, s); break;
@@ -762,6 +761,7 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
       return CHATTS_OK;
     }
   }
+  if (a->tp_reduce) p.tp = tp_issue(a->tp_reduce, false);
   if (rows == 4 && unr == 2) launch_ldsx<4, 2>(p, epilogue, norm, blocks, threads, lds_launch, s);
   else if (rows == 4) launch_ldsx<4, 4>(p, epilogue, norm, blocks, threads, lds_launch, s);
   else if (unr == 2) launch_ldsx<2, 2>(p, epilogue, norm, blocks, threads, lds_launch, s);

@@ -13,8 +13,10 @@
 //     flag (the low-latency protocol: no fence, no separate flag round trip).  The receiver polls its LOCAL buffer until
 //     the tag equals the call's epoch, then adds the W vectors in RANK ORDER - every rank computes bit-identical sums,
 //     so the replicated residual stream never diverges between ranks;
-//   * the epoch is a device-resident call counter bumped by the last workgroup of every collective, never a kernel
-//     argument: a captured decode step replays with fresh epochs.  Slots alternate by epoch parity; a rank can run at
+//   * the epoch is a device-resident call counter bumped by the last workgroup of a collective, never a kernel argument: a
+//     captured decode step replays with fresh epochs.  (Round 4: collectives that ride inside another kernel - the decode
+//     GEMVs with ChattsLinearArgs.tp_reduce - do not bump it; the host counts them and the next bumping collective's epoch
+//     accounts for them: TpParams::idx, tp_common.h.)  Slots alternate by epoch parity; a rank can run at
 //     most one collective ahead of the slowest peer (it needs that peer's contribution to finish), so two slots suffice;
 //   * every spin is bounded (~2 s of the 100 MHz wall clock); a timeout sets a status word instead of hanging the GPU.
 #include <string.h>
@@ -35,7 +37,7 @@ namespace chatts {
 template <int E>
 __global__ __launch_bounds__(1024) void tp_allreduce_kernel(TpParams p, const float* __restrict__ in, const float* resid,
                                                            float* out, int64_t n) {
-  const uint32_t epoch = p.ctr[0] + 1u;
+  const uint32_t epoch = tp_epoch(p);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int64_t base = i0; base < n; base += stride * E) {
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(1024) void tp_allreduce_kernel(TpParams p, const fl
 // (vocab-parallel logits -> full vocabulary, one row per sequence)
 __global__ __launch_bounds__(1024) void tp_allgather_kernel(TpParams p, const float* __restrict__ in, float* out, int64_t rows,
                                                            int64_t row_len) {
-  const uint32_t epoch = p.ctr[0] + 1u;
+  const uint32_t epoch = tp_epoch(p);
   const int64_t n_local = rows * row_len;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(1024) void tp_allgather_kernel(TpParams p, const fl
 __global__ __launch_bounds__(64) void tp_argmax_kernel(TpParams p, const float* __restrict__ logit, const int64_t* __restrict__ token_in,
                                                       int64_t* token, float* token_logit, int64_t* out_tokens, int64_t out_stride,
                                                       int32_t* step_dev, int32_t* pos_dev, int pos_limit) {
-  const uint32_t epoch = p.ctr[0] + 1u;
+  const uint32_t epoch = tp_epoch(p);
   const int lane = threadIdx.x, b = blockIdx.x;
   if (lane < p.world) {
     uint64_t* g = push_ptr(p, lane, epoch) + 2 * b;
@@ -173,6 +175,7 @@ struct ChattsTpComm {
   void* opened[kMaxWorld] = {};      // IPC mappings to close
   bool ipc = false;
   size_t bytes = 0;
+  uint32_t pending = 0;              // collectives issued since the last counter bump (TpParams::idx of the next one)
 };
 
 extern "C" size_t chatts_tp_buffer_bytes(int world, int64_t max_elems) {
@@ -317,7 +320,13 @@ extern "C" ChattsTpComm* chatts_tp_init_loopback(int rank, int world, void* loca
 }
 
 namespace chatts {
-const TpParams* tp_params(const ChattsTpComm* c) { return c ? &c->p : nullptr; }
+TpParams tp_issue(ChattsTpComm* c, bool bumps) {
+  TpParams p = c->p;
+  p.idx = c->pending;
+  c->pending = bumps ? 0u : c->pending + 1u;
+  return p;
+}
+int64_t tp_capacity(const ChattsTpComm* c) { return c ? c->p.max_elems : 0; }
 }  // namespace chatts
 
 extern "C" void chatts_tp_destroy(ChattsTpComm* c) {
@@ -344,6 +353,7 @@ extern "C" int chatts_tp_reset(ChattsTpComm* c, chatts_stream_t stream) {
   CHATTS_REQUIRE(c, CHATTS_E_BADARG, "tp_reset: null comm");
   const int64_t granules = (int64_t)2 * c->p.world * c->p.max_elems;
   hipLaunchKernelGGL(tp_reset_kernel, dim3(256), dim3(256), 0, as_stream(stream), c->p.peer[c->p.rank], granules, c->p.ctr);
+  c->pending = 0;
   CHATTS_CHECK_LAUNCH("tp_reset");
   return CHATTS_OK;
 }
@@ -360,10 +370,10 @@ extern "C" int chatts_allreduce(ChattsTpComm* c, const float* in, float* out, co
                  (long long)n, (long long)c->p.max_elems);
   if (n == 0) return CHATTS_OK;
   if (n <= 16384) {           // decode-sized: one value per thread, every poll of the vector in flight at once
-    hipLaunchKernelGGL(tp_allreduce_kernel<1>, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, as_stream(stream), c->p, in, resid, out, n);
+    hipLaunchKernelGGL(tp_allreduce_kernel<1>, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, as_stream(stream), tp_issue(c, true), in, resid, out, n);
   } else {
     const int64_t b = (n + 4095) / 4096;
-    hipLaunchKernelGGL(tp_allreduce_kernel<4>, dim3((unsigned)(b > 128 ? 128 : b)), dim3(1024), 0, as_stream(stream), c->p, in, resid, out, n);
+    hipLaunchKernelGGL(tp_allreduce_kernel<4>, dim3((unsigned)(b > 128 ? 128 : b)), dim3(1024), 0, as_stream(stream), tp_issue(c, true), in, resid, out, n);
   }
   CHATTS_CHECK_LAUNCH("tp_allreduce");
   return CHATTS_OK;
@@ -375,7 +385,7 @@ extern "C" int chatts_allgather(ChattsTpComm* c, const float* in, float* out, in
                  "allgather: %lld x %lld elements exceed the exchange buffer (%lld)", (long long)rows, (long long)row_len,
                  (long long)c->p.max_elems);
   if (rows * row_len == 0) return CHATTS_OK;
-  hipLaunchKernelGGL(tp_allgather_kernel, dim3(tp_blocks(rows * row_len)), dim3(1024), 0, as_stream(stream), c->p, in, out, rows, row_len);
+  hipLaunchKernelGGL(tp_allgather_kernel, dim3(tp_blocks(rows * row_len)), dim3(1024), 0, as_stream(stream), tp_issue(c, true), in, out, rows, row_len);
   CHATTS_CHECK_LAUNCH("tp_allgather");
   return CHATTS_OK;
 }
@@ -385,7 +395,7 @@ extern "C" int chatts_tp_argmax(ChattsTpComm* c, int batch, const float* local_l
                                 int pos_limit, chatts_stream_t stream) {
   CHATTS_REQUIRE(c && local_logit && local_token && token, CHATTS_E_BADARG, "tp_argmax: null argument");
   CHATTS_REQUIRE(batch >= 1 && 2 * (int64_t)batch <= c->p.max_elems, CHATTS_E_SHAPE, "tp_argmax: batch %d", batch);
-  hipLaunchKernelGGL(tp_argmax_kernel, dim3(batch), dim3(64), 0, as_stream(stream), c->p, local_logit, local_token, token, token_logit,
+  hipLaunchKernelGGL(tp_argmax_kernel, dim3(batch), dim3(64), 0, as_stream(stream), tp_issue(c, true), local_logit, local_token, token, token_logit,
                      out_tokens, out_stride, step_dev, pos_dev, pos_limit);
   CHATTS_CHECK_LAUNCH("tp_argmax");
   return CHATTS_OK;

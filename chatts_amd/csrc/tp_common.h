@@ -22,7 +22,15 @@ struct TpParams {
   // the LOCAL buffer, in the slot of the peer it would have gone to, carrying 0.0 for every peer but the rank itself: the same
   // W stores per element and the same W polls as a real step, zero link latency - what one GPU can measure of a rank's step time.
   int loopback;
+  // Epoch of a collective = ctr[0] + 1 + idx.  ctr[0] counts the collectives COMPLETED up to the last counter bump; idx = collectives
+  // issued since then whose kernels do not bump it (the exchange-carrying GEMVs of a decode step: 96 per token - their launches would
+  // each end with a workgroup barrier and a returning atomic on the arrival counter just to advance a number the host can count
+  // too).  The host tracks idx per communicator (tp_issue); a bumping kernel stores its own epoch into ctr[0], which resets idx.  A
+  // captured step has its idx values baked in and ends with a bumping collective (the token agreement), so every replay starts from
+  // the fresh device counter.
+  uint32_t idx;
 };
+__device__ __forceinline__ uint32_t tp_epoch(const TpParams& p) { return p.ctr[0] + 1u + p.idx; }
 
 __device__ __forceinline__ uint64_t* slot_ptr(const TpParams& p, int owner, uint32_t epoch, int src) {
   return p.peer[owner] + ((int64_t)(epoch & 1u) * p.world + src) * p.max_elems;
@@ -61,7 +69,9 @@ __device__ __forceinline__ void finish_call(const TpParams& p, uint32_t epoch) {
   }
 }
 
-// host (tp.hip): the kernel-side view of a communicator
-const TpParams* tp_params(const ChattsTpComm* c);
+// host (tp.hip): the kernel parameters of the NEXT collective on this communicator (idx filled in; see TpParams::idx).  bumps =
+// the kernel ends with finish_call (stand-alone collectives); false = it leaves the counter to a later one (exchange-carrying GEMVs)
+TpParams tp_issue(ChattsTpComm* c, bool bumps);
+int64_t tp_capacity(const ChattsTpComm* c);
 
 }  // namespace chatts
