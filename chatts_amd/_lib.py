@@ -153,14 +153,13 @@ SIGNATURES = {
     "chatts_decoder_decode_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                            c_void_p]),
     "chatts_decoder_set_tp": (c_int, [c_void_p, c_void_p]),
-    "chatts_decoder_mega_state_bytes": (c_size_t, [c_void_p]),
-    "chatts_decoder_mega_attach": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
-    "chatts_decoder_mega_status": (c_int, [c_void_p]),
-    "chatts_decoder_mega_profile": (c_int, [c_void_p, c_void_p, c_size_t]),
     "chatts_decoder_select_tokens": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                              c_void_p, c_int, C.POINTER(SamplingArgs), c_void_p]),
     # tensor-parallel exchange (tp.hip)
     "chatts_tp_buffer_bytes": (c_size_t, [c_int, c_int64]),
+    "chatts_tp_buffer_bytes_bulk": (c_size_t, [c_int, c_int64, c_int64]),
+    "chatts_tp_bulk_elems": (c_int64, [c_void_p]),
+    "chatts_allreduce_bulk": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "chatts_tp_buffer_alloc": (c_int, [c_size_t, C.POINTER(c_void_p), c_void_p]),
     "chatts_tp_buffer_free": (c_int, [c_void_p]),
     "chatts_tp_init": (c_void_p, [c_int, c_int, c_void_p, c_void_p, c_size_t, c_int64]),

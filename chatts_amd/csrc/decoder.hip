@@ -7,7 +7,6 @@
 #include <vector>
 
 #include "common.h"
-#include "decode_mega.h"
 
 namespace chatts {
 int launch_gemv(const ChattsLinearArgs* a, hipStream_t s);
@@ -40,12 +39,6 @@ struct ChattsDecoder {
   ChattsTpComm* tp = nullptr;   // tensor-parallel exchange (borrowed); required by the whole-step entry points when tp_world > 1
   bool fuse_tp = false;     // set by chatts_decoder_decode_step: the M == 1 o_proj / down_proj GEMVs carry the exchange in their own launch
   bool tp_fused = false;    // ... and whether the last layer part's projection did (otherwise the caller launches chatts_allreduce)
-  // persistent decode step (decode_mega.hip): plan + caller-owned device state (tables, barrier counters); null = not attached
-  MegaHost mega{};
-  bool mega_planned = false;
-  void* mega_state = nullptr;
-  int mega_n_splits = 0;
-  unsigned long long* mega_prof = nullptr;
 };
 
 static int64_t embed_rows(const ChattsDecoder* d) { return d->cfg.embed_rows > 0 ? d->cfg.embed_rows : d->cfg.vocab_local; }
@@ -539,15 +532,33 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
                                       pos_dev, c.max_ctx - 1, nullptr, stream);
 }
 
+// tensor parallel: can the [t, H] sums between the layer halves run as chatts_allreduce_bulk launches of the same call?
+static bool tp_bulk_ready(const ChattsDecoder* d, int t) {
+  return d->tp && chatts_tp_bulk_elems(d->tp) >= (int64_t)t * d->cfg.hidden;
+}
+#define CHATTS_REQUIRE_TP_BULK(d, t, name)                                                                                         \
+  CHATTS_REQUIRE((d)->cfg.tp_world == 1 || tp_bulk_ready((d), (t)), CHATTS_E_BADARG,                                                \
+                 name ": tp_world = %d needs an attached exchange whose bulk region holds t * hidden = %lld float32 (chatts_tp_buffer_bytes_bulk); " \
+                 "otherwise drive chatts_decoder_layer_part_add and all-reduce buffers.delta yourself", (d)->cfg.tp_world,          \
+                 (long long)(t) * (d)->cfg.hidden)
+// x[0:t] += sum over the ranks of delta[0:t]
+static int tp_sum_into_x(ChattsDecoder* d, int t, chatts_stream_t stream) {
+  return chatts_allreduce_bulk(d->tp, d->b.delta, d->b.x, (int64_t)t * d->cfg.hidden, stream);
+}
+
 extern "C" int chatts_decoder_prefill(ChattsDecoder* d, int t, int pos0, chatts_stream_t stream) {
   CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_prefill: null decoder");
-  CHATTS_REQUIRE(d->cfg.tp_world == 1, CHATTS_E_BADARG, "decoder_prefill: TP>1 must drive chatts_decoder_layer_part");
+  CHATTS_REQUIRE(t >= 1 && t <= d->b.t_max, CHATTS_E_SHAPE, "decoder_prefill: t=%d exceeds buffers (%d)", t, d->b.t_max);
+  CHATTS_REQUIRE_TP_BULK(d, t, "decoder_prefill");
+  const bool tp = d->cfg.tp_world > 1;
   d->chain = true;
   d->normed = false;
   int rc = CHATTS_OK;
   for (int l = 0; l < d->cfg.n_layers && rc == CHATTS_OK; ++l) {
     rc = chatts_decoder_layer_part(d, l, 0, t, pos0, nullptr, 1, stream);
+    if (tp && rc == CHATTS_OK) rc = tp_sum_into_x(d, t, stream);
     if (rc == CHATTS_OK) rc = chatts_decoder_layer_part(d, l, 1, t, pos0, nullptr, 1, stream);
+    if (tp && rc == CHATTS_OK) rc = tp_sum_into_x(d, t, stream);
   }
   d->chain = false;
   d->normed = false;
@@ -590,21 +601,32 @@ static int layer_last_row(ChattsDecoder* d, int layer, int t, int pos0, chatts_s
   la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k; la.w8_format = d->cfg.w8_format;
   la.w4 = lw.o4; la.w4_sz = lw.o4_sz; la.ldw4 = la.k / 2; la.w4_group = lw.w4_group;
   la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID;
+  const bool tp = c.tp_world > 1;
+  if (tp && !la.w4) la.tp_reduce = d->tp;                  // row 0 of x += the sum over the ranks, inside the GEMV launch
+  else if (tp) { la.c = d->b.delta; la.resid = nullptr; la.epilogue = CHATTS_EPI_NONE; }
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
-  return chatts_decoder_layer_part(d, layer, 1, 1, 0, nullptr, 1, stream);      // MLP on row 0: the decode path's GEMVs
+  if (tp && !la.tp_reduce && (rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, H, stream)) != 0) return rc;
+  d->fuse_tp = tp;
+  rc = chatts_decoder_layer_part(d, layer, 1, 1, 0, nullptr, 1, stream);      // MLP on row 0: the decode path's GEMVs
+  d->fuse_tp = false;
+  if (rc == CHATTS_OK && tp && !d->tp_fused) rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, H, stream);
+  return rc;
 }
 
 extern "C" int chatts_decoder_prefill_last(ChattsDecoder* d, int t, int pos0, chatts_stream_t stream) {
   CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_prefill_last: null decoder");
-  CHATTS_REQUIRE(d->cfg.tp_world == 1, CHATTS_E_BADARG, "decoder_prefill_last: TP>1 must drive chatts_decoder_layer_part");
   CHATTS_REQUIRE(t >= 1 && t <= d->b.t_max, CHATTS_E_SHAPE, "decoder_prefill_last: t=%d exceeds buffers (%d)", t, d->b.t_max);
+  CHATTS_REQUIRE_TP_BULK(d, t, "decoder_prefill_last");
+  const bool tp = d->cfg.tp_world > 1;
   d->chain = true;
   d->normed = false;
   int rc = CHATTS_OK;
   const int L = d->cfg.n_layers;
   for (int l = 0; l + 1 < L && rc == CHATTS_OK; ++l) {
     rc = chatts_decoder_layer_part(d, l, 0, t, pos0, nullptr, 1, stream);
+    if (tp && rc == CHATTS_OK) rc = tp_sum_into_x(d, t, stream);
     if (rc == CHATTS_OK) rc = chatts_decoder_layer_part(d, l, 1, t, pos0, nullptr, 1, stream);
+    if (tp && rc == CHATTS_OK) rc = tp_sum_into_x(d, t, stream);
   }
   if (rc == CHATTS_OK) rc = layer_last_row(d, L - 1, t, pos0, stream);
   d->chain = false;
@@ -688,103 +710,6 @@ extern "C" int chatts_decoder_logits(ChattsDecoder* d, int row, chatts_stream_t 
   return chatts_linear(&la, stream);
 }
 
-// ---- persistent decode step (decode_mega.hip) -----------------------------------------------------------------------------
-static bool mega_eligible(const ChattsDecoder* d) {
-  if (d->cfg.tp_world != 1) return false;                     // the partial sums of a TP rank leave the GPU between the halves
-  for (const ChattsLayerWeights& lw : d->layers)
-    if (lw.qkv8 || lw.o8 || lw.gate_up8 || lw.down8 || lw.qkv4 || lw.o4 || lw.gate_up4 || lw.down4) return false;   // bf16 stream only
-  return d->w.lm_head8 == nullptr;
-}
-
-extern "C" size_t chatts_decoder_mega_state_bytes(ChattsDecoder* d) {
-  if (!d || !mega_eligible(d)) return 0;
-  if (!d->mega_planned) {
-    const int cus = device_cus();
-    if (cus < 8 || !mega_plan(&d->mega, d->cfg.hidden, d->cfg.n_q, d->cfg.n_kv, d->cfg.inter, d->cfg.vocab_local, cus)) return 0;
-    d->mega_planned = true;
-  }
-  return mega_state_bytes(d->cfg.n_layers, d->mega.nwg);
-}
-
-// state layout: MegaSync | argmax pairs [nwg] | MegaLayer [n_layers]
-static unsigned long long* mega_pairs(const ChattsDecoder* d) {
-  return reinterpret_cast<unsigned long long*>(static_cast<char*>(d->mega_state) + sizeof(MegaSync));
-}
-static MegaLayer* mega_layers(const ChattsDecoder* d) {
-  return reinterpret_cast<MegaLayer*>(static_cast<char*>(d->mega_state) + sizeof(MegaSync) + (((size_t)d->mega.nwg * 8 + 63) / 64) * 64);
-}
-
-extern "C" int chatts_decoder_mega_attach(ChattsDecoder* d, void* state, size_t bytes, int n_splits) {
-  CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_mega_attach: null decoder");
-  if (!state) { d->mega_state = nullptr; return CHATTS_OK; }
-  const size_t need = chatts_decoder_mega_state_bytes(d);
-  CHATTS_REQUIRE(need > 0, CHATTS_E_SHAPE, "decoder_mega_attach: this decoder cannot run the persistent step (tensor parallel, fp8 / int4 "
-                 "weights or an unsupported shape)");
-  CHATTS_REQUIRE(bytes >= need && ((uintptr_t)state % 256) == 0, CHATTS_E_WORKSPACE, "decoder_mega_attach: needs %zu bytes, 256-byte aligned", need);
-  CHATTS_REQUIRE(n_splits >= 1 && n_splits <= 64 && chatts_attn_workspace(1, d->cfg.n_q, n_splits) <= d->b.workspace_bytes, CHATTS_E_WORKSPACE,
-                 "decoder_mega_attach: attention workspace too small for %d key slots", n_splits);
-  d->mega_state = state;
-  d->mega_n_splits = n_splits;
-  std::vector<MegaLayer> tab(d->cfg.n_layers);
-  for (int l = 0; l < d->cfg.n_layers; ++l) {
-    const ChattsLayerWeights& lw = d->layers[l];
-    const ChattsKvCache kc = layer_cache(d, l, 0);          // cache slot 0: the single-sequence decode path
-    tab[l] = MegaLayer{lw.input_norm, lw.qkv, lw.qkv_bias, lw.q_norm, lw.k_norm, lw.o, lw.post_norm, lw.gate_up, lw.down, kc.k, kc.v};
-  }
-  // set-up call (like the exchange buffers of chatts_tp_*): zero the state, upload the layer table, synchronously
-  hipError_t e = hipMemset(state, 0, need);
-  if (e == hipSuccess) e = hipMemcpy(mega_layers(d), tab.data(), tab.size() * sizeof(MegaLayer), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { d->mega_state = nullptr; }
-  CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "decoder_mega_attach: %s", hipGetErrorString(e));
-  return CHATTS_OK;
-}
-
-extern "C" int chatts_decoder_mega_profile(ChattsDecoder* d, void* buf, size_t bytes) {
-  CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_mega_profile: null decoder");
-  const size_t need = ((size_t)2 * (6 * d->cfg.n_layers + 1) * 16 + (size_t)12 * 1024) * sizeof(unsigned long long);
-  CHATTS_REQUIRE(!buf || bytes >= need, CHATTS_E_WORKSPACE, "decoder_mega_profile: needs %zu bytes", need);
-  d->mega_prof = static_cast<unsigned long long*>(buf);
-  return CHATTS_OK;
-}
-
-extern "C" int chatts_decoder_mega_status(ChattsDecoder* d) {
-  CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_mega_status: null decoder");
-  if (!d->mega_state) return 0;
-  unsigned st = 0;
-  const hipError_t e = hipMemcpy(&st, static_cast<char*>(d->mega_state) + offsetof(MegaSync, status), sizeof(st), hipMemcpyDeviceToHost);
-  CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "decoder_mega_status: %s", hipGetErrorString(e));
-  return (int)st;
-}
-
-static int decode_step_mega(ChattsDecoder* d, int32_t* pos_dev, int32_t* step_dev, int64_t* token_dev, float* token_logit_dev,
-                            int64_t* out_tokens, chatts_stream_t stream) {
-  const ChattsDecoderConfig& c = d->cfg;
-  MegaParams p{};
-  p.layers = mega_layers(d);
-  for (int i = 0; i < 5; ++i) p.geom[i] = d->mega.geom[i];
-  p.sync = static_cast<MegaSync*>(d->mega_state);
-  p.argmax_pairs = mega_pairs(d);
-  p.x = d->b.x; p.qkv = d->b.qkv; p.attn = d->b.attn; p.act = d->b.act; p.logits = d->b.logits;
-  p.part_o = reinterpret_cast<float*>(d->b.workspace);
-  p.part_ml = p.part_o + (size_t)c.n_q * d->mega_n_splits * kHeadDim;
-  p.final_norm = d->w.final_norm; p.lm_head = d->w.lm_head; p.embed = d->w.embed; p.cos_tab = d->w.cos_tab; p.sin_tab = d->w.sin_tab;
-  p.kv_table = d->b.kv_block_table;                         // row of cache slot 0
-  p.kv_log_block = d->b.kv_block_table ? kv_log_block(d->b.kv_block_size) : 0;
-  p.pos_dev = pos_dev; p.step_dev = step_dev; p.token_dev = token_dev; p.token_logit_dev = token_logit_dev; p.out_tokens = out_tokens;
-  p.vocab_offset = c.vocab_offset; p.embed_rows = embed_rows(d); p.embed_offset = embed_offset(d);
-  p.eps = c.rms_eps; p.n_layers = c.n_layers; p.hidden = c.hidden; p.n_q = c.n_q; p.n_kv = c.n_kv; p.max_ctx = c.max_ctx;
-  p.n_splits = d->mega_n_splits;
-  p.greedy_tail = d->sampling ? 0 : 1;
-  p.nwg = d->mega.nwg; p.xs_bytes = mega_lds_bytes(d->mega);
-  p.prof = d->mega_prof;
-  int rc = mega_launch(p, d->mega, as_stream(stream));
-  if (rc || !d->sampling) return rc;
-  // sampling: the launch ends with the logits; selection and the next embedding are the ordinary kernels
-  if ((rc = chatts_decoder_select_tokens(d, d->b.logits, 1, c.vocab_local, token_dev, token_logit_dev, out_tokens, 0, step_dev, pos_dev, 0,
-                                         nullptr, stream)) != 0) return rc;
-  return chatts_embed_token(token_dev, d->w.embed, embed_offset(d), embed_rows(d), c.hidden, d->b.x, stream);
-}
-
 extern "C" int chatts_decoder_decode_step(ChattsDecoder* d, int32_t* pos_dev, int32_t* step_dev, int64_t* token_dev,
                                           float* token_logit_dev, int64_t* out_tokens, int n_splits,
                                           chatts_stream_t stream) {
@@ -793,10 +718,6 @@ extern "C" int chatts_decoder_decode_step(ChattsDecoder* d, int32_t* pos_dev, in
   CHATTS_REQUIRE(!tp || d->tp, CHATTS_E_BADARG, "decode_step: tp_world = %d but no exchange attached (chatts_decoder_set_tp)", d->cfg.tp_world);
   int rc;
   const int H = d->cfg.hidden;
-  if (d->mega_state && d->cur_seq == 0 && n_splits == d->mega_n_splits && mega_eligible(d)) {
-    static const bool off = getenv("CHATTS_DECODE_MEGA") && atoi(getenv("CHATTS_DECODE_MEGA")) == 0;
-    if (!off) return decode_step_mega(d, pos_dev, step_dev, token_dev, token_logit_dev, out_tokens, stream);
-  }
   // Tensor parallel: the two exchanges of a layer ride in the o_proj / down_proj GEMV launches (6 launches per layer instead of 8;
   // CHATTS_TP_FUSE=0 keeps the stand-alone chatts_allreduce kernels: same bits - tests/test_gpu_tp_p2p.py)
   const bool fuse_off = getenv("CHATTS_TP_FUSE") && atoi(getenv("CHATTS_TP_FUSE")) == 0;     // (read per call: tests A/B it in one process)

@@ -160,9 +160,130 @@ __global__ __launch_bounds__(64) void tp_argmax_kernel(TpParams p, const float* 
   finish_call(p, epoch);
 }
 
-__global__ void tp_reset_kernel(uint64_t* buf, int64_t granules, uint32_t* ctr) {
+
+// ---- prefill-sized sums: two-shot all-reduce (direct reduce-scatter, then direct all-gather) over the same mapped buffers ---------
+// A prefill chunk sums [T, H] float32 partials twice per layer (16 MB at T = 798): as 8-byte granules that would be 2 x the bytes to
+// all W - 1 peers each (230 MB per rank and sum); RCCL does it well but costs a host-enqueued launch between every two layer
+// halves (96 per chunk, nothing capturable).  Here ONE kernel per sum, enqueued by the same C call as the layer halves
+// (chatts_decoder_prefill under tensor parallelism):
+//   1. scatter: rank r stores slice s of its partial into rank s's buffer (area "from r"), 16 bytes per lane, all W - 1 links busy;
+//      a system-scope fence, then one flag per (source, workgroup) carrying the epoch;
+//   2. rank s waits for its W flags, adds the W areas of its slice IN RANK ORDER (one rank forms each element's sum: every rank
+//      receives the same bits) and stores the reduced slice into every rank's gather area; fence; flag per (slice, workgroup);
+//   3. every rank waits for the W slices and adds them to its residual stream: x += sum.
+// (W - 1) / W of the vector crosses each rank's links twice - 2 x 14 MB over 7 links at T = 798, W = 8.  Workgroup b handles the same
+// sub-range of every slice on every rank, so a workgroup only ever waits for workgroups of the SAME index on other ranks.  Areas
+// and flags alternate by epoch parity like the granule slots; flags carry the epoch, nothing is ever reset.  Plain 16-byte stores
+// into the peers' uncached memory + __threadfence_system() before the flag; the reader fences after its poll.
+struct BulkView {
+  uint32_t* flags;     // [2 phases][W][kBulkMaxBlocks] of this slot
+  float* scatter;      // [W sources][slice_cap]
+  float* gather;       // [W slices][slice_cap]
+};
+__device__ __forceinline__ BulkView bulk_view(const TpParams& p, int owner, uint32_t epoch) {
+  char* base = reinterpret_cast<char*>(p.peer[owner]) + p.bulk_off;
+  const int slot = (int)(epoch & 1u);
+  BulkView v;
+  v.flags = reinterpret_cast<uint32_t*>(base) + (size_t)slot * 2 * kMaxWorld * kBulkMaxBlocks;
+  float* data = reinterpret_cast<float*>(base + kBulkFlagBytes) + (size_t)slot * 2 * p.world * p.slice_cap;
+  v.scatter = data;
+  v.gather = data + (size_t)p.world * p.slice_cap;
+  return v;
+}
+// wait until flag == epoch (one thread); false on timeout
+__device__ __forceinline__ bool wait_flag(uint32_t* f, uint32_t epoch, uint32_t* status) {
+  if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == epoch) return true;
+  const uint64_t t0 = wall_clock64();
+  while (true) {
+    __builtin_amdgcn_s_sleep(2);
+    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == epoch) return true;
+    if (wall_clock64() - t0 > spin_limit(status)) { atomicOr(status, 1u); return false; }
+  }
+}
+
+__global__ __launch_bounds__(256) void tp_allreduce_bulk_kernel(TpParams p, const float* __restrict__ in, float* x, int64_t n) {
+  const uint32_t epoch = tp_epoch(p);
+  const int W = p.world, b = blockIdx.x, tid = threadIdx.x;
+  // slice s = elements [s * slice, (s + 1) * slice) of the vector (multiples of 4 floats); workgroup b owns [lo, hi) of every slice
+  const int64_t slice = ((n + W - 1) / W + 3) / 4 * 4;
+  const int64_t per = ((slice + gridDim.x - 1) / gridDim.x + 3) / 4 * 4;
+  const int64_t lo = (int64_t)b * per, hi = lo + per < slice ? lo + per : slice;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // 1. scatter my partial: slice s goes to rank s (loop-back: into my own "from q" area, zeros for the absent peers)
+  for (int k = 0; k < W; ++k) {
+    const int s = (p.rank + k) % W;
+    const BulkView dst = bulk_view(p, p.loopback ? p.rank : s, epoch);
+    float* area = dst.scatter + (size_t)(p.loopback ? s : p.rank) * p.slice_cap;
+    const int src_slice = p.loopback ? p.rank : s;
+    for (int64_t i = lo + tid * 4; i < hi; i += 256 * 4) {
+      const int64_t g = (int64_t)src_slice * slice + i;
+      f32x4 v = zero;
+      if (!(p.loopback && s != p.rank)) {
+        if (g + 3 < n) v = *reinterpret_cast<const f32x4*>(in + g);
+        else { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; ++e) if (g + e < n) t[e] = in[g + e]; v = (f32x4){t[0], t[1], t[2], t[3]}; }
+      }
+      *reinterpret_cast<f32x4*>(area + i) = v;
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < W) {
+    const int s = (p.rank + tid) % W;
+    const BulkView dst = bulk_view(p, p.loopback ? p.rank : s, epoch);
+    __hip_atomic_store(dst.flags + (size_t)(p.loopback ? s : p.rank) * kBulkMaxBlocks + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // 2. reduce my slice (this workgroup's range) in rank order and hand it to everybody
+  const BulkView mine = bulk_view(p, p.rank, epoch);
+  if (tid < W) (void)wait_flag(mine.flags + (size_t)tid * kBulkMaxBlocks + b, epoch, &p.ctr[2]);     // (a timeout raises the status bit)
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  for (int64_t i = lo + tid * 4; i < hi; i += 256 * 4) {
+    f32x4 sum = *reinterpret_cast<const f32x4*>(mine.scatter + i);
+    for (int src = 1; src < W; ++src) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(mine.scatter + (size_t)src * p.slice_cap + i);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    for (int k = 0; k < W; ++k) {
+      const int q = (p.rank + k) % W;
+      const BulkView dst = bulk_view(p, p.loopback ? p.rank : q, epoch);
+      *reinterpret_cast<f32x4*>(dst.gather + (size_t)(p.loopback ? q : p.rank) * p.slice_cap + i) = (p.loopback && q != p.rank) ? zero : sum;
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < W) {
+    const int q = (p.rank + tid) % W;
+    const BulkView dst = bulk_view(p, p.loopback ? p.rank : q, epoch);
+    __hip_atomic_store(dst.flags + (size_t)(kMaxWorld + (p.loopback ? q : p.rank)) * kBulkMaxBlocks + b, epoch, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // 3. x += the reduced vector (all W slices, this workgroup's range of each)
+  if (tid < W) (void)wait_flag(mine.flags + (size_t)(kMaxWorld + tid) * kBulkMaxBlocks + b, epoch, &p.ctr[2]);
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  for (int s = 0; s < W; ++s) {
+    for (int64_t i = lo + tid * 4; i < hi; i += 256 * 4) {
+      const int64_t g = (int64_t)s * slice + i;
+      if (g >= n) break;
+      const f32x4 r = *reinterpret_cast<const f32x4*>(mine.gather + (size_t)s * p.slice_cap + i);
+      if (g + 3 < n) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + g);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        *reinterpret_cast<f32x4*>(x + g) = v;
+      } else {
+        const float t[4] = {r.x, r.y, r.z, r.w};
+        for (int e = 0; e < 4; ++e) if (g + e < n) x[g + e] += t[e];
+      }
+    }
+  }
+  finish_call(p, epoch);
+}
+
+__global__ void tp_reset_kernel(uint64_t* buf, int64_t granules, uint32_t* ctr, uint32_t* bulk_flags) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < granules; i += stride) buf[i] = 0;
+  if (bulk_flags)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)(kBulkFlagBytes / 4); i += stride) bulk_flags[i] = 0;
   if (blockIdx.x == 0 && threadIdx.x < 4) ctr[threadIdx.x] = 0;
 }
 
@@ -182,6 +303,14 @@ extern "C" size_t chatts_tp_buffer_bytes(int world, int64_t max_elems) {
   if (world < 1 || world > kMaxWorld || max_elems < 1) return 0;
   const int64_t per = (max_elems + 1) / 2 * 2;
   return (size_t)2 * world * per * sizeof(uint64_t) + 256;        // + the counter words at the end
+}
+
+static int64_t bulk_slice_cap(int world, int64_t bulk_elems) { return ((bulk_elems + world - 1) / world + 3) / 4 * 4 + 4; }
+extern "C" size_t chatts_tp_buffer_bytes_bulk(int world, int64_t max_elems, int64_t bulk_elems) {
+  const size_t g = chatts_tp_buffer_bytes(world, max_elems);
+  if (g == 0 || bulk_elems <= 0) return g;
+  // flags, then [2 slots][scatter W areas + gather W slices] of slice_cap floats
+  return g + kBulkFlagBytes + (size_t)2 * 2 * world * bulk_slice_cap(world, bulk_elems) * sizeof(float);
 }
 
 // Exchange buffers are NEVER handed back to the driver while the process lives: a freed buffer goes to a free list and serves a
@@ -263,6 +392,12 @@ static ChattsTpComm* tp_make(int rank, int world, int64_t max_elems, size_t byte
   ChattsTpComm* c = new (std::nothrow) ChattsTpComm();
   if (!c) { set_error("tp_init: out of host memory"); return nullptr; }
   c->p.rank = rank; c->p.world = world; c->p.max_elems = (max_elems + 1) / 2 * 2; c->bytes = bytes;
+  // whatever lies behind the granule slots + counter words is the bulk region (chatts_tp_buffer_bytes_bulk): same layout on every rank
+  const size_t gbytes = chatts_tp_buffer_bytes(world, max_elems);
+  if (bytes > gbytes + kBulkFlagBytes + (size_t)64 * world) {
+    c->p.bulk_off = (int64_t)gbytes;
+    c->p.slice_cap = (int64_t)((bytes - gbytes - kBulkFlagBytes) / ((size_t)2 * 2 * world * sizeof(float))) / 4 * 4;
+  }
   return c;
 }
 
@@ -352,7 +487,8 @@ extern "C" int chatts_tp_status(ChattsTpComm* c) {
 extern "C" int chatts_tp_reset(ChattsTpComm* c, chatts_stream_t stream) {
   CHATTS_REQUIRE(c, CHATTS_E_BADARG, "tp_reset: null comm");
   const int64_t granules = (int64_t)2 * c->p.world * c->p.max_elems;
-  hipLaunchKernelGGL(tp_reset_kernel, dim3(256), dim3(256), 0, as_stream(stream), c->p.peer[c->p.rank], granules, c->p.ctr);
+  hipLaunchKernelGGL(tp_reset_kernel, dim3(256), dim3(256), 0, as_stream(stream), c->p.peer[c->p.rank], granules, c->p.ctr,
+                     c->p.bulk_off ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->p.peer[c->p.rank]) + c->p.bulk_off) : nullptr);
   c->pending = 0;
   CHATTS_CHECK_LAUNCH("tp_reset");
   return CHATTS_OK;
@@ -376,6 +512,28 @@ extern "C" int chatts_allreduce(ChattsTpComm* c, const float* in, float* out, co
     hipLaunchKernelGGL(tp_allreduce_kernel<4>, dim3((unsigned)(b > 128 ? 128 : b)), dim3(1024), 0, as_stream(stream), tp_issue(c, true), in, resid, out, n);
   }
   CHATTS_CHECK_LAUNCH("tp_allreduce");
+  return CHATTS_OK;
+}
+
+extern "C" int64_t chatts_tp_bulk_elems(const ChattsTpComm* c) {
+  return (c && c->p.bulk_off) ? (c->p.slice_cap - 4) * c->p.world : 0;
+}
+
+extern "C" int chatts_allreduce_bulk(ChattsTpComm* c, const float* in, float* x, int64_t n, chatts_stream_t stream) {
+  CHATTS_REQUIRE(c && in && x, CHATTS_E_BADARG, "allreduce_bulk: null argument");
+  CHATTS_REQUIRE(n >= 0 && n <= chatts_tp_bulk_elems(c), CHATTS_E_SHAPE, "allreduce_bulk: %lld elements exceed the bulk region (%lld)",
+                 (long long)n, (long long)chatts_tp_bulk_elems(c));
+  CHATTS_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)x % 16) == 0, CHATTS_E_SHAPE, "allreduce_bulk: pointers must be 16-byte aligned");
+  if (n == 0) return CHATTS_OK;
+  // one workgroup per ~8 KB of a slice, at most kBulkMaxBlocks (every rank computes the same grid from n: the flags are per workgroup)
+  const int64_t slice = ((n + c->p.world - 1) / c->p.world + 3) / 4 * 4;
+  int64_t blocks = (slice + 2047) / 2048;
+  static const int cap = getenv("CHATTS_TP_BULK_BLOCKS") ? atoi(getenv("CHATTS_TP_BULK_BLOCKS")) : 128;
+  if (blocks > cap) blocks = cap;
+  if (blocks > kBulkMaxBlocks) blocks = kBulkMaxBlocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(tp_allreduce_bulk_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), tp_issue(c, true), in, x, n);
+  CHATTS_CHECK_LAUNCH("tp_allreduce_bulk");
   return CHATTS_OK;
 }
 

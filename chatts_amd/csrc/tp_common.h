@@ -29,7 +29,14 @@ struct TpParams {
   // captured step has its idx values baked in and ends with a bumping collective (the token agreement), so every replay starts from
   // the fresh device counter.
   uint32_t idx;
+  // Bulk region (prefill-sized sums, tp_allreduce_bulk_kernel): lies behind the granule slots and the counter words at the same
+  // offset in every rank's buffer - flags [2 slots][2 phases][W][kBulkMaxBlocks] uint32, then per slot W "scatter" areas (one per
+  // source rank) and one "gather" area of W slices, slice_cap floats each.  bulk_off == 0: the buffer has no bulk region.
+  int64_t bulk_off;            // bytes from the buffer base
+  int64_t slice_cap;           // floats per slice (multiple of 4)
 };
+constexpr int kBulkMaxBlocks = 256;
+constexpr size_t kBulkFlagBytes = (size_t)2 * 2 * kMaxWorld * kBulkMaxBlocks * sizeof(uint32_t);
 __device__ __forceinline__ uint32_t tp_epoch(const TpParams& p) { return p.ctr[0] + 1u + p.idx; }
 
 __device__ __forceinline__ uint64_t* slot_ptr(const TpParams& p, int owner, uint32_t epoch, int src) {

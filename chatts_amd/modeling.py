@@ -431,18 +431,11 @@ class ChatTSForCausalLM:
         self._decoder = C.c_void_p(h)
         self._graph = None
         self._graph_batched = None
-        # persistent decode step (csrc/decode_mega.hip): one launch per token instead of 6 per layer; available for TP = 1 on bf16
-        # weights.  OFF by default: bit-identical to the multi-kernel schedule but measured slower on MI355X (6.5 against 5.56 ms per
-        # ChatTS-14B token, profiles/r3_mega_*); CHATTS_DECODE_MEGA=1 or enable_persistent_decode() turns it on
-        self._mega_state = None
-        import os
-        if os.environ.get("CHATTS_DECODE_MEGA", "0") == "1":
-            self.enable_persistent_decode(True)
         if plan.world > 1 and self.use_p2p and getattr(self.comm, "dist", None) is not None and self._tp is None:
             from .tp import P2PExchange
             ex, err = None, None
             try:
-                ex = P2PExchange.create(self.comm, self.exchange_elems())
+                ex = P2PExchange.create(self.comm, self.exchange_elems(), self.exchange_bulk_elems())
             except Exception as e:               # e.g. no IPC mapping between these two devices
                 err = e
             # every rank must take the same path: agree before anyone attaches
@@ -461,33 +454,9 @@ class ChatTSForCausalLM:
                               "decode-sized sums go through RCCL from the host (slower, no hipGraph)")
                 self.use_p2p = False
 
-    def enable_persistent_decode(self, on=True):
-        """Attach / detach the persistent decode step.  -> True when decode_step() will run as one launch per token."""
-        lib = self.lib
-        self._graph = None                        # a captured step has the old schedule baked in
-        if not on:
-            _lib.check(lib.chatts_decoder_mega_attach(self._decoder, None, 0, 0))
-            self._mega_state = None
-            return False
-        nb = int(lib.chatts_decoder_mega_state_bytes(self._decoder))
-        if nb <= 0:
-            self._mega_state = None
-            return False
-        st = torch.zeros(nb + 256, dtype=torch.uint8, device=self.device)
-        off = (-st.data_ptr()) % 256
-        _lib.check(lib.chatts_decoder_mega_attach(self._decoder, st.data_ptr() + off, nb, self.n_splits))
-        self._mega_state = st
-        return True
-
-    def persistent_decode_status(self):
-        """0 = healthy (or not attached); != 0 = a grid barrier of a persistent step timed out: tokens since then are invalid.
-        Synchronises (one word read)."""
-        if self._mega_state is None:
-            return 0
-        rc = int(self.lib.chatts_decoder_mega_status(self._decoder))
-        if rc < 0:
-            _lib.check(rc)
-        return rc
+    def exchange_bulk_elems(self):
+        """float32 elements of the largest prefill-sized sum: one chunk of partial [t_max, H] rows (chatts_allreduce_bulk)"""
+        return self.t_max * self.config.hidden_size
 
     def exchange_elems(self):
         """float32 elements per rank the largest in-step collective moves: [max_batch, H] partial sums, or the logits gather."""
@@ -619,9 +588,13 @@ class ChatTSForCausalLM:
     # ---------------------------------------------------------------------------------------------
     # engine
     # ---------------------------------------------------------------------------------------------
+    def _tp_bulk(self, T):
+        """tensor parallel: the attached exchange can sum [T, H] partials itself (chatts_allreduce_bulk) -> one C call per chunk"""
+        return self._tp is not None and self._tp.bulk_elems >= T * self.config.hidden_size
+
     def _run_layers(self, T, pos0, pos_dev=None, n_splits=1, last_only=False):
         lib, st = self.lib, _lib.stream_ptr()
-        if self.plan.world == 1 and pos_dev is None:
+        if pos_dev is None and (self.plan.world == 1 or self._tp_bulk(T)):
             if last_only:         # only the next token + the KV cache are wanted: the final layer runs for the last row only
                 _lib.check(lib.chatts_decoder_prefill_last(self._decoder, T, pos0, st))
             else:
@@ -710,7 +683,7 @@ class ChatTSForCausalLM:
             raise ValueError(f"sequence of {pos0 + T} tokens exceeds max_ctx={self.max_ctx}")
         if self._kv is not None and (self._kv.capacity_tokens(self._cur_slot) < pos0 + T or self._kv.shared_blocks()):
             self.reserve_kv(self._cur_slot, pos0 + T, write_from=pos0)      # direct callers; generate_* reserve prompt + new tokens up front
-        fast_last = for_next_token and self.plan.world == 1
+        fast_last = for_next_token and (self.plan.world == 1 or self._tp_bulk(min(T, self.t_max)))
         done, last = 0, 0
         while done < T:
             n = min(self.t_max, T - done)
@@ -1340,8 +1313,6 @@ class ChatTSForCausalLM:
         toks = self.buf["out_tokens"][:produced].tolist()
         if self._tp is not None and self._tp.status():
             raise RuntimeError("tensor-parallel exchange timed out (a peer rank did not reach the collective): tokens are invalid")
-        if self._mega_state is not None and self.persistent_decode_status():
-            raise RuntimeError("persistent decode step: a grid barrier timed out (status word set): tokens are invalid")
         if eos:
             for i, t in enumerate(toks):
                 if t in eos:

@@ -14,7 +14,10 @@ Two transports:
   * decode-sized messages ([B, H] float32, 96 per token): `P2PExchange` - the one-shot peer-to-peer kernels of
     csrc/tp.hip (chatts_allreduce / chatts_tp_argmax / chatts_allgather) over IPC-mapped exchange buffers; the whole
     TP decode step is enqueued by ONE C call and captured into ONE hipGraph;
-  * prefill-sized messages ([T, H]): RCCL through torch.distributed (`Comm.all_reduce`) between the two halves of a layer.
+  * prefill-sized messages ([T, H]): chatts_allreduce_bulk - a two-shot all-reduce (direct reduce-scatter, rank-ordered sum by the
+    slice's owner, direct all-gather) over the bulk region of the same buffers, launched by chatts_decoder_prefill itself between
+    the layer halves (one host call per chunk).  RCCL through torch.distributed (`Comm.all_reduce`) remains the path when the
+    exchange is not attached (use_p2p=False, or the IPC mapping could not be set up).
 """
 import ctypes as C
 
@@ -91,14 +94,16 @@ class P2PExchange:
         self.lib, self.handle, self.buf_ptr, self.owns_buffer = lib, C.c_void_p(handle), buf_ptr, owns_buffer
         self.rank, self.world = lib.chatts_tp_rank(self.handle), lib.chatts_tp_world(self.handle)
         self.max_elems = int(lib.chatts_tp_max_elems(self.handle))
+        self.bulk_elems = int(lib.chatts_tp_bulk_elems(self.handle))      # capacity of chatts_allreduce_bulk (0: no bulk region)
 
     @classmethod
-    def create(cls, comm, max_elems):
+    def create(cls, comm, max_elems, bulk_elems=0):
         """Collective over `comm` (a torch.distributed-backed Comm): allocate + export this rank's buffer, exchange the IPC
-        handles out of band (all_gather_object), map every peer.  HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment."""
+        handles out of band (all_gather_object), map every peer.  HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment.
+        bulk_elems > 0 adds the bulk region of chatts_allreduce_bulk (prefill-sized sums of up to that many float32)."""
         from . import _lib
         lib = _lib.load()
-        nbytes = int(lib.chatts_tp_buffer_bytes(comm.world, int(max_elems)))
+        nbytes = int(lib.chatts_tp_buffer_bytes_bulk(comm.world, int(max_elems), int(bulk_elems)))
         ptr = C.c_void_p()
         hbuf = (C.c_uint8 * _lib.TP_HANDLE_BYTES)()
         _lib.check(lib.chatts_tp_buffer_alloc(nbytes, C.byref(ptr), hbuf))
@@ -114,12 +119,12 @@ class P2PExchange:
         return cls(lib, h, ptr)
 
     @classmethod
-    def create_local_group(cls, world, max_elems):
+    def create_local_group(cls, world, max_elems, bulk_elems=0):
         """`world` exchanges living in THIS process on the current device (single-GPU emulation of TP: every 'rank' runs on
         its own stream; peers are plain device pointers, no IPC)."""
         from . import _lib
         lib = _lib.load()
-        nbytes = int(lib.chatts_tp_buffer_bytes(world, int(max_elems)))
+        nbytes = int(lib.chatts_tp_buffer_bytes_bulk(world, int(max_elems), int(bulk_elems)))
         ptrs = []
         for _ in range(world):
             ptr = C.c_void_p()
@@ -135,13 +140,13 @@ class P2PExchange:
         return out
 
     @classmethod
-    def create_loopback(cls, rank, world, max_elems):
+    def create_loopback(cls, rank, world, max_elems, bulk_elems=0):
         """ONE rank of a `world`-rank group alone on the current device (chatts_tp_init_loopback): its pushes land in its own
         buffer, the absent peers contribute zeros.  Same stores and polls per element as a real step, zero link latency - what a
         single GPU can MEASURE of a rank's step time at the shard shapes of TP = 2 / 4 / 8 (tools/tp_shard_step.py).  Timing only."""
         from . import _lib
         lib = _lib.load()
-        nbytes = int(lib.chatts_tp_buffer_bytes(world, int(max_elems)))
+        nbytes = int(lib.chatts_tp_buffer_bytes_bulk(world, int(max_elems), int(bulk_elems)))
         ptr = C.c_void_p()
         _lib.check(lib.chatts_tp_buffer_alloc(nbytes, C.byref(ptr), None))
         h = lib.chatts_tp_init_loopback(rank, world, ptr, nbytes, int(max_elems))
@@ -164,6 +169,12 @@ class P2PExchange:
         _lib.check(self.lib.chatts_allreduce(self.handle, inp.data_ptr(), out.data_ptr(), _lib.ptr(resid), inp.numel(),
                                              _lib.stream_ptr()))
         return out
+
+    def all_reduce_bulk(self, inp, x):
+        """x += sum over the ranks of inp (prefill-sized: the two-shot kernel over the bulk region)"""
+        from . import _lib
+        _lib.check(self.lib.chatts_allreduce_bulk(self.handle, inp.data_ptr(), x.data_ptr(), inp.numel(), _lib.stream_ptr()))
+        return x
 
     def all_gather(self, inp, rows=1):
         from . import _lib

@@ -38,8 +38,9 @@ const char* chatts_last_error(void);
  * (2: plane operands, sampler, decoder plane buffers; 3: post-norm planes of chatts_linear;
  *  4: tensor-parallel exchange chatts_tp_* / chatts_allreduce, decoder embed_rows + TP buffers, chatts_decoder_select_tokens;
  *  6: persistent decode step chatts_decoder_mega_*; the attention 'parts' form and its ChattsLinearArgs fields removed;
- *  7: ChattsLinearArgs.tp_reduce (exchange inside the projection's launch), chatts_tp_init_loopback, chatts_decoder_prefill under
- *     tensor parallelism with chatts_allreduce_large). */
+ *  7: ChattsLinearArgs.tp_reduce (exchange inside the projection's launch), chatts_tp_init_loopback, chatts_allreduce_bulk +
+ *     chatts_decoder_prefill(_last) under tensor parallelism, chatts_decoder_logits_batched; the persistent decode step
+ *     chatts_decoder_mega_* is gone - built and measured slower than the captured multi-kernel step in round 3). */
 #define CHATTS_ABI_VERSION 7
 int chatts_abi_version(void);
 /* Number of CUs of the current device (grid sizing), or <0. */
@@ -359,6 +360,9 @@ int chatts_embed_token(const int64_t* token_dev, const chatts_bf16* table, int64
 #define CHATTS_TP_MAX_WORLD 8
 /* bytes of one rank's exchange buffer for collectives of up to max_elems float32 per rank */
 size_t chatts_tp_buffer_bytes(int world, int64_t max_elems);
+/* the same plus a BULK region for prefill-sized sums of up to bulk_elems float32 (chatts_allreduce_bulk); the init calls below
+ * recognise the region from the buffer's size */
+size_t chatts_tp_buffer_bytes_bulk(int world, int64_t max_elems, int64_t bulk_elems);
 /* hipExtMallocWithFlags(uncached) + zero fill + (handle != NULL) hipIpcGetMemHandle into handle[CHATTS_TP_HANDLE_BYTES] */
 int chatts_tp_buffer_alloc(size_t bytes, void** dev_ptr, uint8_t* handle);
 /* Returns the buffer to the library's free list (a later chatts_tp_buffer_alloc re-uses it, zero-filled); the driver gets the
@@ -384,6 +388,13 @@ int chatts_tp_status(ChattsTpComm*);
 int chatts_tp_reset(ChattsTpComm*, chatts_stream_t stream);
 /* out[i] = (resid ? resid[i] : 0) + sum over ranks of in[i], ranks added in rank order; n <= max_elems; out may alias resid */
 int chatts_allreduce(ChattsTpComm*, const float* in, float* out, const float* resid, int64_t n, chatts_stream_t stream);
+/* x[i] += sum over ranks of in[i] for PREFILL-sized vectors ([T, H] partial sums, SURVEY.md section 5.8 "large"): a two-shot
+ * all-reduce - direct reduce-scatter into the owner's buffer, the owner adds the W contributions in rank order, direct all-gather -
+ * as ONE kernel over the bulk region of the exchange buffers; n <= chatts_tp_bulk_elems(comm) (0 = the buffer has no bulk region).
+ * Bit-identical results on all ranks; graph-capturable like the other collectives.  Replaces the host-enqueued RCCL all-reduce
+ * between the layer halves of a prefill chunk (vLLM's RowParallelLinear all-reduce, demo/demo_vllm.py:30). */
+int64_t chatts_tp_bulk_elems(const ChattsTpComm*);
+int chatts_allreduce_bulk(ChattsTpComm*, const float* in, float* x, int64_t n, chatts_stream_t stream);
 /* in [rows, row_len] per rank -> out [rows, world * row_len] (row b = the ranks' rows b concatenated in rank order) */
 int chatts_allgather(ChattsTpComm*, const float* in, float* out, int64_t rows, int64_t row_len, chatts_stream_t stream);
 /* per sequence b < batch: the global greedy token from every rank's local (max logit, global token id); ties -> lowest id;
@@ -532,7 +543,9 @@ int chatts_decoder_decode_step_batched(ChattsDecoder*, int batch, int32_t* pos_d
  * chatts_decoder_decode_step_batched as a call of its own (compute_logits for a batch, chatts_vllm.py:603-610). */
 int chatts_decoder_logits_batched(ChattsDecoder*, int batch, float* logits_all, chatts_stream_t stream);
 
-/* TP=1 fast paths: all layers back to back on the stream (no host round trip, graph-capturable). */
+/* All layers back to back on the stream (no host round trip, graph-capturable).  tp_world == 1, or tp_world > 1 with an exchange
+ * attached (chatts_decoder_set_tp) whose bulk region holds t * hidden float32: the [t, H] sums between the layer halves are then
+ * chatts_allreduce_bulk launches of the same call - one host call per prefill chunk on every rank. */
 int chatts_decoder_prefill(ChattsDecoder*, int t, int pos0, chatts_stream_t stream);
 /* The same for a chunk whose hidden states nobody reads except to pick the NEXT token (the last chunk of a prompt): the final
  * layer writes K / V of all t rows into the cache but runs attention, o_proj and the MLP for the last row only (as GEMVs).
@@ -553,24 +566,6 @@ int chatts_decoder_logits(ChattsDecoder*, int row, chatts_stream_t stream);
 int chatts_decoder_decode_step(ChattsDecoder*, int32_t* pos_dev, int32_t* step_dev,
                                int64_t* token_dev, float* token_logit_dev, int64_t* out_tokens,
                                int n_splits, chatts_stream_t stream);
-
-/* Persistent decode step (csrc/decode_mega.hip): with a state buffer attached, chatts_decoder_decode_step runs a whole token -
- * every layer's projections, attention, lm_head, greedy token, decode-loop state, next input embedding - as ONE launch whose
- * weight stream never stops at a projection boundary (the replacement for the 291 dependent launches of the multi-kernel
- * schedule; bit-identical results; measured SLOWER than that schedule on MI355X - DESIGN.md section 5 - so callers attach it only on
- * request).  Available for tensor_parallel_size 1, bf16 weights, cache slot 0; otherwise, or with CHATTS_DECODE_MEGA=0 in the
- * environment, decode_step keeps the multi-kernel schedule.
- *   chatts_decoder_mega_state_bytes: device bytes the caller must provide (0 = this decoder cannot use it);
- *   chatts_decoder_mega_attach: binds the buffer (256-byte aligned) and uploads the layer table - a SET-UP call: it zero-fills
- *     and copies synchronously; n_splits = the key-slot count decode_step will be called with; state == NULL detaches;
- *   chatts_decoder_mega_status: synchronising diagnostic; != 0 = a grid barrier inside a step timed out (bounded spins): the
- *     tokens since then are invalid and every later step returns immediately until the buffer is re-attached. */
-size_t chatts_decoder_mega_state_bytes(ChattsDecoder*);
-int chatts_decoder_mega_attach(ChattsDecoder*, void* state, size_t bytes, int n_splits);
-int chatts_decoder_mega_status(ChattsDecoder*);
-/* diagnostics: when buf != NULL ([2][6 * n_layers + 1][16] uint64 device memory) the following steps record s_memtime stamps of two
- * workgroups at every phase edge (tools/mega_profile.py prints the breakdown); NULL switches it off again. */
-int chatts_decoder_mega_profile(ChattsDecoder*, void* buf, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -193,7 +193,7 @@ def test_exchange_buffers_are_recycled_not_freed():
 
 def _shards(cfg, world, seed, **kw):
     ms = [ChatTSForCausalLM.from_synthetic(cfg, seed=seed, comm=FakeComm(r, world), **kw) for r in range(world)]
-    exs = P2PExchange.create_local_group(world, ms[0].exchange_elems())
+    exs = P2PExchange.create_local_group(world, ms[0].exchange_elems(), ms[0].exchange_bulk_elems())
     for m, e in zip(ms, exs):
         m.attach_exchange(e)
     return ms
@@ -327,6 +327,100 @@ def test_exchange_inside_the_gemv_launch_equals_the_standalone_kernels_at_14b_wi
         for i, (a, b) in enumerate(zip(runs["0"][2], runs["1"][2])):
             assert torch.equal(a, b)
             assert rel_err(b.cpu().numpy(), want["logits"][i + 2].numpy()) < 1e-3
+    finally:
+        for m in ms:
+            m._tp.close()
+            m._tp = None
+
+
+@_retry_if_peer_stalled
+def test_bulk_allreduce_two_shot_local_group():
+    """chatts_allreduce_bulk (prefill-sized sums: direct reduce-scatter, rank-ordered sum by the slice's owner, direct all-gather, ONE
+    kernel): x += sum over the ranks, bit-identical on both ranks and equal to the rank-ordered float32 sum - sizes with ragged last
+    slices and last workgroups, both slot parities, the bench prompt's [798, 5120], and a granule collective in between (the two
+    protocols share the epoch counter)."""
+    world = 2
+    exs = P2PExchange.create_local_group(world, 8192, bulk_elems=1024 * 5120)
+    assert all(e.bulk_elems >= 1024 * 5120 for e in exs)
+    try:
+        g = torch.Generator().manual_seed(11)
+        for it, n in enumerate([5120, 4, 20, 4100, 798 * 5120, 33 * 5120 + 8, 1024 * 5120, 16 * 5120]):
+            ins = [(torch.randn(n, generator=g) * (r + 1)).cuda() for r in range(world)]
+            x0 = torch.randn(n, generator=g).cuda()
+            xs = [x0.clone() for _ in range(world)]
+            torch.cuda.synchronize()
+            _on_streams(world, lambda r: exs[r].all_reduce_bulk(ins[r], xs[r]))
+            torch.cuda.synchronize()
+            if any(e.status() for e in exs):
+                raise _PeerStalled()
+            want = x0 + (ins[0] + ins[1])                # the owner adds the contributions in rank order, then x += sum
+            for r in range(world):
+                assert torch.equal(xs[r], want), (it, n, r)
+            if it == 2:                                  # a decode-sized granule collective between two bulk ones
+                outs = [torch.empty(5120, device="cuda") for _ in range(world)]
+                _on_streams(world, lambda r: exs[r].all_reduce(ins[r][:20].repeat(256), out=outs[r]))
+                torch.cuda.synchronize()
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], (ins[0][:20] + ins[1][:20]).repeat(256))
+        x = torch.zeros(8, device="cuda")
+        with pytest.raises(_lib.ChattsError):            # beyond the bulk region
+            _lib.check(exs[0].lib.chatts_allreduce_bulk(exs[0].handle, x.data_ptr(), x.data_ptr(), 1024 * 5120 + 64, _lib.stream_ptr()))
+    finally:
+        for e in exs:
+            e.close()
+
+
+@_retry_if_peer_stalled
+def test_tp2_prefill_in_one_call_equals_the_host_driven_form():
+    """chatts_decoder_prefill / _prefill_last under tensor parallelism: all layer halves AND the [T, H] sums between them
+    (chatts_allreduce_bulk) behind ONE C call per chunk on every rank - the residual stream, the KV cache and the first token's
+    logits carry the same bits as the host-driven form (layer halves + rank-ordered sums played by the test), 14B widths, 2 layers,
+    a 300-row chunk; then the last-row-only final layer (prefill_last: o_proj / down_proj GEMVs carrying their exchange) gives
+    the same next-token logits within float32 rounding."""
+    import bench
+    world, seed = 2, 0
+    cfg = cfgmod.preset("chatts-14b", num_hidden_layers=2)
+    proc, prompt, series, lengths = bench.build_inputs(cfg, 4, 96)
+    inputs = proc(text=[prompt], timeseries=series, padding=True, return_tensors="pt")
+    ids = inputs["input_ids"][0].tolist()
+    ms = _shards(cfg, world, seed, max_ctx=1024, max_prefill_tokens=512, use_graph=False)
+    try:
+        assert all(m._tp_bulk(512) for m in ms)
+        mm = ms[0].get_multimodal_embeddings(timeseries=inputs["timeseries"].cuda(), valid_lengths=proc.last_lengths)
+        full = ms[0].expand_input_ids(ids, [(L + 15) // 16 for L in lengths])
+        emb = ms[0].get_input_embeddings(torch.tensor(full), mm)
+        T = len(full)
+        assert 96 <= T <= 512
+        _emulated_prefill(ms, emb, T)                    # host-driven: layer_part per shard, sums added by the test in rank order
+        torch.cuda.synchronize()
+        ref_x = ms[0].buf["x"][:T].clone()
+        ref_k = [m.buf["kv_k"].clone() for m in ms]
+        lg_ref = []
+        for m in ms:
+            _lib.check(m.lib.chatts_decoder_logits(m._decoder, T - 1, _lib.stream_ptr()))
+            lg_ref.append(m.buf["logits"].clone())
+        for m in ms:
+            m.reset(); m.buf["kv_k"].zero_(); m.buf["kv_v"].zero_()
+
+        def one_call(r, last):
+            ms[r].buf["x"][:T].copy_(emb)
+            ms[r]._run_layers(T, 0, last_only=last)
+        _on_streams(world, lambda r: one_call(r, False))
+        torch.cuda.synchronize()
+        if any(m._tp.status() for m in ms):
+            raise _PeerStalled()
+        for r, m in enumerate(ms):
+            assert torch.equal(m.buf["x"][:T], ref_x), r
+            assert torch.equal(m.buf["kv_k"], ref_k[r]), r
+        # the last-row-only form: same cache, next-token logits equal up to the GEMV-vs-GEMM summation order of the final layer
+        _on_streams(world, lambda r: one_call(r, True))
+        torch.cuda.synchronize()
+        if any(m._tp.status() for m in ms):
+            raise _PeerStalled()
+        assert torch.equal(ms[0].buf["x"][:1], ms[1].buf["x"][:1])
+        for r, m in enumerate(ms):
+            assert torch.equal(m.buf["kv_k"], ref_k[r]), r
+            _lib.check(m.lib.chatts_decoder_logits(m._decoder, 0, _lib.stream_ptr()))
+            assert rel_err(m.buf["logits"].cpu().numpy(), lg_ref[r].cpu().numpy()) < 2e-5
     finally:
         for m in ms:
             m._tp.close()

@@ -10,8 +10,9 @@ Rank 0 of a W-rank group is built at FULL depth (48 layers; 28 GB / W of decoder
 so the captured decode step issues exactly the stores, polls and launches of a real TP step - only the xGMI hop is missing (and the
 "sums" are this rank's partials alone: TIMING ONLY, the tokens mean nothing).  Measured per W:
   * decode: ms per graph-replayed step (batch 1, ctx = the 798-token bench prompt), the DESIGN.md section 6 model's compute term;
-  * prefill: ms for this rank's share of the 798-token prompt (layer halves back to back; the [T, H] all-reduces between them are
-    NOT included - a lone rank has nobody to reduce with - and are modelled separately);
+  * prefill: ms for this rank's share of the 798-token prompt as ONE chatts_decoder_prefill_last call: layer halves + the two-shot
+    [T, H] sums between them (chatts_allreduce_bulk, looped back: the kernel's stores, flags and local passes are real, the 2 x 14 MB
+    that would cross the links are local writes - the link time is modelled separately);
   * optional --batch B --weights fp8: the B-wide decode step of config 5 at ctx --ctx.
 The link term (96 exchanges x one xGMI hop, prefill all-reduce bandwidth) stays the only modelled part of a TP estimate."""
 import argparse
@@ -65,15 +66,15 @@ def main():
     fuse = os.environ.get("CHATTS_TP_FUSE", "1") != "0"
     res = {"model": args.model, "layers": cfg.num_hidden_layers, "batch": args.batch, "weights": args.weights,
            "exchange": "in the o_proj / down_proj GEMV launches (ChattsLinearArgs.tp_reduce)" if fuse else "stand-alone chatts_allreduce kernels",
-           "note": "ONE rank on ONE GPU, loop-back exchange: real launches / stores / polls of a TP step, zero link latency; prefill excludes "
-                   "the [T, H] all-reduces", "worlds": {}}
+           "note": "ONE rank on ONE GPU, loop-back exchange: real launches / stores / polls of a TP step (decode) and of the two-shot "
+                   "[T, H] sums (prefill), zero link latency / local instead of remote writes", "worlds": {}}
     B = max(1, args.batch)
     for W in [int(w) for w in args.worlds.split(",")]:
         t0 = time.time()
         model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, comm=LoneRank(W) if W > 1 else None, max_ctx=2048, max_prefill_tokens=1024,
                                                  weight_format=args.weights, max_batch=B)
         if W > 1:
-            model.attach_exchange(P2PExchange.create_loopback(0, W, model.exchange_elems()))
+            model.attach_exchange(P2PExchange.create_loopback(0, W, model.exchange_elems(), model.exchange_bulk_elems()))
         torch.cuda.synchronize()
         row = {"weight_gb_this_rank": model.weight_bytes_local() / 1e9, "build_s": time.time() - t0}
         ser = inputs["timeseries"].cuda()
@@ -94,7 +95,7 @@ def main():
             if i:
                 pre.append((time.perf_counter() - t0) * 1e3)
         row["prompt_tokens"] = T
-        row["prefill_ms_compute_only"] = sorted(pre)[len(pre) // 2]
+        row["prefill_ms"] = sorted(pre)[len(pre) // 2]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if B == 1:
             for _ in range(args.warmup):
