@@ -33,13 +33,37 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) float q_s[GMAX * kHeadDim];
   __shared__ __attribute__((aligned(16))) float knew_s[kHeadDim];
   __shared__ __attribute__((aligned(16))) float vnew_s[kHeadDim];
-  attn_decode_wave<false, GMAX>(p, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, q_s, knew_s, vnew_s);
+  attn_decode_wave<GMAX>(p, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, q_s, knew_s, vnew_s, p.part_o, p.part_ml,
+                         (size_t)blockIdx.z * p.n_q + blockIdx.x * (p.n_q / p.n_kv));
 }
 
 // out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots): attn_combine_wave
 // (attn_decode.h), one workgroup (2 waves) per head.
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnParams p) {
-  attn_combine_wave<false>(p, blockIdx.x, blockIdx.y, threadIdx.x, threadIdx.x & 63);
+  attn_combine_wave(p, blockIdx.x, blockIdx.y, threadIdx.x, threadIdx.x & 63, p.part_o, p.part_ml,
+                    ((size_t)blockIdx.y * p.n_q + blockIdx.x) * p.n_splits);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decode, workgroup form: grid (n_kv, batch), NWV waves.  Wave w is tile slot w of NWV (it walks tiles w, w + NWV, ... with the next
+// tile prefetched under the current one); the NWV partials of every head of the group meet in LDS and waves 0 .. 2 G - 1 merge them
+// (attn_combine_wave: two waves per head) - no partials in HBM, no second launch.  The launch that disappears is worth ~4.9 us per
+// layer and a further tile costs a wave ~0.7 us, so this is the form for contexts of up to 8 tiles per wave (NWV = 16: 2048 positions);
+// longer caches keep the one-wave-per-slot kernel + attn_decode_combine_kernel, whose latency does not grow with the context.
+// Bit-identical to that pair at n_splits = NWV.  All waves of the workgroup share q_s (they write the same values).
+// ---------------------------------------------------------------------------------------------------
+template <int GMAX, int NWV>
+__global__ __launch_bounds__(64 * NWV) void attn_decode_wg_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) float q_s[GMAX * kHeadDim];
+  __shared__ __attribute__((aligned(16))) float knew_s[kHeadDim];
+  __shared__ __attribute__((aligned(16))) float vnew_s[kHeadDim];
+  __shared__ __attribute__((aligned(16))) float po_s[GMAX * NWV * kHeadDim];
+  __shared__ __attribute__((aligned(16))) float pml_s[GMAX * NWV * 2];
+  const int hk = blockIdx.x, seq = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  attn_decode_wave<GMAX, (NWV <= 8)>(p, hk, wave, seq, lane, q_s, knew_s, vnew_s, po_s, pml_s, 0);      // (p.n_splits == NWV)
+  __syncthreads();
+  const int G = p.n_q / p.n_kv;
+  if (wave < 2 * G) attn_combine_wave(p, hk * G + (wave >> 1), seq, (wave & 1) * 64 + lane, lane, po_s, pml_s, (size_t)(wave >> 1) * NWV);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -820,6 +844,27 @@ int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int 
   if (const int rc = bind_cache(p, cache)) return rc;
   p.q_norm_w = q_norm_w; p.k_norm_w = k_norm_w; p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.eps = norm_eps;
   p.seq_stride = seq_stride; p.out_hi = out_hi; p.out_lo = out_lo; p.kv_round = kv_round_mode();
+  // Workgroup form (attn_decode_wg_kernel): one launch, partials merged in LDS - for caches of up to 8 tiles per wave (2048 positions
+  // at 16 waves; groups of 6..8 query heads run 8 waves for their registers: 1024 positions).  One workgroup per (kv head, sequence)
+  // means one CU pulls a sequence's whole K / V: fine when n_kv x batch workgroups cover the chip (batched decode), a per-CU bandwidth
+  // limit for a single sequence (0.8 MB per kv head at ctx 800) - hence CHATTS_ATTN_WG: 0 never, 1 batched steps of >= 4 sequences,
+  // 2 whenever the cache is short enough.  Default 0 until it is measured to win (profiles/r4_attn_wg_ab.txt).
+  {
+    const char* e = getenv("CHATTS_ATTN_WG");
+    const int mode = e ? atoi(e) : 0;
+    const int G = n_q / n_kv;
+    const int nwv = G <= 5 ? 16 : 8;
+    if ((mode >= 2 || (mode == 1 && batch >= 4)) && (cache->max_ctx + kDTile - 1) / kDTile <= nwv * 8) {
+      p.n_splits = nwv;
+      const dim3 grid(n_kv, batch);
+      if (G <= 4) hipLaunchKernelGGL((attn_decode_wg_kernel<4, 16>), grid, dim3(1024), 0, as_stream(stream), p);
+      else if (G == 5) hipLaunchKernelGGL((attn_decode_wg_kernel<5, 16>), grid, dim3(1024), 0, as_stream(stream), p);
+      else if (G == 6) hipLaunchKernelGGL((attn_decode_wg_kernel<6, 8>), grid, dim3(512), 0, as_stream(stream), p);
+      else hipLaunchKernelGGL((attn_decode_wg_kernel<kMaxGroup, 8>), grid, dim3(512), 0, as_stream(stream), p);
+      CHATTS_CHECK_LAUNCH("attn_decode_wg");
+      return CHATTS_OK;
+    }
+  }
   const int rc = bind_workspace(p, workspace, workspace_bytes);
   if (rc) return rc;
   const dim3 grid(n_kv, n_splits, batch);

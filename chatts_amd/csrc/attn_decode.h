@@ -1,20 +1,12 @@
-// attn_decode.h - the batch-1 decode attention as per-wave device functions, shared by the stand-alone kernels (attention.hip)
-// and the persistent decode step (decode_mega.hip): same instructions, same summation order, bit-identical results.
+// attn_decode.h - the decode attention as per-wave device functions, shared by the two forms of the kernel (attention.hip): one wave
+// per workgroup with the partials merged by a second launch, and one workgroup per (kv head, sequence) that merges its waves'
+// partials in LDS.  Same instructions and summation order in both: bit-identical results at equal slot counts.
 #pragma once
 #include <math.h>
 
 #include "common.h"
 
 namespace chatts {
-
-// write-through stores for data another workgroup reads inside the SAME launch (agent-scope relaxed atomic store = `sc1`)
-__device__ __forceinline__ void wt_store1(float* p, float v) {
-  __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wt_store2(float* p, float a, float b) {      // p 8-byte aligned
-  const unsigned long long bits = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 constexpr int kMaxGroup = 8;
 constexpr int kTile = 64;    // prefill kernel: keys per tile
@@ -69,13 +61,12 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 // ---------------------------------------------------------------------------------------------------
 // decode: grid (n_kv, n_slots), 64 threads.  Slot s walks tiles s, s + n_slots, ... of 16 keys.
 // ---------------------------------------------------------------------------------------------------
-// One wave's work: kv head hk, tile slot `slot` of sequence `seq`, in two stages so that a caller which knows its task before
-// the projections are ready (decode_mega.hip) can have the cache rows in registers by then:
-//   attn_decode_preload: everything that does not depend on this step's qkv - the position, the slot's first K / V tile, cos / sin;
+// One wave's work: kv head hk, tile slot `slot` of sequence `seq`, in two stages:
+//   attn_decode_preload: everything that does not depend on this step's qkv - the position, the slot's first K tile, cos / sin;
 //   attn_decode_finish : q prologue, new K / V row, scores, softmax, P.V, the partial.
-// q_s [kMaxGroup * 128], knew_s / vnew_s [128] are this wave's private LDS scratch (16-byte aligned).  WT: the partials are
-// stored write-through (agent-scope relaxed atomics = `sc1` stores) for consumers inside the SAME launch; the stand-alone kernel
-// uses plain stores.
+// q_s [GMAX * 128], knew_s / vnew_s [128] are LDS scratch (16-byte aligned) - private to the wave, or shared by the waves of a
+// workgroup that all work on the same (kv head, sequence): they write the same q values, and only the owner wave touches knew_s /
+// vnew_s.  The partial of head g goes to part_o[(head_base + g0 + g) * NS + slot] / part_ml[..] - global workspace or LDS.
 struct AttnTileRegs {       // what a wave keeps between the two stages: the slot's first K tile, cos / sin, the position
   f32x4 kv[8];
   float c, s;
@@ -148,9 +139,10 @@ __device__ __forceinline__ bool attn_decode_preload(const AttnParams& p, const i
 // GMAX: query heads of the group this wave handles at most; it takes heads g0 .. g0 + gn - 1 of kv head hk's group (the stand-alone
 // kernel: all of them, GMAX = kMaxGroup; the persistent step splits a group over two waves).  Heads are independent of each
 // other, so the split does not change a single operation of any head.  The wave with g0 == 0 stores the new K / V row.
-template <bool WT, int GMAX, bool PF>
+template <int GMAX, bool PF>
 __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
-                                                   AttnTileRegs& t, float* q_s, float* knew_s, float* vnew_s, const int g0, const int gn) {
+                                                   AttnTileRegs& t, float* q_s, float* knew_s, float* vnew_s, const int g0, const int gn,
+                                                   float* part_o, float* part_ml, const size_t head_base) {
   const int NS = p.n_splits;
   const int G = p.n_q / p.n_kv;
   const int pos = t.pos;
@@ -317,41 +309,37 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
       // even keys were summed by lanes 0-31, odd keys by lanes 32-63: one exchange gives the totals (written by the lower half)
       f32x4 o = acc[g];
       o.x += __shfl_xor(o.x, 32, 64); o.y += __shfl_xor(o.y, 32, 64); o.z += __shfl_xor(o.z, 32, 64); o.w += __shfl_xor(o.w, 32, 64);
-      const size_t pi = ((size_t)seq * p.n_q + hk * G + g0 + g) * NS + slot;
+      const size_t pi = (head_base + g0 + g) * NS + slot;
       const float mn = m_run[g] * 0.6931471805599453f;       // m back to nats for the combine
-      if (WT) {
-        if (lane < 32) { wt_store2(p.part_o + pi * kHeadDim + vc * 4, o.x, o.y); wt_store2(p.part_o + pi * kHeadDim + vc * 4 + 2, o.z, o.w); }
-        if (lane == 0) wt_store2(p.part_ml + pi * 2, mn, l_run[g]);
-      } else {
-        if (lane < 32) *reinterpret_cast<f32x4*>(p.part_o + pi * kHeadDim + vc * 4) = o;
-        if (lane == 0) { p.part_ml[pi * 2] = mn; p.part_ml[pi * 2 + 1] = l_run[g]; }
-      }
+      if (lane < 32) *reinterpret_cast<f32x4*>(part_o + pi * kHeadDim + vc * 4) = o;
+      if (lane == 0) { part_ml[pi * 2] = mn; part_ml[pi * 2 + 1] = l_run[g]; }
     }
   }
 }
 
 
 // GMAX >= the group size: the per-head registers are sized by it (a Qwen2-14B group of 5 in registers for 8 costs the third wave per SIMD)
-template <bool WT, int GMAX = kMaxGroup>
+template <int GMAX = kMaxGroup, bool PF = true>
 __device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
-                                                 float* q_s, float* knew_s, float* vnew_s) {
+                                                 float* q_s, float* knew_s, float* vnew_s, float* part_o, float* part_ml,
+                                                 const size_t head_base) {
   AttnTileRegs t;
   if (!attn_decode_preload(p, hk, slot, seq, lane, t)) return;
-  attn_decode_finish<WT, GMAX, true>(p, hk, slot, seq, lane, t, q_s, knew_s, vnew_s, 0, p.n_q / p.n_kv);
+  attn_decode_finish<GMAX, PF>(p, hk, slot, seq, lane, t, q_s, knew_s, vnew_s, 0, p.n_q / p.n_kv, part_o, part_ml, head_base);
 }
 
 // out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots).  One workgroup
 // (2 waves) per head; lane s of each wave holds (m_s, l_s), weights are broadcast by shuffle, and 16 independent
 // o_s[d] loads are in flight per thread: no LDS, no barrier.
-// One wave's half of a head: d = half * 64 + lane (the stand-alone kernel runs two waves per head).
-template <bool WT>
-__device__ __forceinline__ void attn_combine_wave(const AttnParams& p, const int hq, const int seq, const int d, const int lane) {
+// One wave's half of a head: d = half * 64 + lane (two waves per head).  The partials of head hq are part_o / part_ml rows
+// base .. base + n_splits - 1 (global workspace: base = (seq * n_q + hq) * n_splits; LDS of the workgroup form: its local head index).
+__device__ __forceinline__ void attn_combine_wave(const AttnParams& p, const int hq, const int seq, const int d, const int lane,
+                                                  const float* part_o, const float* part_ml, const size_t base) {
   const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;
   const int ntiles = pos < 0 ? 0 : pos / kDTile + 1;         // parked slot: no partials exist, the row is written as zeros
   const int ns = ntiles < p.n_splits ? ntiles : p.n_splits;
-  const size_t base = ((size_t)seq * p.n_q + hq) * p.n_splits;
   float m = -INFINITY, l = 0.f;
-  if (lane < ns) { m = p.part_ml[(base + lane) * 2]; l = p.part_ml[(base + lane) * 2 + 1]; }
+  if (lane < ns) { m = part_ml[(base + lane) * 2]; l = part_ml[(base + lane) * 2 + 1]; }
   const float M = wave_max(m);
   const float w = lane < ns ? expf(m - M) : 0.f;
   const float den = wave_sum(w * l);
@@ -361,7 +349,7 @@ __device__ __forceinline__ void attn_combine_wave(const AttnParams& p, const int
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
       const int s = s0 + u < ns ? s0 + u : ns - 1;
-      o[u] = p.part_o[(base + s) * kHeadDim + d];
+      o[u] = part_o[(base + s) * kHeadDim + d];
     }
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
@@ -375,8 +363,6 @@ __device__ __forceinline__ void attn_combine_wave(const AttnParams& p, const int
     const __bf16 h = (__bf16)v;
     p.out_hi[oi] = __builtin_bit_cast(uint16_t, h);
     p.out_lo[oi] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
-  } else if (WT) {
-    wt_store1(p.out + oi, v);
   } else {
     p.out[oi] = v;
   }

@@ -1222,3 +1222,38 @@ def test_gemv_ksplit_at_tensor_parallel_shard_shapes(lib, ks, monkeypatch):
         assert rel_err(out.cpu().numpy(), want) < 2e-5, (epi, n, k)
         again = _linear(lib, a, w, None if nob else bias, resid if nob else None, epi, nw if norm else None)
         assert torch.equal(out, again)
+
+
+@pytest.mark.parametrize("n_q,n_kv,norm", [(40, 8, False), (5, 1, False), (32, 8, True), (8, 2, False)])
+def test_attention_decode_workgroup_form_equals_the_two_kernel_form(lib, n_q, n_kv, norm, monkeypatch):
+    """attn_decode_wg_kernel (one workgroup per (kv head, sequence), partials merged in LDS, no second launch) == attn_decode_kernel +
+    attn_decode_combine_kernel at the same slot count, bit for bit: outputs and the K / V rows written, batched (parked slot included)
+    and single sequence, positions that leave slots empty and positions that give every wave several tiles."""
+    import ctypes as C
+    d, max_ctx, B = 128, 1024, 5
+    nwv = 16 if n_q // n_kv <= 5 else 8
+    g = torch.Generator().manual_seed(n_q)
+    qkv = torch.randn((B, (n_q + 2 * n_kv) * d), generator=g).to(DEV)
+    kc0 = torch.randn((B, n_kv, max_ctx, d), generator=g).to(DEV)
+    vc0 = torch.randn((B, n_kv, max_ctx, d), generator=g).to(DEV)
+    pos = torch.tensor([3, 200, -1, 1000, 37], dtype=torch.int32, device=DEV)        # slot 2 is parked
+    qn = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV) if norm else None
+    kn = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV) if norm else None
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, dtype=torch.float64) / 64))
+    ang = torch.arange(max_ctx, dtype=torch.float64)[:, None] * inv[None]
+    cos, sin = torch.cos(ang).float().to(DEV).contiguous(), torch.sin(ang).float().to(DEV).contiguous()
+    ws = torch.zeros(int(lib.chatts_attn_workspace(B, n_q, 64)) + 256, dtype=torch.uint8, device=DEV)
+    runs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("CHATTS_ATTN_WG", mode)
+        kc, vc = kc0.clone(), vc0.clone()
+        out = torch.full((B, n_q * d), float("nan"), device=DEV)
+        cache = _lib.KvCache(k=kc.data_ptr(), v=vc.data_ptr(), max_ctx=max_ctx, block_table=None, block_size=0, table_stride=0)
+        _lib.check(lib.chatts_attention_decode_batched(qkv.data_ptr(), B, n_q, n_kv, _lib.ptr(qn), _lib.ptr(kn), 1e-6, cos.data_ptr(),
+                                                       sin.data_ptr(), 0, pos.data_ptr(), C.byref(cache), n_kv * max_ctx * d, out.data_ptr(),
+                                                       nwv, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        runs[mode] = (out, kc, vc)
+    for a, b in zip(runs["0"], runs["2"]):
+        assert torch.equal(a, b)
+    assert not torch.isnan(runs["2"][0]).any() and torch.count_nonzero(runs["2"][0][2]) == 0      # the parked row is written as zeros

@@ -34,7 +34,8 @@ def _run(flow, world, tmp_path, extra_env=None):
             if res["pass"] or not any(res["exchange_status_per_rank"]):
                 return res, r
             os.remove(out)
-        print(f"[tp multiprocess] attempt {attempt} rc={r.returncode}\n{r.stdout[-1500:]}\n{r.stderr[-3000:]}", flush=True)
+        why = "\n".join(l for l in r.stderr.splitlines() if "tp_parity_worker rank" in l or "Error" in l)[-3000:]
+        print(f"[tp multiprocess] attempt {attempt} rc={r.returncode}\n{r.stdout[-1500:]}\n{why}", flush=True)
     pytest.fail(f"tools/tp_parity_worker.py --flow {flow} did not produce a result (rc {r.returncode})")
 
 

@@ -180,4 +180,17 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:           # the launcher only reports exit codes: leave the reason where the caller can read it
+        if not isinstance(e, SystemExit):
+            import traceback
+            msg = f"[tp_parity_worker rank {os.environ.get('RANK', '?')}] {type(e).__name__}: {e}\n{traceback.format_exc()}"
+            print(msg, file=sys.stderr, flush=True)
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", f"tp_parity_worker_rank{os.environ.get('RANK', 'x')}.err"), "w") as f:
+                    f.write(msg)
+            except OSError:
+                pass
+        raise
