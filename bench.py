@@ -100,6 +100,25 @@ def admit_batched(model, proc, prompt, reqs, budget, pack=True):
     return T, ttfts, packs
 
 
+def pmc_traffic_entry(entry, files_key="code_files"):
+    """A counter-measured traffic figure of profiles/pmc_traffic.json is quoted only for the code it was measured on: the entry carries
+    a digest of its kernel sources (tools/pmc_traffic.py); if the checked-out sources differ the caller gets (None, why)."""
+    import hashlib
+    if not entry or not entry.get("code_digest"):
+        return None, "no counter pass recorded for this kernel on the current code (entry has no code_digest)"
+    h = hashlib.sha256()
+    try:
+        for f in entry.get(files_key, []):
+            h.update(f.encode())
+            with open(os.path.join(ROOT, f), "rb") as fh:
+                h.update(fh.read())
+    except OSError as e:
+        return None, f"cannot hash the kernel sources: {e}"
+    if h.hexdigest()[:16] != entry["code_digest"]:
+        return None, f"stale: {entry.get('source', 'the recorded pass')} was collected on other kernel sources (digest {entry['code_digest']})"
+    return entry, None
+
+
 def median(xs):
     s = sorted(xs)
     return s[len(s) // 2]
@@ -346,11 +365,12 @@ def workload_key(args):
 
 def parity_reference(args):
     """The committed FULL-DEPTH oracle run of this workload (tools/parity_full_depth.py: CPU float32 oracle, all layers, same
-    inputs, seed 0), or None.  Round-3 files are keyed by the workload; the two round-2 files cover the headline / config-2 lines."""
+    inputs, seed 0), or None.  Files are keyed by the workload; the newest round's run wins (round 4 re-ran the headline and the 8B
+    line on the code that changed the decode attention's summation order, the greedy tail and the qkv epilogue in round 3)."""
     key = workload_key(args)
     if key is None:
         return None, None
-    cands = [os.path.join(ROOT, "profiles", f"r3_parity_{key}_full.json")]
+    cands = [os.path.join(ROOT, "profiles", f"r4_parity_{key}_full.json"), os.path.join(ROOT, "profiles", f"r3_parity_{key}_full.json")]
     if args.weights == "bf16" and args.batch <= 1 and getattr(args, "lengths", "uniform") == "uniform":
         cands.append(os.path.join(ROOT, "profiles", f"r2_parity_{key.split('_')[0]}_full.json"))
     for path in cands:
@@ -366,7 +386,8 @@ def parity_check(args, toks):
     """Compare the tokens this run generated with the committed full-depth oracle run of the SAME workload.  toks: the token list
     (batch 1) or one list per cache slot (batched workloads: the oracle run records the slots it covered)."""
     if getattr(args, "precision", "bf16x2") != "bf16x2":
-        return False, {"reason": "speed mode: logits are outside the 1e-3 tolerance by construction (profiles/r2_speed_mode_14b.json)"}
+        return False, {"reason": "speed mode: logits are outside the 1e-3 tolerance by construction (profiles/r2_speed_mode_14b.json, "
+                                 "profiles/r4_fp8_speed_mode.json)"}
     if args.layers is not None:
         return False, {"reason": "truncated depth (debug run)"}
     path, ref = parity_reference(args)
@@ -447,7 +468,9 @@ def bench_batched(args, model, cfg, comm, world, device):
                    "tp_exchange": None if world == 1 else ("p2p one-shot kernels (csrc/tp.hip)" if model._tp is not None else "rccl, host-driven"),
                    "weights_note": None if args.weights == "bf16" else
                    "fp8 copies are streamed by the decode GEMMs and widened to bf16 while staged (no v_mfma fp8 issue: the 1e-3 "
-                   "logit bar needs f32-exact products of the f32 activations); prefill keeps the bf16 copy",
+                   "logit bar needs f32-exact products of the f32 activations); prefill keeps the bf16 copy" if args.precision != "fp8" else
+                   "SPEED MODE precision=fp8 - NOT the parity-grade line: prefill chunks and the TS encoder quantise activations per row to "
+                   "e4m3 and multiply fp8 x fp8 (v_mfma_scale_f32_16x16x128_f8f6f4); decode steps as in the default",
                    "first_tokens_seq0": toks[0][:8]},
         "ttft_ms_p50": median(ttfts), "batch_admit_ms_total": admit_ms, "packed_prefill_passes": packs,
         "per_sequence_tokens_per_s": args.steps / dt,
@@ -470,8 +493,9 @@ def bench_batched(args, model, cfg, comm, world, device):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f).get("batched", {}).get(workload_key(args))
         if pmc and world == 1:
-            res["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-            res["roofline"]["traffic_source"] = pmc["source"]
+            ok, why = pmc_traffic_entry(pmc)
+            res["roofline"]["traffic"] = ok["hbm_bytes_per_launch"] if ok else None
+            res["roofline"]["traffic_source"] = ok["source"] if ok else why
     except (OSError, ValueError, KeyError):
         pass
     try:        # the TS encoder at the patch count of the WHOLE batch (config 5: 16 x 8 x 1024 points = 8192 patches: MFMA-bound)
@@ -544,8 +568,9 @@ def main():
     ap.add_argument("--max-ctx", type=int, default=2048, help="KV-cache length (longer prompts, e.g. --series 30, need more)")
     ap.add_argument("--batch", type=int, default=1, help="> 1: continuous-batching workload (BASELINE.json config 5): B prompts decode "
                     "together; a step = one B-wide decode step; value = aggregate tokens/s")
-    ap.add_argument("--precision", default="bf16x2", choices=["bf16x2", "bf16"], help="bf16 = the optional speed mode (single-pass "
-                    "bf16 activations in the prefill GEMMs; not parity grade, labelled as such); default bf16x2")
+    ap.add_argument("--precision", default="bf16x2", choices=["bf16x2", "bf16", "fp8"], help="bf16 / fp8 = the optional SPEED modes (bf16: "
+                    "single-pass bf16 activations in the prefill GEMMs; fp8: --weights fp8 only, prefill GEMMs and the TS encoder on the fp8 "
+                    "matrix pipe); not parity grade, labelled as such; default bf16x2")
     ap.add_argument("--kv-block", type=int, default=0, help="block-paged KV cache with this many positions per block (0 = one "
                     "contiguous cache per slot, the default)")
     ap.add_argument("--no-pack", action="store_true", help="--batch: admit the prompts one by one instead of packed prefill passes")
@@ -682,14 +707,15 @@ def main():
     ms_step = dt / args.steps * 1e3
 
     roof = roofline_gate_up(model)
-    traffic = None          # HBM bytes per launch from the separate rocprofv3 --pmc pass (TP=1 shape only)
+    traffic, traffic_note, pmc = None, None, None     # HBM bytes per launch from the separate rocprofv3 --pmc pass (TP=1 shape only)
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
         if world == 1 and args.model == "chatts-14b" and args.weights == "bf16":
-            traffic = pmc["hbm_bytes_per_launch"]
-    except Exception:
-        pmc = None
+            ok, traffic_note = pmc_traffic_entry(pmc)
+            traffic = ok["hbm_bytes_per_launch"] if ok else None
+    except Exception as e:
+        traffic_note = f"profiles/pmc_traffic.json unreadable: {e}"
     step_bytes = model.weight_bytes_local()
     result = {
         "metric": f"generated tokens/sec (greedy, batch 1) + p50 TTFT, {'ChatTS-8B' if args.model == 'chatts-8b' else 'ChatTS-14B'}, "
@@ -714,13 +740,17 @@ def main():
         "decode_frac_of_bf16_mfma_roofline": (2.0 * step_bytes / 2 / (dt / args.steps)) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
         "roofline": {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": (pmc or {}).get("source") if traffic else None, "kernel": roof["kernel"],
+                     "traffic_source": (pmc or {}).get("source") if traffic else traffic_note, "kernel": roof["kernel"],
                      "avg_us": roof["avg_us"], "bytes_per_launch": roof["bytes_per_launch"],
                      "launches_timed": roof["launches"]},
     }
     result["parity_checked"], result["parity"] = parity_check(args, toks)
     try:        # north_star: "rocprof HBM GB/s on the TS-encoder" - the encoder's own roofline line, at the workload's shape
         result["ts_encoder_roofline"] = ts_encoder_roofline(model, ser, lengths)
+        if world == 1 and args.model == "chatts-14b" and (args.series, args.length, args.lengths) == (8, 256, "uniform"):
+            ok, why = pmc_traffic_entry((pmc or {}).get("ts_encoder"))
+            result["ts_encoder_roofline"]["traffic"] = ok["hbm_fetch_bytes_per_call"] if ok else None
+            result["ts_encoder_roofline"]["traffic_source"] = ok["source"] if ok else why
     except Exception as e:
         result["ts_encoder_roofline"] = {"error": f"{type(e).__name__}: {e}"}
     try:        # secondary evidence: MFMA utilisation of the prefill's dominant GEMM (north_star asks for it beside the HBM rate)

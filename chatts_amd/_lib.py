@@ -46,6 +46,12 @@ class LinearArgs(C.Structure):
                 ("w8_format", c_int), ("tp_reduce", c_void_p)]
 
 
+class LinearFp8Args(C.Structure):
+    _fields_ = [("a8", c_void_p), ("a_scale", c_void_p), ("w8", c_void_p), ("w_scale", c_void_p), ("bias", c_void_p), ("resid", c_void_p),
+                ("c", c_void_p), ("m", c_int), ("n", c_int), ("k", c_int), ("lda8", c_int), ("ldw8", c_int), ("ldc", c_int),
+                ("epilogue", c_int)]
+
+
 class KvCache(C.Structure):
     _fields_ = [("k", c_void_p), ("v", c_void_p), ("max_ctx", c_int),
                 ("block_table", c_void_p), ("block_size", c_int), ("table_stride", c_int)]      # paged form: block_table != NULL
@@ -107,6 +113,9 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chatts_linear_workspace": (c_size_t, [c_int, c_int, c_int]),
     "chatts_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
+    "chatts_quantize_rows_fp8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p]),
+    "chatts_linear_fp8": (c_int, [C.POINTER(LinearFp8Args), c_void_p]),
+    "chatts_decoder_set_prefill_fp8": (c_int, [c_void_p, c_int]),
     "chatts_split_bf16x2": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "chatts_embed_merge": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -37,6 +37,7 @@ struct ChattsDecoder {
   bool sampling = false;    // token selection of the decode steps: greedy argmax, or the sampler with `sa`
   ChattsSamplingArgs sa{};
   ChattsTpComm* tp = nullptr;   // tensor-parallel exchange (borrowed); required by the whole-step entry points when tp_world > 1
+  bool prefill_fp8 = false; // SPEED MODE (chatts_decoder_set_prefill_fp8): prefill chunks of >= 16 rows multiply fp8 x fp8 (gemm_fp8.hip)
   bool fuse_tp = false;     // set by chatts_decoder_decode_step: the M == 1 o_proj / down_proj GEMVs carry the exchange in their own launch
   bool tp_fused = false;    // ... and whether the last layer part's projection did (otherwise the caller launches chatts_allreduce)
 };
@@ -279,11 +280,75 @@ extern "C" int chatts_decoder_select_sequence(ChattsDecoder* d, int seq) {
   return CHATTS_OK;
 }
 
+// ---- SPEED MODE: a prefill chunk's layer half on the fp8 matrix pipe (gemm_fp8.hip) ----------------------------------------------
+// Activation rows are quantised per token (RMSNorm fused), the four projections are fp8 x fp8 GEMMs on the e4m3 weight copies;
+// RoPE / cache write / attention / residual stream stay float32.  Scratch: the bf16 plane buffers as byte arrays, xn for the row scales.
+extern "C" int chatts_decoder_set_prefill_fp8(ChattsDecoder* d, int on) {
+  CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_set_prefill_fp8: null decoder");
+  if (on) {
+    const ChattsDecoderConfig& c = d->cfg;
+    CHATTS_REQUIRE(c.w8_format == CHATTS_W8_FP8, CHATTS_E_BADARG, "decoder_set_prefill_fp8: the 8-bit weight copies are not e4m3");
+    for (const ChattsLayerWeights& lw : d->layers)
+      CHATTS_REQUIRE(lw.qkv8 && lw.o8 && lw.gate_up8 && lw.down8, CHATTS_E_BADARG, "decoder_set_prefill_fp8: a layer has no fp8 weight copies "
+                     "(weight_format=\"fp8\")");
+    CHATTS_REQUIRE(c.hidden % 128 == 0 && c.inter % 128 == 0, CHATTS_E_SHAPE, "decoder_set_prefill_fp8: hidden / inter must be multiples of 128");
+    CHATTS_REQUIRE(d->b.planes_hi && d->b.planes_lo && d->b.planes2_hi && d->b.xn && d->b.t_max >= 1, CHATTS_E_BADARG,
+                   "decoder_set_prefill_fp8: the plane buffers and xn are needed as scratch");
+  }
+  d->prefill_fp8 = on != 0;
+  return CHATTS_OK;
+}
+
+static int layer_part_fp8(ChattsDecoder* d, int layer, int part, int t, int pos0, const int32_t* pos0_dev, chatts_stream_t stream) {
+  const ChattsDecoderConfig& c = d->cfg;
+  const ChattsLayerWeights& lw = d->layers[layer];
+  const bool tp = c.tp_world > 1;
+  const int H = c.hidden, na = c.n_q * kHeadDim, qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim;
+  uint8_t* a8 = reinterpret_cast<uint8_t*>(d->b.planes_hi);
+  uint8_t* b8 = reinterpret_cast<uint8_t*>(d->b.planes_lo);
+  float* sa = d->b.xn;
+  float* sb = d->b.xn + d->b.t_max;
+  d->normed = false;
+  d->tp_fused = false;
+  int rc;
+  ChattsLinearFp8Args f{};
+  if (part == 0) {
+    if ((rc = chatts_quantize_rows_fp8(d->b.x, t, H, H, lw.input_norm, c.rms_eps, a8, H, sa, stream)) != 0) return rc;
+    f.a8 = a8; f.a_scale = sa; f.w8 = lw.qkv8; f.w_scale = lw.qkv8_scale; f.bias = lw.qkv_bias; f.c = d->b.qkv;
+    f.m = t; f.n = qkv_n; f.k = H; f.lda8 = H; f.ldw8 = H; f.ldc = qkv_n; f.epilogue = CHATTS_EPI_NONE;
+    if ((rc = chatts_linear_fp8(&f, stream)) != 0) return rc;
+    ChattsKvCache kc = layer_cache(d, layer, d->cur_seq);
+    if ((rc = chatts_rope_kv_write(d->b.qkv, t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, pos0, pos0_dev,
+                                   &kc, stream)) != 0) return rc;
+    if ((rc = attention_impl(d->b.qkv, t, c.n_q, c.n_kv, pos0, pos0_dev, &kc, d->b.attn, nullptr, nullptr, 1, d->b.workspace,
+                             d->b.workspace_bytes, stream)) != 0) return rc;
+    if ((rc = chatts_quantize_rows_fp8(d->b.attn, t, na, na, nullptr, 0.f, b8, na, sb, stream)) != 0) return rc;
+    f = ChattsLinearFp8Args{};
+    f.a8 = b8; f.a_scale = sb; f.w8 = lw.o8; f.w_scale = lw.o8_scale; f.m = t; f.n = H; f.k = na; f.lda8 = na; f.ldw8 = na; f.ldc = H;
+    if (tp) { f.c = d->b.delta; f.epilogue = CHATTS_EPI_NONE; }
+    else { f.c = d->b.x; f.resid = d->b.x; f.epilogue = CHATTS_EPI_RESID; }
+    return chatts_linear_fp8(&f, stream);
+  }
+  if ((rc = chatts_quantize_rows_fp8(d->b.x, t, H, H, lw.post_norm, c.rms_eps, a8, H, sa, stream)) != 0) return rc;
+  f.a8 = a8; f.a_scale = sa; f.w8 = lw.gate_up8; f.w_scale = lw.gate_up8_scale; f.c = d->b.act;
+  f.m = t; f.n = 2 * c.inter; f.k = H; f.lda8 = H; f.ldw8 = H; f.ldc = c.inter; f.epilogue = CHATTS_EPI_SWIGLU;
+  if ((rc = chatts_linear_fp8(&f, stream)) != 0) return rc;
+  uint8_t* c8 = reinterpret_cast<uint8_t*>(d->b.planes2_hi);
+  if ((rc = chatts_quantize_rows_fp8(d->b.act, t, c.inter, c.inter, nullptr, 0.f, c8, c.inter, sb, stream)) != 0) return rc;
+  f = ChattsLinearFp8Args{};
+  f.a8 = c8; f.a_scale = sb; f.w8 = lw.down8; f.w_scale = lw.down8_scale; f.m = t; f.n = H; f.k = c.inter; f.lda8 = c.inter; f.ldw8 = c.inter;
+  f.ldc = H;
+  if (tp) { f.c = d->b.delta; f.epilogue = CHATTS_EPI_NONE; }
+  else { f.c = d->b.x; f.resid = d->b.x; f.epilogue = CHATTS_EPI_RESID; }
+  return chatts_linear_fp8(&f, stream);
+}
+
 extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, int t, int pos0,
                                          const int32_t* pos0_dev, int n_splits, chatts_stream_t stream) {
   CHATTS_REQUIRE(d && layer >= 0 && layer < d->cfg.n_layers && (part == 0 || part == 1), CHATTS_E_BADARG,
                  "decoder_layer_part: bad arguments");
   CHATTS_REQUIRE(t >= 1 && t <= d->b.t_max, CHATTS_E_SHAPE, "decoder_layer_part: t=%d exceeds buffers (%d)", t, d->b.t_max);
+  if (d->prefill_fp8 && t >= 16) return layer_part_fp8(d, layer, part, t, pos0, pos0_dev, stream);      // speed mode, prefill chunks only
   const ChattsDecoderConfig& c = d->cfg;
   const ChattsLayerWeights& lw = d->layers[layer];
   const bool tp = c.tp_world > 1;
@@ -628,7 +693,17 @@ extern "C" int chatts_decoder_prefill_last(ChattsDecoder* d, int t, int pos0, ch
     if (rc == CHATTS_OK) rc = chatts_decoder_layer_part(d, l, 1, t, pos0, nullptr, 1, stream);
     if (tp && rc == CHATTS_OK) rc = tp_sum_into_x(d, t, stream);
   }
-  if (rc == CHATTS_OK) rc = layer_last_row(d, L - 1, t, pos0, stream);
+  if (rc == CHATTS_OK && d->prefill_fp8 && t >= 16) {      // speed mode: the final layer at full width too, then the last row moves to row 0
+    rc = chatts_decoder_layer_part(d, L - 1, 0, t, pos0, nullptr, 1, stream);
+    if (tp && rc == CHATTS_OK) rc = tp_sum_into_x(d, t, stream);
+    if (rc == CHATTS_OK) rc = chatts_decoder_layer_part(d, L - 1, 1, t, pos0, nullptr, 1, stream);
+    if (tp && rc == CHATTS_OK) rc = tp_sum_into_x(d, t, stream);
+    if (rc == CHATTS_OK && t > 1) {
+      const hipError_t e = hipMemcpyAsync(d->b.x, d->b.x + (size_t)(t - 1) * d->cfg.hidden, (size_t)d->cfg.hidden * sizeof(float),
+                                          hipMemcpyDeviceToDevice, as_stream(stream));
+      if (e != hipSuccess) { set_error("prefill_last: row copy: %s", hipGetErrorString(e)); rc = CHATTS_E_LAUNCH; }
+    }
+  } else if (rc == CHATTS_OK) rc = layer_last_row(d, L - 1, t, pos0, stream);
   d->chain = false;
   d->normed = false;
   return rc;
@@ -644,12 +719,23 @@ static int layer_part0_packed(ChattsDecoder* d, int layer, int t, const ChattsPr
   const ChattsLayerWeights& lw = d->layers[layer];
   const int H = c.hidden, qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim, na = c.n_q * kHeadDim;
   int rc;
+  const bool f8 = d->prefill_fp8 && t >= 16;          // speed mode: qkv and o_proj as fp8 x fp8 GEMMs (layer_part_fp8's arithmetic)
   ChattsLinearArgs la{};
-  la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = t; la.n = qkv_n; la.k = H;
-  la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
-  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
-  if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
-  if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+  if (f8) {
+    d->normed = false;
+    uint8_t* a8 = reinterpret_cast<uint8_t*>(d->b.planes_hi);
+    if ((rc = chatts_quantize_rows_fp8(d->b.x, t, H, H, lw.input_norm, c.rms_eps, a8, H, d->b.xn, stream)) != 0) return rc;
+    ChattsLinearFp8Args f{};
+    f.a8 = a8; f.a_scale = d->b.xn; f.w8 = lw.qkv8; f.w_scale = lw.qkv8_scale; f.bias = lw.qkv_bias; f.c = d->b.qkv;
+    f.m = t; f.n = qkv_n; f.k = H; f.lda8 = H; f.ldw8 = H; f.ldc = qkv_n; f.epilogue = CHATTS_EPI_NONE;
+    if ((rc = chatts_linear_fp8(&f, stream)) != 0) return rc;
+  } else {
+    la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = t; la.n = qkv_n; la.k = H;
+    la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
+    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
+    if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
+    if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+  }
   for (int i = 0; i < n_segs; ++i) {
     const ChattsPrefillSegment& sg = segs[i];
     ChattsKvCache kc = layer_cache(d, layer, sg.slot);
@@ -659,6 +745,15 @@ static int layer_part0_packed(ChattsDecoder* d, int layer, int t, const ChattsPr
     const int ks = 1;
     if ((rc = attention_impl(q, sg.t, c.n_q, c.n_kv, sg.pos0, nullptr, &kc, d->b.attn + (size_t)sg.row0 * na, nullptr, nullptr, ks,
                              d->b.workspace, d->b.workspace_bytes, stream)) != 0) return rc;
+  }
+  if (f8) {
+    uint8_t* b8 = reinterpret_cast<uint8_t*>(d->b.planes_lo);
+    float* sb = d->b.xn + d->b.t_max;
+    if ((rc = chatts_quantize_rows_fp8(d->b.attn, t, na, na, nullptr, 0.f, b8, na, sb, stream)) != 0) return rc;
+    ChattsLinearFp8Args f{};
+    f.a8 = b8; f.a_scale = sb; f.w8 = lw.o8; f.w_scale = lw.o8_scale; f.m = t; f.n = H; f.k = na; f.lda8 = na; f.ldw8 = na; f.ldc = H;
+    f.c = d->b.x; f.resid = d->b.x; f.epilogue = CHATTS_EPI_RESID;
+    return chatts_linear_fp8(&f, stream);
   }
   la = ChattsLinearArgs{};
   la.a = d->b.attn; la.w = lw.o; la.m = t; la.n = H; la.k = na; la.lda = na; la.ldw = na; la.ldc = H;

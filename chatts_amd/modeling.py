@@ -107,8 +107,13 @@ class ChatTSForCausalLM:
         # in the prefill GEMMs: logits ~5e-5 of the float32 oracle).  "bf16" = SPEED mode: the prefill GEMMs
         # multiply the bf16-rounded activations only - half the matrix work, logits ~1e-2, what a bf16 HF / vLLM run computes.
         # PROCESS-WIDE (the library reads CHATTS_GEMM_PRECISION per call): every model of this process follows the last setting.
-        if precision not in (None, "bf16x2", "bf16"):
-            raise ValueError("precision must be None / 'bf16x2' (parity grade) or 'bf16' (speed mode)")
+        # "fp8" = SPEED mode on the CDNA4 fp8 matrix pipe (needs weight_format="fp8", BASELINE.json config 5): prefill chunks and the
+        # TS encoder quantise their activations per row to e4m3 and multiply fp8 x fp8 (v_mfma_scale_f32_16x16x128_f8f6f4: 4x less
+        # matrix time than bf16x2), logits ~1e-2 from the default; decode steps are unchanged.  Per model, not process-wide.
+        if precision not in (None, "bf16x2", "bf16", "fp8"):
+            raise ValueError("precision must be None / 'bf16x2' (parity grade), 'bf16' or 'fp8' (speed modes)")
+        if precision == "fp8" and weight_format != "fp8":
+            raise ValueError("precision='fp8' multiplies the fp8 weight copies: it needs weight_format='fp8'")
         if precision is not None:
             import os
             if precision == "bf16":
@@ -431,6 +436,9 @@ class ChatTSForCausalLM:
         self._decoder = C.c_void_p(h)
         self._graph = None
         self._graph_batched = None
+        if self.precision == "fp8":              # speed mode: prefill chunks and the TS encoder on the fp8 matrix pipe
+            _lib.check(lib.chatts_decoder_set_prefill_fp8(self._decoder, 1))
+            self.ts_encoder.set_precision("fp8")
         if plan.world > 1 and self.use_p2p and getattr(self.comm, "dist", None) is not None and self._tp is None:
             from .tp import P2PExchange
             ex, err = None, None
@@ -590,6 +598,9 @@ class ChatTSForCausalLM:
     # ---------------------------------------------------------------------------------------------
     def _tp_bulk(self, T):
         """tensor parallel: the attached exchange can sum [T, H] partials itself (chatts_allreduce_bulk) -> one C call per chunk"""
+        import os
+        if os.environ.get("CHATTS_TP_BULK", "1") == "0":          # A/B and fault isolation: the host-driven sums (RCCL / gloo) instead
+            return False
         return self._tp is not None and self._tp.bulk_elems >= T * self.config.hidden_size
 
     def _run_layers(self, T, pos0, pos_dev=None, n_splits=1, last_only=False):

@@ -43,6 +43,8 @@ class TimeSeriesEmbedding:
         if self.hidden_size % 32:
             raise ValueError("ts hidden_size must be a multiple of 32")
         self.device = torch.device(device)
+        self.precision = "bf16x2"                     # "fp8": SPEED mode, see set_precision
+        self._w8 = None
         self.position_embedding = None               # f32 [max_seq+1, emb]
         self.weights = [None] * self.num_layers      # bf16 [H, Kpad_l]
         self.biases = [None] * self.num_layers       # f32 [H]
@@ -94,6 +96,60 @@ class TimeSeriesEmbedding:
                 ld = self.layer_k(l)
                 w = torch.zeros((s.rows, ld), dtype=torch.bfloat16, device=self.device)
                 self.weights[l] = synth.fill_device(w, s, seed, ld=ld)
+
+    def set_precision(self, precision):
+        """"bf16x2" (default, parity grade: float32 activations as bf16 hi + lo planes) or "fp8" - the SPEED mode of
+        ChatTSForCausalLM(precision="fp8"): calls with >= 64 patches quantise activations per row to e4m3 and run the MLP as fp8 x fp8
+        GEMMs (chatts_linear_fp8, v_mfma_scale_f32_16x16x128_f8f6f4) on per-row power-of-two-scaled e4m3 copies of the weights; features
+        ~1e-2 from the default.  Fewer patches than 64 keep the default path (weight-streaming bound: nothing to gain)."""
+        if precision not in ("bf16x2", "fp8"):
+            raise ValueError("TimeSeriesEmbedding precision must be 'bf16x2' or 'fp8'")
+        self.precision = precision
+        self._w8 = None
+
+    def _fp8_weights(self):
+        if self._w8 is None:
+            from .modeling import quantize_fp8_rows
+            self._w8 = []
+            for l, w in enumerate(self.weights):
+                k = (w.shape[1] + 127) // 128 * 128           # K of the fp8 GEMM: whole 128-byte MFMA steps (zero padded)
+                wp = torch.zeros((w.shape[0], k), dtype=torch.bfloat16, device=w.device)
+                wp[:, :w.shape[1]] = w
+                q, sc, _ = quantize_fp8_rows(wp)
+                self._w8.append((q, sc, k))
+        return self._w8
+
+    def _replay_fp8(self):
+        """the fp8 speed-mode form of replay_last: patchify -> [quantise rows -> fp8 GEMM (+bias, GELU)] x layers"""
+        import ctypes as C
+        lib = _lib.load()
+        x, row_off_dev, vl_dev, n, lmax, maxvl, P, out = self._last
+        w8 = self._fp8_weights()
+        H, dev, st = self.hidden_size, x.device, _lib.stream_ptr()
+        k0 = w8[0][2]
+        key = ("fp8", P, dev)
+        if getattr(self, "_buf8_key", None) != key:
+            self._bufs8 = dict(feat=torch.empty((P, k0), dtype=torch.float32, device=dev), h=torch.empty((P, H), dtype=torch.float32, device=dev),
+                               a8=torch.empty((P, max(k0, H)), dtype=torch.uint8, device=dev), sa=torch.empty(P, dtype=torch.float32, device=dev))
+            self._buf8_key = key
+        B = self._bufs8
+        pa = _lib.PatchifyArgs(series=_lib.ptr(x), row_off=_lib.ptr(row_off_dev), valid_len=_lib.ptr(vl_dev),
+                               pos_table=_lib.ptr(self.position_embedding), out=_lib.ptr(B["feat"]), n_series=n, lmax=lmax,
+                               patch_size=self.patch_size, mode=self.mode, emb_dim=self.embedding_dim, max_seq_len=self.max_sequence_length,
+                               max_valid_len=maxvl, total_patches=P, ld_out=k0, out_hi=None, out_lo=None)
+        _lib.check(lib.chatts_ts_patchify(C.byref(pa), st))
+        src, k = B["feat"], k0
+        for l in range(self.num_layers):
+            _lib.check(lib.chatts_quantize_rows_fp8(_lib.ptr(src), P, k, k, None, 0.0, _lib.ptr(B["a8"]), k, _lib.ptr(B["sa"]), st))
+            last = l == self.num_layers - 1
+            q, sc, kq = w8[l]
+            dst = out if last else B["h"]
+            fa = _lib.LinearFp8Args(a8=_lib.ptr(B["a8"]), a_scale=_lib.ptr(B["sa"]), w8=_lib.ptr(q), w_scale=_lib.ptr(sc),
+                                    bias=_lib.ptr(self.biases[l]), resid=None, c=_lib.ptr(dst), m=P, n=H, k=kq, lda8=k, ldw8=kq, ldc=H,
+                                    epilogue=_lib.EPI_NONE if last else _lib.EPI_GELU)
+            _lib.check(lib.chatts_linear_fp8(C.byref(fa), st))
+            src, k = B["h"], H
+        return out
 
     def weight_bytes(self):
         n = sum(w.numel() * 2 for w in self.weights) + sum(b.numel() * 4 for b in self.biases)
@@ -178,6 +234,8 @@ class TimeSeriesEmbedding:
         """Enqueue the kernels of the most recent forward() again (same device inputs and buffers): what bench.py times
         between HIP events for the encoder's roofline line - no host-side staging in the timed region."""
         import ctypes as C
+        if self.precision == "fp8" and self._last[6] >= 64:
+            return self._replay_fp8()
         lib, B = _lib.load(), self._bufs
         x, row_off_dev, vl_dev, n, lmax, maxvl, P, out = self._last
         _lib.check(lib.chatts_ts_encode(_lib.ptr(x), _lib.ptr(row_off_dev), _lib.ptr(vl_dev), n, lmax, maxvl, P,

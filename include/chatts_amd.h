@@ -211,6 +211,31 @@ int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, 
 int chatts_linear(const ChattsLinearArgs* args, chatts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * SPEED MODE, not parity grade: fp8 x fp8 projections on the CDNA4 block-scaled matrix pipe (v_mfma_scale_f32_16x16x128_f8f6f4 with
+ * unit block scales: twice the bf16 MFMA rate, and ONE pass instead of the two of the bf16x2 split).  What vLLM does with an fp8
+ * quant_config (the reference passes it through: chatts_vllm.py:475,481; BASELINE.json config 5 "fp8 weights (CDNA4 fp8 MFMA)"):
+ * activations are quantised per row (token) on the fly, weights are the per-row power-of-two-scaled e4m3 copies of
+ * ChattsLinearArgs.w8.  Results differ from the float32-activation default by ~1e-2 (3-bit mantissas): selected only by
+ * precision="fp8" for the MFMA-bound stages (prefill chunks, the TS encoder at thousands of patches), labelled wherever it is printed.
+ * ------------------------------------------------------------------------------------------- */
+/* q[m, :] = e4m3fn(x'[m, :] / scale[m]), scale[m] = max|x'[m, :]| / 448 (1 for an all-zero row); x' = x, or RMSNorm(x) with weight
+ * norm_w when norm_w != NULL (Qwen2RMSNorm.forward).  K % 4 == 0; q rows ldq bytes apart. */
+int chatts_quantize_rows_fp8(const float* x, int m, int k, int ldx, const float* norm_w, float norm_eps, uint8_t* q, int ldq,
+                             float* scale, chatts_stream_t stream);
+typedef struct ChattsLinearFp8Args {
+  const uint8_t* a8;       /* [M, lda8] e4m3fn activations (chatts_quantize_rows_fp8) */
+  const float* a_scale;    /* [M] */
+  const uint8_t* w8;       /* [N, ldw8] e4m3fn weights, row-major like ChattsLinearArgs.w8 */
+  const float* w_scale;    /* [N] */
+  const float* bias;       /* [N] or NULL (SWIGLU: interleaved like the rows) */
+  const float* resid;      /* EPI_RESID: [M, ldc]; may alias c */
+  float* c;                /* [M, ldc] float32 (SWIGLU: [M, N / 2]) */
+  int m, n, k, lda8, ldw8, ldc, epilogue;      /* K % 128 == 0 (zero pad both operands); CHATTS_EPI_* */
+} ChattsLinearFp8Args;
+/* C = epilogue(a_scale[m] * w_scale[n] * sum_k a8[m, k] * w8[n, k]), float32 accumulate */
+int chatts_linear_fp8(const ChattsLinearFp8Args* args, chatts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Embedding gather + TS merge.  Replaces get_input_embeddings (chatts_vllm.py:564-574) =
  * embed_tokens(ids) then vLLM merge_multimodal_embeddings: rows whose id == ts_token_id are
  * overwritten, in order, by the TS rows.  ids_host (optional) lets the count check run on the host
@@ -511,6 +536,12 @@ int chatts_residual_add(float* x, const float* delta, int64_t n, chatts_stream_t
  * one host call per exchange point instead of two.  add_delta == 0: identical to chatts_decoder_layer_part. */
 int chatts_decoder_layer_part_add(ChattsDecoder*, int add_delta, int layer, int part, int t, int pos0,
                                   const int32_t* pos0_dev, int n_splits, chatts_stream_t stream);
+
+/* SPEED MODE switch for the prefill chunks (t >= 16 rows) of this decoder: on != 0 runs their four projections as fp8 x fp8 GEMMs
+ * (chatts_quantize_rows_fp8 + chatts_linear_fp8, RMSNorm fused into the quantisation) on the fp8 weight copies; needs every layer's
+ * qkv8 / o8 / gate_up8 / down8 in e4m3 (w8_format FP8) and K multiples of 128.  NOT parity grade (~1e-2 on logits); decode steps,
+ * attention, norms, KV cache and logits are unchanged.  Returns CHATTS_E_BADARG when the copies are missing. */
+int chatts_decoder_set_prefill_fp8(ChattsDecoder*, int on);
 
 /* Attach the tensor-parallel exchange (tp_world > 1): chatts_decoder_decode_step(_batched) then run whole TP steps on the
  * stream - partial o_proj / down_proj sums are all-reduced into the residual stream by chatts_allreduce, tokens are agreed on

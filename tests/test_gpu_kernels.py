@@ -1257,3 +1257,75 @@ def test_attention_decode_workgroup_form_equals_the_two_kernel_form(lib, n_q, n_
     for a, b in zip(runs["0"], runs["2"]):
         assert torch.equal(a, b)
     assert not torch.isnan(runs["2"][0]).any() and torch.count_nonzero(runs["2"][0][2]) == 0      # the parked row is written as zeros
+
+
+def _fp8_ref_quant(x, norm_w=None, eps=1e-6):
+    """chatts_quantize_rows_fp8's arithmetic in torch: (optional RMSNorm,) scale = amax / 448, e4m3fn codes of x * (1 / scale)"""
+    xf = x.float()
+    if norm_w is not None:
+        rstd = torch.rsqrt((xf.double() ** 2).mean(dim=1, keepdim=True) + eps).float()
+        xf = norm_w[None] * (xf * rstd)
+    amax = xf.abs().amax(dim=1)
+    s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    q = (xf * (1.0 / s)[:, None]).to(torch.float8_e4m3fn)
+    return q, s
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k", [(200, 256, 384), (130, 5120, 5120), (17, 640, 128), (1207, 896, 640), (64, 1024, 13824)])
+def test_linear_fp8_speed_mode_is_the_exact_product_of_the_quantised_operands(lib, epi, m, n, k):
+    """gemm_fp8.hip (v_mfma_scale_f32_16x16x128_f8f6f4, SPEED mode): the kernel's only approximation is the quantisation itself - its
+    output equals, to float32 summation order, the float64 product of the e4m3 codes x scales it was given, for every epilogue, ragged
+    M / N tiles, K from one to 108 MFMA steps.  (How far fp8 activations are from the float32 path is measured end to end:
+    profiles/r4_fp8_speed_mode.json - this test pins the kernel.)"""
+    import ctypes as C
+    g = torch.Generator().manual_seed(m + n + k + epi)
+    x = (torch.randn((m, k), generator=g) * 0.7).to(DEV)
+    x[:, 0] = torch.linspace(-3, 3, m).to(DEV)                          # asymmetric structure (guide rule 16)
+    w = (torch.randn((n, k), generator=g) * 0.05).to(DEV)
+    w[:, 0] = torch.linspace(-1, 1, n).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    resid = torch.randn((m, ncols), generator=g).to(DEV)
+    q8 = torch.empty((m, k), dtype=torch.uint8, device=DEV)
+    sa = torch.empty(m, dtype=torch.float32, device=DEV)
+    _lib.check(lib.chatts_quantize_rows_fp8(x.data_ptr(), m, k, k, None, 0.0, q8.data_ptr(), k, sa.data_ptr(), _lib.stream_ptr()))
+    q_ref, s_ref = _fp8_ref_quant(x)
+    assert torch.equal(sa, s_ref)
+    assert (q8 != q_ref.view(torch.uint8)).float().mean().item() < 1e-4           # (ties of x * (1 / s) may round the other way)
+    wq, ws = _fp8_ref_quant(w)
+    w8 = wq.view(torch.uint8).contiguous()
+    out = torch.full((m, ncols), float("nan"), device=DEV)
+    fa = _lib.LinearFp8Args(a8=q8.data_ptr(), a_scale=sa.data_ptr(), w8=w8.data_ptr(), w_scale=ws.data_ptr(), bias=bias.data_ptr(),
+                            resid=resid.data_ptr() if epi == _lib.EPI_RESID else None, c=out.data_ptr(), m=m, n=n, k=k, lda8=k, ldw8=k,
+                            ldc=ncols, epilogue=epi)
+    _lib.check(lib.chatts_linear_fp8(C.byref(fa), _lib.stream_ptr()))
+    a_deq = q8.view(torch.float8_e4m3fn).double().cpu() * sa.double().cpu()[:, None]
+    w_deq = w8.view(torch.float8_e4m3fn).double().cpu() * ws.double().cpu()[:, None]
+    y = a_deq @ w_deq.T + bias.double().cpu()
+    if epi == _lib.EPI_GELU:
+        y = torch.nn.functional.gelu(y)
+    elif epi == _lib.EPI_RESID:
+        y = y + resid.double().cpu()
+    elif epi == _lib.EPI_SWIGLU:
+        v = y.view(m, n // 32, 2, 16)
+        y = (torch.nn.functional.silu(v[:, :, 0]) * v[:, :, 1]).reshape(m, n // 2)
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu().numpy(), y.numpy()) < 2e-5
+
+
+def test_quantize_rows_fp8_fuses_rmsnorm(lib):
+    m, k = 37, 5120
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((m, k), generator=g).to(DEV)
+    x[5] = 0.0                                                              # an all-zero row: scale 1, codes 0
+    nw = (1 + 0.1 * torch.randn(k, generator=g)).to(DEV)
+    q8 = torch.empty((m, k), dtype=torch.uint8, device=DEV)
+    sa = torch.empty(m, dtype=torch.float32, device=DEV)
+    _lib.check(lib.chatts_quantize_rows_fp8(x.data_ptr(), m, k, k, nw.data_ptr(), 1e-6, q8.data_ptr(), k, sa.data_ptr(), _lib.stream_ptr()))
+    deq = q8.view(torch.float8_e4m3fn).double().cpu() * sa.double().cpu()[:, None]
+    xd = x.double().cpu()
+    want = nw.double().cpu()[None] * (xd * torch.rsqrt((xd ** 2).mean(dim=1, keepdim=True) + 1e-6))
+    assert sa[5].item() == 1.0 and torch.count_nonzero(q8[5] & 0x7f) == 0
+    assert rel_err(deq.numpy(), want.numpy()) < 0.04                       # e4m3: 3 mantissa bits, round to nearest
+    assert (deq.abs().amax(dim=1)[:5] - want.abs().amax(dim=1)[:5]).abs().max() < 1e-4      # the row maximum maps to 448 exactly

@@ -2,20 +2,23 @@
 """One PROCESS per tensor-parallel rank, all on ONE GPU: the real exchange (IPC-mapped buffers, the in-launch exchange of the decode
 GEMVs, chatts_tp_argmax, the whole TP step as one hipGraph per rank) at ChatTS-14B widths against the unsharded float32 oracle.
 
-    export HSA_ENABLE_IPC_MODE_LEGACY=0 CHATTS_FORCE_DEVICE=0 CHATTS_DIST_BACKEND=gloo CHATTS_TP_FUSE_BLOCKS=48
+    export HSA_ENABLE_IPC_MODE_LEGACY=0 CHATTS_FORCE_DEVICE=0 CHATTS_DIST_BACKEND=gloo CHATTS_TP_FUSE_BLOCKS=48 CHATTS_TP_BULK_BLOCKS=16
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29531 \
         tools/tp_parity_worker.py --flow headline --out gpurun_out/r4_tp8_parity_headline.json
 
 Flows (bench.py's inputs, seed 0, depth --layers so that the CPU oracle takes seconds):
-  headline  8 x 256 prompt (798 tokens), greedy generate_one: prefill through chatts_decoder_layer_part_add + host all-reduce (gloo
-            here, RCCL on a real node), first token by the (max, idx) agreement, then graph-replayed TP decode steps;
+  headline  8 x 256 prompt (798 tokens), greedy generate_one: prefill as ONE chatts_decoder_prefill_last call per rank (layer halves +
+            two-shot chatts_allreduce_bulk sums over the IPC-mapped buffers), first token by the (max, idx) agreement, then
+            graph-replayed TP decode steps;
   config4   30 series of mixed lengths (3.5k tokens -> four prefill chunks), the same;
   config5   fp8 weights, 16 different 8 x 1024 prompts admitted one by one into 16 cache slots, then the 16-wide TP decode graph.
 Rank 0 additionally builds the W shard models of the same synthetic checkpoint in its own process (no exchange) only to re-assemble the
 weights the ranks hold (oracle/from_device.sharded_state_dict - with fp8 every shard picks its row scales over its own slice), runs the
 oracle (oracle/ - TEST INFRASTRUCTURE), gathers every rank's logits slices and residual-stream digests, and writes the verdict:
 identical greedy tokens, logits within 1e-3 (norm-wise and max-abs over max logit), bit-identical residual streams on all ranks.
-CHATTS_TP_FUSE_BLOCKS caps the grid of the exchange-carrying GEMVs so that W ranks' launches are resident together on the one device.
+CHATTS_TP_FUSE_BLOCKS / CHATTS_TP_BULK_BLOCKS cap the grids of the exchange-carrying GEMVs / the bulk all-reduce so that W ranks' launches -
+which wait for each other - are resident together on the ONE device (measured: 8 x 128 bulk workgroups from 8 processes stall, 8 x 16 run;
+profiles/r4_tp_multiprocess_bulk_blocks.txt).  One process per GPU needs neither.
 What this cannot show is the xGMI hop: every "peer" buffer lives in the same HBM."""
 import argparse
 import hashlib
