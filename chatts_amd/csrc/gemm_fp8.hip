@@ -11,10 +11,12 @@
 //     OCP e4m3fn codes (v_cvt_pk_fp8_f32, round to nearest even, saturating) + the row's float32 scale: vLLM's dynamic per-token
 //     activation quantisation;
 //   * gemm_fp8_kernel: C[m, n] = epilogue(sa[m] * sw[n] * sum_k A8[m, k] W8[n, k]) with v_mfma_scale_f32_16x16x128_f8f6f4 (both
-//     operand formats e4m3, block scales fixed to 1.0: the instruction is the only fp8 form that runs at twice the bf16 rate) - 128 x
-//     128 x 128 tiles, 4 waves of 64 x 64, operands staged global -> registers -> LDS (rows padded to 144 bytes: the 32-byte
-//     fragment reads of 16 rows spread over the banks), next tile's global loads in flight under the current tile's MFMAs.
+//     operand formats e4m3, block scales fixed to 1.0: the instruction is the only fp8 form that runs at twice the bf16 rate) - 256 x
+//     256 x 128 or 128 x 256 x 128 tiles, 8 waves, operands staged global -> registers -> LDS (rows padded to 144 bytes: the 32-byte
+//     fragment reads of 16 rows spread over the banks), the global loads of the K-step after next in flight under the MFMAs.
 //     Weights: the per-row power-of-two-scaled e4m3 copies the fp8 decode path already streams (ChattsLinearArgs.w8).
+#include <type_traits>
+
 #include "common.h"
 
 namespace chatts {
@@ -80,86 +82,123 @@ struct GemmFp8Params {
   int m, n, k, lda, ldw, ldc;
 };
 
-constexpr int kF8BM = 128, kF8BN = 128, kF8BK = 128;      // BK in bytes = fp8 values
-constexpr int kF8Row = kF8BK + 16;                          // padded LDS row (bytes)
-constexpr int kF8Tile = kF8BM * kF8Row;                     // one operand tile in LDS
+constexpr int kF8BN = 256, kF8BK = 128;                     // BK in bytes = fp8 values per MFMA step
+constexpr int kF8Row = kF8BK + 16;                          // padded LDS row (bytes): the 32-byte fragment reads of 16 rows spread over the banks
+constexpr int kF8Threads = 512;
 
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu8_f(float x) { return x / (1.0f + expf(-x)); }
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_fp8_kernel(GemmFp8Params p) {
+// Tile (64 WM) x 256 x 128, eight waves as WM x (8 / WM), every wave 64 rows x (256 / (8 / WM)) columns: WM = 4 -> 256 x 256 with
+// 64 x 128 wave tiles (128 accumulator registers), WM = 2 -> 128 x 256 with 64 x 64 wave tiles.  An fp8 tile-step is a quarter of the
+// bf16x2 step's matrix time for the same operand bytes, so the tile has to be this large for the CU's fetch rate (~64 GB/s measured
+// with the first 128 x 128 version: 1.95 us per K-step against 0.21 us of MFMA) to keep the pipe fed: 256 flop per fetched byte at
+// WM = 4, 171 at WM = 2; the launcher picks per shape by rounds of workgroups.  Operands: global -> registers (TWO K-steps ahead) ->
+// LDS (two stages) -> fragments.
+template <int EPI, int WM>
+__global__ __launch_bounds__(kF8Threads) void gemm_fp8_kernel(GemmFp8Params p) {
+  constexpr int WN = 8 / WM, BM = 64 * WM, FN = kF8BN / WN / 16, NA = BM / 64;       // FN column fragments per wave; NA A pieces per thread
+  constexpr int A_TILE = BM * kF8Row, STAGE = (BM + kF8BN) * kF8Row;
   extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 stages][A tile | W tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = blockIdx.x * kF8BN, m0 = blockIdx.y * kF8BM;
-  // staging: thread t loads 16-byte piece (row = t / 8 + 32 j, column block t % 8) of both tiles, j < 4
+  const int wm = wave / WN, wn = wave % WN;
+  const int n0 = blockIdx.x * kF8BN, m0 = blockIdx.y * BM;
+  // staging: thread t moves 16-byte piece (row t / 8 + 64 j, column block t % 8) of A (j < NA) and of W (j < 4)
   const int srow = tid >> 3, scol = (tid & 7) * 16;
-  const uint8_t* ag[4];
+  const uint8_t* ag[NA];
   const uint8_t* wg[4];
-  bool aok[4];
+  bool aok[NA];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ar = m0 + srow + 32 * j, wr = n0 + srow + 32 * j;
+  for (int j = 0; j < NA; ++j) {
+    const int ar = m0 + srow + 64 * j;
     aok[j] = ar < p.m;
     ag[j] = p.a8 + (size_t)(aok[j] ? ar : 0) * p.lda + scol;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int wr = n0 + srow + 64 * j;
     wg[j] = p.w8 + (size_t)(wr < p.n ? wr : 0) * p.ldw + scol;
   }
-  i32x4 ra[4], rw[4];
-  auto gload = [&](int k0) {
+  constexpr int DEPTH = WM == 4 ? 1 : 2;        // K-steps of global loads in flight (the 256-row tile has no registers for a second set)
+  i32x4 ra[DEPTH][NA], rw[DEPTH][4];
+  auto gload = [&](auto setc, int k0) {
+    constexpr int S = decltype(setc)::value;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ra[j] = aok[j] ? *reinterpret_cast<const i32x4*>(ag[j] + k0) : (i32x4){0, 0, 0, 0};
-      rw[j] = *reinterpret_cast<const i32x4*>(wg[j] + k0);
-    }
-  };
-  auto lstore = [&](int stage) {
-    char* at = smem + (size_t)stage * 2 * kF8Tile;
-    char* wt = at + kF8Tile;
+    for (int j = 0; j < NA; ++j) ra[S][j] = aok[j] ? *reinterpret_cast<const i32x4*>(ag[j] + k0) : (i32x4){0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<i32x4*>(at + (srow + 32 * j) * kF8Row + scol) = ra[j];
-      *reinterpret_cast<i32x4*>(wt + (srow + 32 * j) * kF8Row + scol) = rw[j];
-    }
+    for (int j = 0; j < 4; ++j) rw[S][j] = *reinterpret_cast<const i32x4*>(wg[j] + k0);
   };
-  f32x4 acc[4][4];
+  auto lstore = [&](auto setc, int stage) {
+    constexpr int S = decltype(setc)::value;
+    char* at = smem + (size_t)stage * STAGE;
+    char* wt = at + A_TILE;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<i32x4*>(at + (srow + 64 * j) * kF8Row + scol) = ra[S][j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<i32x4*>(wt + (srow + 64 * j) * kF8Row + scol) = rw[S][j];
+  };
+  f32x4 acc[4][FN];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.k / kF8BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  // fragment addresses: lane l holds row (l % 16) of a 16-row block, K bytes 32 (l / 16) .. + 31 (A and W alike: the dot product
-  // pairs equal byte positions of equal lane groups)
+  // fragment addresses: lane l holds row (l % 16) of a 16-row block, K bytes 32 (l / 16) .. + 31 (A and W alike: the instruction pairs
+  // equal byte positions of equal lane groups)
   const int frow = lane & 15, fcol = (lane >> 4) * 32;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * kF8BK);
-    const char* at = smem + (size_t)cur * 2 * kF8Tile + (size_t)(wm * 64 + frow) * kF8Row + fcol;
-    const char* wt = smem + (size_t)cur * 2 * kF8Tile + kF8Tile + (size_t)(wn * 64 + frow) * kF8Row + fcol;
-    i32x8 af[4], bf[4];
+  auto compute = [&](int stage) {
+    const char* at = smem + (size_t)stage * STAGE + (size_t)(wm * 64 + frow) * kF8Row + fcol;
+    const char* wt = smem + (size_t)stage * STAGE + A_TILE + (size_t)(wn * (kF8BN / WN) + frow) * kF8Row + fcol;
+    i32x8 af[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const i32x4 lo = *reinterpret_cast<const i32x4*>(at + i * 16 * kF8Row), hi = *reinterpret_cast<const i32x4*>(at + i * 16 * kF8Row + 16);
       af[i] = (i32x8){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      const i32x4 l2 = *reinterpret_cast<const i32x4*>(wt + i * 16 * kF8Row), h2 = *reinterpret_cast<const i32x4*>(wt + i * 16 * kF8Row + 16);
-      bf[i] = (i32x8){l2.x, l2.y, l2.z, l2.w, h2.x, h2.y, h2.z, h2.w};
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < FN; ++j) {
+      const i32x4 lo = *reinterpret_cast<const i32x4*>(wt + j * 16 * kF8Row), hi = *reinterpret_cast<const i32x4*>(wt + j * 16 * kF8Row + 16);
+      const i32x8 bf = (i32x8){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i], bf[j], acc[i][j], 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7f7f7f7f,
-                                                                     0, 0x7f7f7f7f /* E8M0 127 = 2^0 */);
-    if (kt + 1 < nk) lstore(cur ^ 1);
+      for (int i = 0; i < 4; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i], bf, acc[i][j], 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7f7f7f7f, 0,
+                                                                     0x7f7f7f7f /* E8M0 127 = 2^0 */);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  const int nk = p.k / kF8BK;
+  gload(S0{}, 0);
+  if constexpr (DEPTH == 1) {
+    lstore(S0{}, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) gload(S0{}, (kt + 1) * kF8BK);
+      compute(kt & 1);
+      if (kt + 1 < nk) lstore(S0{}, (kt & 1) ^ 1);
+      __syncthreads();
+    }
+  } else {
+  if (nk > 1) gload(S1{}, kF8BK);
+  lstore(S0{}, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even step: stage 0 holds kt; register set 0 is free -> kt + 2; set 1 holds kt + 1 -> stage 1
+    if (kt + 2 < nk) gload(S0{}, (kt + 2) * kF8BK);
+    compute(0);
+    if (kt + 1 < nk) lstore(S1{}, 1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // odd step: stage 1 holds kt + 1; set 1 is free -> kt + 3; set 0 holds kt + 2 -> stage 0
+    if (kt + 3 < nk) gload(S1{}, (kt + 3) * kF8BK);
+    compute(1);
+    if (kt + 2 < nk) lstore(S0{}, 0);
     __syncthreads();
   }
+  }
 
-  // epilogue: acc[i][j][r] = C[m0 + wm 64 + i 16 + (lane / 16) 4 + r][n0 + wn 64 + j 16 + lane % 16]
-  const int crow0 = m0 + wm * 64 + (lane >> 4) * 4, ccol0 = n0 + wn * 64 + (lane & 15);
+  // epilogue: acc[i][j][r] = C[m0 + wm 64 + i 16 + (lane / 16) 4 + r][n0 + wn (256 / WN) + j 16 + lane % 16]
+  const int crow0 = m0 + wm * 64 + (lane >> 4) * 4, ccol0 = n0 + wn * (kF8BN / WN) + (lane & 15);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -169,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(GemmFp8Params p) {
       const float sa = p.a_scale[row];
       if (EPI == CHATTS_EPI_SWIGLU) {          // column tiles alternate gate / up (W rows interleaved in blocks of 16)
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) {
+        for (int j = 0; j < FN; j += 2) {
           const int cg = ccol0 + j * 16, cu = cg + 16;
           if (cu >= p.n) continue;
           const float ar[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
@@ -180,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(GemmFp8Params p) {
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < FN; ++j) {
           const int col = ccol0 + j * 16;
           if (col >= p.n) continue;
           const float ar[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
@@ -192,6 +231,38 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(GemmFp8Params p) {
         }
       }
     }
+  }
+}
+
+template <int EPI>
+static void launch_fp8(const GemmFp8Params& p, hipStream_t s) {
+  // 256- or 128-row tiles: whole rounds of workgroups over the CUs decide (a 256-row tile-step costs ~1.9x a 128-row one)
+  const int cus = device_cus() > 0 ? device_cus() : 256;
+  const long nt = (p.n + kF8BN - 1) / kF8BN;
+  const long t256 = nt * ((p.m + 255) / 256), t128 = nt * ((p.m + 127) / 128);
+  // (the 256-row form spills ~40 registers as compiled by ROCm 7.2: priced accordingly until it is measured to win)
+  const double c256 = 2.2 * (double)((t256 + cus - 1) / cus), c128 = 1.0 * (double)((t128 + cus - 1) / cus);
+  int wm = c256 < c128 ? 4 : 2;
+  if (const char* e = getenv("CHATTS_FP8_BM")) wm = atoi(e) == 256 ? 4 : atoi(e) == 128 ? 2 : wm;
+  static bool attr_done = false;
+  if (!attr_done) {          // up to 147 KB of dynamic LDS: above the 64 KB default cap
+    const int big = 2 * (256 + kF8BN) * kF8Row, small = 2 * (128 + kF8BN) * kF8Row;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_NONE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_GELU, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_RESID, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_SWIGLU, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_NONE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, small);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_GELU, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, small);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_RESID, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, small);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_SWIGLU, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, small);
+    attr_done = true;
+  }
+  if (wm == 4) {
+    const dim3 grid((unsigned)nt, (p.m + 255) / 256);
+    hipLaunchKernelGGL((gemm_fp8_kernel<EPI, 4>), grid, dim3(kF8Threads), (size_t)2 * (256 + kF8BN) * kF8Row, s, p);
+  } else {
+    const dim3 grid((unsigned)nt, (p.m + 127) / 128);
+    hipLaunchKernelGGL((gemm_fp8_kernel<EPI, 2>), grid, dim3(kF8Threads), (size_t)2 * (128 + kF8BN) * kF8Row, s, p);
   }
 }
 
@@ -224,21 +295,11 @@ extern "C" int chatts_linear_fp8(const ChattsLinearFp8Args* a, chatts_stream_t s
   CHATTS_REQUIRE(a->ldc >= ncols, CHATTS_E_SHAPE, "linear_fp8: ldc=%d < %d", a->ldc, ncols);
   CHATTS_REQUIRE(a->epilogue != CHATTS_EPI_RESID || a->resid, CHATTS_E_BADARG, "linear_fp8: EPI_RESID without resid");
   GemmFp8Params p{a->a8, a->a_scale, a->w8, a->w_scale, a->bias, a->resid, a->c, a->m, a->n, a->k, a->lda8, a->ldw8, a->ldc};
-  const dim3 grid((a->n + kF8BN - 1) / kF8BN, (a->m + kF8BM - 1) / kF8BM);
-  const size_t lds = (size_t)2 * 2 * kF8Tile;
-  static bool attr_done = false;
-  if (!attr_done) {          // 73 KB of dynamic LDS: above the 64 KB default cap
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<CHATTS_EPI_SWIGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
   switch (a->epilogue) {
-    case CHATTS_EPI_GELU: hipLaunchKernelGGL(gemm_fp8_kernel<CHATTS_EPI_GELU>, grid, dim3(256), lds, as_stream(stream), p); break;
-    case CHATTS_EPI_RESID: hipLaunchKernelGGL(gemm_fp8_kernel<CHATTS_EPI_RESID>, grid, dim3(256), lds, as_stream(stream), p); break;
-    case CHATTS_EPI_SWIGLU: hipLaunchKernelGGL(gemm_fp8_kernel<CHATTS_EPI_SWIGLU>, grid, dim3(256), lds, as_stream(stream), p); break;
-    case CHATTS_EPI_NONE: hipLaunchKernelGGL(gemm_fp8_kernel<CHATTS_EPI_NONE>, grid, dim3(256), lds, as_stream(stream), p); break;
+    case CHATTS_EPI_GELU: launch_fp8<CHATTS_EPI_GELU>(p, as_stream(stream)); break;
+    case CHATTS_EPI_RESID: launch_fp8<CHATTS_EPI_RESID>(p, as_stream(stream)); break;
+    case CHATTS_EPI_SWIGLU: launch_fp8<CHATTS_EPI_SWIGLU>(p, as_stream(stream)); break;
+    case CHATTS_EPI_NONE: launch_fp8<CHATTS_EPI_NONE>(p, as_stream(stream)); break;
     default: CHATTS_REQUIRE(false, CHATTS_E_BADARG, "linear_fp8: epilogue %d", a->epilogue);
   }
   CHATTS_CHECK_LAUNCH("gemm_fp8");
