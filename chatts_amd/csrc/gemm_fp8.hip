@@ -12,8 +12,8 @@
 //     activation quantisation;
 //   * gemm_fp8_kernel: C[m, n] = epilogue(sa[m] * sw[n] * sum_k A8[m, k] W8[n, k]) with v_mfma_scale_f32_16x16x128_f8f6f4 (both
 //     operand formats e4m3, block scales fixed to 1.0: the instruction is the only fp8 form that runs at twice the bf16 rate) - 256 x
-//     256 x 128 or 128 x 256 x 128 tiles, 8 waves, operands staged global -> registers -> LDS (rows padded to 144 bytes: the 32-byte
-//     fragment reads of 16 rows spread over the banks), the global loads of the K-step after next in flight under the MFMAs.
+//     256 x 128 or 128 x 256 x 128 tiles, 8 waves, operands staged global -> registers -> LDS (XOR-swizzled 128-byte rows: conflict-free
+//     fragment reads), the global loads of the K-step after next in flight under the MFMAs.
 //     Weights: the per-row power-of-two-scaled e4m3 copies the fp8 decode path already streams (ChattsLinearArgs.w8).
 #include <type_traits>
 
@@ -83,7 +83,12 @@ struct GemmFp8Params {
 };
 
 constexpr int kF8BN = 256, kF8BK = 128;                     // BK in bytes = fp8 values per MFMA step
-constexpr int kF8Row = kF8BK + 16;                          // padded LDS row (bytes): the 32-byte fragment reads of 16 rows spread over the banks
+constexpr int kF8Row = kF8BK;                               // LDS rows of 128 bytes; 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7)
+// (the bf16 LDS-DMA kernel's swizzle, gemm.hip).  A lane group g = lane / 16 of a fragment takes chunks g and g + 4 of its row - the
+// instruction pairs equal byte positions of equal lane groups in A and B, so WHICH 32 of the 128 K bytes a group holds is free as long
+// as both operands agree - and with that choice every 16-lane service group of both ds_read_b128 touches 16 distinct 16-byte bank
+// groups.  (First version: contiguous 32 bytes per lane, rows padded to 144 bytes: SQ_LDS_BANK_CONFLICT = 36 % of the LDS cycles.)
+__device__ __forceinline__ int f8_lds_off(int r, int c) { return r * kF8BK + ((c ^ ((r >> 1) & 7)) << 4); }
 constexpr int kF8Threads = 512;
 
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
@@ -102,7 +107,13 @@ __global__ __launch_bounds__(kF8Threads) void gemm_fp8_kernel(GemmFp8Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 stages][A tile | W tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int n0 = blockIdx.x * kF8BN, m0 = blockIdx.y * BM;
+  // Tile order.  Workgroup b runs on XCD b % 8 and every XCD has its own L2, so the (W panel major, M-tile minor) sequence is cut into
+  // 8 contiguous ranges, one per XCD: the M-tiles of a panel run side by side on ONE XCD and its L2 fetches the panel once (with the
+  // N-major order of the first version every M-tile re-streamed all of W: 8 x 141 MB for gate_up at M = 1024 - an HBM-bound GEMM).
+  const int mt_count = (p.m + BM - 1) / BM, nt_count = (p.n + kF8BN - 1) / kF8BN, total = mt_count * nt_count;
+  const int per_xcd = (total + 7) / 8, idx = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || idx >= total) return;
+  const int n0 = (idx / mt_count) * kF8BN, m0 = (idx % mt_count) * BM;
   // staging: thread t moves 16-byte piece (row t / 8 + 64 j, column block t % 8) of A (j < NA) and of W (j < 4)
   const int srow = tid >> 3, scol = (tid & 7) * 16;
   const uint8_t* ag[NA];
@@ -133,9 +144,9 @@ __global__ __launch_bounds__(kF8Threads) void gemm_fp8_kernel(GemmFp8Params p) {
     char* at = smem + (size_t)stage * STAGE;
     char* wt = at + A_TILE;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) *reinterpret_cast<i32x4*>(at + (srow + 64 * j) * kF8Row + scol) = ra[S][j];
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<i32x4*>(at + f8_lds_off(srow + 64 * j, tid & 7)) = ra[S][j];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<i32x4*>(wt + (srow + 64 * j) * kF8Row + scol) = rw[S][j];
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<i32x4*>(wt + f8_lds_off(srow + 64 * j, tid & 7)) = rw[S][j];
   };
   f32x4 acc[4][FN];
 #pragma unroll
@@ -143,21 +154,22 @@ __global__ __launch_bounds__(kF8Threads) void gemm_fp8_kernel(GemmFp8Params p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // fragment addresses: lane l holds row (l % 16) of a 16-row block, K bytes 32 (l / 16) .. + 31 (A and W alike: the instruction pairs
-  // equal byte positions of equal lane groups)
-  const int frow = lane & 15, fcol = (lane >> 4) * 32;
+  // fragment addresses: lane l holds row (l % 16) of a 16-row block and the 16-byte chunks g, g + 4 of its K bytes (g = l / 16); row
+  // blocks start at multiples of 16, so the swizzle term (r >> 1) & 7 of a lane is the same for every block
+  const int frow = lane & 15, fg = lane >> 4, fsw = (frow >> 1) & 7;
+  const int fo0 = frow * kF8BK + ((fg ^ fsw) << 4), fo1 = frow * kF8BK + (((fg + 4) ^ fsw) << 4);
   auto compute = [&](int stage) {
-    const char* at = smem + (size_t)stage * STAGE + (size_t)(wm * 64 + frow) * kF8Row + fcol;
-    const char* wt = smem + (size_t)stage * STAGE + A_TILE + (size_t)(wn * (kF8BN / WN) + frow) * kF8Row + fcol;
+    const char* at = smem + (size_t)stage * STAGE + (size_t)(wm * 64) * kF8Row;
+    const char* wt = smem + (size_t)stage * STAGE + A_TILE + (size_t)(wn * (kF8BN / WN)) * kF8Row;
     i32x8 af[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const i32x4 lo = *reinterpret_cast<const i32x4*>(at + i * 16 * kF8Row), hi = *reinterpret_cast<const i32x4*>(at + i * 16 * kF8Row + 16);
+      const i32x4 lo = *reinterpret_cast<const i32x4*>(at + i * 16 * kF8Row + fo0), hi = *reinterpret_cast<const i32x4*>(at + i * 16 * kF8Row + fo1);
       af[i] = (i32x8){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      const i32x4 lo = *reinterpret_cast<const i32x4*>(wt + j * 16 * kF8Row), hi = *reinterpret_cast<const i32x4*>(wt + j * 16 * kF8Row + 16);
+      const i32x4 lo = *reinterpret_cast<const i32x4*>(wt + j * 16 * kF8Row + fo0), hi = *reinterpret_cast<const i32x4*>(wt + j * 16 * kF8Row + fo1);
       const i32x8 bf = (i32x8){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(kF8Threads) void gemm_fp8_kernel(GemmFp8Params p) {
       if (kt + 1 < nk) gload(S0{}, (kt + 1) * kF8BK);
       compute(kt & 1);
       if (kt + 1 < nk) lstore(S0{}, (kt & 1) ^ 1);
-      __syncthreads();
+      __syncthreads();          // (one register set: the store has to wait for this step's loads, it cannot move ahead of the MFMAs)
     }
   } else {
   if (nk > 1) gload(S1{}, kF8BK);
@@ -184,6 +196,8 @@ __global__ __launch_bounds__(kF8Threads) void gemm_fp8_kernel(GemmFp8Params p) {
   __syncthreads();
   for (int kt = 0; kt < nk; kt += 2) {
     // even step: stage 0 holds kt; register set 0 is free -> kt + 2; set 1 holds kt + 1 -> stage 1
+    // (moving the LDS stores of the next stage AHEAD of this step's MFMAs was measured: 367 -> 407 us for the 8192 x 5120 x 5120
+    //  layer - the stores then wait for global loads that are only one step old; behind the MFMAs the loads have had two steps)
     if (kt + 2 < nk) gload(S0{}, (kt + 2) * kF8BK);
     compute(0);
     if (kt + 1 < nk) lstore(S1{}, 1);
@@ -258,10 +272,10 @@ static void launch_fp8(const GemmFp8Params& p, hipStream_t s) {
     attr_done = true;
   }
   if (wm == 4) {
-    const dim3 grid((unsigned)nt, (p.m + 255) / 256);
+    const dim3 grid((unsigned)((t256 + 7) / 8 * 8));
     hipLaunchKernelGGL((gemm_fp8_kernel<EPI, 4>), grid, dim3(kF8Threads), (size_t)2 * (256 + kF8BN) * kF8Row, s, p);
   } else {
-    const dim3 grid((unsigned)nt, (p.m + 127) / 128);
+    const dim3 grid((unsigned)((t128 + 7) / 8 * 8));
     hipLaunchKernelGGL((gemm_fp8_kernel<EPI, 2>), grid, dim3(kF8Threads), (size_t)2 * (128 + kF8BN) * kF8Row, s, p);
   }
 }

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; O=gpurun_out; R=$PWD
 timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "fp8_speed or quantize_rows_fp8" > $O/r4i_fp8_tests.log 2>&1; echo "fp8 kernel tests rc=$?"; tail -4 $O/r4i_fp8_tests.log | cut -c1-300
 timeout 900 python tools/fp8_speed_mode.py > $O/r4i_fp8_mode.log 2>&1; echo "fp8 speed mode rc=$?"; tail -1 $O/r4i_fp8_mode.log | cut -c1-1200
-CHATTS_FP8_BM=256 timeout 900 python tools/fp8_speed_mode.py 12 > $O/r4i_fp8_mode_bm256.log 2>&1; echo "bm256 (12 layers)"; tail -1 $O/r4i_fp8_mode_bm256.log | cut -c1-700
+
 CHATTS_FP8_BM=128 timeout 900 python tools/fp8_speed_mode.py 12 > $O/r4i_fp8_mode_bm128.log 2>&1; echo "bm128 (12 layers)"; tail -1 $O/r4i_fp8_mode_bm128.log | cut -c1-700
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/kt9
 timeout 600 rocprofv3 --kernel-trace -d /tmp/kt9 -o p -- python $R/tools/fp8_speed_mode.py 4 > /tmp/kt9.log 2>&1; echo "rocprof rc=$?"

@@ -16,7 +16,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+OUT = os.environ.get("PMC_TRAFFIC_OUT") or os.path.join(ROOT, "profiles", "pmc_traffic.json")      # (a GPU-box job writes under gpurun_out/)
 GEMV_FILES = ["chatts_amd/csrc/gemv.hip", "chatts_amd/csrc/gemv_common.h", "chatts_amd/csrc/tp_common.h", "chatts_amd/csrc/common.h"]
 TS_FILES = ["chatts_amd/csrc/gemm.hip", "chatts_amd/csrc/ts_frontend.hip", "chatts_amd/csrc/common.h"]
 BATCHED_FILES = ["chatts_amd/csrc/gemm.hip", "chatts_amd/csrc/attention.hip", "chatts_amd/csrc/attn_decode.h", "chatts_amd/csrc/common.h"]
@@ -39,11 +39,13 @@ def counter_rows(db):
 
 
 def load():
-    try:
-        with open(OUT) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return {}
+    for path in (OUT, os.path.join(ROOT, "profiles", "pmc_traffic.json")):
+        try:
+            with open(path) as f:
+                return json.load(f)
+        except (OSError, ValueError):
+            continue
+    return {}
 
 
 def save(d):
@@ -87,6 +89,22 @@ def ts(db, cmd, src):
         print(k)
 
 
+def batched(db, cmd, src, key="14b_8x1024_fp8_b16"):
+    rows = counter_rows(db)
+    gu = max((r for r in rows if "gemm_stream_kernel" in r[0]), key=lambda r: r[4])         # gate_up: the weight stream with the most bytes
+    at = max((r for r in rows if "attn_decode_kernel" in r[0]), key=lambda r: r[4])
+    d = load()
+    inter, B = 13824, 16
+    d.setdefault("batched", {})[key] = {
+        "source": f"{src} ({cmd}, MI355X, round 4)", "code_digest": code_digest(BATCHED_FILES), "code_files": BATCHED_FILES,
+        "kernel": f"{gu[0].split('(')[0].replace('void chatts::', '')} (gate_up_proj + SwiGLU, M = {B}, grid {gu[1]})",
+        "fetch_size_kib_per_launch": round(gu[4], 1), "gfx950_fetch_correction": 2.0, "write_bytes_per_launch": B * inter * 2 * 2,
+        "hbm_bytes_per_launch": int(gu[4] * 1024 * 2 + B * inter * 4), "algorithmic_bytes_per_launch": 143208448,
+        "attn_decode_kernel": {"fetch_size_kib_per_launch": round(at[4], 1), "hbm_bytes_per_launch": int(at[4] * 1024 * 2), "avg_us_under_pmc": round(at[5], 2)}}
+    save(d)
+    print(json.dumps(d["batched"][key]))
+
+
 def ts_run():
     """the TS encoder alone, N calls (what the ts pass profiles): bench.py's inputs, a 1-layer decoder to keep the build short"""
     sys.path.insert(0, ROOT)
@@ -113,6 +131,8 @@ if __name__ == "__main__":
         headline(*sys.argv[2:5])
     elif what == "ts":
         ts(*sys.argv[2:5])
+    elif what == "batched":
+        batched(*sys.argv[2:5])
     elif what == "digest":
         print(code_digest(GEMV_FILES), code_digest(TS_FILES), code_digest(BATCHED_FILES))
     else:
