@@ -80,6 +80,7 @@ struct GemmFp8Params {
   const float* resid;      // [M, ldc] (EPI_RESID)
   float* c;                // [M, ldc]  (SWIGLU: [M, N / 2])
   int m, n, k, lda, ldw, ldc;
+  int order;               // 0: N-tile fastest (consecutive workgroups share the A tile); 1: 8 contiguous (panel major, M-tile minor) ranges, one per XCD
 };
 
 constexpr int kF8BN = 256, kF8BK = 128;                     // BK in bytes = fp8 values per MFMA step
@@ -111,9 +112,16 @@ __global__ __launch_bounds__(kF8Threads) void gemm_fp8_kernel(GemmFp8Params p) {
   // 8 contiguous ranges, one per XCD: the M-tiles of a panel run side by side on ONE XCD and its L2 fetches the panel once (with the
   // N-major order of the first version every M-tile re-streamed all of W: 8 x 141 MB for gate_up at M = 1024 - an HBM-bound GEMM).
   const int mt_count = (p.m + BM - 1) / BM, nt_count = (p.n + kF8BN - 1) / kF8BN, total = mt_count * nt_count;
-  const int per_xcd = (total + 7) / 8, idx = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per_xcd || idx >= total) return;
-  const int n0 = (idx / mt_count) * kF8BN, m0 = (idx % mt_count) * BM;
+  const int per_xcd = (total + 7) / 8;
+  int idx = (int)blockIdx.x, n0, m0;
+  if (p.order) {
+    idx = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || idx >= total) return;
+    n0 = (idx / mt_count) * kF8BN; m0 = (idx % mt_count) * BM;
+  } else {
+    if (idx >= total) return;
+    n0 = (idx % nt_count) * kF8BN; m0 = (idx / nt_count) * BM;
+  }
   // staging: thread t moves 16-byte piece (row t / 8 + 64 j, column block t % 8) of A (j < NA) and of W (j < 4)
   const int srow = tid >> 3, scol = (tid & 7) * 16;
   const uint8_t* ag[NA];
@@ -308,7 +316,8 @@ extern "C" int chatts_linear_fp8(const ChattsLinearFp8Args* a, chatts_stream_t s
   const int ncols = a->epilogue == CHATTS_EPI_SWIGLU ? a->n / 2 : a->n;
   CHATTS_REQUIRE(a->ldc >= ncols, CHATTS_E_SHAPE, "linear_fp8: ldc=%d < %d", a->ldc, ncols);
   CHATTS_REQUIRE(a->epilogue != CHATTS_EPI_RESID || a->resid, CHATTS_E_BADARG, "linear_fp8: EPI_RESID without resid");
-  GemmFp8Params p{a->a8, a->a_scale, a->w8, a->w_scale, a->bias, a->resid, a->c, a->m, a->n, a->k, a->lda8, a->ldw8, a->ldc};
+  static const int order = getenv("CHATTS_FP8_ORDER") ? atoi(getenv("CHATTS_FP8_ORDER")) : 1;
+  GemmFp8Params p{a->a8, a->a_scale, a->w8, a->w_scale, a->bias, a->resid, a->c, a->m, a->n, a->k, a->lda8, a->ldw8, a->ldc, order};
   switch (a->epilogue) {
     case CHATTS_EPI_GELU: launch_fp8<CHATTS_EPI_GELU>(p, as_stream(stream)); break;
     case CHATTS_EPI_RESID: launch_fp8<CHATTS_EPI_RESID>(p, as_stream(stream)); break;

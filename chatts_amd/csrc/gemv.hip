@@ -726,11 +726,16 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   if (!a->tp_reduce && rows == 2 && unr == 2 && nchunks >= 4) {
     int ks = 1;
     const double per_cu = (double)p.tasks / cus;
+    const int rounds = (nchunks + 1) / 2;                   // chunk pairs of a row: a wave should keep at least one
     if (per_cu < 6.0) {
       ks = (int)(12.0 / (per_cu > 0.25 ? per_cu : 0.25) + 0.999);
-      const int rounds = (nchunks + 1) / 2;                 // chunk pairs of a row: a wave should keep at least one
       if (ks > rounds) ks = rounds;
       if (ks > 8) ks = 8;
+    } else if (per_cu < 16.0 && (double)a->n * a->k * 2.0 < 48e6) {
+      // a SHARD-sized matrix whose row groups alone half-fill the chip (gate_up of a TP = 8 rank: 35 MB, 13.5 waves per CU): every wave
+      // still walks K / 1024 dependent round trips; one chunk pair per wave measured 1.2 us per launch better (profiles/r4_tp_shard_step*).
+      // The 48 MB bound keeps every TP = 1 shape (o_proj: 52 MB, 10 waves per CU) on the whole-K kernel.
+      ks = rounds > 8 ? 8 : rounds;
     }
     ks = env_int("CHATTS_GEMV_KS", ks);
     if (ks > 16) ks = 16;
