@@ -826,7 +826,7 @@ int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int 
                                   const float* k_norm_w, float norm_eps, const float* cos_tab, const float* sin_tab, int pos,
                                   const int32_t* pos_dev, const ChattsKvCache* cache, size_t seq_stride, float* out,
                                   uint16_t* out_hi, uint16_t* out_lo, int n_splits, void* workspace, size_t workspace_bytes,
-                                  chatts_stream_t stream) {
+                                  chatts_stream_t stream, const SlabOut* slabs) {
   CHATTS_REQUIRE(batch >= 1 && n_q > 0 && n_kv > 0 && n_splits >= 1 && n_splits <= kMaxSlots, CHATTS_E_BADARG,
                  "attention_decode: bad sizes (batch >= 1, 1 <= n_splits <= %d)", kMaxSlots);
   CHATTS_REQUIRE(qkv_raw && (out || (out_hi && out_lo)) && cos_tab && sin_tab && cache && cache->k && cache->v, CHATTS_E_BADARG,
@@ -844,6 +844,9 @@ int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int 
   if (const int rc = bind_cache(p, cache)) return rc;
   p.q_norm_w = q_norm_w; p.k_norm_w = k_norm_w; p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.eps = norm_eps;
   p.seq_stride = seq_stride; p.out_hi = out_hi; p.out_lo = out_lo; p.kv_round = kv_round_mode();
+  if (slabs && slabs->sk > 0) {      // qkv_raw = the projection's split-K slabs (same workspace: the partials go behind them, see the caller)
+    p.qkv_sk = slabs->sk; p.qkv_plane = slabs->plane; p.qkv_scale = slabs->scale; p.qkv_bias = slabs->bias;
+  }
   // Workgroup form (attn_decode_wg_kernel): one launch, partials merged in LDS - for caches of up to 8 tiles per wave (2048 positions
   // at 16 waves; groups of 6..8 query heads run 8 waves for their registers: 1024 positions).  One workgroup per (kv head, sequence)
   // means one CU pulls a sequence's whole K / V: fine when n_kv x batch workgroups cover the chip (batched decode), a per-CU bandwidth
@@ -888,7 +891,7 @@ extern "C" int chatts_attention_decode_batched(const float* qkv_raw, int batch, 
                                                void* workspace, size_t workspace_bytes, chatts_stream_t stream) {
   return chatts::attention_decode_batched_impl(qkv_raw, batch, n_q, n_kv, q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos,
                                                pos_dev, cache, seq_stride, out, nullptr, nullptr, n_splits, workspace,
-                                               workspace_bytes, stream);
+                                               workspace_bytes, stream, nullptr);
 }
 
 extern "C" int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int n_kv, const float* q_norm_w,

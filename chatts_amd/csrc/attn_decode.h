@@ -33,6 +33,12 @@ struct AttnParams {
   // sequence b looks its blocks up in table + b * table_stride, seq_stride is not used
   const int32_t* table;
   int log_block, table_stride;
+  // decode, optional: qkv is not a finished [T, n] buffer but the split-K partial slabs of the projection (SlabOut, common.h): element
+  // (seq, col) = (sum_{s < qkv_sk} qkv[s * qkv_plane + seq * n + col]) (* qkv_scale[col]) (+ qkv_bias[col]); qkv_sk == 0: plain buffer
+  const float* qkv_scale;
+  const float* qkv_bias;
+  int qkv_sk;
+  size_t qkv_plane;
   uint16_t* out_hi;    // decode combine, optional: the output as bf16 hi / lo planes [T, n_q * 128] (the o_proj operand of the
   uint16_t* out_lo;    // weight-streaming kernel) instead of float32 `out`
   int kv_round;        // experiment knob, see kv_round_f (0 = off)
@@ -147,7 +153,18 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
   const int G = p.n_q / p.n_kv;
   const int pos = t.pos;
   const int ntiles = pos / kDTile + 1;
-  const float* qkv = p.qkv + (size_t)seq * (p.n_q + 2 * p.n_kv) * kHeadDim;
+  const int qkv_n = (p.n_q + 2 * p.n_kv) * kHeadDim;
+  const float* qkv = p.qkv + (size_t)seq * qkv_n;
+  // element `col` of this sequence's projection row: read, or summed from the projection's split-K slabs in split order, then the
+  // 8-bit copy's column scale and the bias - splitk_epilogue_v4_kernel's arithmetic, whose launch this replaces
+  auto qkv_at = [&](const int col) __attribute__((always_inline)) -> float {
+    if (p.qkv_sk == 0) return qkv[col];
+    float v = 0.f;
+    for (int s = 0; s < p.qkv_sk; ++s) v += qkv[(size_t)s * p.qkv_plane + col];
+    if (p.qkv_scale) v *= p.qkv_scale[col];
+    if (p.qkv_bias) v += p.qkv_bias[col];
+    return v;
+  };
   float* kcache = p.kc + (p.table ? 0 : (size_t)seq * p.seq_stride);
   float* vcache = p.vc + (p.table ? 0 : (size_t)seq * p.seq_stride);
   const KvLayout kvl{p.table ? p.table + (size_t)seq * p.table_stride : nullptr, p.n_kv, p.max_ctx, p.log_block};
@@ -163,16 +180,16 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
 #pragma unroll
     for (int g = 0; g < GMAX; ++g) {
       if (g < gn) {
-        const float* src = qkv + (size_t)(hk * G + g0 + g) * kHeadDim;
-        float a = src[lane], b = src[lane + 64];
+        const int src = (hk * G + g0 + g) * kHeadDim;
+        float a = qkv_at(src + lane), b = qkv_at(src + lane + 64);
         norm_rope(a, b, p.q_norm_w, p.eps, c, s, lane);
         q_s[g * kHeadDim + lane] = a;
         q_s[g * kHeadDim + lane + 64] = b;
       }
     }
     if (owner) {                                // the new K/V row: to the cache and to LDS
-      const float* ks = qkv + (size_t)(p.n_q + hk) * kHeadDim;
-      float a = ks[lane], b = ks[lane + 64];
+      const int ks = (p.n_q + hk) * kHeadDim;
+      float a = qkv_at(ks + lane), b = qkv_at(ks + lane + 64);
       norm_rope(a, b, p.k_norm_w, p.eps, c, s, lane);
       a = kv_round_f(a, p.kv_round); b = kv_round_f(b, p.kv_round);
       knew_s[lane] = a;
@@ -180,8 +197,8 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
       const size_t noff = kv_tile_off(kvl, hk, pos);      // row of the new token
       float* kd = kcache + noff;
       if (g0 == 0) { kd[lane] = a; kd[lane + 64] = b; }
-      const float* vs = qkv + (size_t)(p.n_q + p.n_kv + hk) * kHeadDim;
-      const float va = kv_round_f(vs[lane], p.kv_round), vb = kv_round_f(vs[lane + 64], p.kv_round);
+      const int vs = (p.n_q + p.n_kv + hk) * kHeadDim;
+      const float va = kv_round_f(qkv_at(vs + lane), p.kv_round), vb = kv_round_f(qkv_at(vs + lane + 64), p.kv_round);
       vnew_s[lane] = va;
       vnew_s[lane + 64] = vb;
       float* vd = vcache + noff;

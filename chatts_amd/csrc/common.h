@@ -154,6 +154,16 @@ struct RopeFuse {
 // `row` = this head's 128 floats of the qkv buffer (q is written back there)
 __device__ __forceinline__ void rope_kv_head(float a, float b, int h, int pos, int lane, float* row, const RopeFuse& r);
 
+// A projection whose split-K partial slabs are LEFT in the workspace for its consumer to sum (the batched decode attention reads the
+// qkv projection that way: one launch less per layer).  Filled by launch_gemm when it skipped the epilogue: element (row, col) =
+// (sum over s < sk of ws[s * plane + row * n + col]) (* scale[col]) (+ bias[col]) - splitk_epilogue_v4_kernel's arithmetic and order.
+struct SlabOut {
+  int sk;                 // 0: the epilogue ran as usual (c holds the result)
+  size_t plane;           // floats per slab (m * n)
+  const float* scale;     // per-column scale of an 8-bit weight copy, or null
+  const float* bias;
+};
+
 inline hipStream_t as_stream(chatts_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 int device_cus();

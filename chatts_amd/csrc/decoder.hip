@@ -10,11 +10,11 @@
 
 namespace chatts {
 int launch_gemv(const ChattsLinearArgs* a, hipStream_t s);
-int launch_gemm(const ChattsLinearArgs* a, hipStream_t s, const RopeFuse* rope = nullptr, bool* rope_done = nullptr);
+int launch_gemm(const ChattsLinearArgs* a, hipStream_t s, const RopeFuse* rope = nullptr, bool* rope_done = nullptr, SlabOut* slabs = nullptr);
 int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w, const float* k_norm_w,
                                   float norm_eps, const float* cos_tab, const float* sin_tab, int pos, const int32_t* pos_dev,
                                   const ChattsKvCache* cache, size_t seq_stride, float* out, uint16_t* out_hi, uint16_t* out_lo,
-                                  int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream);
+                                  int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream, const SlabOut* slabs = nullptr);
 int attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev, const ChattsKvCache* cache, float* out,
                    uint16_t* out_hi, uint16_t* out_lo, int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream);
 int launch_split_bf16x2(const float* x, int m, int k, int ldx, uint16_t* hi, uint16_t* lo, int ldp, hipStream_t s);
@@ -47,12 +47,13 @@ static int64_t embed_offset(const ChattsDecoder* d) { return d->cfg.embed_rows >
 
 extern "C" size_t chatts_linear_workspace(int m, int n, int k) { return gemm_workspace(m, n, k); }
 
-static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const RopeFuse* rope, bool* rope_done);
+static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const RopeFuse* rope, bool* rope_done, SlabOut* slabs = nullptr);
 extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) { return linear_impl(a, stream, nullptr, nullptr); }
 
 // rope / rope_done: the qkv projection of a prefill chunk may carry rope_kv_kernel's work in its split-K epilogue (*rope_done says
 // whether it did; otherwise the caller launches chatts_rope_kv_write as before)
-static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const RopeFuse* rope, bool* rope_done) {
+static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const RopeFuse* rope, bool* rope_done, SlabOut* slabs) {
+  if (slabs) slabs->sk = 0;
   CHATTS_REQUIRE(a != nullptr, CHATTS_E_BADARG, "linear: null args");
   CHATTS_REQUIRE(a->m >= 0 && a->n > 0 && a->k > 0, CHATTS_E_BADARG, "linear: bad sizes m=%d n=%d k=%d", a->m, a->n, a->k);
   if (a->m == 0) return CHATTS_OK;
@@ -92,7 +93,7 @@ static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const 
   if (a->tp_reduce) CHATTS_REQUIRE(a->m == 1, CHATTS_E_BADARG, "linear: tp_reduce is available for M == 1 (the decode GEMV) only");
   if (a->m == 1 && a->epilogue != CHATTS_EPI_GELU) return launch_gemv(a, as_stream(stream));
   CHATTS_REQUIRE(a->norm_w == nullptr, CHATTS_E_BADARG, "linear: fused RMSNorm is only available for M == 1");
-  return launch_gemm(a, as_stream(stream), rope, rope_done);
+  return launch_gemm(a, as_stream(stream), rope, rope_done, slabs);
 }
 
 extern "C" int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, chatts_bf16* lo, int ld_planes,
@@ -496,13 +497,22 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H; la.w8_format = d->cfg.w8_format;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
     if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
-    if ((rc = chatts_linear(&la, stream)) != 0) return rc;
+    // The attention kernel can sum the projection's split-K slabs itself while it loads q / k / v (SlabOut): the projection then
+    // skips its epilogue launch (~5 us per layer at 16 sequences).  The slabs stay at the head of the workspace, the attention
+    // partials go behind them - when the workspace holds both.  CHATTS_QKV_FOLD=0: the separate epilogue.
+    const size_t slab_room = (gemm_workspace(batch, qkv_n, H) + 255) / 256 * 256;
+    const bool fold_off = getenv("CHATTS_QKV_FOLD") && atoi(getenv("CHATTS_QKV_FOLD")) == 0;      // (read per call: tests A/B it in one process)
+    const bool fold = !fold_off && batch >= 2 && slab_room + chatts_attn_workspace(batch, c.n_q, n_splits) <= d->b.workspace_bytes;
+    SlabOut so{};
+    if ((rc = linear_impl(&la, stream, nullptr, nullptr, fold ? &so : nullptr)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, 0);
     const bool attn_planes = planes_path(d, batch, c.n_q * kHeadDim, lw.o8 != nullptr);   // the combine writes o_proj's operand format
-    if ((rc = attention_decode_batched_impl(d->b.qkv, batch, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
-                                            d->w.sin_tab, 0, pos_dev, &kc, seq_stride(d), d->b.attn,
-                                            attn_planes ? d->b.planes_hi : nullptr, attn_planes ? d->b.planes_lo : nullptr,
-                                            n_splits, d->b.workspace, d->b.workspace_bytes, stream)) != 0) return rc;
+    const bool folded = so.sk > 0;
+    if ((rc = attention_decode_batched_impl(folded ? reinterpret_cast<const float*>(d->b.workspace) : d->b.qkv, batch, c.n_q, c.n_kv,
+                                            lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, 0, pos_dev, &kc, seq_stride(d),
+                                            d->b.attn, attn_planes ? d->b.planes_hi : nullptr, attn_planes ? d->b.planes_lo : nullptr,
+                                            n_splits, static_cast<char*>(d->b.workspace) + (folded ? slab_room : 0),
+                                            d->b.workspace_bytes - (folded ? slab_room : 0), stream, folded ? &so : nullptr)) != 0) return rc;
     la = ChattsLinearArgs{};
     la.a = d->b.attn; la.w = lw.o; la.m = batch; la.n = H; la.k = c.n_q * kHeadDim;
     la.lda = la.k; la.ldw = la.k; la.ldc = H;

@@ -1442,7 +1442,8 @@ static int launch_dma(const GemmParams& p, const ChattsLinearArgs* a, int sk, hi
   return w32 ? launch_dma_t<false, true>(p, a, sk, s) : launch_dma_t<false, false>(p, a, sk, s);
 }
 
-int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rope, bool* rope_done) {
+int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rope, bool* rope_done, SlabOut* slabs) {
+  if (slabs) slabs->sk = 0;
   int bm, sk;
   ChattsLinearArgs a_copy;
   const ChattsLinearArgs* a = a_in;
@@ -1559,6 +1560,11 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
                        sk, a->m, a->n, a->bias, a->c, a->ldc, *rope);
     CHATTS_CHECK_LAUNCH("splitk_epilogue_rope");
     *rope_done = true;
+    return CHATTS_OK;
+  }
+  if (slabs && sk > 1 && sk <= 8 && a->epilogue == CHATTS_EPI_NONE && !post_norm && !a->c_hi && p.sk_T == 0) {
+    // the consumer sums the slabs itself (SlabOut): no epilogue launch
+    slabs->sk = sk; slabs->plane = (size_t)a->m * a->n; slabs->scale = a->w8 ? a->w8_scale : nullptr; slabs->bias = a->bias;
     return CHATTS_OK;
   }
   if (sk > 1 && sk <= 8 && a->epilogue != CHATTS_EPI_SWIGLU && p.sk_T == 0 && a->n % 4 == 0 && a->ldc % 4 == 0 &&

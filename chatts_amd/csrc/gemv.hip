@@ -731,10 +731,12 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
       ks = (int)(12.0 / (per_cu > 0.25 ? per_cu : 0.25) + 0.999);
       if (ks > rounds) ks = rounds;
       if (ks > 8) ks = 8;
-    } else if (per_cu < 16.0 && (double)a->n * a->k * 2.0 < 48e6) {
+    } else if (norm && per_cu < 16.0 && (double)a->n * a->k * 2.0 < 48e6) {
       // a SHARD-sized matrix whose row groups alone half-fill the chip (gate_up of a TP = 8 rank: 35 MB, 13.5 waves per CU): every wave
       // still walks K / 1024 dependent round trips; one chunk pair per wave measured 1.2 us per launch better (profiles/r4_tp_shard_step*).
-      // The 48 MB bound keeps every TP = 1 shape (o_proj: 52 MB, 10 waves per CU) on the whole-K kernel.
+      // The 48 MB bound keeps every TP = 1 shape (o_proj: 52 MB, 10 waves per CU) on the whole-K kernel; `norm` restricts the rule to
+      // the column-parallel projections (qkv, gate_up: RMSNorm in the prologue) - the row-parallel ones (o_proj, down_proj) must sum
+      // a row in the same order whether or not they carry the exchange (tp_reduce), which the K-split form does not implement.
       ks = rounds > 8 ? 8 : rounds;
     }
     ks = env_int("CHATTS_GEMV_KS", ks);

@@ -350,6 +350,10 @@ class ChatTSForCausalLM:
         for m in range(2, self.max_batch + 1):     # batched lm_head
             ws_bytes = max(ws_bytes, int(lib.chatts_linear_workspace(m, plan.vocab, H)))
         ws_bytes = max(ws_bytes, int(lib.chatts_attn_workspace(self.max_batch, plan.nq, self.n_splits)) + 256)
+        if self.max_batch > 1:       # batched steps keep the qkv projection's split-K slabs AND the attention partials in the workspace
+            qn = (plan.nq + 2 * plan.nkv) * d
+            slab = max(int(lib.chatts_linear_workspace(m, qn, H)) for m in range(2, self.max_batch + 1))
+            ws_bytes = max(ws_bytes, slab + 512 + int(lib.chatts_attn_workspace(self.max_batch, plan.nq, self.n_splits)))
         MB = self.max_batch
         f32 = dict(dtype=torch.float32, device=dev)
         qkv_n = (plan.nq + 2 * plan.nkv) * d
