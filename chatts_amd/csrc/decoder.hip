@@ -498,11 +498,13 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
     if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
     // The attention kernel can sum the projection's split-K slabs itself while it loads q / k / v (SlabOut): the projection then
-    // skips its epilogue launch (~5 us per layer at 16 sequences).  The slabs stay at the head of the workspace, the attention
-    // partials go behind them - when the workspace holds both.  CHATTS_QKV_FOLD=0: the separate epilogue.
+    // skips its epilogue launch.  The slabs stay at the head of the workspace, the attention partials go behind them - when the
+    // workspace holds both.  OPT-IN (CHATTS_QKV_FOLD=1): measured SLOWER at config 5 - 6.79 against 6.15 ms per step - every one of the
+    // 16 key-slot waves of a (kv head, sequence) repeats the 5 x sk slab loads of its group's q rows on its critical path, which
+    // costs more than the 5 us launch it removes (profiles/r4_qkv_fold_ab.txt).  Same tokens, logits within 1e-6 (tests/test_gpu_e2e.py).
     const size_t slab_room = (gemm_workspace(batch, qkv_n, H) + 255) / 256 * 256;
-    const bool fold_off = getenv("CHATTS_QKV_FOLD") && atoi(getenv("CHATTS_QKV_FOLD")) == 0;      // (read per call: tests A/B it in one process)
-    const bool fold = !fold_off && batch >= 2 && slab_room + chatts_attn_workspace(batch, c.n_q, n_splits) <= d->b.workspace_bytes;
+    const bool fold_on = getenv("CHATTS_QKV_FOLD") && atoi(getenv("CHATTS_QKV_FOLD")) == 1;      // (read per call: tests A/B it in one process)
+    const bool fold = fold_on && batch >= 2 && slab_room + chatts_attn_workspace(batch, c.n_q, n_splits) <= d->b.workspace_bytes;
     SlabOut so{};
     if ((rc = linear_impl(&la, stream, nullptr, nullptr, fold ? &so : nullptr)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, 0);
