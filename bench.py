@@ -465,7 +465,8 @@ def bench_batched(args, model, cfg, comm, world, device):
         "data": "synthetic",
         "config": {"workload": label, "model": args.model, "batch": B, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
                    "parallelism": f"tp{world}", "decode_graph": model.graph_capturable(), "kv_block": model.kv_block_size or None,
-                   "tp_exchange": None if world == 1 else ("p2p one-shot kernels (csrc/tp.hip)" if model._tp is not None else "rccl, host-driven"),
+                   "tp_exchange": None if world == 1 else ("p2p over IPC-mapped buffers (csrc/tp.hip): decode exchanges inside the o_proj / down_proj GEMV launches, prefill sums = two-shot "
+                                                          "bulk kernel inside chatts_decoder_prefill" if model._tp is not None else "rccl, host-driven"),
                    "weights_note": None if args.weights == "bf16" else
                    "fp8 copies are streamed by the decode GEMMs and widened to bf16 while staged (no v_mfma fp8 issue: the 1e-3 "
                    "logit bar needs f32-exact products of the f32 activations); prefill keeps the bf16 copy" if args.precision != "fp8" else
@@ -639,7 +640,8 @@ def main():
 
     # TTFT + warm-up run twice at most: under TP a peer-to-peer exchange that stalls on this node (bounded spins, status word) is
     # replaced by the host-driven RCCL path on every rank and the stage is repeated - the line then says tp_exchange = rccl
-    tp_exchange = None if world == 1 else ("p2p one-shot kernels (csrc/tp.hip)" if model._tp is not None else "rccl, host-driven")
+    tp_exchange = None if world == 1 else ("p2p over IPC-mapped buffers (csrc/tp.hip): decode exchanges inside the o_proj / down_proj GEMV launches, prefill sums = two-shot "
+                                                          "bulk kernel inside chatts_decoder_prefill" if model._tp is not None else "rccl, host-driven")
     if world > 1 and model._tp is not None and rank == 0 and os.environ.get("CHATTS_BENCH_INJECT_P2P_STALL"):
         # test hook (tools/jobs/tp2_single_device.sh): rank 0 enters a collective alone - it times out and leaves the exchange broken
         model._tp.all_reduce(torch.ones(64, device=device))

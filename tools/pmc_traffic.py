@@ -91,7 +91,8 @@ def ts(db, cmd, src):
 
 def batched(db, cmd, src, key="14b_8x1024_fp8_b16"):
     rows = counter_rows(db)
-    gu = max((r for r in rows if "gemm_stream_kernel" in r[0]), key=lambda r: r[4])         # gate_up: the weight stream with the most bytes
+    # gate_up: the per-layer weight stream with the most bytes (>= 40 launches: lm_head runs once per step and is larger)
+    gu = max((r for r in rows if "gemm_stream_kernel" in r[0] and r[3] >= 40), key=lambda r: r[4])
     at = max((r for r in rows if "attn_decode_kernel" in r[0]), key=lambda r: r[4])
     d = load()
     inter, B = 13824, 16
