@@ -209,20 +209,27 @@ __global__ __launch_bounds__(256) void tp_allreduce_bulk_kernel(TpParams p, cons
   const int64_t per = ((slice + gridDim.x - 1) / gridDim.x + 3) / 4 * 4;
   const int64_t lo = (int64_t)b * per, hi = lo + per < slice ? lo + per : slice;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  // 1. scatter my partial: slice s goes to rank s (loop-back: into my own "from q" area, zeros for the absent peers)
-  for (int k = 0; k < W; ++k) {
-    const int s = (p.rank + k) % W;
-    const BulkView dst = bulk_view(p, p.loopback ? p.rank : s, epoch);
-    float* area = dst.scatter + (size_t)(p.loopback ? s : p.rank) * p.slice_cap;
-    const int src_slice = p.loopback ? p.rank : s;
-    for (int64_t i = lo + tid * 4; i < hi; i += 256 * 4) {
-      const int64_t g = (int64_t)src_slice * slice + i;
-      f32x4 v = zero;
-      if (!(p.loopback && s != p.rank)) {
-        if (g + 3 < n) v = *reinterpret_cast<const f32x4*>(in + g);
-        else { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; ++e) if (g + e < n) t[e] = in[g + e]; v = (f32x4){t[0], t[1], t[2], t[3]}; }
+  // 1. scatter my partial: slice s goes to rank s (loop-back: into my own "from q" area, zeros for the absent peers).  All W loads of
+  //    a thread's position are issued before the first store: W independent requests in flight per lane.
+  for (int64_t i = lo + tid * 4; i < hi; i += 256 * 4) {
+    f32x4 v[kMaxWorld];
+#pragma unroll
+    for (int k = 0; k < kMaxWorld; ++k) {
+      const int s = (p.rank + k) % W;
+      const int64_t g = (int64_t)(p.loopback ? p.rank : s) * slice + i;
+      v[k] = zero;
+      if (k < W && !(p.loopback && s != p.rank)) {
+        if (g + 3 < n) v[k] = *reinterpret_cast<const f32x4*>(in + g);
+        else { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; ++e) if (g + e < n) t[e] = in[g + e]; v[k] = (f32x4){t[0], t[1], t[2], t[3]}; }
       }
-      *reinterpret_cast<f32x4*>(area + i) = v;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxWorld; ++k) {
+      if (k < W) {
+        const int s = (p.rank + k) % W;
+        const BulkView dst = bulk_view(p, p.loopback ? p.rank : s, epoch);
+        *reinterpret_cast<f32x4*>(dst.scatter + (size_t)(p.loopback ? s : p.rank) * p.slice_cap + i) = v[k];
+      }
     }
   }
   __threadfence_system();
@@ -238,15 +245,21 @@ __global__ __launch_bounds__(256) void tp_allreduce_bulk_kernel(TpParams p, cons
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   for (int64_t i = lo + tid * 4; i < hi; i += 256 * 4) {
-    f32x4 sum = *reinterpret_cast<const f32x4*>(mine.scatter + i);
-    for (int src = 1; src < W; ++src) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(mine.scatter + (size_t)src * p.slice_cap + i);
-      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-    }
-    for (int k = 0; k < W; ++k) {
-      const int q = (p.rank + k) % W;
-      const BulkView dst = bulk_view(p, p.loopback ? p.rank : q, epoch);
-      *reinterpret_cast<f32x4*>(dst.gather + (size_t)(p.loopback ? q : p.rank) * p.slice_cap + i) = (p.loopback && q != p.rank) ? zero : sum;
+    f32x4 c[kMaxWorld];
+#pragma unroll
+    for (int src = 0; src < kMaxWorld; ++src)
+      c[src] = src < W ? *reinterpret_cast<const f32x4*>(mine.scatter + (size_t)src * p.slice_cap + i) : zero;      // W loads in flight
+    f32x4 sum = c[0];
+#pragma unroll
+    for (int src = 1; src < kMaxWorld; ++src)
+      if (src < W) { sum.x += c[src].x; sum.y += c[src].y; sum.z += c[src].z; sum.w += c[src].w; }                    // rank order
+#pragma unroll
+    for (int k = 0; k < kMaxWorld; ++k) {
+      if (k < W) {
+        const int q = (p.rank + k) % W;
+        const BulkView dst = bulk_view(p, p.loopback ? p.rank : q, epoch);
+        *reinterpret_cast<f32x4*>(dst.gather + (size_t)(p.loopback ? q : p.rank) * p.slice_cap + i) = (p.loopback && q != p.rank) ? zero : sum;
+      }
     }
   }
   __threadfence_system();
@@ -261,17 +274,24 @@ __global__ __launch_bounds__(256) void tp_allreduce_bulk_kernel(TpParams p, cons
   if (tid < W) (void)wait_flag(mine.flags + (size_t)(kMaxWorld + tid) * kBulkMaxBlocks + b, epoch, &p.ctr[2]);
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  for (int s = 0; s < W; ++s) {
-    for (int64_t i = lo + tid * 4; i < hi; i += 256 * 4) {
+  for (int64_t i = lo + tid * 4; i < hi; i += 256 * 4) {          // (all W slices of a position: 2 W independent loads in flight per lane)
+    f32x4 r[kMaxWorld], xv[kMaxWorld];
+#pragma unroll
+    for (int s = 0; s < kMaxWorld; ++s) {
       const int64_t g = (int64_t)s * slice + i;
-      if (g >= n) break;
-      const f32x4 r = *reinterpret_cast<const f32x4*>(mine.gather + (size_t)s * p.slice_cap + i);
+      r[s] = s < W ? *reinterpret_cast<const f32x4*>(mine.gather + (size_t)s * p.slice_cap + i) : zero;
+      xv[s] = (s < W && g + 3 < n) ? *reinterpret_cast<const f32x4*>(x + g) : zero;
+    }
+#pragma unroll
+    for (int s = 0; s < kMaxWorld; ++s) {
+      const int64_t g = (int64_t)s * slice + i;
+      if (s >= W || g >= n) continue;
       if (g + 3 < n) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(x + g);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        f32x4 v = xv[s];
+        v.x += r[s].x; v.y += r[s].y; v.z += r[s].z; v.w += r[s].w;
         *reinterpret_cast<f32x4*>(x + g) = v;
       } else {
-        const float t[4] = {r.x, r.y, r.z, r.w};
+        const float t[4] = {r[s].x, r[s].y, r[s].z, r[s].w};
         for (int e = 0; e < 4; ++e) if (g + e < n) x[g + e] += t[e];
       }
     }
@@ -505,7 +525,12 @@ extern "C" int chatts_allreduce(ChattsTpComm* c, const float* in, float* out, co
   CHATTS_REQUIRE(n >= 0 && n <= c->p.max_elems, CHATTS_E_SHAPE, "allreduce: %lld elements exceed the exchange buffer (%lld)",
                  (long long)n, (long long)c->p.max_elems);
   if (n == 0) return CHATTS_OK;
-  if (n <= 16384) {           // decode-sized: one value per thread, every poll of the vector in flight at once
+  // One value per thread with every poll of the vector in flight at once, as long as the grid stays small: up to 128 workgroups
+  // (131072 values: the [16, H] sums of a 16-wide decode step - 19.0 us with the 4-values-per-thread form on 20 workgroups, the
+  // largest item of a TP = 8 rank's batched step, profiles/r4_tp8_cfg5_shard_kernel_trace.txt).  CHATTS_TP_AR_BLOCKS lowers the bound
+  // for several ranks emulated on ONE device (their waiting grids must be resident together).
+  static const int ar_cap = getenv("CHATTS_TP_AR_BLOCKS") ? atoi(getenv("CHATTS_TP_AR_BLOCKS")) : 128;
+  if ((n + 1023) / 1024 <= (ar_cap > 16 ? ar_cap : 16)) {
     hipLaunchKernelGGL(tp_allreduce_kernel<1>, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, as_stream(stream), tp_issue(c, true), in, resid, out, n);
   } else {
     const int64_t b = (n + 4095) / 4096;

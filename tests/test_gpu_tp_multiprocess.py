@@ -21,7 +21,7 @@ def _run(flow, world, tmp_path, extra_env=None):
     out = str(tmp_path / f"tp{world}_{flow}.json")
     env = dict(os.environ)
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", CHATTS_FORCE_DEVICE="0", CHATTS_DIST_BACKEND="gloo", CHATTS_TP_FUSE_BLOCKS="48",
-               CHATTS_TP_BULK_BLOCKS="16", OMP_NUM_THREADS="16")      # (grid caps: W ranks' waiting launches must be resident together on ONE device)
+               CHATTS_TP_BULK_BLOCKS="16", CHATTS_TP_AR_BLOCKS="16", OMP_NUM_THREADS="16")      # (grid caps: W ranks' waiting launches must be resident together on ONE device)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.update(extra_env or {})
