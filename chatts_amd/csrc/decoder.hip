@@ -12,6 +12,8 @@
 namespace chatts {
 int launch_gemv(const ChattsLinearArgs* a, hipStream_t s);
 int launch_gemm(const ChattsLinearArgs* a, hipStream_t s, const RopeFuse* rope = nullptr, bool* rope_done = nullptr, SlabOut* slabs = nullptr);
+int tp_allreduce_slabs(ChattsTpComm* c, const float* ws, const SlabOut& so, int ncols, float* out, const float* resid, int64_t n,
+                       chatts_stream_t stream);      // tp.hip
 int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w, const float* k_norm_w,
                                   float norm_eps, const float* cos_tab, const float* sin_tab, int pos, const int32_t* pos_dev,
                                   const ChattsKvCache* cache, size_t seq_stride, float* out, uint16_t* out_hi, uint16_t* out_lo,

@@ -79,8 +79,6 @@ __device__ __forceinline__ void finish_call(const TpParams& p, uint32_t epoch) {
 // host (tp.hip): the kernel parameters of the NEXT collective on this communicator (idx filled in; see TpParams::idx).  bumps =
 // the kernel ends with finish_call (stand-alone collectives); false = it leaves the counter to a later one (exchange-carrying GEMVs)
 TpParams tp_issue(ChattsTpComm* c, bool bumps);
-int tp_allreduce_slabs(ChattsTpComm* c, const float* ws, const SlabOut& so, int ncols, float* out, const float* resid, int64_t n,
-                       chatts_stream_t stream);
 int64_t tp_capacity(const ChattsTpComm* c);
 
 }  // namespace chatts
