@@ -318,13 +318,14 @@ __global__ __launch_bounds__(256, 3) void attn_prefill_mfma_kernel(AttnParams p)
     // and four independent chains in flight are what hides them (measured with s_memtime: this block was 3.5k cycles per
     // tile as a per-row loop with expf, against 2k cycles for the 64 MFMAs of Q.K^T).
     float mx[4], ps[4], alpha[4], m_ref[4];
+    const bool diag = k0 + KT - 1 > pos0 + q0 + wave * 16;  // wave-uniform: only such a tile holds keys some row of this wave cannot see
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       mx[r] = -INFINITY;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         float sc = s_acc[nb][r] * scale2;
-        if (k0 + nb * 16 + ccol > qpos[r]) sc = -INFINITY;  // causal mask
+        if (diag && k0 + nb * 16 + ccol > qpos[r]) sc = -INFINITY;  // causal mask
         s_acc[nb][r] = sc;
         mx[r] = fmaxf(mx[r], sc);
       }
@@ -612,13 +613,20 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16x3_kernel(AttnParams 
     for (int r = 0; r < 4; ++r) ps[r] += row_ror4(ps[r]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) ps[r] += row_ror8(ps[r]);
+    // no running maximum of this wave's rows moved (every alpha == 1.0f exactly): the 32 rescaling multiplies would change nothing
+    const bool moved = __builtin_amdgcn_ballot_w64(alpha[0] != 1.f || alpha[1] != 1.f || alpha[2] != 1.f || alpha[3] != 1.f) != 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       l_run[r] = l_run[r] * alpha[r] + ps[r];
 #pragma unroll
-      for (int db = 0; db < 8; ++db) o_acc[db][r] *= alpha[r];
-#pragma unroll
       for (int nb = 0; nb < NB; ++nb) p_s[(crow0 + r) * PS + nb * 16 + ccol] = s_acc[nb][r];
+    }
+    if (moved) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int db = 0; db < 8; ++db) o_acc[db][r] *= alpha[r];
+      }
     }
     __builtin_amdgcn_wave_barrier();                        // P is wave private: LDS ops of one wave stay in order
     // P as the A operand of P.V: query row arow, keys kq*8 .. kq*8+7 (two conflict-free ds_read_b128 of the [16][36] tile)
@@ -663,6 +671,233 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_bf16x3_kernel(AttnParams 
           p.out[oi + db * 16 + ccol] = v;
         }
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// prefill with K / V planes: the flash loop on TRANSPOSED tiles.  kv_planes_kernel splits the sequence's K / V rows into bf16 hi / lo
+// planes ONCE per layer and chunk (attn_prefill_bf16x3_kernel does it once per (query tile, query head): 65 times per tile at T = 798);
+// attn_prefill_planes_kernel then computes S^T = K.Q^T and O^T = V^T.P^T, which puts "query = lane & 15" on every operand:
+//   * S^T in the C layout gives a lane 8 keys of ONE query: the row maximum is an in-lane maximum + two lane exchanges (xor 16, 32)
+//     instead of 4 rows x 4 DPP steps, the row sum stays a per-lane partial until the very end, one alpha per lane;
+//   * those 8 probabilities ARE the B fragment of V^T.P^T - P never goes through LDS.  The MFMA's K index is a free choice as long as
+//     A and B agree: slot 8 g + j of lane group g means key 4 g + j (j < 4) or 16 + 4 g + (j - 4), and kv_planes_kernel writes the
+//     V^T rows in that slot order, so the A fragment is still one 16-byte LDS read;
+//   * O^T in the C layout gives a lane 4 consecutive head dims of its query: alpha applies as is, the output is 16-byte stores.
+// Staging is 8 16-byte copies per thread.  Same three-pass bf16 split products as the kernel above; the sums run in another order, so
+// the two agree to rounding (tests: both against the float64 reference).  Needs the host to know pos0 (plane count) and a free
+// workspace; otherwise the kernel above runs.
+// Plane layout, per (kv head, 32-key tile) 32 KB: K_hi [32 keys][128], K_lo, V^T_hi [128 dims][32 slots], V^T_lo; rows past the last
+// key repeat it (finite values behind the causal mask).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kv_planes_kernel(AttnParams p, int n_keys, uint16_t* planes) {
+  constexpr int KT = 32;
+  const int tid = threadIdx.x, kt = blockIdx.x, hk = blockIdx.y;
+  const KvLayout kvl{p.table, p.n_kv, p.max_ctx, p.log_block};
+  const size_t toff = kv_tile_off(kvl, hk, kt * KT);
+  uint16_t* dst = planes + ((size_t)hk * gridDim.x + kt) * (4 * KT * kHeadDim);
+  const int last = n_keys - 1 - kt * KT;                    // last valid row inside this tile (>= 0)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                             // K: thread = (key, 4 dims), rows stay rows
+    const int idx = tid + i * 256;
+    const int key = idx >> 5, c4 = idx & 31;
+    const int kr = key <= last ? key : last;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p.kc + toff + (size_t)kr * kHeadDim + c4 * 4);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    abf16x4_t h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 hh = (__bf16)x[e];
+      h[e] = hh;
+      l[e] = (__bf16)(x[e] - (float)hh);
+    }
+    *reinterpret_cast<abf16x4_t*>(dst + key * kHeadDim + c4 * 4) = h;
+    *reinterpret_cast<abf16x4_t*>(dst + KT * kHeadDim + key * kHeadDim + c4 * 4) = l;
+  }
+  // V transposed: thread = (head dim, 16 keys kg*16 ..); a wave reads 64 consecutive dims of one key (256 contiguous bytes) per load.
+  // Keys kg*16 + 4 g + j (j = 0..3) go to slots 8 g + 4 kg + j.
+  const int d = tid & 127, kg = tid >> 7;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    abf16x4_t h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = kg * 16 + 4 * g + j;
+      const int vr = key <= last ? key : last;
+      const float x = p.vc[toff + (size_t)vr * kHeadDim + d];
+      const __bf16 hh = (__bf16)x;
+      h[j] = hh;
+      l[j] = (__bf16)(x - (float)hh);
+    }
+    *reinterpret_cast<abf16x4_t*>(dst + 2 * KT * kHeadDim + d * KT + 8 * g + 4 * kg) = h;
+    *reinterpret_cast<abf16x4_t*>(dst + 3 * KT * kHeadDim + d * KT + 8 * g + 4 * kg) = l;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_prefill_planes_kernel(AttnParams p) {
+  constexpr int KT = 32, KROW = 272, VROW = 80;
+  __shared__ __attribute__((aligned(16))) char k_hi[KT * KROW];
+  __shared__ __attribute__((aligned(16))) char k_lo[KT * KROW];
+  __shared__ __attribute__((aligned(16))) char vt_hi[kHeadDim * VROW];
+  __shared__ __attribute__((aligned(16))) char vt_lo[kHeadDim * VROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hq = blockIdx.y;
+  const int G = p.n_q / p.n_kv, hk = hq / G;
+  const int heads = p.n_q + 2 * p.n_kv;
+  const int T = p.t, pos0 = p.pos0;
+  const int qt = gridDim.x - 1 - blockIdx.x;                // heaviest query tiles (most key tiles) first
+  const int q0 = qt * 64;
+  const int qi = lane & 15, g = lane >> 4;                  // this lane's query (of the wave's 16) and its group of 8 K-values / 4 C rows
+  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // d^-1/2 * log2(e): the softmax runs on exp2
+
+  abf16x8_t q_hi[4], q_lo[4];                                // B fragments of Q^T: query qi, dims ks*32 + g*8 .. +7
+  {
+    int qrow = q0 + wave * 16 + qi;
+    if (qrow > T - 1) qrow = T - 1;                         // padded rows compute garbage that is never stored
+    const float* qp = p.qkv + ((size_t)qrow * heads + hq) * kHeadDim + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + ks * 32), b = *reinterpret_cast<const f32x4*>(qp + ks * 32 + 4);
+      const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      split8(x, q_hi[ks], q_lo[ks]);
+    }
+  }
+  const int qpos = pos0 + q0 + wave * 16 + qi;
+  float m_run = -INFINITY, l_part = 0.f;                    // l_part: this lane's 8 slots only; the four groups meet after the loop
+  f32x4 o_acc[8];                                           // O^T: head dims db*16 + 4 g + r of query qi
+#pragma unroll
+  for (int db = 0; db < 8; ++db) o_acc[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int last_q = q0 + 63 < T - 1 ? q0 + 63 : T - 1;
+  const int nkt = (pos0 + last_q) / KT + 1;                 // tiles up to the last key any row of this workgroup may see
+  // 512 16-byte chunks per 8 KB plane: thread takes chunks tid and tid + 256.  K chunk j: key j >> 4, column j & 15; V^T chunk j: dim
+  // j >> 2, column j & 3.  Loads run TWO tiles ahead in two register sets: a tile's matrix work (~1.4k cycles) does not cover an L2
+  // round trip.
+  f32x4 kreg[2][4], vreg[2][4];
+  const uint16_t* src0 = p.kv_planes + (size_t)hk * p.kv_plane_tiles * (4 * KT * kHeadDim) + tid * 8;
+  auto load_tile = [&](int kt, f32x4 (&kr)[4], f32x4 (&vr)[4]) {
+    if (kt >= nkt) return;
+    const uint16_t* src = src0 + (size_t)kt * (4 * KT * kHeadDim);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      kr[i] = *reinterpret_cast<const f32x4*>(src + i * 2048);
+      kr[2 + i] = *reinterpret_cast<const f32x4*>(src + KT * kHeadDim + i * 2048);
+      vr[i] = *reinterpret_cast<const f32x4*>(src + 2 * KT * kHeadDim + i * 2048);
+      vr[2 + i] = *reinterpret_cast<const f32x4*>(src + 3 * KT * kHeadDim + i * 2048);
+    }
+  };
+  auto store_tile = [&](int kt, const f32x4 (&kr)[4], const f32x4 (&vr)[4]) {
+    if (kt >= nkt) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = tid + i * 256;
+      *reinterpret_cast<f32x4*>(k_hi + (j >> 4) * KROW + (j & 15) * 16) = kr[i];
+      *reinterpret_cast<f32x4*>(k_lo + (j >> 4) * KROW + (j & 15) * 16) = kr[2 + i];
+      *reinterpret_cast<f32x4*>(vt_hi + (j >> 2) * VROW + (j & 3) * 16) = vr[i];
+      *reinterpret_cast<f32x4*>(vt_lo + (j >> 2) * VROW + (j & 3) * 16) = vr[2 + i];
+    }
+  };
+  auto tile = [&](int kt) {
+    const int k0 = kt * KT;
+    if (kt >= nkt || k0 > pos0 + q0 + wave * 16 + 15) return;      // no tile / every score of this wave masked: wave-uniform skip
+
+    f32x4 s_acc[2];                                         // S^T: keys k0 + nb*16 + 4 g + r, query qi
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) s_acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int off = (nb * 16 + qi) * KROW + ks * 64 + g * 16;
+        const abf16x8_t ah = *reinterpret_cast<const abf16x8_t*>(k_hi + off);
+        const abf16x8_t al = *reinterpret_cast<const abf16x8_t*>(k_lo + off);
+        s_acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, q_lo[ks], s_acc[nb], 0, 0, 0);
+        s_acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, q_hi[ks], s_acc[nb], 0, 0, 0);
+        s_acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, q_hi[ks], s_acc[nb], 0, 0, 0);
+      }
+    }
+    const bool diag = k0 + KT - 1 > pos0 + q0 + wave * 16;  // wave-uniform: only such a tile holds keys some query of this wave cannot see
+    float e[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sc = s_acc[nb][r] * scale2;
+        if (diag && k0 + nb * 16 + 4 * g + r > qpos) sc = -INFINITY;   // causal mask
+        e[nb * 4 + r] = sc;
+        mx = fmaxf(mx, sc);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      e[j] = __builtin_amdgcn_exp2f(e[j] - m_ref);
+      ps += e[j];
+    }
+    l_part = l_part * alpha + ps;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {    // some running maximum of this wave moved
+#pragma unroll
+      for (int db = 0; db < 8; ++db) {
+        o_acc[db].x *= alpha; o_acc[db].y *= alpha; o_acc[db].z *= alpha; o_acc[db].w *= alpha;
+      }
+    }
+    abf16x8_t p_hi, p_lo;                                    // B fragment of P^T: slots 8 g .. 8 g + 7 of query qi
+    split8(e, p_hi, p_lo);
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {                        // head dims db*16 .. db*16+15: A fragment = 8 slots of dim db*16 + qi
+      const int off = (db * 16 + qi) * VROW + g * 16;
+      const abf16x8_t vh = *reinterpret_cast<const abf16x8_t*>(vt_hi + off);
+      const abf16x8_t vl = *reinterpret_cast<const abf16x8_t*>(vt_lo + off);
+      o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, p_lo, o_acc[db], 0, 0, 0);
+      o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, p_hi, o_acc[db], 0, 0, 0);
+      o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, p_hi, o_acc[db], 0, 0, 0);
+    }
+  };
+  load_tile(0, kreg[0], vreg[0]);
+  load_tile(1, kreg[1], vreg[1]);
+  for (int kt = 0; kt < nkt; kt += 2) {
+    __syncthreads();                                        // the previous tile has been consumed by every wave
+    store_tile(kt, kreg[0], vreg[0]);
+    __syncthreads();
+    load_tile(kt + 2, kreg[0], vreg[0]);
+    tile(kt);
+    if (kt + 1 >= nkt) break;
+    __syncthreads();
+    store_tile(kt + 1, kreg[1], vreg[1]);
+    __syncthreads();
+    load_tile(kt + 3, kreg[1], vreg[1]);
+    tile(kt + 1);
+  }
+  float l = l_part + __shfl_xor(l_part, 16);
+  l += __shfl_xor(l, 32);
+  const int qrow = q0 + wave * 16 + qi;
+  if (qrow >= T) return;
+  const float inv = 1.0f / l;
+  const size_t oi = ((size_t)qrow * p.n_q + hq) * kHeadDim + 4 * g;
+#pragma unroll
+  for (int db = 0; db < 8; ++db) {
+#pragma clang fp contract(off)   // lo = split of the ROUNDED product, as chatts_split_bf16x2 of the float32 output would give
+    const float v[4] = {o_acc[db].x * inv, o_acc[db].y * inv, o_acc[db].z * inv, o_acc[db].w * inv};
+    if (p.out_hi) {
+      abf16x4_t h, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const __bf16 hh = (__bf16)v[j];
+        h[j] = hh;
+        lo[j] = (__bf16)(v[j] - (float)hh);
+      }
+      *reinterpret_cast<abf16x4_t*>(p.out_hi + oi + db * 16) = h;
+      *reinterpret_cast<abf16x4_t*>(p.out_lo + oi + db * 16) = lo;
+    } else {
+      *reinterpret_cast<f32x4*>(p.out + oi + db * 16) = (f32x4){v[0], v[1], v[2], v[3]};
     }
   }
 }
@@ -801,7 +1036,19 @@ int chatts::attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0,
   if (t >= 16 && n_splits <= 4 && (!force_rows || out_hi)) {
     // (64-key tiles were measured too: 155 us vs 148 us at T = 798 - the per-tile work is not what is slow)
     const int bf16x3 = getenv("CHATTS_ATTN_BF16X3") ? atoi(getenv("CHATTS_ATTN_BF16X3")) : 1;      // 0: the float32-MFMA kernel
-    if (bf16x3) hipLaunchKernelGGL(attn_prefill_bf16x3_kernel, dim3((t + 63) / 64, n_q, n_splits), dim3(256), 0, as_stream(stream), p);
+    // K / V split into bf16 planes once (kv_planes_kernel) when the caller's workspace is free (one key split) and holds them
+    static const bool planes_on = !getenv("CHATTS_ATTN_PLANES") || atoi(getenv("CHATTS_ATTN_PLANES")) != 0;
+    const int n_keys = pos0 + t, tiles = (n_keys + 31) / 32;
+    const size_t plane_bytes = (size_t)tiles * n_kv * 4 * 32 * kHeadDim * sizeof(uint16_t);
+    const bool planes = bf16x3 && planes_on && !pos0_dev && n_splits == 1 && t >= 64 && workspace && workspace_bytes >= plane_bytes &&
+                        ((uintptr_t)workspace % 16) == 0;
+    if (planes) {
+      uint16_t* pl = static_cast<uint16_t*>(workspace);
+      hipLaunchKernelGGL(kv_planes_kernel, dim3(tiles, n_kv), dim3(256), 0, as_stream(stream), p, n_keys, pl);
+      CHATTS_CHECK_LAUNCH("kv_planes");
+      p.kv_planes = pl; p.kv_plane_tiles = tiles;
+      hipLaunchKernelGGL(attn_prefill_planes_kernel, dim3((t + 63) / 64, n_q, 1), dim3(256), 0, as_stream(stream), p);
+    } else if (bf16x3) hipLaunchKernelGGL(attn_prefill_bf16x3_kernel, dim3((t + 63) / 64, n_q, n_splits), dim3(256), 0, as_stream(stream), p);
     else hipLaunchKernelGGL(attn_prefill_mfma_kernel<32>, dim3((t + 63) / 64, n_q, n_splits), dim3(256), 0, as_stream(stream), p);
     CHATTS_CHECK_LAUNCH("attn_prefill_mfma");
     if (n_splits > 1) {

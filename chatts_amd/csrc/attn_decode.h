@@ -42,6 +42,10 @@ struct AttnParams {
   uint16_t* out_hi;    // decode combine, optional: the output as bf16 hi / lo planes [T, n_q * 128] (the o_proj operand of the
   uint16_t* out_lo;    // weight-streaming kernel) instead of float32 `out`
   int kv_round;        // experiment knob, see kv_round_f (0 = off)
+  // prefill (bf16x3 kernel), optional: this sequence's K / V rows 0 .. kv_plane_keys-1 already split into bf16 hi / lo planes by
+  // kv_planes_kernel, per (kv head, 32-key tile) 32 KB: K_hi [32][128], K_lo, V^T_hi [128][32], V^T_lo.  NULL: split while staging
+  const uint16_t* kv_planes;
+  int kv_plane_tiles;  // tiles per kv head
 };
 
 // rotate one 128-wide head held as (a = x[lane], b = x[lane+64]) by the wave; optional RMSNorm first

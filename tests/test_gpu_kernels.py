@@ -1123,6 +1123,44 @@ def test_attention_paged_equals_contiguous(lib, monkeypatch, block, bf16x3, T, p
     assert not torch.isnan(out_a).any() and torch.equal(out_a, out_b)
 
 
+@pytest.mark.parametrize("paged,nq,nkv,T,pos0", [
+    (False, 10, 2, 64, 0), (False, 10, 2, 65, 31), (False, 10, 2, 130, 100), (False, 10, 2, 798, 0), (False, 5, 1, 200, 300),
+    (False, 5, 1, 1000, 24), (True, 10, 2, 65, 31), (True, 10, 2, 200, 300), (True, 5, 1, 798, 0), (True, 8, 8, 130, 100)])
+def test_attention_prefill_on_kv_planes(lib, paged, nq, nkv, T, pos0):
+    """attn_prefill_planes_kernel (K / V rows split into bf16 hi / lo planes ONCE by kv_planes_kernel, transposed tiles S^T = K.Q^T,
+    O^T = V^T.P^T; taken when the caller's workspace is free and large enough) against the float64 reference and against
+    attn_prefill_bf16x3_kernel, which splits every tile while it stages it (workspace too small): the same three-pass products summed
+    in another order.  Rows past the context are never read in either form (NaN there), contiguous and block-paged caches."""
+    max_ctx = 1024
+    g = torch.Generator().manual_seed(T * 7 + pos0 + nq)
+    qkv = torch.randn((T, (nq + 2 * nkv) * 128), generator=g)
+    kc = torch.randn((nkv, max_ctx, 128), generator=g)
+    vc = torch.randn((nkv, max_ctx, 128), generator=g)
+    kc[:, 17] *= 4.0     # a spiky key so the online-softmax rescale path is exercised
+    want = _ref_attention(qkv.view(T, nq + 2 * nkv, 128)[:, :nq], kc, vc, pos0).numpy()
+    qd, kd, vd = qkv.to(DEV), kc.to(DEV), vc.to(DEV)
+    kd[:, pos0 + T:] = float("nan")
+    vd[:, pos0 + T:] = float("nan")
+    if paged:
+        pk, pv, table = _to_pool(kd, vd, 64, seed=T)
+        cache = _lib.KvCache(k=pk.data_ptr(), v=pv.data_ptr(), max_ctx=max_ctx, block_table=table.data_ptr(), block_size=64,
+                             table_stride=table.numel())
+    else:
+        cache = _lib.KvCache(k=kd.data_ptr(), v=vd.data_ptr(), max_ctx=max_ctx)
+    plane_bytes = ((pos0 + T + 31) // 32) * nkv * 4 * 32 * 128 * 2
+    outs = []
+    for wsb in (plane_bytes - 16, plane_bytes):              # too small (split while staging), then exactly enough (planes)
+        ws = torch.full((wsb,), 0xFF, dtype=torch.uint8, device=DEV)
+        out = torch.full((T, nq * 128), float("nan"), device=DEV)
+        _lib.check(lib.chatts_attention(qd.data_ptr(), T, nq, nkv, pos0, None, C.byref(cache), out.data_ptr(), 1, ws.data_ptr(), wsb, st()))
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy().reshape(T, nq, 128))
+        assert bool((ws != 0xFF).any()) == (wsb == plane_bytes)      # the planes really were (not) written
+    assert not np.isnan(outs[1]).any()
+    assert rel_err(outs[1], want) < 3e-5 and rel_err(outs[0], want) < 3e-5
+    assert rel_err(outs[1], outs[0]) < 1e-5
+
+
 def test_paged_cache_argument_errors(lib):
     kc = torch.zeros((2, 192, 128), device=DEV)
     table = torch.zeros(3, dtype=torch.int32, device=DEV)

@@ -39,3 +39,22 @@ for mode in ("0", "1"):
         e1.record(st)
         torch.cuda.synchronize()
         print("bf16x3=%s key-splits %d: %.1f us  (rel. diff to the float32-MFMA kernel %.1e)" % (mode, NS, e0.elapsed_time(e1) * 1e3 / 20, err))
+# the same with the K / V rows split into bf16 planes once (kv_planes_kernel + the copy-staging kernel: workspace large enough)
+split_out = out.clone()
+wsb = ((T + 31) // 32) * nkv * 4 * 32 * d * 2
+ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+NS = 1
+run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(st)
+for _ in range(20):
+    run()
+e1.record(st)
+torch.cuda.synchronize()
+os.environ["CHATTS_ATTN_BF16X3"] = "1"
+ws16 = torch.empty(16, dtype=torch.uint8, device=DEV)
+_lib.check(lib.chatts_attention(qkv.data_ptr(), T, nq, nkv, 0, None, C.byref(cache), split_out.data_ptr(), 1, ws16.data_ptr(), 16, st.cuda_stream))
+torch.cuda.synchronize()
+print("K / V planes + transposed tiles (kv_planes_kernel + attn_prefill_planes_kernel): %.1f us, rel. diff to split-while-staging %.1e"
+      % (e0.elapsed_time(e1) * 1e3 / 20, float((out - split_out).norm() / split_out.norm())))
