@@ -284,7 +284,11 @@ int chatts_rope_kv_write(float* qkv, int t, int n_q, int n_kv, const float* q_no
 /* Causal GQA attention of T query rows (positions pos0..pos0+T-1) against cache rows [0, pos].
  * q is read from qkv [T, (n_q+2*n_kv)*128]; out [T, n_q*128].  float32 scores, softmax and PV.
  * n_splits > 1: key tiles are strided over n_splits workgroups per (row, kv-head), partials go to workspace and
- * are combined by a second kernel.  workspace >= chatts_attn_workspace() (needed whenever n_splits > 1). */
+ * are combined by a second kernel.  workspace >= chatts_attn_workspace() (needed whenever n_splits > 1).
+ * n_splits == 1, T >= 64, host-side pos0: if the (optional) workspace holds ceil((pos0 + T) / 32) * n_kv * 32 KB, the call first splits the
+ * sequence's K / V rows into bf16 hi / lo planes there (kv_planes_kernel) and runs the prefill kernel that reads them
+ * (attn_prefill_planes_kernel); a smaller or NULL workspace selects the kernel that splits while it stages - same products, sums in
+ * another order (both <= 3e-5 from float64).  The workspace contents are scratch either way. */
 size_t chatts_attn_workspace(int t, int n_q, int n_splits);
 int chatts_attention(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev,
                      const ChattsKvCache* cache, float* out, int n_splits, void* workspace,
