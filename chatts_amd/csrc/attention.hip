@@ -736,7 +736,11 @@ __global__ __launch_bounds__(256) void kv_planes_kernel(AttnParams p, int n_keys
 }
 
 __global__ __launch_bounds__(256, 2) void attn_prefill_planes_kernel(AttnParams p) {
-  constexpr int KT = 32, KROW = 272, VROW = 80;
+  // LDS rows WITHOUT padding, 16-byte chunks XOR-swizzled for ds_read_b128's lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...:
+  // every group holds each qi once, with g = g0 for eight of them and g0 + 1 for the other eight): K chunk c of key k sits at
+  // c ^ (k & 15), V^T chunk c of dim d at c ^ ((d >> 2) & 2) - each group then covers all 64 banks exactly once (272- / 80-byte padded
+  // rows, right for 16 consecutive lanes, gave every group a 2-way conflict: 44 % of the LDS cycles).
+  constexpr int KT = 32, KROW = 256, VROW = 64;
   __shared__ __attribute__((aligned(16))) char k_hi[KT * KROW];
   __shared__ __attribute__((aligned(16))) char k_lo[KT * KROW];
   __shared__ __attribute__((aligned(16))) char vt_hi[kHeadDim * VROW];
@@ -792,10 +796,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_planes_kernel(AttnParams 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int j = tid + i * 256;
-      *reinterpret_cast<f32x4*>(k_hi + (j >> 4) * KROW + (j & 15) * 16) = kr[i];
-      *reinterpret_cast<f32x4*>(k_lo + (j >> 4) * KROW + (j & 15) * 16) = kr[2 + i];
-      *reinterpret_cast<f32x4*>(vt_hi + (j >> 2) * VROW + (j & 3) * 16) = vr[i];
-      *reinterpret_cast<f32x4*>(vt_lo + (j >> 2) * VROW + (j & 3) * 16) = vr[2 + i];
+      const int ko = (j >> 4) * KROW + (((j & 15) ^ ((j >> 4) & 15)) << 4);
+      const int vo = (j >> 2) * VROW + (((j & 3) ^ ((j >> 4) & 2)) << 4);         // (d >> 2) & 2 with d = j >> 2
+      *reinterpret_cast<f32x4*>(k_hi + ko) = kr[i];
+      *reinterpret_cast<f32x4*>(k_lo + ko) = kr[2 + i];
+      *reinterpret_cast<f32x4*>(vt_hi + vo) = vr[i];
+      *reinterpret_cast<f32x4*>(vt_lo + vo) = vr[2 + i];
     }
   };
   auto tile = [&](int kt) {
@@ -809,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_planes_kernel(AttnParams 
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
-        const int off = (nb * 16 + qi) * KROW + ks * 64 + g * 16;
+        const int off = (nb * 16 + qi) * KROW + (((ks * 4 + g) ^ qi) << 4);
         const abf16x8_t ah = *reinterpret_cast<const abf16x8_t*>(k_hi + off);
         const abf16x8_t al = *reinterpret_cast<const abf16x8_t*>(k_lo + off);
         s_acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, q_lo[ks], s_acc[nb], 0, 0, 0);
@@ -853,7 +859,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_planes_kernel(AttnParams 
     split8(e, p_hi, p_lo);
 #pragma unroll
     for (int db = 0; db < 8; ++db) {                        // head dims db*16 .. db*16+15: A fragment = 8 slots of dim db*16 + qi
-      const int off = (db * 16 + qi) * VROW + g * 16;
+      const int off = (db * 16 + qi) * VROW + ((g ^ ((qi >> 2) & 2)) << 4);
       const abf16x8_t vh = *reinterpret_cast<const abf16x8_t*>(vt_hi + off);
       const abf16x8_t vl = *reinterpret_cast<const abf16x8_t*>(vt_lo + off);
       o_acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, p_lo, o_acc[db], 0, 0, 0);
