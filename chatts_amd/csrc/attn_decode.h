@@ -46,6 +46,9 @@ struct AttnParams {
   // kv_planes_kernel, per (kv head, 32-key tile) 32 KB: K_hi [32][128], K_lo, V^T_hi [128][32], V^T_lo.  NULL: split while staging
   const uint16_t* kv_planes;
   int kv_plane_tiles;  // tiles per kv head
+  // attn_prefill_planes_kernel's 1-D grid: query tiles per head and, when n_kv divides 8, the number of XCDs that share one kv head
+  // (8 / n_kv; 0 = no XCD-aware order) - see the kernel
+  int units, xcd_share;
 };
 
 // rotate one 128-wide head held as (a = x[lane], b = x[lane+64]) by the wave; optional RMSNorm first
