@@ -29,7 +29,7 @@ class TsWeights(C.Structure):
                 ("b", c_void_p * 8)]
 
 
-ABI_VERSION = 7            # CHATTS_ABI_VERSION of include/chatts_amd.h this binding was written against (checked by load())
+ABI_VERSION = 8            # CHATTS_ABI_VERSION of include/chatts_amd.h this binding was written against (checked by load())
 TILE_COUNTERS = 4096      # CHATTS_TILE_COUNTERS
 W8_FP8, W8_INT8 = 0, 1     # ChattsLinearArgs.w8_format
 
@@ -132,6 +132,9 @@ SIGNATURES = {
     "chatts_attention_decode_batched": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                                                 c_void_p, c_int, c_void_p, C.POINTER(KvCache), c_size_t, c_void_p, c_int,
                                                 c_void_p, c_size_t, c_void_p]),
+    "chatts_attention_decode_batched_fold": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
+                                                     c_void_p, c_int, c_void_p, C.POINTER(KvCache), c_size_t, c_void_p, c_int,
+                                                     c_void_p, c_size_t, c_void_p, c_void_p]),
     "chatts_argmax_batched": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_int, c_void_p]),
     "chatts_argmax_workspace": (c_size_t, [c_int]),

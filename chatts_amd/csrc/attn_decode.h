@@ -71,6 +71,19 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// 8-byte write-through store / L1-bypassing load (relaxed, agent scope: `global_store_dwordx2 ... sc1` / `global_load_dwordx2 ... sc1`):
+// how the partials travel between workgroups INSIDE one launch (attn_decode_fold_kernel) - payload sc1, `s_waitcnt vmcnt(0)`, then a
+// relaxed agent-scope ticket; the reader polls the ticket word relaxed and reads the payload sc1.  No fences.
+__device__ __forceinline__ void st_wt64(float* p, float a, float b) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ld_wt64(const float* p, float& a, float& b) {
+  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  a = __uint_as_float((unsigned)v);
+  b = __uint_as_float((unsigned)(v >> 32));
+}
+
 // ---------------------------------------------------------------------------------------------------
 // decode: grid (n_kv, n_slots), 64 threads.  Slot s walks tiles s, s + n_slots, ... of 16 keys.
 // ---------------------------------------------------------------------------------------------------
@@ -152,7 +165,7 @@ __device__ __forceinline__ bool attn_decode_preload(const AttnParams& p, const i
 // GMAX: query heads of the group this wave handles at most; it takes heads g0 .. g0 + gn - 1 of kv head hk's group (the stand-alone
 // kernel: all of them, GMAX = kMaxGroup; the persistent step splits a group over two waves).  Heads are independent of each
 // other, so the split does not change a single operation of any head.  The wave with g0 == 0 stores the new K / V row.
-template <int GMAX, bool PF>
+template <int GMAX, bool PF, bool WT = false>
 __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
                                                    AttnTileRegs& t, float* q_s, float* knew_s, float* vnew_s, const int g0, const int gn,
                                                    float* part_o, float* part_ml, const size_t head_base) {
@@ -335,8 +348,13 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
       o.x += __shfl_xor(o.x, 32, 64); o.y += __shfl_xor(o.y, 32, 64); o.z += __shfl_xor(o.z, 32, 64); o.w += __shfl_xor(o.w, 32, 64);
       const size_t pi = (head_base + g0 + g) * NS + slot;
       const float mn = m_run[g] * 0.6931471805599453f;       // m back to nats for the combine
-      if (lane < 32) *reinterpret_cast<f32x4*>(part_o + pi * kHeadDim + vc * 4) = o;
-      if (lane == 0) { part_ml[pi * 2] = mn; part_ml[pi * 2 + 1] = l_run[g]; }
+      if constexpr (WT) {       // read by another workgroup of this launch
+        if (lane < 32) { st_wt64(part_o + pi * kHeadDim + vc * 4, o.x, o.y); st_wt64(part_o + pi * kHeadDim + vc * 4 + 2, o.z, o.w); }
+        if (lane == 0) st_wt64(part_ml + pi * 2, mn, l_run[g]);
+      } else {
+        if (lane < 32) *reinterpret_cast<f32x4*>(part_o + pi * kHeadDim + vc * 4) = o;
+        if (lane == 0) { part_ml[pi * 2] = mn; part_ml[pi * 2 + 1] = l_run[g]; }
+      }
     }
   }
 }
@@ -392,5 +410,54 @@ __device__ __forceinline__ void attn_combine_wave(const AttnParams& p, const int
   }
 }
 
+// One WAVE merges one head from write-through partials (attn_decode_fold_kernel): the weights as in attn_combine_wave (lane s holds
+// (m_s, l_s)); lanes 0-31 sum the even slots, lanes 32-63 the odd ones of dims 4 c .. 4 c + 3 (c = lane & 31), 16 slots = 32 8-byte
+// loads in flight per lane and batch, one exchange at the end.
+__device__ __forceinline__ void attn_merge_head_wt(const AttnParams& p, const int hq, const int seq, const int ns, const int lane,
+                                                   const float* part_o, const float* part_ml) {
+  const size_t base = ((size_t)seq * p.n_q + hq) * p.n_splits;
+  float m = -INFINITY, l = 0.f;
+  if (lane < ns) ld_wt64(part_ml + (base + lane) * 2, m, l);
+  const float M = wave_max(m);
+  const float w = lane < ns ? expf(m - M) : 0.f;
+  const float den = wave_sum(w * l);
+  const int half = lane >> 5, c = lane & 31;
+  f32x4 num = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < ns; s0 += 32) {
+    f32x4 o[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int s = s0 + 2 * u + half;
+      const float* src = part_o + (base + (s < ns ? s : ns - 1)) * kHeadDim + c * 4;      // (clamped: its weight is 0)
+      float e0, e1, e2, e3;
+      ld_wt64(src, e0, e1);
+      ld_wt64(src + 2, e2, e3);
+      o[u] = (f32x4){e0, e1, e2, e3};
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float ws = __shfl(w, (s0 + 2 * u + half) & 63, 64);
+      num.x = fmaf(ws, o[u].x, num.x); num.y = fmaf(ws, o[u].y, num.y); num.z = fmaf(ws, o[u].z, num.z); num.w = fmaf(ws, o[u].w, num.w);
+    }
+  }
+  num.x += __shfl_xor(num.x, 32, 64); num.y += __shfl_xor(num.y, 32, 64); num.z += __shfl_xor(num.z, 32, 64); num.w += __shfl_xor(num.w, 32, 64);
+  if (lane >= 32) return;
+  const size_t oi = ((size_t)seq * p.n_q + hq) * kHeadDim + c * 4;
+  const float v[4] = {num.x / den, num.y / den, num.z / den, num.w / den};
+  if (p.out_hi) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t hv, lv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const __bf16 h = (__bf16)v[r];
+      hv[r] = h;
+      lv[r] = (__bf16)(v[r] - (float)h);
+    }
+    *reinterpret_cast<bf16x4_t*>(p.out_hi + oi) = hv;
+    *reinterpret_cast<bf16x4_t*>(p.out_lo + oi) = lv;
+  } else {
+    *reinterpret_cast<f32x4*>(p.out + oi) = (f32x4){v[0], v[1], v[2], v[3]};
+  }
+}
 
 }  // namespace chatts

@@ -17,7 +17,8 @@ int tp_allreduce_slabs(ChattsTpComm* c, const float* ws, const SlabOut& so, int 
 int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w, const float* k_norm_w,
                                   float norm_eps, const float* cos_tab, const float* sin_tab, int pos, const int32_t* pos_dev,
                                   const ChattsKvCache* cache, size_t seq_stride, float* out, uint16_t* out_hi, uint16_t* out_lo,
-                                  int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream, const SlabOut* slabs = nullptr);
+                                  int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream, const SlabOut* slabs = nullptr,
+                                  int32_t* arrive_cnt = nullptr);
 int attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev, const ChattsKvCache* cache, float* out,
                    uint16_t* out_hi, uint16_t* out_lo, int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream);
 int launch_split_bf16x2(const float* x, int m, int k, int ldx, uint16_t* hi, uint16_t* lo, int ldp, hipStream_t s);
@@ -393,10 +394,10 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
       return rc;
     }
     bool attn_out_planes = false;
-    if (t == 1) {   // decode: RoPE + cache write fused into the attention kernel
-      if ((rc = chatts_attention_decode_fused(d->b.qkv, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
-                                                     d->w.sin_tab, pos0, pos0_dev, &kc, d->b.attn, n_splits, d->b.workspace,
-                                                     d->b.workspace_bytes, stream)) != 0) {
+    if (t == 1) {   // decode: RoPE + cache write fused into the attention kernel; with arrival words at hand the merge too
+      if ((rc = attention_decode_batched_impl(d->b.qkv, 1, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, pos0,
+                                              pos0_dev, &kc, 0, d->b.attn, nullptr, nullptr, n_splits, d->b.workspace, d->b.workspace_bytes,
+                                              stream, nullptr, d->b.tile_counters)) != 0) {
         return rc;
       }
     } else {
@@ -525,7 +526,8 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
                                             lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, 0, pos_dev, &kc, seq_stride(d),
                                             d->b.attn, attn_planes ? d->b.planes_hi : nullptr, attn_planes ? d->b.planes_lo : nullptr,
                                             n_splits, static_cast<char*>(d->b.workspace) + (folded ? slab_room : 0),
-                                            d->b.workspace_bytes - (folded ? slab_room : 0), stream, folded ? &so : nullptr)) != 0) return rc;
+                                            d->b.workspace_bytes - (folded ? slab_room : 0), stream, folded ? &so : nullptr,
+                                            d->b.tile_counters)) != 0) return rc;
     la = ChattsLinearArgs{};
     la.a = d->b.attn; la.w = lw.o; la.m = batch; la.n = H; la.k = c.n_q * kHeadDim;
     la.lda = la.k; la.ldw = la.k; la.ldc = H;

@@ -23,7 +23,7 @@
 #include <string.h>
 #include <type_traits>
 
-#include "common.h"
+#include "gemm_common.h"
 
 // cache-policy bits of the prefill GEMM's LDS-DMA loads (A/B knobs, compile time): 0 = default, 2 = non-temporal
 #ifndef CHATTS_DMA_A_AUX
@@ -35,28 +35,24 @@
 
 namespace chatts {
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-
-struct GemmParams {
-  const float* a;
-  const uint16_t* w;
-  const float* bias;
-  const float* resid;
-  float* c;          // final output, or split-K partials [sk][M][N]
-  int m, n, k, lda, ldw, ldc, epilogue;
-  int k_per_split;   // multiple of 32
-  int direct;        // 1: apply epilogue here; 0: write raw partials
-  const uint8_t* w8;     // optional fp8 (e4m3fn) copy of W: streamed instead of the bf16 copy, widened (exactly) to
-  const float* w8_scale; // bf16 while it is staged to LDS; the per-row power-of-two scale is applied in the epilogue
-  int ldw8;
-  int w8_format;         // CHATTS_W8_FP8 / CHATTS_W8_INT8 (gemm_stream_kernel only; the other kernels never see an int8 copy)
-  uint16_t* c_hi;        // optional: the output goes out as bf16 hi / lo planes [M, ldcp] (the next GEMM's operand
-  uint16_t* c_lo;        // format) instead of float32 c
-  int ldcp;
-  int sk_T, sk_nk;       // stream-K (gemm_dma_kernel only): T = tiles * K-steps per tile, sk_nk = K-steps per tile; 0 = off
-  int32_t* fix_cnt;      // gemm_stream_kernel, split-K: per-tile arrival counters -> the last workgroup of a tile runs the epilogue
-  float* c_out;          // ... into the real output (c holds the partial slabs)
-};
+// ---- timeline probe (diagnostic builds only: -DCHATTS_GEMM_PROBE, tools/build_variant.py) --------------------------------------
+// One 16-word record per workgroup of gemm_dma_kernel: compute wave 0 stamps entry / first stage published / K loop done / stores
+// drained, loader wave 0 stamps entry / prologue issued / first stage landed, with the 100 MHz s_memrealtime counter (comparable
+// across CUs) plus s_memtime at both ends (shader clock -> effective frequency) and the CU the workgroup ran on.
+#ifdef CHATTS_GEMM_PROBE
+constexpr int kProbeRecs = 1 << 16;
+__device__ unsigned long long g_gemm_probe[kProbeRecs * 16];
+__device__ __forceinline__ unsigned long long probe_rt() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ unsigned long long probe_clk() { return __builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ unsigned probe_cu() {
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+  const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+  return ((xcc & 15u) << 16) | ((hw >> 8) & 0xffffu);
+}
+#define PROBE(slot, expr) do { if (lane == 0 && prec) prec[slot] = (expr); } while (0)
+#else
+#define PROBE(slot, expr) do { } while (0)
+#endif
 
 // ---- stream-K decomposition (gemm_dma_kernel) -------------------------------------------------------------------
 // The (tile, K-step) space of a GEMM is linear: tile t owns steps [t * nk, (t + 1) * nk), tiles in (N-panel major, M-tile
@@ -74,19 +70,6 @@ __device__ __host__ __forceinline__ int sk_range_of(int step, int T) {          
 __device__ __host__ __forceinline__ int sk_tile_nseg(int tile, int T, int nk) {
   return sk_range_of((tile + 1) * nk - 1, T) - sk_range_of(tile * nk, T) + 1;
 }
-
-__device__ __forceinline__ void store_planes(uint16_t* hi, uint16_t* lo, size_t off, float v) {
-  // no contraction: when v is a product (SwiGLU) the compiler would otherwise fold it into the subtraction as an FMA and
-  // lo would no longer be the split of the ROUNDED float32 value the float32 path stores
-#pragma clang fp contract(off)
-  const __bf16 h = (__bf16)v;
-  const __bf16 l = (__bf16)(v - (float)h);
-  hi[off] = __builtin_bit_cast(uint16_t, h);
-  lo[off] = __builtin_bit_cast(uint16_t, l);
-}
-
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float silu_g(float x) { return x / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ int lds_off(int r, int c) {   // byte offset of 16-byte chunk c of row r
   return r * 64 + ((c ^ (((r >> 3) & 1) << 1)) << 4);
@@ -404,9 +387,6 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(GemmParams p) {
 // XCD mapping: workgroup b runs on XCD b % 8.  The (N-panel major, M-tile minor) tile sequence is cut into 8 contiguous,
 // equally long ranges, one per XCD: the M-tiles of a W panel stay adjacent on one XCD (its L2 fetches the panel once),
 // and no XCD gets a whole panel more than another (108 panels over 8 XCDs as 14/13 cost a 4th round of workgroups).
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
 __device__ __forceinline__ int lds_off128(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
 constexpr int kDmaBN = 256, kDmaBK = 64, kDmaLds = 2 * (2 * 128 * 128 + kDmaBN * 128), kDmaThreads = 768;
@@ -486,6 +466,13 @@ __global__ __launch_bounds__(W32 ? 512 : kDmaThreads) void gemm_dma_kernel(GemmP
   const int nt = idx / mt_count, mt = idx - nt * mt_count;
   const int m0 = mt * BM, n0 = nt * BN;
   const int nk = (kend - kbeg) / BK;           // the launcher makes k_per_split a multiple of 64; nk >= 1
+#ifdef CHATTS_GEMM_PROBE
+  const unsigned prec_i = blockIdx.z * gridDim.x + blockIdx.x;
+  unsigned long long* prec = (prec_i < (unsigned)kProbeRecs && (wave == 0 || wave == NCOMPUTE)) ? g_gemm_probe + (size_t)prec_i * 16 + (wave ? 8 : 0) : nullptr;
+  PROBE(0, probe_rt());
+  PROBE(1, probe_clk());
+  if (wave == 0) { PROBE(6, ((unsigned long long)probe_cu() << 32) | (unsigned)idx); PROBE(7, ((unsigned long long)nk << 32) | (unsigned)(p.m - m0)); }
+#endif
 
   if (wave >= NCOMPUTE) {
     // ---- loader wave L: 1 KB pieces (8 rows x 128 B) {L, L+4, ...} of each plane, 16 per stage.  Piece q = rows
@@ -526,6 +513,7 @@ __global__ __launch_bounds__(W32 ? 512 : kDmaThreads) void gemm_dma_kernel(GemmP
     issue(0);
     if (nk > 1) {
       issue(1);
+      PROBE(2, probe_rt());                                         // prologue pieces issued
       int a_live = 0;                                               // a ragged tile issues fewer than 16 pieces per stage
 #pragma unroll
       for (int h = 0; h < NA; ++h) a_live += m0 + (L + NLOAD * h) * 8 < p.m;
@@ -539,6 +527,7 @@ __global__ __launch_bounds__(W32 ? 512 : kDmaThreads) void gemm_dma_kernel(GemmP
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    PROBE(3, probe_rt());                                           // stage 0 landed
     __builtin_amdgcn_s_barrier();                                   // publishes stage 0
     for (int kt = 0; kt + 1 < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // stage kt+1 landed (issued a whole K-step ago)
@@ -654,6 +643,7 @@ __global__ __launch_bounds__(W32 ? 512 : kDmaThreads) void gemm_dma_kernel(GemmP
     };
 
     __builtin_amdgcn_s_barrier();                // stage 0 published
+    PROBE(2, probe_rt());
     read_b(0, 0);
     if constexpr (!SINGLE) read_a(0, 0, 1, alo[0]);
     read_a(0, 0, 0, ahi[0]);
@@ -691,7 +681,13 @@ __global__ __launch_bounds__(W32 ? 512 : kDmaThreads) void gemm_dma_kernel(GemmP
     case 3: k_loop(std::integral_constant<int, 3>{}); break;
     default: k_loop(std::integral_constant<int, 4>{}); break;
   }
+  PROBE(3, probe_rt());                          // K loop done
   gemm_store<FM, FN, TM, TN, false>(p, acc, m0, n0, wm, wn, lane, slab);
+#ifdef CHATTS_GEMM_PROBE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PROBE(4, probe_rt());                          // stores drained
+  PROBE(5, probe_clk());
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1292,6 +1288,19 @@ static bool use_dma(const ChattsLinearArgs* a) {
   return a->m >= gemm_env_int("CHATTS_GEMM_DMA_MIN_M", kDmaMinM) && gemm_env_int("CHATTS_GEMM_DMA", 1) != 0;
 }
 
+// The round-5 prefill kernel (gemm_ring.hip) takes every call the LDS-DMA kernel took whose epilogue operands allow 16-byte accesses
+// (its lanes hold 4 consecutive output columns).  CHATTS_GEMM_RING=0 keeps the round-4 kernel for A/B runs.
+static bool use_ring(const ChattsLinearArgs* a) {
+  if (gemm_env_int("CHATTS_GEMM_RING", 1) == 0) return false;
+  if (a->w8 || a->k % 64 != 0 || a->ldc % 4 != 0 || a->n % 16 != 0) return false;
+  if (((uintptr_t)a->bias % 16) || ((uintptr_t)a->resid % 16) || ((uintptr_t)a->c % 16)) return false;
+  if (a->c_hi && (a->ld_cplanes % 4 != 0 || ((uintptr_t)a->c_hi % 8) || ((uintptr_t)a->c_lo % 8))) return false;
+  return true;
+}
+static void pick_ring(const ChattsLinearArgs* a, RingGeom& g) {
+  ring_pick(a->m, a->n, a->k, device_cus(), gemm_env_int("CHATTS_GEMM_T", 0), gemm_env_int("CHATTS_GEMM_SK", 0), g);
+}
+
 // DMA geometry: 128 x 256 tiles, one 8-wave workgroup per CU.
 static void pick_dma_geometry(int m, int n, int k, int& sk) {
   // Few tiles (the TS-encoder MLP: P <= 128 patches x 5120 columns = 20 tiles): split K as far as ONE round of workgroups
@@ -1399,6 +1408,11 @@ size_t gemm_workspace(int m, int n, int k) {
   pick_geometry(m, n, k, bm, sk);
   pick_dma_geometry(m, n, k, sk2);
   if (sk2 > sk) sk = sk2;
+  if (m >= kDmaMinM && k % 64 == 0) {          // the ring kernel's own split choice
+    RingGeom g;
+    ring_pick(m, n, k, device_cus(), gemm_env_int("CHATTS_GEMM_T", 0), gemm_env_int("CHATTS_GEMM_SK", 0), g);
+    if (g.sk > sk) sk = g.sk;
+  }
   if (m >= 256 && k % kDmaBK == 0) {
     const int slabs = pick_streamk(m, n, k, sk2);
     if (slabs > sk) sk = slabs;
@@ -1454,11 +1468,15 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
   }
   const bool stream = use_stream(a);
   const bool dma = !stream && use_dma(a);
+  bool ring = false;
+  RingGeom rg{};
   if (stream) {
     sk = pick_stream_sk(a->n, a->k, a->w8 != nullptr);
     bm = 16;
   } else if (dma) {
-    pick_dma_geometry(a->m, a->n, a->k, sk);
+    ring = use_ring(a);
+    if (ring) { pick_ring(a, rg); sk = rg.sk; }
+    else pick_dma_geometry(a->m, a->n, a->k, sk);
     bm = 128;
   } else {
     CHATTS_REQUIRE(a->a, CHATTS_E_SHAPE, "linear: a == NULL needs K %% %d == 0 (K=%d) for the plane path", kDmaBK, a->k);
@@ -1468,7 +1486,7 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
   sk = (a->k + kps - 1) / kps;
   GemmParams p;
   p.sk_T = 0; p.sk_nk = 0;
-  if (dma && a->epilogue != CHATTS_EPI_SWIGLU) {
+  if (dma && !ring && a->epilogue != CHATTS_EPI_SWIGLU) {
     const int slabs = pick_streamk(a->m, a->n, a->k, sk);
     if (slabs > 0) {                     // stream-K: every tile goes through `slabs` split-K slabs (some tiles use fewer)
       const int tiles = ((a->n + kDmaBN - 1) / kDmaBN) * ((a->m + 127) / 128);
@@ -1515,6 +1533,14 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
     else if (stages == 3) rc = launch_stream_t<3, false>(p, a, sk, s);
     else if (stages == 5) rc = launch_stream_t<5, false>(p, a, sk, s);
     else rc = launch_stream_t<4, false>(p, a, sk, s);
+    if (rc) return rc;
+  } else if (ring) {
+    rg.sk = sk;                      // (k_per_split was rounded to whole K-steps: the split count may have shrunk)
+    rg.units = rg.T * rg.P * sk;
+    int wpx = (rg.units + 7) / 8;
+    if (wpx > device_cus() / 8) wpx = device_cus() / 8;
+    rg.wpx = wpx < 1 ? 1 : wpx;
+    const int rc = launch_ring(p, a->a_hi, a->a_lo, a->ld_planes, rg, dma_single_pass(), s);
     if (rc) return rc;
   } else if (dma) {
     const int rc = launch_dma(p, a, sk, s);
@@ -1589,3 +1615,16 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
 }
 
 }  // namespace chatts
+
+#ifdef CHATTS_GEMM_PROBE
+// diagnostic builds only (not in include/chatts_amd.h): copy the probe records to the host and clear them
+extern "C" int chatts_debug_gemm_probe(void* dst, size_t bytes) {
+  const size_t all = sizeof(unsigned long long) * chatts::kProbeRecs * 16;
+  if (bytes > all) bytes = all;
+  if (hipDeviceSynchronize() != hipSuccess) return CHATTS_E_LAUNCH;
+  if (dst && hipMemcpyFromSymbol(dst, HIP_SYMBOL(chatts::g_gemm_probe), bytes) != hipSuccess) return CHATTS_E_LAUNCH;
+  void* sym = nullptr;
+  if (hipGetSymbolAddress(&sym, HIP_SYMBOL(chatts::g_gemm_probe)) != hipSuccess || hipMemset(sym, 0, all) != hipSuccess) return CHATTS_E_LAUNCH;
+  return CHATTS_OK;
+}
+#endif

@@ -40,8 +40,9 @@ const char* chatts_last_error(void);
  *  6: persistent decode step chatts_decoder_mega_*; the attention 'parts' form and its ChattsLinearArgs fields removed;
  *  7: ChattsLinearArgs.tp_reduce (exchange inside the projection's launch), chatts_tp_init_loopback, chatts_allreduce_bulk +
  *     chatts_decoder_prefill(_last) under tensor parallelism, chatts_decoder_logits_batched; the persistent decode step
- *     chatts_decoder_mega_* is gone - built and measured slower than the captured multi-kernel step in round 3). */
-#define CHATTS_ABI_VERSION 7
+ *     chatts_decoder_mega_* is gone - built and measured slower than the captured multi-kernel step in round 3);
+ *  8: chatts_attention_decode_batched_fold (decode attention in one launch). */
+#define CHATTS_ABI_VERSION 8
 int chatts_abi_version(void);
 /* Number of CUs of the current device (grid sizing), or <0. */
 int chatts_device_cus(void);
@@ -312,6 +313,15 @@ int chatts_attention_decode_batched(const float* qkv_raw, int batch, int n_q, in
                                     const float* sin_tab, int pos, const int32_t* pos_dev,
                                     const ChattsKvCache* cache, size_t seq_stride, float* out, int n_splits,
                                     void* workspace, size_t workspace_bytes, chatts_stream_t stream);
+/* The same in ONE launch: `arrive` = n_kv * batch int32 words in device memory (<= CHATTS_TILE_COUNTERS; zero before the first use,
+ * left zero by every completed call, not shared between streams).  The slot waves publish their partials write-through and draw a
+ * ticket; the last min(n_q / n_kv, slots) arrivers of a (sequence, kv head) merge the group's heads and write the output rows - the
+ * second launch of the form above (its merge kernel) disappears.  Same weights, the weighted sums in another order (<= 1e-6 relative). */
+int chatts_attention_decode_batched_fold(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w,
+                                         const float* k_norm_w, float norm_eps, const float* cos_tab,
+                                         const float* sin_tab, int pos, const int32_t* pos_dev,
+                                         const ChattsKvCache* cache, size_t seq_stride, float* out, int n_splits,
+                                         void* workspace, size_t workspace_bytes, int32_t* arrive, chatts_stream_t stream);
 
 /* logits [V] float32 -> *token (first index of the maximum, like torch.argmax); optionally also
  * appends the token to out_tokens[*step_dev] and increments *step_dev and *pos_dev (decode loop

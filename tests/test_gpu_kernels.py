@@ -693,6 +693,57 @@ def test_attention_decode_batched_equals_per_sequence(lib):
     assert torch.equal(kc_b[:, 0], kc0[:, 0]) and torch.equal(kc_b[:, 2], kc0[:, 2])
 
 
+@pytest.mark.parametrize("nq,nkv,splits", [(40, 8, 64), (5, 1, 64), (32, 8, 16), (10, 2, 3), (8, 8, 64)])
+def test_attention_decode_in_one_launch_equals_the_two_kernel_form(lib, nq, nkv, splits):
+    """chatts_attention_decode_batched_fold (the last arriving waves of a (sequence, kv head) merge its heads inside the launch) against
+    the two-launch form: same cache rows, outputs equal up to the order of the weighted sums; positions with fewer tiles than heads,
+    one tile, a parked sequence, slots walking several tiles; the arrival words are back at zero, and a second call on them (a replay)
+    gives the same bits as the first."""
+    max_ctx, B = 2048, 6
+    g = torch.Generator().manual_seed(nq * 131 + splits)
+    raw = torch.randn((B, (nq + 2 * nkv) * 128), generator=g).to(DEV)
+    kc0 = torch.randn((B, nkv, max_ctx, 128), generator=g).to(DEV)
+    vc0 = torch.randn((B, nkv, max_ctx, 128), generator=g).to(DEV)
+    pos = [0, 17, 47, 830, -1, 2047]
+    for b, p_ in enumerate(pos):
+        kc0[b, :, max(p_, 0):] = float("nan")
+        vc0[b, :, max(p_, 0):] = float("nan")
+    qn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV)
+    kn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV)
+    cos, sin = _rope_tables(max_ctx)
+    wsb = int(lib.chatts_attn_workspace(B, nq, splits))
+    pos_dev = torch.tensor(pos, dtype=torch.int32, device=DEV)
+    seq_stride = nkv * max_ctx * 128
+
+    def run(fold, words=None):
+        ws = torch.full((wsb // 4,), float("nan"), device=DEV)       # stale partials of another kernel must never be read
+        ka, va = kc0.clone(), vc0.clone()
+        ca = _lib.KvCache(k=ka.data_ptr(), v=va.data_ptr(), max_ctx=max_ctx)
+        out = torch.full((B, nq * 128), float("nan"), device=DEV)
+        args = (raw.data_ptr(), B, nq, nkv, qn.data_ptr(), kn.data_ptr(), 1e-6, cos.data_ptr(), sin.data_ptr(), 0, pos_dev.data_ptr(),
+                C.byref(ca), seq_stride, out.data_ptr(), splits, ws.data_ptr(), wsb)
+        if fold:
+            _lib.check(lib.chatts_attention_decode_batched_fold(*args, words.data_ptr(), st()))
+        else:
+            _lib.check(lib.chatts_attention_decode_batched(*args, st()))
+        torch.cuda.synchronize()
+        return out, ka, va
+
+    out_a, ka, va = run(False)
+    words = torch.zeros(_lib.TILE_COUNTERS, dtype=torch.int32, device=DEV)
+    out_b, kb, vb = run(True, words)
+    assert int(words.abs().sum()) == 0, "arrival words not re-armed"
+    out_c, _, _ = run(True, words)
+    assert int(words.abs().sum()) == 0
+    live = [b for b, p_ in enumerate(pos) if p_ >= 0]
+    assert not torch.isnan(out_b[live]).any()
+    assert torch.equal(out_b[4], torch.zeros_like(out_b[4])) and torch.equal(out_a[4], out_b[4])      # parked row: zeros in both forms
+    for b in live:
+        assert torch.equal(kb[b, :, :pos[b] + 1], ka[b, :, :pos[b] + 1]) and torch.equal(vb[b, :, :pos[b] + 1], va[b, :, :pos[b] + 1])
+        assert rel_err(out_b[b].cpu().numpy(), out_a[b].cpu().numpy()) < 1e-6, b
+    assert torch.equal(out_b, out_c)
+
+
 @pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
 @pytest.mark.parametrize("norm", [False, True])
 @pytest.mark.parametrize("n,k", [(1024, 512), (5120, 5120), (96, 2048), (5120, 13824), (2048, 16 * 17)])
