@@ -30,7 +30,6 @@ class TsWeights(C.Structure):
 
 
 ABI_VERSION = 8            # CHATTS_ABI_VERSION of include/chatts_amd.h this binding was written against (checked by load())
-TILE_COUNTERS = 4096      # CHATTS_TILE_COUNTERS
 W8_FP8, W8_INT8 = 0, 1     # ChattsLinearArgs.w8_format
 
 
@@ -42,7 +41,7 @@ class LinearArgs(C.Structure):
                 ("a_hi", c_void_p), ("a_lo", c_void_p), ("ld_planes", c_int),
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("ld_cplanes", c_int),
                 ("post_norm_w", c_void_p), ("post_norm_eps", c_float), ("post_hi", c_void_p), ("post_lo", c_void_p), ("ld_post", c_int),
-                ("w4", c_void_p), ("w4_sz", c_void_p), ("ldw4", c_int), ("w4_group", c_int), ("tile_counters", c_void_p),
+                ("w4", c_void_p), ("w4_sz", c_void_p), ("ldw4", c_int), ("w4_group", c_int),
                 ("w8_format", c_int), ("tp_reduce", c_void_p)]
 
 
@@ -95,8 +94,7 @@ class DecoderBuffers(C.Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("t_max", c_int), ("max_batch", c_int),
                 ("planes_hi", c_void_p), ("planes_lo", c_void_p), ("planes2_hi", c_void_p), ("planes2_lo", c_void_p),
                 ("tp_pair_logit", c_void_p), ("tp_pair_token", c_void_p), ("logits_full", c_void_p),
-                ("kv_block_table", c_void_p), ("kv_block_size", c_int), ("kv_table_stride", c_int), ("kv_pool_blocks", c_int),
-                ("tile_counters", c_void_p)]
+                ("kv_block_table", c_void_p), ("kv_block_size", c_int), ("kv_table_stride", c_int), ("kv_pool_blocks", c_int)]
 
 
 # name -> (restype, argtypes); this table IS the list of symbols include/chatts_amd.h declares
@@ -104,6 +102,10 @@ SIGNATURES = {
     "chatts_last_error": (C.c_char_p, []),
     "chatts_abi_version": (c_int, []),
     "chatts_device_cus": (c_int, []),
+    "chatts_set_option": (c_int, [C.c_char_p, c_int]),
+    "chatts_unset_option": (c_int, [C.c_char_p]),
+    "chatts_get_option": (c_int, [C.c_char_p, C.POINTER(c_int), C.POINTER(c_int)]),
+    "chatts_option_name": (C.c_char_p, [c_int]),
     "chatts_fill_hash": (c_int, [c_void_p, c_int, c_uint32, c_float, c_int, c_int64, c_int64, c_int64, c_int64,
                                  c_int64, c_int64, c_void_p]),
     "chatts_ts_normalise": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -132,9 +134,6 @@ SIGNATURES = {
     "chatts_attention_decode_batched": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                                                 c_void_p, c_int, c_void_p, C.POINTER(KvCache), c_size_t, c_void_p, c_int,
                                                 c_void_p, c_size_t, c_void_p]),
-    "chatts_attention_decode_batched_fold": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
-                                                     c_void_p, c_int, c_void_p, C.POINTER(KvCache), c_size_t, c_void_p, c_int,
-                                                     c_void_p, c_size_t, c_void_p, c_void_p]),
     "chatts_argmax_batched": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_int, c_void_p]),
     "chatts_argmax_workspace": (c_size_t, [c_int]),
@@ -183,6 +182,8 @@ SIGNATURES = {
     "chatts_tp_max_elems": (c_int64, [c_void_p]),
     "chatts_tp_status": (c_int, [c_void_p]),
     "chatts_tp_reset": (c_int, [c_void_p, c_void_p]),
+    "chatts_tp_flush_epochs": (c_int, [c_void_p, c_void_p]),
+    "chatts_tp_pending": (c_int, [c_void_p]),
     "chatts_allreduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "chatts_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "chatts_tp_argmax": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
@@ -226,7 +227,79 @@ def load():
         raise RuntimeError(f"{path} has ABI version {lib.chatts_abi_version()}, this package binds version {ABI_VERSION} "
                            "(include/chatts_amd.h: CHATTS_ABI_VERSION): rebuild it with `python -m chatts_amd.build --force`")
     _LIB = lib
+    sync_env()
     return lib
+
+
+def option_names():
+    """the tuning options the library knows (chatts_option_name)"""
+    lib, out, i = load(), [], 0
+    while True:
+        n = lib.chatts_option_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
+
+
+def set_option(name, value):
+    """chatts_set_option: select an alternative path / launch geometry (None = back to the shipped choice)"""
+    lib = load()
+    if value is None:
+        check(lib.chatts_unset_option(name.encode()))
+    else:
+        check(lib.chatts_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v, isset = c_int(0), c_int(0)
+    check(load().chatts_get_option(name.encode(), C.byref(v), C.byref(isset)))
+    return v.value if isset.value else None
+
+
+class options:
+    """with _lib.options(GEMM_SK=2, ROPE_FUSE=0): ...   - set for the block, restored afterwards"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
+
+
+_ENV_ALIASES = {"bf16x2": 0, "bf16": 1}      # CHATTS_GEMM_PRECISION=bf16
+
+
+def sync_env():
+    """Make the options mirror the process environment: every known option NAME takes the value of CHATTS_<NAME> when that variable is
+    set and goes back to unset otherwise.  Called once by load(); tools that flip os.environ between calls call it again.  This is
+    the ONLY place the environment reaches the library: the C side never calls getenv."""
+    lib = _LIB
+    if lib is None:
+        return
+    lib.chatts_unset_option(None)
+    i = 0
+    while True:
+        n = lib.chatts_option_name(i)
+        if n is None:
+            break
+        i += 1
+        v = os.environ.get("CHATTS_" + n.decode())
+        if v is None or v == "":
+            continue
+        try:
+            iv = _ENV_ALIASES[v] if v in _ENV_ALIASES else int(v)
+        except ValueError:
+            raise RuntimeError(f"CHATTS_{n.decode()}={v!r}: tuning options are integers")
+        check(lib.chatts_set_option(n, iv))
 
 
 def check(rc):

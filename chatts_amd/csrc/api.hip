@@ -15,6 +15,27 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// tuning options: see common.h.  Plain ints behind relaxed atomics: a host thread may set one while another enqueues (a torn
+// read is impossible; which value a concurrent call sees is the caller's business).
+static const int kOptUnset = -2147483647 - 1;
+static int g_opts[OPT_COUNT];
+static bool g_opts_ready = false;
+static const char* const g_opt_names[OPT_COUNT] = {
+#define CHATTS_OPT_NAME(name) #name,
+    CHATTS_OPTIONS(CHATTS_OPT_NAME)
+#undef CHATTS_OPT_NAME
+};
+static void opts_init() {
+  if (__atomic_load_n(&g_opts_ready, __ATOMIC_ACQUIRE)) return;
+  for (int i = 0; i < OPT_COUNT; ++i) __atomic_store_n(&g_opts[i], kOptUnset, __ATOMIC_RELAXED);
+  __atomic_store_n(&g_opts_ready, true, __ATOMIC_RELEASE);
+}
+int opt_get(ChattsOpt o, int dflt) {
+  if (!__atomic_load_n(&g_opts_ready, __ATOMIC_ACQUIRE)) return dflt;
+  const int v = __atomic_load_n(&g_opts[o], __ATOMIC_RELAXED);
+  return v == kOptUnset ? dflt : v;
+}
+
 int device_cus() {
   static thread_local int cus = 0;
   if (cus > 0) return cus;
@@ -71,6 +92,43 @@ using namespace chatts;
 extern "C" const char* chatts_last_error(void) { return g_err; }
 extern "C" int chatts_abi_version(void) { return CHATTS_ABI_VERSION; }
 extern "C" int chatts_device_cus(void) { return device_cus(); }
+
+static int opt_index(const char* name) {
+  if (!name) return -1;
+  if (strncmp(name, "CHATTS_", 7) == 0) name += 7;
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strcmp(name, g_opt_names[i]) == 0) return i;
+  return -1;
+}
+extern "C" int chatts_set_option(const char* name, int value) {
+  const int i = opt_index(name);
+  CHATTS_REQUIRE(i >= 0, CHATTS_E_BADARG, "set_option: unknown option '%s'", name ? name : "(null)");
+  opts_init();
+  __atomic_store_n(&g_opts[i], value, __ATOMIC_RELAXED);
+  return CHATTS_OK;
+}
+extern "C" int chatts_unset_option(const char* name) {
+  if (name == nullptr) {      // all of them
+    opts_init();
+    for (int i = 0; i < OPT_COUNT; ++i) __atomic_store_n(&g_opts[i], kOptUnset, __ATOMIC_RELAXED);
+    return CHATTS_OK;
+  }
+  const int i = opt_index(name);
+  CHATTS_REQUIRE(i >= 0, CHATTS_E_BADARG, "unset_option: unknown option '%s'", name);
+  opts_init();
+  __atomic_store_n(&g_opts[i], kOptUnset, __ATOMIC_RELAXED);
+  return CHATTS_OK;
+}
+extern "C" int chatts_get_option(const char* name, int* value, int* is_set) {
+  const int i = opt_index(name);
+  CHATTS_REQUIRE(i >= 0 && value, CHATTS_E_BADARG, "get_option: unknown option '%s'", name ? name : "(null)");
+  opts_init();
+  const int v = __atomic_load_n(&g_opts[i], __ATOMIC_RELAXED);
+  *value = v == kOptUnset ? 0 : v;
+  if (is_set) *is_set = v != kOptUnset;
+  return CHATTS_OK;
+}
+extern "C" const char* chatts_option_name(int index) { return index >= 0 && index < OPT_COUNT ? g_opt_names[index] : nullptr; }
 
 extern "C" int chatts_fill_hash(void* dst, int out_f32, uint32_t key, float base, int shift, int64_t rows,
                                 int64_t cols, int64_t ld, int64_t row0, int64_t col0, int64_t full_cols,

@@ -45,82 +45,6 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnParams p) 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// decode, ONE launch (round 5): the slot waves of attn_decode_kernel + the merge of attn_decode_combine_kernel by the waves that
-// arrive last.  Every wave with keys writes its partials write-through, drains them and draws a ticket from the (sequence, kv head)
-// arrival word; the last min(G, slots) arrivers each take heads of the group (ticket -> head), wait until the word says that every
-// slot has arrived (bounded spin; they are the last, so it is a short one), merge their heads from L1-bypassing loads and write the
-// output row.  The last merger re-arms the word.  What it removes is the second launch of every layer's attention island (4.9 us +
-// the boundary); what it adds is one returning atomic per wave and ~2 us of serial merge for the last waves.
-// cnt: n_kv * batch int32 in device memory, zero before the first launch (ChattsDecoderBuffers.tile_counters).
-// ---------------------------------------------------------------------------------------------------
-template <int GMAX>
-__global__ __launch_bounds__(64) void attn_decode_fold_kernel(AttnParams p, int32_t* cnt) {
-  __shared__ __attribute__((aligned(16))) float q_s[GMAX * kHeadDim];
-  __shared__ __attribute__((aligned(16))) float knew_s[kHeadDim];
-  __shared__ __attribute__((aligned(16))) float vnew_s[kHeadDim];
-  const int hk = blockIdx.x, slot = blockIdx.y, seq = blockIdx.z, lane = threadIdx.x;
-  const int G = p.n_q / p.n_kv;
-  AttnTileRegs t;
-  if (!attn_decode_preload(p, hk, slot, seq, lane, t)) {
-    if (t.pos < 0 && slot == 0) {                 // parked sequence: its output row is zeros (attn_combine_wave's rule)
-      for (int g = 0; g < G; ++g) {
-        const size_t oi = ((size_t)seq * p.n_q + hk * G + g) * kHeadDim;
-        if (p.out_hi) { p.out_hi[oi + lane] = 0; p.out_hi[oi + lane + 64] = 0; p.out_lo[oi + lane] = 0; p.out_lo[oi + lane + 64] = 0; }
-        else { p.out[oi + lane] = 0.f; p.out[oi + lane + 64] = 0.f; }
-      }
-    }
-    return;
-  }
-  attn_decode_finish<GMAX, true, true>(p, hk, slot, seq, lane, t, q_s, knew_s, vnew_s, 0, G, p.part_o, p.part_ml,
-                                       (size_t)seq * p.n_q + hk * G);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the partials have left this CU
-  const int ntiles = t.pos / kDTile + 1;
-  const int ns = ntiles < p.n_splits ? ntiles : p.n_splits;
-  int* word = cnt + seq * p.n_kv + hk;
-  int ticket = 0;
-  if (lane == 0) ticket = __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  ticket = __builtin_amdgcn_readfirstlane(ticket);
-  const int mc = ns < G ? ns : G;
-  const int mi = ticket - (ns - mc);
-  if (mi < 0) return;
-  if (lane == 0) {
-    const uint64_t t0 = wall_clock64();
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ns) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > 20000000ull) break;          // 0.2 s: never hang the device (the result is then garbage, like any lost launch)
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  for (int g = mi; g < G; g += mc) attn_merge_head_wt(p, hk * G + g, seq, ns, lane, p.part_o, p.part_ml);
-  if (lane == 0) {
-    const int d = __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d == ns + mc - 1) __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// decode, workgroup form: grid (n_kv, batch), NWV waves.  Wave w is tile slot w of NWV (it walks tiles w, w + NWV, ... with the next
-// tile prefetched under the current one); the NWV partials of every head of the group meet in LDS and waves 0 .. 2 G - 1 merge them
-// (attn_combine_wave: two waves per head) - no partials in HBM, no second launch.  The launch that disappears is worth ~4.9 us per
-// layer and a further tile costs a wave ~0.7 us, so this is the form for contexts of up to 8 tiles per wave (NWV = 16: 2048 positions);
-// longer caches keep the one-wave-per-slot kernel + attn_decode_combine_kernel, whose latency does not grow with the context.
-// Bit-identical to that pair at n_splits = NWV.  All waves of the workgroup share q_s (they write the same values).
-// ---------------------------------------------------------------------------------------------------
-template <int GMAX, int NWV>
-__global__ __launch_bounds__(64 * NWV) void attn_decode_wg_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) float q_s[GMAX * kHeadDim];
-  __shared__ __attribute__((aligned(16))) float knew_s[kHeadDim];
-  __shared__ __attribute__((aligned(16))) float vnew_s[kHeadDim];
-  __shared__ __attribute__((aligned(16))) float po_s[GMAX * NWV * kHeadDim];
-  __shared__ __attribute__((aligned(16))) float pml_s[GMAX * NWV * 2];
-  const int hk = blockIdx.x, seq = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  attn_decode_wave<GMAX, (NWV <= 8)>(p, hk, wave, seq, lane, q_s, knew_s, vnew_s, po_s, pml_s, 0);      // (p.n_splits == NWV)
-  __syncthreads();
-  const int G = p.n_q / p.n_kv;
-  if (wave < 2 * G) attn_combine_wave(p, hk * G + (wave >> 1), seq, (wave & 1) * 64 + lane, lane, po_s, pml_s, (size_t)(wave >> 1) * NWV);
-}
-
-// ---------------------------------------------------------------------------------------------------
 // prefill: grid (n_kv, T, n_splits), 256 threads, 64-key tiles.
 //   phase 1  scores: 4 lanes per key (32 dims each), xor-shuffle reduce
 //   phase 2  one wave per head: tile max / rescale factor / p = exp(s - m) written back to LDS
@@ -1108,12 +1032,12 @@ int chatts::attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0,
     const int rc = bind_workspace(p, workspace, workspace_bytes);
     if (rc) return rc;
   }
-  static const bool force_rows = getenv("CHATTS_ATTN_ROWS") != nullptr;   // debugging aid: VALU kernel for every T
+  const bool force_rows = opt_get(OPT_ATTN_ROWS, 0) != 0;   // debugging aid: VALU kernel for every T
   if (t >= 16 && n_splits <= 4 && (!force_rows || out_hi)) {
     // (64-key tiles were measured too: 155 us vs 148 us at T = 798 - the per-tile work is not what is slow)
-    const int bf16x3 = getenv("CHATTS_ATTN_BF16X3") ? atoi(getenv("CHATTS_ATTN_BF16X3")) : 1;      // 0: the float32-MFMA kernel
+    const int bf16x3 = opt_get(OPT_ATTN_BF16X3, 1);      // 0: the float32-MFMA kernel
     // K / V split into bf16 planes once (kv_planes_kernel) when the caller's workspace is free (one key split) and holds them
-    static const bool planes_on = !getenv("CHATTS_ATTN_PLANES") || atoi(getenv("CHATTS_ATTN_PLANES")) != 0;
+    const bool planes_on = opt_get(OPT_ATTN_PLANES, 1) != 0;
     const int n_keys = pos0 + t, tiles = (n_keys + 31) / 32;
     const size_t plane_bytes = (size_t)tiles * n_kv * 4 * 32 * kHeadDim * sizeof(uint16_t);
     const bool planes = bf16x3 && planes_on && !pos0_dev && n_splits == 1 && t >= 64 && workspace && workspace_bytes >= plane_bytes &&
@@ -1124,7 +1048,7 @@ int chatts::attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0,
       hipLaunchKernelGGL(kv_planes_kernel, dim3(tiles, n_kv), dim3(256), 0, as_stream(stream), p, n_keys, pl);
       CHATTS_CHECK_LAUNCH("kv_planes");
       p.kv_planes = pl; p.kv_plane_tiles = tiles;
-      static const bool xcd_on = !getenv("CHATTS_ATTN_XCD") || atoi(getenv("CHATTS_ATTN_XCD")) != 0;
+      const bool xcd_on = opt_get(OPT_ATTN_XCD, 1) != 0;
       p.units = nqt;
       p.xcd_share = xcd_on && n_kv <= 8 && 8 % n_kv == 0 ? 8 / n_kv : 0;
       const int G = n_q / n_kv;
@@ -1155,7 +1079,7 @@ int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int 
                                   const float* k_norm_w, float norm_eps, const float* cos_tab, const float* sin_tab, int pos,
                                   const int32_t* pos_dev, const ChattsKvCache* cache, size_t seq_stride, float* out,
                                   uint16_t* out_hi, uint16_t* out_lo, int n_splits, void* workspace, size_t workspace_bytes,
-                                  chatts_stream_t stream, const SlabOut* slabs, int32_t* arrive_cnt) {
+                                  chatts_stream_t stream) {
   CHATTS_REQUIRE(batch >= 1 && n_q > 0 && n_kv > 0 && n_splits >= 1 && n_splits <= kMaxSlots, CHATTS_E_BADARG,
                  "attention_decode: bad sizes (batch >= 1, 1 <= n_splits <= %d)", kMaxSlots);
   CHATTS_REQUIRE(qkv_raw && (out || (out_hi && out_lo)) && cos_tab && sin_tab && cache && cache->k && cache->v, CHATTS_E_BADARG,
@@ -1173,44 +1097,9 @@ int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int 
   if (const int rc = bind_cache(p, cache)) return rc;
   p.q_norm_w = q_norm_w; p.k_norm_w = k_norm_w; p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.eps = norm_eps;
   p.seq_stride = seq_stride; p.out_hi = out_hi; p.out_lo = out_lo; p.kv_round = kv_round_mode();
-  if (slabs && slabs->sk > 0) {      // qkv_raw = the projection's split-K slabs (same workspace: the partials go behind them, see the caller)
-    p.qkv_sk = slabs->sk; p.qkv_plane = slabs->plane; p.qkv_scale = slabs->scale; p.qkv_bias = slabs->bias;
-  }
-  // Workgroup form (attn_decode_wg_kernel): one launch, partials merged in LDS - for caches of up to 8 tiles per wave (2048 positions
-  // at 16 waves; groups of 6..8 query heads run 8 waves for their registers: 1024 positions).  One workgroup per (kv head, sequence)
-  // means one CU pulls a sequence's whole K / V: fine when n_kv x batch workgroups cover the chip (batched decode), a per-CU bandwidth
-  // limit for a single sequence (0.8 MB per kv head at ctx 800) - hence CHATTS_ATTN_WG: 0 never, 1 batched steps of >= 4 sequences,
-  // 2 whenever the cache is short enough.  Default 0 until it is measured to win (profiles/r4_attn_wg_ab.txt).
-  {
-    const char* e = getenv("CHATTS_ATTN_WG");
-    const int mode = e ? atoi(e) : 0;
-    const int G = n_q / n_kv;
-    const int nwv = G <= 5 ? 16 : 8;
-    if ((mode >= 2 || (mode == 1 && batch >= 4)) && (cache->max_ctx + kDTile - 1) / kDTile <= nwv * 8) {
-      p.n_splits = nwv;
-      const dim3 grid(n_kv, batch);
-      if (G <= 4) hipLaunchKernelGGL((attn_decode_wg_kernel<4, 16>), grid, dim3(1024), 0, as_stream(stream), p);
-      else if (G == 5) hipLaunchKernelGGL((attn_decode_wg_kernel<5, 16>), grid, dim3(1024), 0, as_stream(stream), p);
-      else if (G == 6) hipLaunchKernelGGL((attn_decode_wg_kernel<6, 8>), grid, dim3(512), 0, as_stream(stream), p);
-      else hipLaunchKernelGGL((attn_decode_wg_kernel<kMaxGroup, 8>), grid, dim3(512), 0, as_stream(stream), p);
-      CHATTS_CHECK_LAUNCH("attn_decode_wg");
-      return CHATTS_OK;
-    }
-  }
   const int rc = bind_workspace(p, workspace, workspace_bytes);
   if (rc) return rc;
   const dim3 grid(n_kv, n_splits, batch);
-  static const bool fold_on = !getenv("CHATTS_ATTN_FOLD") || atoi(getenv("CHATTS_ATTN_FOLD")) != 0;
-  if (arrive_cnt && fold_on && n_kv * batch <= CHATTS_TILE_COUNTERS && p.qkv_sk == 0) {      // one launch: the last arrivers merge
-    switch (n_q / n_kv) {
-      case 1: case 2: case 3: case 4: hipLaunchKernelGGL(attn_decode_fold_kernel<4>, grid, dim3(64), 0, as_stream(stream), p, arrive_cnt); break;
-      case 5: hipLaunchKernelGGL(attn_decode_fold_kernel<5>, grid, dim3(64), 0, as_stream(stream), p, arrive_cnt); break;
-      case 6: hipLaunchKernelGGL(attn_decode_fold_kernel<6>, grid, dim3(64), 0, as_stream(stream), p, arrive_cnt); break;
-      default: hipLaunchKernelGGL(attn_decode_fold_kernel<kMaxGroup>, grid, dim3(64), 0, as_stream(stream), p, arrive_cnt); break;
-    }
-    CHATTS_CHECK_LAUNCH("attn_decode_fold");
-    return CHATTS_OK;
-  }
   switch (n_q / n_kv) {       // registers sized for the group (every head's arithmetic is the same in all instantiations)
     case 1: case 2: case 3: case 4: hipLaunchKernelGGL(attn_decode_kernel<4>, grid, dim3(64), 0, as_stream(stream), p); break;
     case 5: hipLaunchKernelGGL(attn_decode_kernel<5>, grid, dim3(64), 0, as_stream(stream), p); break;
@@ -1231,19 +1120,7 @@ extern "C" int chatts_attention_decode_batched(const float* qkv_raw, int batch, 
                                                void* workspace, size_t workspace_bytes, chatts_stream_t stream) {
   return chatts::attention_decode_batched_impl(qkv_raw, batch, n_q, n_kv, q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos,
                                                pos_dev, cache, seq_stride, out, nullptr, nullptr, n_splits, workspace,
-                                               workspace_bytes, stream, nullptr, nullptr);
-}
-
-extern "C" int chatts_attention_decode_batched_fold(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w,
-                                                    const float* k_norm_w, float norm_eps, const float* cos_tab,
-                                                    const float* sin_tab, int pos, const int32_t* pos_dev,
-                                                    const ChattsKvCache* cache, size_t seq_stride, float* out, int n_splits,
-                                                    void* workspace, size_t workspace_bytes, int32_t* arrive, chatts_stream_t stream) {
-  CHATTS_REQUIRE(arrive && n_kv * batch <= CHATTS_TILE_COUNTERS, CHATTS_E_BADARG, "attention_decode_fold: needs n_kv * batch <= %d arrival words",
-                 CHATTS_TILE_COUNTERS);
-  return chatts::attention_decode_batched_impl(qkv_raw, batch, n_q, n_kv, q_norm_w, k_norm_w, norm_eps, cos_tab, sin_tab, pos,
-                                               pos_dev, cache, seq_stride, out, nullptr, nullptr, n_splits, workspace,
-                                               workspace_bytes, stream, nullptr, arrive);
+                                               workspace_bytes, stream);
 }
 
 extern "C" int chatts_attention_decode_fused(const float* qkv_raw, int n_q, int n_kv, const float* q_norm_w,

@@ -1,6 +1,7 @@
-// attn_decode.h - the decode attention as per-wave device functions, shared by the two forms of the kernel (attention.hip): one wave
-// per workgroup with the partials merged by a second launch, and one workgroup per (kv head, sequence) that merges its waves'
-// partials in LDS.  Same instructions and summation order in both: bit-identical results at equal slot counts.
+// attn_decode.h - the decode attention as per-wave device functions (attention.hip: one wave per (kv head, tile slot, sequence), the
+// partials merged by a second launch).  Two other forms were built on these functions, measured and removed: one workgroup per (kv
+// head, sequence) merging in LDS (round 4, profiles/r4_attn_wg_ab.txt) and the merge by the last-arriving waves of the same launch
+// (round 5, profiles/r5_attn_fold_ab.txt: 16.1 us against 8.95 + 4.88 - five dependent round trips behind the last arriver).
 #pragma once
 #include <math.h>
 
@@ -33,12 +34,6 @@ struct AttnParams {
   // sequence b looks its blocks up in table + b * table_stride, seq_stride is not used
   const int32_t* table;
   int log_block, table_stride;
-  // decode, optional: qkv is not a finished [T, n] buffer but the split-K partial slabs of the projection (SlabOut, common.h): element
-  // (seq, col) = (sum_{s < qkv_sk} qkv[s * qkv_plane + seq * n + col]) (* qkv_scale[col]) (+ qkv_bias[col]); qkv_sk == 0: plain buffer
-  const float* qkv_scale;
-  const float* qkv_bias;
-  int qkv_sk;
-  size_t qkv_plane;
   uint16_t* out_hi;    // decode combine, optional: the output as bf16 hi / lo planes [T, n_q * 128] (the o_proj operand of the
   uint16_t* out_lo;    // weight-streaming kernel) instead of float32 `out`
   int kv_round;        // experiment knob, see kv_round_f (0 = off)
@@ -69,19 +64,6 @@ __device__ __forceinline__ void norm_rope(float& a, float& b, const float* nw, f
 
 __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-
-// 8-byte write-through store / L1-bypassing load (relaxed, agent scope: `global_store_dwordx2 ... sc1` / `global_load_dwordx2 ... sc1`):
-// how the partials travel between workgroups INSIDE one launch (attn_decode_fold_kernel) - payload sc1, `s_waitcnt vmcnt(0)`, then a
-// relaxed agent-scope ticket; the reader polls the ticket word relaxed and reads the payload sc1.  No fences.
-__device__ __forceinline__ void st_wt64(float* p, float a, float b) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void ld_wt64(const float* p, float& a, float& b) {
-  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  a = __uint_as_float((unsigned)v);
-  b = __uint_as_float((unsigned)(v >> 32));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -165,7 +147,7 @@ __device__ __forceinline__ bool attn_decode_preload(const AttnParams& p, const i
 // GMAX: query heads of the group this wave handles at most; it takes heads g0 .. g0 + gn - 1 of kv head hk's group (the stand-alone
 // kernel: all of them, GMAX = kMaxGroup; the persistent step splits a group over two waves).  Heads are independent of each
 // other, so the split does not change a single operation of any head.  The wave with g0 == 0 stores the new K / V row.
-template <int GMAX, bool PF, bool WT = false>
+template <int GMAX, bool PF>
 __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
                                                    AttnTileRegs& t, float* q_s, float* knew_s, float* vnew_s, const int g0, const int gn,
                                                    float* part_o, float* part_ml, const size_t head_base) {
@@ -175,16 +157,7 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
   const int ntiles = pos / kDTile + 1;
   const int qkv_n = (p.n_q + 2 * p.n_kv) * kHeadDim;
   const float* qkv = p.qkv + (size_t)seq * qkv_n;
-  // element `col` of this sequence's projection row: read, or summed from the projection's split-K slabs in split order, then the
-  // 8-bit copy's column scale and the bias - splitk_epilogue_v4_kernel's arithmetic, whose launch this replaces
-  auto qkv_at = [&](const int col) __attribute__((always_inline)) -> float {
-    if (p.qkv_sk == 0) return qkv[col];
-    float v = 0.f;
-    for (int s = 0; s < p.qkv_sk; ++s) v += qkv[(size_t)s * p.qkv_plane + col];
-    if (p.qkv_scale) v *= p.qkv_scale[col];
-    if (p.qkv_bias) v += p.qkv_bias[col];
-    return v;
-  };
+  auto qkv_at = [&](const int col) __attribute__((always_inline)) -> float { return qkv[col]; };
   float* kcache = p.kc + (p.table ? 0 : (size_t)seq * p.seq_stride);
   float* vcache = p.vc + (p.table ? 0 : (size_t)seq * p.seq_stride);
   const KvLayout kvl{p.table ? p.table + (size_t)seq * p.table_stride : nullptr, p.n_kv, p.max_ctx, p.log_block};
@@ -348,13 +321,8 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
       o.x += __shfl_xor(o.x, 32, 64); o.y += __shfl_xor(o.y, 32, 64); o.z += __shfl_xor(o.z, 32, 64); o.w += __shfl_xor(o.w, 32, 64);
       const size_t pi = (head_base + g0 + g) * NS + slot;
       const float mn = m_run[g] * 0.6931471805599453f;       // m back to nats for the combine
-      if constexpr (WT) {       // read by another workgroup of this launch
-        if (lane < 32) { st_wt64(part_o + pi * kHeadDim + vc * 4, o.x, o.y); st_wt64(part_o + pi * kHeadDim + vc * 4 + 2, o.z, o.w); }
-        if (lane == 0) st_wt64(part_ml + pi * 2, mn, l_run[g]);
-      } else {
-        if (lane < 32) *reinterpret_cast<f32x4*>(part_o + pi * kHeadDim + vc * 4) = o;
-        if (lane == 0) { part_ml[pi * 2] = mn; part_ml[pi * 2 + 1] = l_run[g]; }
-      }
+      if (lane < 32) *reinterpret_cast<f32x4*>(part_o + pi * kHeadDim + vc * 4) = o;
+      if (lane == 0) { part_ml[pi * 2] = mn; part_ml[pi * 2 + 1] = l_run[g]; }
     }
   }
 }
@@ -407,56 +375,6 @@ __device__ __forceinline__ void attn_combine_wave(const AttnParams& p, const int
     p.out_lo[oi] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
   } else {
     p.out[oi] = v;
-  }
-}
-
-// One WAVE merges one head from write-through partials (attn_decode_fold_kernel): the weights as in attn_combine_wave (lane s holds
-// (m_s, l_s)); lanes 0-31 sum the even slots, lanes 32-63 the odd ones of dims 4 c .. 4 c + 3 (c = lane & 31), 16 slots = 32 8-byte
-// loads in flight per lane and batch, one exchange at the end.
-__device__ __forceinline__ void attn_merge_head_wt(const AttnParams& p, const int hq, const int seq, const int ns, const int lane,
-                                                   const float* part_o, const float* part_ml) {
-  const size_t base = ((size_t)seq * p.n_q + hq) * p.n_splits;
-  float m = -INFINITY, l = 0.f;
-  if (lane < ns) ld_wt64(part_ml + (base + lane) * 2, m, l);
-  const float M = wave_max(m);
-  const float w = lane < ns ? expf(m - M) : 0.f;
-  const float den = wave_sum(w * l);
-  const int half = lane >> 5, c = lane & 31;
-  f32x4 num = {0.f, 0.f, 0.f, 0.f};
-  for (int s0 = 0; s0 < ns; s0 += 32) {
-    f32x4 o[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int s = s0 + 2 * u + half;
-      const float* src = part_o + (base + (s < ns ? s : ns - 1)) * kHeadDim + c * 4;      // (clamped: its weight is 0)
-      float e0, e1, e2, e3;
-      ld_wt64(src, e0, e1);
-      ld_wt64(src + 2, e2, e3);
-      o[u] = (f32x4){e0, e1, e2, e3};
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const float ws = __shfl(w, (s0 + 2 * u + half) & 63, 64);
-      num.x = fmaf(ws, o[u].x, num.x); num.y = fmaf(ws, o[u].y, num.y); num.z = fmaf(ws, o[u].z, num.z); num.w = fmaf(ws, o[u].w, num.w);
-    }
-  }
-  num.x += __shfl_xor(num.x, 32, 64); num.y += __shfl_xor(num.y, 32, 64); num.z += __shfl_xor(num.z, 32, 64); num.w += __shfl_xor(num.w, 32, 64);
-  if (lane >= 32) return;
-  const size_t oi = ((size_t)seq * p.n_q + hq) * kHeadDim + c * 4;
-  const float v[4] = {num.x / den, num.y / den, num.z / den, num.w / den};
-  if (p.out_hi) {
-    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-    bf16x4_t hv, lv;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const __bf16 h = (__bf16)v[r];
-      hv[r] = h;
-      lv[r] = (__bf16)(v[r] - (float)h);
-    }
-    *reinterpret_cast<bf16x4_t*>(p.out_hi + oi) = hv;
-    *reinterpret_cast<bf16x4_t*>(p.out_lo + oi) = lv;
-  } else {
-    *reinterpret_cast<f32x4*>(p.out + oi) = (f32x4){v[0], v[1], v[2], v[3]};
   }
 }
 

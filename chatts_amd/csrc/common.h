@@ -154,17 +154,25 @@ struct RopeFuse {
 // `row` = this head's 128 floats of the qkv buffer (q is written back there)
 __device__ __forceinline__ void rope_kv_head(float a, float b, int h, int pos, int lane, float* row, const RopeFuse& r);
 
-// A projection whose split-K partial slabs are LEFT in the workspace for its consumer to sum (the batched decode attention reads the
-// qkv projection that way: one launch less per layer).  Filled by launch_gemm when it skipped the epilogue: element (row, col) =
-// (sum over s < sk of ws[s * plane + row * n + col]) (* scale[col]) (+ bias[col]) - splitk_epilogue_v4_kernel's arithmetic and order.
-struct SlabOut {
-  int sk;                 // 0: the epilogue ran as usual (c holds the result)
-  size_t plane;           // floats per slab (m * n)
-  const float* scale;     // per-column scale of an 8-bit weight copy, or null
-  const float* bias;
-};
-
 inline hipStream_t as_stream(chatts_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- tuning options (chatts_set_option, api.hip) ---------------------------------------------------------------------------------
+// A fixed table of named integers, process-wide, all UNSET by default = the shipped, measured-best choice.  The entry points read
+// the table (one relaxed load); nothing in the library reads the environment.  The host sets an option explicitly (A/B runs, the
+// bit-identity tests of alternative paths, geometry sweeps): chatts_amd._lib.set_option / _lib.options(...).
+#define CHATTS_OPTIONS(X)                                                                                                        \
+  X(GEMM_SK) X(GEMM_T) X(GEMM_BM) X(GEMM_PRECISION) X(GEMM_PLANES_MIN_M) X(GEMM_STREAM) X(GEMM_STREAM_STAGES) X(GEMM_STREAM_WAVES)   \
+  X(GEMM_STREAM_MB) X(GEMM_STREAM_MB_WAVES) X(GEMM_ABLATE) X(EPI_V4) X(EPI_NORM_Q) X(POST_NORM_SMALL_M) X(ROPE_FUSE) X(ATTN_BF16X3)  \
+  X(ATTN_PLANES) X(ATTN_XCD) X(ATTN_ROWS) X(ATTN_KSPLIT) X(ARGMAX_2STAGE) X(TS_F32_PATH) X(KV_ROUND) X(TP_FUSE) X(TP_FUSE_BLOCKS)       \
+  X(TP_BULK_BLOCKS) X(TP_AR_BLOCKS) X(GEMV_ROWS) X(GEMV_UNR) X(GEMV_NW) X(GEMV_OCC) X(GEMV_BLOCKS) X(GEMV_LDSPAD) X(GEMV_KS) X(FP8_BM) \
+  X(FP8_ORDER)
+enum ChattsOpt {
+#define CHATTS_OPT_ENUM(name) OPT_##name,
+  CHATTS_OPTIONS(CHATTS_OPT_ENUM)
+#undef CHATTS_OPT_ENUM
+  OPT_COUNT
+};
+int opt_get(ChattsOpt o, int dflt);      // the option's value, or dflt while it is unset
 
 int device_cus();
 
@@ -217,7 +225,7 @@ __device__ __forceinline__ float kv_round_f(float v, int mode) {
   if (mode == 3) return (float)(_Float16)v;
   return v;
 }
-inline int kv_round_mode() { const char* e = getenv("CHATTS_KV_ROUND"); return e ? atoi(e) : 0; }
+inline int kv_round_mode() { return opt_get(OPT_KV_ROUND, 0); }
 
 __device__ __forceinline__ void rope_kv_head(float a, float b, int h, int pos, int lane, float* row, const RopeFuse& r) {
 #pragma clang fp contract(off)

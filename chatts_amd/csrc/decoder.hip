@@ -11,14 +11,11 @@
 
 namespace chatts {
 int launch_gemv(const ChattsLinearArgs* a, hipStream_t s);
-int launch_gemm(const ChattsLinearArgs* a, hipStream_t s, const RopeFuse* rope = nullptr, bool* rope_done = nullptr, SlabOut* slabs = nullptr);
-int tp_allreduce_slabs(ChattsTpComm* c, const float* ws, const SlabOut& so, int ncols, float* out, const float* resid, int64_t n,
-                       chatts_stream_t stream);      // tp.hip
+int launch_gemm(const ChattsLinearArgs* a, hipStream_t s, const RopeFuse* rope = nullptr, bool* rope_done = nullptr);
 int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w, const float* k_norm_w,
                                   float norm_eps, const float* cos_tab, const float* sin_tab, int pos, const int32_t* pos_dev,
                                   const ChattsKvCache* cache, size_t seq_stride, float* out, uint16_t* out_hi, uint16_t* out_lo,
-                                  int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream, const SlabOut* slabs = nullptr,
-                                  int32_t* arrive_cnt = nullptr);
+                                  int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream);
 int attention_impl(const float* qkv, int t, int n_q, int n_kv, int pos0, const int32_t* pos0_dev, const ChattsKvCache* cache, float* out,
                    uint16_t* out_hi, uint16_t* out_lo, int n_splits, void* workspace, size_t workspace_bytes, chatts_stream_t stream);
 int launch_split_bf16x2(const float* x, int m, int k, int ldx, uint16_t* hi, uint16_t* lo, int ldp, hipStream_t s);
@@ -51,13 +48,12 @@ static int64_t embed_offset(const ChattsDecoder* d) { return d->cfg.embed_rows >
 
 extern "C" size_t chatts_linear_workspace(int m, int n, int k) { return gemm_workspace(m, n, k); }
 
-static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const RopeFuse* rope, bool* rope_done, SlabOut* slabs = nullptr);
+static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const RopeFuse* rope, bool* rope_done);
 extern "C" int chatts_linear(const ChattsLinearArgs* a, chatts_stream_t stream) { return linear_impl(a, stream, nullptr, nullptr); }
 
 // rope / rope_done: the qkv projection of a prefill chunk may carry rope_kv_kernel's work in its split-K epilogue (*rope_done says
 // whether it did; otherwise the caller launches chatts_rope_kv_write as before)
-static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const RopeFuse* rope, bool* rope_done, SlabOut* slabs) {
-  if (slabs) slabs->sk = 0;
+static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const RopeFuse* rope, bool* rope_done) {
   CHATTS_REQUIRE(a != nullptr, CHATTS_E_BADARG, "linear: null args");
   CHATTS_REQUIRE(a->m >= 0 && a->n > 0 && a->k > 0, CHATTS_E_BADARG, "linear: bad sizes m=%d n=%d k=%d", a->m, a->n, a->k);
   if (a->m == 0) return CHATTS_OK;
@@ -97,7 +93,7 @@ static int linear_impl(const ChattsLinearArgs* a, chatts_stream_t stream, const 
   if (a->tp_reduce) CHATTS_REQUIRE(a->m == 1, CHATTS_E_BADARG, "linear: tp_reduce is available for M == 1 (the decode GEMV) only");
   if (a->m == 1 && a->epilogue != CHATTS_EPI_GELU) return launch_gemv(a, as_stream(stream));
   CHATTS_REQUIRE(a->norm_w == nullptr, CHATTS_E_BADARG, "linear: fused RMSNorm is only available for M == 1");
-  return launch_gemm(a, as_stream(stream), rope, rope_done, slabs);
+  return launch_gemm(a, as_stream(stream), rope, rope_done);
 }
 
 extern "C" int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, chatts_bf16* lo, int ld_planes,
@@ -201,10 +197,7 @@ static int norm_into(ChattsDecoder* d, const float* norm_w, ChattsLinearArgs* la
 
 // The residual-updating projection (o_proj / down_proj, tp_world == 1) also produces the NEXT projection's operand:
 // RMSNorm(x) with `next_norm_w` as planes 0, when that projection will take the plane path for the same M.
-static bool gemm_post_norm_small_m() {
-  const char* e = getenv("CHATTS_POST_NORM_SMALL_M");
-  return !e || atoi(e) != 0;
-}
+static bool gemm_post_norm_small_m() { return opt_get(OPT_POST_NORM_SMALL_M, 1) != 0; }
 static void request_post_norm(ChattsDecoder* d, ChattsLinearArgs* la, const float* next_norm_w, bool next_fp8) {
   if (!d->chain || d->cfg.tp_world > 1 || !next_norm_w || la->epilogue != CHATTS_EPI_RESID) return;
   // the fused epilogue runs one workgroup per row - fine for a prefill chunk; at batched-decode M it needs several workgroups per row,
@@ -214,14 +207,6 @@ static void request_post_norm(ChattsDecoder* d, ChattsLinearArgs* la, const floa
   la->post_norm_w = next_norm_w; la->post_norm_eps = d->cfg.rms_eps;
   la->post_hi = d->b.planes_hi; la->post_lo = d->b.planes_lo; la->ld_post = la->n;
   d->normed = true;
-}
-
-// batched decode under tensor parallelism, OPT-IN (CHATTS_TP_SLABS=1): the exchange sums the projection's split-K slabs itself instead
-// of a split-K epilogue launch + chatts_allreduce on its output.  Same values; measured no faster (4.63 vs 4.59 ms per 16-wide step of a
-// TP = 8 rank: what the launch saves, the slab loads inside the exchange's few workgroups cost) - the two-launch form stays the default.
-static bool tp_slabs_on() {
-  const char* e = getenv("CHATTS_TP_SLABS");
-  return e && atoi(e) == 1;
 }
 
 extern "C" int chatts_decoder_set_sampling(ChattsDecoder* d, const ChattsSamplingArgs* sa) {
@@ -384,7 +369,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     }
     ChattsKvCache kc = layer_cache(d, layer, d->cur_seq);
     bool rope_done = false;
-    const bool rope_fuse = !(getenv("CHATTS_ROPE_FUSE") && atoi(getenv("CHATTS_ROPE_FUSE")) == 0);
+    const bool rope_fuse = opt_get(OPT_ROPE_FUSE, 1) != 0;
     if (t > 1 && rope_fuse) {   // prefill: the projection's split-K epilogue (when it has one) also rotates q / k and fills the cache
       RopeFuse rf;
       if ((rc = rope_fuse_prepare(t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, pos0, pos0_dev, &kc,
@@ -394,24 +379,24 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
       return rc;
     }
     bool attn_out_planes = false;
-    if (t == 1) {   // decode: RoPE + cache write fused into the attention kernel; with arrival words at hand the merge too
-      if ((rc = attention_decode_batched_impl(d->b.qkv, 1, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, pos0,
-                                              pos0_dev, &kc, 0, d->b.attn, nullptr, nullptr, n_splits, d->b.workspace, d->b.workspace_bytes,
-                                              stream, nullptr, d->b.tile_counters)) != 0) {
+    if (t == 1) {   // decode: RoPE + cache write fused into the attention kernel
+      if ((rc = chatts_attention_decode_fused(d->b.qkv, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
+                                                     d->w.sin_tab, pos0, pos0_dev, &kc, d->b.attn, n_splits, d->b.workspace,
+                                                     d->b.workspace_bytes, stream)) != 0) {
         return rc;
       }
     } else {
       if (!rope_done && (rc = chatts_rope_kv_write(d->b.qkv, t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab,
                                                    d->w.sin_tab, pos0, pos0_dev, &kc, stream)) != 0) return rc;
       // long chunks: split the keys over 2 workgroups per (query tile, head) - one sequence has too few waves otherwise
-      static const int env_ks = getenv("CHATTS_ATTN_KSPLIT") ? atoi(getenv("CHATTS_ATTN_KSPLIT")) : 0;
+      const int env_ks = opt_get(OPT_ATTN_KSPLIT, 0);
       // (the bf16x3 kernel is fast enough per tile that the second key split + its combine launch no longer pay: 73.3 us
       // against 74.0 + 12 at T = 798; the float32-MFMA kernel, CHATTS_ATTN_BF16X3=0, still wants the split)
-      const bool f32_attn = getenv("CHATTS_ATTN_BF16X3") && atoi(getenv("CHATTS_ATTN_BF16X3")) == 0;
+      const bool f32_attn = opt_get(OPT_ATTN_BF16X3, 1) == 0;
       int ks = env_ks >= 1 && env_ks <= 4 ? env_ks : (t >= 256 && f32_attn ? 2 : 1);
       if (chatts_attn_workspace(t, c.n_q, ks) > d->b.workspace_bytes) ks = 1;
       // ... and, on the plane path, let the attention kernel (or its combine) write o_proj's operand format itself
-      const bool out_planes = t >= 16 && planes_path(d, t, c.n_q * kHeadDim) && !getenv("CHATTS_ATTN_ROWS");
+      const bool out_planes = t >= 16 && planes_path(d, t, c.n_q * kHeadDim) && opt_get(OPT_ATTN_ROWS, 0) == 0;
       if ((rc = attention_impl(d->b.qkv, t, c.n_q, c.n_kv, pos0, pos0_dev, &kc, d->b.attn, out_planes ? d->b.planes_hi : nullptr,
                                out_planes ? d->b.planes_lo : nullptr, ks, d->b.workspace, d->b.workspace_bytes, stream)) != 0)
         return rc;
@@ -507,44 +492,22 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = batch; la.n = qkv_n; la.k = H;
     la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
     la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H; la.w8_format = d->cfg.w8_format;
-    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
+    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
-    // The attention kernel can sum the projection's split-K slabs itself while it loads q / k / v (SlabOut): the projection then
-    // skips its epilogue launch.  The slabs stay at the head of the workspace, the attention partials go behind them - when the
-    // workspace holds both.  OPT-IN (CHATTS_QKV_FOLD=1): measured SLOWER at config 5 - 6.79 against 6.15 ms per step - every one of the
-    // 16 key-slot waves of a (kv head, sequence) repeats the 5 x sk slab loads of its group's q rows on its critical path, which
-    // costs more than the 5 us launch it removes (profiles/r4_qkv_fold_ab.txt).  Same tokens, logits within 1e-6 (tests/test_gpu_e2e.py).
-    const size_t slab_room = (gemm_workspace(batch, qkv_n, H) + 255) / 256 * 256;
-    const bool fold_on = getenv("CHATTS_QKV_FOLD") && atoi(getenv("CHATTS_QKV_FOLD")) == 1;      // (read per call: tests A/B it in one process)
-    const bool fold = fold_on && batch >= 2 && slab_room + chatts_attn_workspace(batch, c.n_q, n_splits) <= d->b.workspace_bytes;
-    SlabOut so{};
-    if ((rc = linear_impl(&la, stream, nullptr, nullptr, fold ? &so : nullptr)) != 0) return rc;
+    if ((rc = chatts_linear(&la, stream)) != 0) return rc;
     ChattsKvCache kc = layer_cache(d, layer, 0);
     const bool attn_planes = planes_path(d, batch, c.n_q * kHeadDim, lw.o8 != nullptr);   // the combine writes o_proj's operand format
-    const bool folded = so.sk > 0;
-    if ((rc = attention_decode_batched_impl(folded ? reinterpret_cast<const float*>(d->b.workspace) : d->b.qkv, batch, c.n_q, c.n_kv,
-                                            lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, 0, pos_dev, &kc, seq_stride(d),
-                                            d->b.attn, attn_planes ? d->b.planes_hi : nullptr, attn_planes ? d->b.planes_lo : nullptr,
-                                            n_splits, static_cast<char*>(d->b.workspace) + (folded ? slab_room : 0),
-                                            d->b.workspace_bytes - (folded ? slab_room : 0), stream, folded ? &so : nullptr,
-                                            d->b.tile_counters)) != 0) return rc;
+    if ((rc = attention_decode_batched_impl(d->b.qkv, batch, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, 0,
+                                            pos_dev, &kc, seq_stride(d), d->b.attn, attn_planes ? d->b.planes_hi : nullptr,
+                                            attn_planes ? d->b.planes_lo : nullptr, n_splits, d->b.workspace, d->b.workspace_bytes,
+                                            stream)) != 0) return rc;
     la = ChattsLinearArgs{};
     la.a = d->b.attn; la.w = lw.o; la.m = batch; la.n = H; la.k = c.n_q * kHeadDim;
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
     la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k; la.w8_format = d->cfg.w8_format;
-    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
+    la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if (attn_planes) { la.a = nullptr; la.a_hi = d->b.planes_hi; la.a_lo = d->b.planes_lo; la.ld_planes = la.k; }
     d->tp_fused = false;
-    if (tp && d->chain && d->tp && tp_slabs_on()) {      // the exchange reads the projection's split-K slabs itself (tp_allreduce_slabs)
-      la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE;
-      SlabOut so{};
-      if ((rc = linear_impl(&la, stream, nullptr, nullptr, &so)) != 0) return rc;
-      if (so.sk > 0) {
-        d->tp_fused = true;
-        return tp_allreduce_slabs(d->tp, reinterpret_cast<const float*>(d->b.workspace), so, H, d->b.x, d->b.x, (int64_t)batch * H, stream);
-      }
-      return CHATTS_OK;                                  // (no split: delta holds the partial, the caller's chatts_allreduce follows)
-    }
     if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
     else { la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID; }
     // The residual stream ping-pongs x -> xn (here) -> x (down_proj) inside a chained step, so that the post-norm epilogue may use
@@ -562,7 +525,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   la.w = lw.gate_up; la.c = d->b.act; la.m = batch; la.n = 2 * c.inter; la.k = H;
   la.lda = H; la.ldw = H; la.ldc = c.inter; la.epilogue = CHATTS_EPI_SWIGLU;
   la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H; la.w8_format = d->cfg.w8_format;
-  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if ((rc = norm_into(d, lw.post_norm, &la, stream)) != 0) return rc;
   const bool act_planes = planes_path(d, batch, c.inter, lw.down8 != nullptr) && planes_path(d, batch, H, lw.gate_up8 != nullptr);
   if (act_planes) { la.c = nullptr; la.c_hi = d->b.planes2_hi; la.c_lo = d->b.planes2_lo; la.ld_cplanes = c.inter; }
@@ -571,20 +534,9 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   la.a = d->b.act; la.w = lw.down; la.m = batch; la.n = H; la.k = c.inter;
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
   la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter; la.w8_format = d->cfg.w8_format;
-  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes; la.tile_counters = d->b.tile_counters;
+  la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if (act_planes) { la.a = nullptr; la.a_hi = d->b.planes2_hi; la.a_lo = d->b.planes2_lo; la.ld_planes = c.inter; }
   d->tp_fused = false;
-  if (tp && d->chain && d->tp && tp_slabs_on()) {
-    la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE;
-    SlabOut so{};
-    d->x_in_xn = false;
-    if ((rc = linear_impl(&la, stream, nullptr, nullptr, &so)) != 0) return rc;
-    if (so.sk > 0) {
-      d->tp_fused = true;
-      return tp_allreduce_slabs(d->tp, reinterpret_cast<const float*>(d->b.workspace), so, H, d->b.x, d->b.x, (int64_t)batch * H, stream);
-    }
-    return CHATTS_OK;
-  }
   if (tp) { la.c = d->b.delta; la.epilogue = CHATTS_EPI_NONE; }
   else { la.c = d->b.x; la.resid = d->x_in_xn ? d->b.xn : d->b.x; la.epilogue = CHATTS_EPI_RESID; }
   d->x_in_xn = false;
@@ -623,6 +575,8 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
   const bool tp = d->cfg.tp_world > 1;
   CHATTS_REQUIRE(!tp || d->tp, CHATTS_E_BADARG, "decode_step_batched: tp_world = %d but no exchange attached (chatts_decoder_set_tp)",
                  d->cfg.tp_world);
+  CHATTS_REQUIRE(!tp || chatts_tp_pending(d->tp) == 0, CHATTS_E_BADARG, "decode_step_batched: the exchange has %d collectives whose epochs were "
+                 "never settled (chatts_tp_flush_epochs)", tp ? chatts_tp_pending(d->tp) : 0);
   int rc;
   const ChattsDecoderConfig& c = d->cfg;
   // the step STARTS by loading the input embeddings from the current tokens (so a prefill of another request may
@@ -754,6 +708,9 @@ extern "C" int chatts_decoder_prefill_last(ChattsDecoder* d, int t, int pos0, ch
   } else if (rc == CHATTS_OK) rc = layer_last_row(d, L - 1, t, pos0, stream);
   d->chain = false;
   d->normed = false;
+  // the last row's o_proj / down_proj carried their exchange without advancing the device-side call counter (host-counted epochs):
+  // settle it here, so that whatever runs next on this communicator - a replayed decode graph above all - starts from a flushed count
+  if (tp && d->tp) { const int frc = chatts_tp_flush_epochs(d->tp, stream); if (rc == CHATTS_OK) rc = frc; }
   return rc;
 }
 
@@ -859,12 +816,13 @@ extern "C" int chatts_decoder_decode_step(ChattsDecoder* d, int32_t* pos_dev, in
   CHATTS_REQUIRE(d && pos_dev && step_dev && token_dev, CHATTS_E_BADARG, "decode_step: null argument");
   const bool tp = d->cfg.tp_world > 1;
   CHATTS_REQUIRE(!tp || d->tp, CHATTS_E_BADARG, "decode_step: tp_world = %d but no exchange attached (chatts_decoder_set_tp)", d->cfg.tp_world);
+  CHATTS_REQUIRE(!tp || chatts_tp_pending(d->tp) == 0, CHATTS_E_BADARG, "decode_step: the exchange has %d collectives whose epochs were never settled "
+                 "(chatts_tp_flush_epochs): a step enqueued or captured now would reuse their epochs", tp ? chatts_tp_pending(d->tp) : 0);
   int rc;
   const int H = d->cfg.hidden;
   // Tensor parallel: the two exchanges of a layer ride in the o_proj / down_proj GEMV launches (6 launches per layer instead of 8;
   // CHATTS_TP_FUSE=0 keeps the stand-alone chatts_allreduce kernels: same bits - tests/test_gpu_tp_p2p.py)
-  const bool fuse_off = getenv("CHATTS_TP_FUSE") && atoi(getenv("CHATTS_TP_FUSE")) == 0;     // (read per call: tests A/B it in one process)
-  d->fuse_tp = tp && !fuse_off;
+  d->fuse_tp = tp && opt_get(OPT_TP_FUSE, 1) != 0;
   rc = CHATTS_OK;
   for (int l = 0; l < d->cfg.n_layers && rc == CHATTS_OK; ++l) {
     rc = chatts_decoder_layer_part(d, l, 0, 1, 0, pos_dev, n_splits, stream);
@@ -873,7 +831,10 @@ extern "C" int chatts_decoder_decode_step(ChattsDecoder* d, int32_t* pos_dev, in
     if (rc == CHATTS_OK && tp && !d->tp_fused) rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, H, stream);    // ... and down_proj
   }
   d->fuse_tp = false;
-  if (rc) return rc;
+  if (rc) {      // a refused launch part-way: settle the epochs of the exchange-carrying GEMVs that WERE issued (every rank fails alike)
+    if (tp) (void)chatts_tp_flush_epochs(d->tp, stream);
+    return rc;
+  }
   if ((rc = chatts_decoder_logits(d, 0, stream)) != 0) return rc;
   if ((rc = chatts_decoder_select_tokens(d, d->b.logits, 1, d->cfg.vocab_local, token_dev, token_logit_dev, out_tokens, 0, step_dev,
                                          pos_dev, 0, nullptr, stream)) != 0) return rc;

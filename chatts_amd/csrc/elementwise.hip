@@ -246,7 +246,7 @@ size_t argmax_scratch_bytes(int batch) { return (size_t)batch * kArgmaxParts * (
 int argmax_batched_scratch(const float* logits, int batch, int64_t logits_stride, int64_t vocab, int64_t vocab_offset, int64_t* token,
                            float* token_logit, int64_t* out_tokens, int64_t out_stride, int32_t* step_dev, int32_t* pos_dev,
                            int pos_limit, void* scratch, size_t scratch_bytes, hipStream_t s) {
-  static const bool off = getenv("CHATTS_ARGMAX_2STAGE") && atoi(getenv("CHATTS_ARGMAX_2STAGE")) == 0;
+  const bool off = opt_get(OPT_ARGMAX_2STAGE, 1) == 0;
   if (!scratch || scratch_bytes < argmax_scratch_bytes(batch) || vocab < 4096 || off)
     return chatts_argmax_batched(logits, batch, logits_stride, vocab, vocab_offset, token, token_logit, out_tokens, out_stride, step_dev,
                                  pos_dev, pos_limit, reinterpret_cast<chatts_stream_t>(s));

@@ -22,9 +22,6 @@ struct GemmParams {
   uint16_t* c_hi;        // optional: the output goes out as bf16 hi / lo planes [M, ldcp] (the next GEMM's operand
   uint16_t* c_lo;        // format) instead of float32 c
   int ldcp;
-  int sk_T, sk_nk;       // stream-K (gemm_dma_kernel only): T = tiles * K-steps per tile, sk_nk = K-steps per tile; 0 = off
-  int32_t* fix_cnt;      // gemm_stream_kernel, split-K: per-tile arrival counters -> the last workgroup of a tile runs the epilogue
-  float* c_out;          // ... into the real output (c holds the partial slabs)
 };
 
 __device__ __forceinline__ void store_planes(uint16_t* hi, uint16_t* lo, size_t off, float v) {
@@ -40,12 +37,14 @@ __device__ __forceinline__ void store_planes(uint16_t* hi, uint16_t* lo, size_t 
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu_g(float x) { return x / (1.0f + expf(-x)); }
 
+constexpr int kRingPanel = 256;      // W rows per panel of the prefill kernel
 // gemm_ring.hip: the prefill kernel's decomposition (M-tiles per panel, K splits) and launcher
 struct RingGeom {
   int T, sk;          // M-tiles per panel, K splits
   int F, P;           // 16-row fragments of M, W panels
   int units;          // T * P * sk, ordered (split, panel, M-tile): the M-tiles of a panel are adjacent
   int wpx;            // workgroups per XCD (grid = 8 * wpx)
+  int ablate;         // diagnostic builds (-DCHATTS_GEMM_PROBE) only: 1 = no LDS-DMA, 2 = no fragment reads in the loop, 4 = no MFMAs
 };
 void ring_pick(int m, int n, int k, int cus, int force_t, int force_sk, RingGeom& g);
 int launch_ring(const GemmParams& p, const uint16_t* a_hi, const uint16_t* a_lo, int ldp, const RingGeom& g, bool single, hipStream_t s);

@@ -265,7 +265,7 @@ static void launch_fp8(const GemmFp8Params& p, hipStream_t s) {
   // (the 256-row form spills ~40 registers as compiled by ROCm 7.2: priced accordingly until it is measured to win)
   const double c256 = 2.2 * (double)((t256 + cus - 1) / cus), c128 = 1.0 * (double)((t128 + cus - 1) / cus);
   int wm = c256 < c128 ? 4 : 2;
-  if (const char* e = getenv("CHATTS_FP8_BM")) wm = atoi(e) == 256 ? 4 : atoi(e) == 128 ? 2 : wm;
+  { const int e = opt_get(OPT_FP8_BM, 0); wm = e == 256 ? 4 : e == 128 ? 2 : wm; }
   static bool attr_done = false;
   if (!attr_done) {          // up to 147 KB of dynamic LDS: above the 64 KB default cap
     const int big = 2 * (256 + kF8BN) * kF8Row, small = 2 * (128 + kF8BN) * kF8Row;
@@ -316,7 +316,7 @@ extern "C" int chatts_linear_fp8(const ChattsLinearFp8Args* a, chatts_stream_t s
   const int ncols = a->epilogue == CHATTS_EPI_SWIGLU ? a->n / 2 : a->n;
   CHATTS_REQUIRE(a->ldc >= ncols, CHATTS_E_SHAPE, "linear_fp8: ldc=%d < %d", a->ldc, ncols);
   CHATTS_REQUIRE(a->epilogue != CHATTS_EPI_RESID || a->resid, CHATTS_E_BADARG, "linear_fp8: EPI_RESID without resid");
-  static const int order = getenv("CHATTS_FP8_ORDER") ? atoi(getenv("CHATTS_FP8_ORDER")) : 1;
+  const int order = opt_get(OPT_FP8_ORDER, 1);
   GemmFp8Params p{a->a8, a->a_scale, a->w8, a->w_scale, a->bias, a->resid, a->c, a->m, a->n, a->k, a->lda8, a->ldw8, a->ldc, order};
   switch (a->epilogue) {
     case CHATTS_EPI_GELU: launch_fp8<CHATTS_EPI_GELU>(p, as_stream(stream)); break;

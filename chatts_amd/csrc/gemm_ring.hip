@@ -30,7 +30,7 @@
 
 namespace chatts {
 
-constexpr int kRingBN = 256, kRingMaxF = 10, kRingSlots = 4;
+constexpr int kRingBN = kRingPanel, kRingMaxF = 10, kRingSlots = 4;
 constexpr int kRingAPlane = kRingMaxF * 16 * 64;             // 10 KB: one plane of a half-stage
 constexpr int kRingWOff = 2 * kRingAPlane;
 constexpr int kRingHalf = kRingWOff + kRingBN * 64;          // 36 KB
@@ -48,7 +48,9 @@ __device__ unsigned long long g_ring_probe[kRingProbeRecs * 16];
 #define RPROBE_CLK() __builtin_amdgcn_s_memtime()
 #define RPROBE_RT() __builtin_amdgcn_s_memrealtime()
 #define RPROBE_ADD(var, t0) do { (var) += RPROBE_CLK() - (t0); } while (0)
+#define RABLATE(bit) (g.ablate & (bit))
 #else
+#define RABLATE(bit) 0
 #define RPROBE_CLK() 0ull
 #define RPROBE_RT() 0ull
 #define RPROBE_ADD(var, t0) do { (void)(t0); } while (0)
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
       const size_t koff = (size_t)hh * 64;
 #pragma unroll
       for (int h = 0; h < 9; ++h)
-        if (h < np) __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + koff), (lptr_t)(base + dst[h]), 16, 0, 0);
+        if (h < np && !RABLATE(1)) __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + koff), (lptr_t)(base + dst[h]), 16, 0, 0);
       const int n = np;
       ++gi;
       if (++hh == nh_cur) {
@@ -322,6 +324,7 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
         for (int i = 0; i < FML; ++i) dst[i] = *reinterpret_cast<const bf16x8_t*>(base + plane * kRingAPlane + a_off + i * 1024);
       };
       auto sweep = [&](const bf16x8_t (&af)[FML], const bf16x8_t (&wfr)[4]) {      // D = W . A^T: operands swapped
+        if (RABLATE(4)) return;
 #pragma unroll
         for (int i = 0; i < FML; ++i)
 #pragma unroll
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
         pc_t = RPROBE_CLK();
         __builtin_amdgcn_s_barrier();                          // h + 1 is published; the loaders refill the slot of h
         RPROBE_ADD(pc_bar, pc_t);
-        if (more) {
+        if (more && !RABLATE(2)) {
           const char* nb = slot(h + 1);
           read_w(nb, wnxt);
           if constexpr (!SINGLE) read_a(nb, 1, alo);
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
         __builtin_amdgcn_sched_barrier(0);
         sweep(ahi, wcur);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) read_a(slot(h + 1), 0, ahi);
+        if (more && !RABLATE(2)) read_a(slot(h + 1), 0, ahi);
       };
       {
         const char* b0 = slot(0);
@@ -402,38 +405,39 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 // (T, sk) per shape: a cost model in cycles of the slowest workgroup - rounds x (K-steps x step + a per-unit constant) + the split-K
-// epilogue launch.  A step of a tile with f fragments costs max(MFMA, DMA): 16 f MFMAs of 16 cycles per SIMD against (32 f + 256) x
-// 128 B at the ~32 B per clock and CU the four loader waves deliver.
+// epilogue launch.  Fitted to the probe build's numbers (profiles/r5_ring_probe_first.txt): a 64-deep step of a tile with f fragments
+// takes ~235 f + 900 cycles (f = 6: 2330, 7-8: 2650-2680, 9: 3020 - the 16 f MFMAs per SIMD and the (32 f + 256) x 128 bytes of LDS-DMA
+// overlap only partly), a unit costs ~9000 cycles of prologue + epilogue, a split-K epilogue ~6 us + its slab traffic at ~5 TB/s.
 void ring_pick(int m, int n, int k, int cus, int force_t, int force_sk, RingGeom& g) {
   const int F = (m + 15) / 16, P = (n + kRingBN - 1) / kRingBN, nk = k / 64;
   g.F = F; g.P = P;
   const int slots = cus >= 8 ? (cus / 8) * 8 : 8;
   double best = 1e30;
-  int bt = (F + kRingMaxF - 1) / kRingMaxF, bs = 1;
   const int tmin = (F + kRingMaxF - 1) / kRingMaxF;
+  int bt = tmin, bs = 1;
   int tmax = (F + 2) / 3;                              // >= 3 fragments per tile
   if (tmax < tmin) tmax = tmin;
   for (int T = tmin; T <= tmax; ++T) {
     const int fmax = (F + T - 1) / T;
-    const double mfma = 256.0 * fmax, dma = 128.0 * fmax + 1024.0;
-    const double step = mfma > dma ? mfma : dma;
-    for (int sk = 1; sk <= 4; ++sk) {
-      if (sk > 1 && nk / sk < 8) break;
+    const double step = 235.0 * fmax + 900.0;
+    for (int sk = 1; sk <= 16; ++sk) {
+      if (sk > 1 && nk / sk < 4) break;
       const long long units = (long long)T * P * sk;
       const long long rounds = (units + slots - 1) / slots;
       const int steps = (nk + sk - 1) / sk;
-      double t = (double)rounds * (steps * step + 8000.0);
-      if (sk > 1) t += 12000.0 + (double)(sk + 2) * m * n * 4.0 / 2500.0;      // slab round trip at ~5 TB/s (cycles at ~2 GHz) + launch
+      double t = (double)rounds * (steps * step + 9000.0);
+      if (sk > 1) t += 12000.0 + (double)(sk + 2) * m * n * 4.0 / 2500.0;
       if (t < best) { best = t; bt = T; bs = sk; }
     }
   }
   if (force_t >= tmin && force_t <= F) bt = force_t;
-  if (force_sk >= 1 && force_sk <= 8 && nk / force_sk >= 2) bs = force_sk;
+  if (force_sk >= 1 && force_sk <= 16 && nk / force_sk >= 1) bs = force_sk;
   g.T = bt; g.sk = bs;
   g.units = bt * P * bs;
   int wpx = (g.units + 7) / 8;
   if (wpx > slots / 8) wpx = slots / 8;
   g.wpx = wpx;
+  g.ablate = 0;
 }
 
 template <bool SINGLE>

@@ -598,11 +598,6 @@ static void launch8_norm(const GemvParams& p, bool norm, int blocks, int threads
   else hipLaunchKernelGGL((gemv8_ldsx_kernel<2, 2, EPI, false>), dim3(blocks), dim3(threads), lds, s, p);
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-
 // Waves per workgroup (and workgroups per CU, 0 = whatever fits) of the bf16 GEMV for a shape: the sweep results of
 // tools/gemv_sweep.py.  Also read by decode_mega.hip, whose fused RMSNorm reproduces this kernel's summation order.
 void gemv_default_geometry(int n, int k, int epilogue, int cus, int* nw_out, int* occ_out) {
@@ -654,34 +649,34 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   // Geometry from the sweep in tools/gemv_sweep.py (profiles/gemv_sweep_r1.log): 2 rows x 2 chunks in flight per lane
   // wins on every decode shape; what varies is how many waves share one staged copy of x and how many
   // workgroups a CU should hold.
-  int rows = env_int("CHATTS_GEMV_ROWS", 2);
+  int rows = opt_get(OPT_GEMV_ROWS, 2);
   if (rows != 4) rows = 2;
-  int unr = env_int("CHATTS_GEMV_UNR", 2);
+  int unr = opt_get(OPT_GEMV_UNR, 2);
   if (unr != 4) unr = 2;
   int nw_auto, occ_auto;
   gemv_default_geometry(a->n, a->k, a->epilogue, cus, &nw_auto, &occ_auto);
-  int nw = env_int("CHATTS_GEMV_NW", nw_auto);
+  int nw = opt_get(OPT_GEMV_NW, nw_auto);
   if (nw < 1 || nw > 16) nw = 4;
   int occ = (int)((150 * 1024) / lds);          // workgroups per CU that fit in LDS
   const int wave_cap = 32 / nw;                  // 32 waves per CU
   if (occ > wave_cap) occ = wave_cap;
   if (occ_auto && occ > occ_auto) occ = occ_auto;
   if (occ < 1) occ = 1;
-  occ = env_int("CHATTS_GEMV_OCC", occ);
+  occ = opt_get(OPT_GEMV_OCC, occ);
   const int upt = swiglu ? rows / 2 : rows;
   p.tasks = (units + upt - 1) / upt;
   int blocks = (p.tasks + nw - 1) / nw;
   if (blocks > cus * occ) blocks = cus * occ;
-  blocks = env_int("CHATTS_GEMV_BLOCKS", blocks);
+  blocks = opt_get(OPT_GEMV_BLOCKS, blocks);
   // several emulated ranks on ONE device (tests, tools/jobs): their exchange-carrying launches wait for each other, so all of them
   // must be resident at once - cap the grid (results do not depend on it: a row is always summed by one wave in the same order)
-  if (a->tp_reduce) { const int cap = env_int("CHATTS_TP_FUSE_BLOCKS", 0); if (cap > 0 && blocks > cap) blocks = cap; }
+  if (a->tp_reduce) { const int cap = opt_get(OPT_TP_FUSE_BLOCKS, 0); if (cap > 0 && blocks > cap) blocks = cap; }
   if (blocks < 1) blocks = 1;
   const int threads = nw * 64;
   // CHATTS_GEMV_LDSPAD = p: declare 1/p of a CU's LDS, so that exactly p workgroups fit per CU and a grid of
   // cus * p workgroups is necessarily spread evenly (every CU streams the same number of bytes)
   size_t lds_launch = lds;
-  const int pad = env_int("CHATTS_GEMV_LDSPAD", 0);
+  const int pad = opt_get(OPT_GEMV_LDSPAD, 0);
   if (pad >= 1 && (size_t)(160 * 1024 / pad) / 16 * 16 > lds) lds_launch = (size_t)(160 * 1024 / pad) / 16 * 16;
   if (lds_launch > 64 * 1024 && lds <= 64 * 1024) lds_launch = 64 * 1024;      // default dynamic-LDS cap (still 2 per CU)
   if (a->w4 != nullptr) {                       // 4-bit codes: 2 rows x 4 chunks of 1024 elements (8-byte loads) in flight
@@ -691,7 +686,7 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
     int blocks4 = (p.tasks + nw - 1) / nw;
     // ~5 VALU ops per weight make this kernel ALU-latency bound: it wants every wave slot the registers allow (89 VGPRs -> 5 per
     // SIMD = 20 per CU), i.e. two workgroups per CU, not the one of the bf16 layouts
-    const int occ4 = env_int("CHATTS_GEMV_OCC", 20 / nw >= 1 ? 20 / nw : 1);
+    const int occ4 = opt_get(OPT_GEMV_OCC, 20 / nw >= 1 ? 20 / nw : 1);
     if (blocks4 > cus * occ4) blocks4 = cus * occ4;
     if (blocks4 < 1) blocks4 = 1;
     switch (a->epilogue) {
@@ -708,7 +703,7 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
     p.tasks = (units + (swiglu ? 1 : 2) - 1) / (swiglu ? 1 : 2);
     int blocks8 = (p.tasks + nw - 1) / nw;
     if (blocks8 > cus * occ) blocks8 = cus * occ;
-    if (a->tp_reduce) { const int cap = env_int("CHATTS_TP_FUSE_BLOCKS", 0); if (cap > 0 && blocks8 > cap) blocks8 = cap; }
+    if (a->tp_reduce) { const int cap = opt_get(OPT_TP_FUSE_BLOCKS, 0); if (cap > 0 && blocks8 > cap) blocks8 = cap; }
     if (blocks8 < 1) blocks8 = 1;
     if (a->tp_reduce) p.tp = tp_issue(a->tp_reduce, false);      // (after the last check that can refuse the call: one issue per launch)
     switch (epilogue) {
@@ -739,7 +734,7 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
       // a row in the same order whether or not they carry the exchange (tp_reduce), which the K-split form does not implement.
       ks = rounds > 8 ? 8 : rounds;
     }
-    ks = env_int("CHATTS_GEMV_KS", ks);
+    ks = opt_get(OPT_GEMV_KS, ks);
     if (ks > 16) ks = 16;
     if (ks > 1) {
       int groups = 16 / ks;

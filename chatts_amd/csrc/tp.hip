@@ -34,29 +34,9 @@ namespace chatts {
 // E elements per thread.  The exchange is pure latency, so nothing is serialised: a thread first pushes its E values to all W
 // ranks (E * W independent stores), then keeps ALL of its E * W polls in flight at once and re-issues only the granules that
 // have not arrived (tools/tp_exchange_bench.py: a one-at-a-time poll loop cost 15 us for 5120 values, this form ~1/2 of that).
-// Optional input form: the rank's vector is still lying in the workspace as the split-K slabs of the projection that produced it
-// (SlabOut, common.h): in[i] = (sum_{s < sk} ws[s * plane + i]) (* scale[i % ncols]) (+ bias[i % ncols]) - the arithmetic of
-// splitk_epilogue_kernel, whose launch (and the partial vector's round trip) the exchange then replaces.
-struct TpSlabIn {
-  const float* ws;      // null: read `in`
-  int sk, ncols;
-  size_t plane;
-  const float* scale;
-  const float* bias;
-};
-__device__ __forceinline__ float tp_input(const float* __restrict__ in, const TpSlabIn& sl, int64_t i) {
-  if (!sl.ws) return in[i];
-  float v = 0.f;
-  for (int s = 0; s < sl.sk; ++s) v += sl.ws[(size_t)s * sl.plane + i];
-  const int col = (int)(i % sl.ncols);
-  if (sl.scale) v *= sl.scale[col];
-  if (sl.bias) v += sl.bias[col];
-  return v;
-}
-
 template <int E>
 __global__ __launch_bounds__(1024) void tp_allreduce_kernel(TpParams p, const float* __restrict__ in, const float* resid,
-                                                           float* out, int64_t n, TpSlabIn sl) {
+                                                           float* out, int64_t n) {
   const uint32_t epoch = tp_epoch(p);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -65,7 +45,7 @@ __global__ __launch_bounds__(1024) void tp_allreduce_kernel(TpParams p, const fl
     for (int e = 0; e < E; ++e) {
       const int64_t i = base + (int64_t)e * stride;
       if (i < n) {
-        const uint32_t bits = __float_as_uint(tp_input(in, sl, i));
+        const uint32_t bits = __float_as_uint(in[i]);
         for (int k = 0; k < p.world; ++k) {                   // start with myself, then ring order: spreads the links
           const int q = (p.rank + k) % p.world;
           put(push_ptr(p, q, epoch) + i, epoch, push_bits(p, q, bits));
@@ -524,6 +504,19 @@ extern "C" int chatts_tp_status(ChattsTpComm* c) {
   return (int)(v & 0x7fffffffu);
 }
 
+namespace chatts {
+__global__ void tp_bump_kernel(uint32_t* ctr, uint32_t by) { ctr[0] += by; }
+}  // namespace chatts
+extern "C" int chatts_tp_pending(const ChattsTpComm* c) { return c ? (int)c->pending : 0; }
+extern "C" int chatts_tp_flush_epochs(ChattsTpComm* c, chatts_stream_t stream) {
+  CHATTS_REQUIRE(c, CHATTS_E_BADARG, "tp_flush_epochs: null comm");
+  if (c->pending == 0) return CHATTS_OK;
+  hipLaunchKernelGGL(tp_bump_kernel, dim3(1), dim3(1), 0, as_stream(stream), c->p.ctr, c->pending);
+  CHATTS_CHECK_LAUNCH("tp_flush_epochs");
+  c->pending = 0;
+  return CHATTS_OK;
+}
+
 extern "C" int chatts_tp_reset(ChattsTpComm* c, chatts_stream_t stream) {
   CHATTS_REQUIRE(c, CHATTS_E_BADARG, "tp_reset: null comm");
   const int64_t granules = (int64_t)2 * c->p.world * c->p.max_elems;
@@ -540,9 +533,8 @@ static int tp_blocks(int64_t n) {      // gather / argmax: one 1024-thread workg
   return (int)(b > 64 ? 64 : b);
 }
 
-static int allreduce_launch(ChattsTpComm* c, const float* in, float* out, const float* resid, int64_t n, const TpSlabIn& sl,
-                            chatts_stream_t stream) {
-  CHATTS_REQUIRE(c && (in || sl.ws) && out, CHATTS_E_BADARG, "allreduce: null argument");
+extern "C" int chatts_allreduce(ChattsTpComm* c, const float* in, float* out, const float* resid, int64_t n, chatts_stream_t stream) {
+  CHATTS_REQUIRE(c && in && out, CHATTS_E_BADARG, "allreduce: null argument");
   CHATTS_REQUIRE(n >= 0 && n <= c->p.max_elems, CHATTS_E_SHAPE, "allreduce: %lld elements exceed the exchange buffer (%lld)",
                  (long long)n, (long long)c->p.max_elems);
   if (n == 0) return CHATTS_OK;
@@ -550,29 +542,16 @@ static int allreduce_launch(ChattsTpComm* c, const float* in, float* out, const 
   // (131072 values: the [16, H] sums of a 16-wide decode step - 19.0 us with the 4-values-per-thread form on 20 workgroups, the
   // largest item of a TP = 8 rank's batched step, profiles/r4_tp8_cfg5_shard_kernel_trace.txt).  CHATTS_TP_AR_BLOCKS lowers the bound
   // for several ranks emulated on ONE device (their waiting grids must be resident together).
-  static const int ar_cap = getenv("CHATTS_TP_AR_BLOCKS") ? atoi(getenv("CHATTS_TP_AR_BLOCKS")) : 128;
+  const int ar_cap = opt_get(OPT_TP_AR_BLOCKS, 128);
   if ((n + 1023) / 1024 <= (ar_cap > 16 ? ar_cap : 16)) {
-    hipLaunchKernelGGL(tp_allreduce_kernel<1>, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, as_stream(stream), tp_issue(c, true), in, resid, out, n, sl);
+    hipLaunchKernelGGL(tp_allreduce_kernel<1>, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, as_stream(stream), tp_issue(c, true), in, resid, out, n);
   } else {
     const int64_t b = (n + 4095) / 4096;
-    hipLaunchKernelGGL(tp_allreduce_kernel<4>, dim3((unsigned)(b > 128 ? 128 : b)), dim3(1024), 0, as_stream(stream), tp_issue(c, true), in, resid, out, n, sl);
+    hipLaunchKernelGGL(tp_allreduce_kernel<4>, dim3((unsigned)(b > 128 ? 128 : b)), dim3(1024), 0, as_stream(stream), tp_issue(c, true), in, resid, out, n);
   }
   CHATTS_CHECK_LAUNCH("tp_allreduce");
   return CHATTS_OK;
 }
-
-extern "C" int chatts_allreduce(ChattsTpComm* c, const float* in, float* out, const float* resid, int64_t n, chatts_stream_t stream) {
-  return allreduce_launch(c, in, out, resid, n, TpSlabIn{}, stream);
-}
-
-namespace chatts {
-// out = resid + sum over the ranks of THIS rank's projection output, read straight from its split-K slabs (SlabOut): the batched
-// decode step's o_proj / down_proj under tensor parallelism - no split-K epilogue launch, no partial vector in HBM.  ncols = N.
-int tp_allreduce_slabs(ChattsTpComm* c, const float* ws, const SlabOut& so, int ncols, float* out, const float* resid, int64_t n,
-                       chatts_stream_t stream) {
-  return allreduce_launch(c, nullptr, out, resid, n, TpSlabIn{ws, so.sk, ncols, so.plane, so.scale, so.bias}, stream);
-}
-}  // namespace chatts
 
 extern "C" int64_t chatts_tp_bulk_elems(const ChattsTpComm* c) {
   return (c && c->p.bulk_off) ? (c->p.slice_cap - 4) * c->p.world : 0;
@@ -587,7 +566,7 @@ extern "C" int chatts_allreduce_bulk(ChattsTpComm* c, const float* in, float* x,
   // one workgroup per ~8 KB of a slice, at most kBulkMaxBlocks (every rank computes the same grid from n: the flags are per workgroup)
   const int64_t slice = ((n + c->p.world - 1) / c->p.world + 3) / 4 * 4;
   int64_t blocks = (slice + 2047) / 2048;
-  static const int cap = getenv("CHATTS_TP_BULK_BLOCKS") ? atoi(getenv("CHATTS_TP_BULK_BLOCKS")) : 128;
+  const int cap = opt_get(OPT_TP_BULK_BLOCKS, 128);
   if (blocks > cap) blocks = cap;
   if (blocks > kBulkMaxBlocks) blocks = kBulkMaxBlocks;
   if (blocks < 1) blocks = 1;

@@ -212,7 +212,7 @@ extern "C" int chatts_ts_encode(const float* series, const int32_t* row_off, con
   // (gemm_stream_kernel for P <= 16: the 213 MB of MLP weights are streamed once; gemm_dma_kernel above).  The values are
   // the splits of exactly the float32 numbers the float32 path would hold, so both paths give the same result.
   const int P = total_patches, H = w->hidden;
-  const bool planes = P > 1 && w->in_features_pad % 64 == 0 && H % 64 == 0 && getenv("CHATTS_TS_F32_PATH") == nullptr;
+  const bool planes = P > 1 && w->in_features_pad % 64 == 0 && H % 64 == 0 && opt_get(OPT_TS_F32_PATH, 0) == 0;
   auto hi_of = [&](float* buf) { return reinterpret_cast<chatts_bf16*>(buf); };
   auto lo_of = [&](float* buf, int k) { return reinterpret_cast<chatts_bf16*>(buf) + (size_t)P * k; };
   if (planes) { pa.out = nullptr; pa.out_hi = hi_of(feat); pa.out_lo = lo_of(feat, w->in_features_pad); }

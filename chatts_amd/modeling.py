@@ -106,7 +106,7 @@ class ChatTSForCausalLM:
         # precision: None / "bf16x2" = the parity-grade default (float32 activations carried as bf16 hi + lo planes, two MFMA passes
         # in the prefill GEMMs: logits ~5e-5 of the float32 oracle).  "bf16" = SPEED mode: the prefill GEMMs
         # multiply the bf16-rounded activations only - half the matrix work, logits ~1e-2, what a bf16 HF / vLLM run computes.
-        # PROCESS-WIDE (the library reads CHATTS_GEMM_PRECISION per call): every model of this process follows the last setting.
+        # PROCESS-WIDE (the library's GEMM_PRECISION option, chatts_set_option): every model of this process follows the last setting.
         # "fp8" = SPEED mode on the CDNA4 fp8 matrix pipe (needs weight_format="fp8", BASELINE.json config 5): prefill chunks and the
         # TS encoder quantise their activations per row to e4m3 and multiply fp8 x fp8 (v_mfma_scale_f32_16x16x128_f8f6f4: 4x less
         # matrix time than bf16x2), logits ~1e-2 from the default; decode steps are unchanged.  Per model, not process-wide.
@@ -115,11 +115,7 @@ class ChatTSForCausalLM:
         if precision == "fp8" and weight_format != "fp8":
             raise ValueError("precision='fp8' multiplies the fp8 weight copies: it needs weight_format='fp8'")
         if precision is not None:
-            import os
-            if precision == "bf16":
-                os.environ["CHATTS_GEMM_PRECISION"] = "bf16"
-            else:
-                os.environ.pop("CHATTS_GEMM_PRECISION", None)
+            _lib.set_option("GEMM_PRECISION", 1 if precision == "bf16" else None)
         self.precision = precision or "bf16x2"
         self.device = torch.device(device)
         self.comm = comm or LocalComm()
@@ -350,10 +346,6 @@ class ChatTSForCausalLM:
         for m in range(2, self.max_batch + 1):     # batched lm_head
             ws_bytes = max(ws_bytes, int(lib.chatts_linear_workspace(m, plan.vocab, H)))
         ws_bytes = max(ws_bytes, int(lib.chatts_attn_workspace(self.max_batch, plan.nq, self.n_splits)) + 256)
-        if self.max_batch > 1:       # batched steps keep the qkv projection's split-K slabs AND the attention partials in the workspace
-            qn = (plan.nq + 2 * plan.nkv) * d
-            slab = max(int(lib.chatts_linear_workspace(m, qn, H)) for m in range(2, self.max_batch + 1))
-            ws_bytes = max(ws_bytes, slab + 512 + int(lib.chatts_attn_workspace(self.max_batch, plan.nq, self.n_splits)))
         MB = self.max_batch
         f32 = dict(dtype=torch.float32, device=dev)
         qkv_n = (plan.nq + 2 * plan.nkv) * d
@@ -390,7 +382,6 @@ class ChatTSForCausalLM:
             # tensor parallel: scratch of the token agreement (chatts_decoder_select_tokens)
             "tp_pair_logit": torch.zeros(MB, **f32) if plan.world > 1 else None,
             "tp_pair_token": torch.zeros(MB, dtype=torch.int64, device=dev) if plan.world > 1 else None,
-            "tile_counters": torch.zeros(_lib.TILE_COUNTERS, dtype=torch.int32, device=dev),     # arrival counters of the split-K tiles
             "logits_full": torch.zeros((MB, plan.vocab * plan.world), **f32) if plan.world > 1 else None,
         }
         # single-sequence views (slot 0): the batch-1 fast path and its hipGraph use these
@@ -432,8 +423,7 @@ class ChatTSForCausalLM:
                                  tp_pair_token=_lib.ptr(B["tp_pair_token"]), logits_full=_lib.ptr(B["logits_full"]),
                                  kv_block_table=_lib.ptr(B["kv_table"]), kv_block_size=self.kv_block_size,
                                  kv_table_stride=(self.max_ctx // self.kv_block_size) if self.kv_block_size else 0,
-                                 kv_pool_blocks=self._kv.n_blocks if self._kv is not None else 0,
-                                 tile_counters=_lib.ptr(B["tile_counters"]))
+                                 kv_pool_blocks=self._kv.n_blocks if self._kv is not None else 0)
         h = lib.chatts_decoder_create(C.byref(dc), C.byref(dw), C.byref(db))
         if not h:
             raise _lib.ChattsError(-1, lib.chatts_last_error().decode())

@@ -41,11 +41,27 @@ const char* chatts_last_error(void);
  *  7: ChattsLinearArgs.tp_reduce (exchange inside the projection's launch), chatts_tp_init_loopback, chatts_allreduce_bulk +
  *     chatts_decoder_prefill(_last) under tensor parallelism, chatts_decoder_logits_batched; the persistent decode step
  *     chatts_decoder_mega_* is gone - built and measured slower than the captured multi-kernel step in round 3);
- *  8: chatts_attention_decode_batched_fold (decode attention in one launch). */
+ *  8: chatts_set_option / chatts_unset_option / chatts_get_option / chatts_option_name (tuning knobs: the library no longer reads the
+ *     environment); ChattsLinearArgs.tile_counters, ChattsDecoderBuffers.tile_counters and CHATTS_TILE_COUNTERS removed (the in-launch
+ *     split-K fix-up they served was measured slower twice); chatts_tp_flush_epochs. */
 #define CHATTS_ABI_VERSION 8
 int chatts_abi_version(void);
 /* Number of CUs of the current device (grid sizing), or <0. */
 int chatts_device_cus(void);
+
+/* Tuning options: named integer knobs, process-wide, all UNSET by default (= the shipped, measured-best choice).  They select
+ * alternative paths that were built and measured (A/B runs, the bit-identity tests between kernel forms) and launch geometries for
+ * sweeps; none is a fallback.  The library never reads the environment: a host that wants CHATTS_<NAME>=v honoured calls
+ * chatts_set_option("<NAME>", v) (chatts_amd/_lib.py does so once, at load).  Names (a leading "CHATTS_" is ignored): GEMM_SK GEMM_T
+ * GEMM_BM GEMM_PRECISION (1 = the bf16 speed mode) GEMM_PLANES_MIN_M GEMM_STREAM GEMM_STREAM_STAGES GEMM_STREAM_WAVES GEMM_STREAM_MB
+ * GEMM_STREAM_MB_WAVES EPI_V4 EPI_NORM_Q POST_NORM_SMALL_M ROPE_FUSE ATTN_BF16X3 ATTN_PLANES ATTN_XCD ATTN_ROWS ATTN_KSPLIT ARGMAX_2STAGE
+ * TS_F32_PATH KV_ROUND TP_FUSE TP_FUSE_BLOCKS TP_BULK_BLOCKS TP_AR_BLOCKS GEMV_ROWS GEMV_UNR GEMV_NW GEMV_OCC GEMV_BLOCKS GEMV_LDSPAD GEMV_KS
+ * FP8_BM FP8_ORDER (DESIGN.md section 11 says what each selects and where it was measured).  A set / unset is a relaxed atomic store: safe
+ * beside running calls, which see either value.  chatts_unset_option(NULL) clears all.  chatts_option_name(i) enumerates (NULL at the end). */
+int chatts_set_option(const char* name, int value);
+int chatts_unset_option(const char* name);
+int chatts_get_option(const char* name, int* value, int* is_set);
+const char* chatts_option_name(int index);
 
 /* ---------------------------------------------------------------------------------------------
  * Synthetic weights.  No reference twin: checkpoints cannot travel to the GPU box, so weights are
@@ -176,12 +192,6 @@ typedef struct ChattsLinearArgs {
   const uint8_t* w4;
   const float* w4_sz;
   int ldw4, w4_group;
-  /* optional (2 <= M <= 16 on planes, split-K): CHATTS_TILE_COUNTERS int32 in device memory, ZERO before the first use and not
-   * shared between streams.  When set, the workgroup that finishes a 128-column tile LAST (a per-tile arrival counter, reset by
-   * that workgroup) sums the tile's partial slabs in the fixed split order and applies the epilogue inside the GEMM launch:
-   * the same arithmetic as the separate epilogue launch it replaces (bit-identical), one launch less per projection.  Honoured only
-   * under CHATTS_GEMM_FIXUP=1: measured SLOWER than the launch it saves on MI355X (profiles/r3_cfg5_split_k_fixup_ab.txt). */
-  int32_t* tile_counters;
   /* encoding of `w8`: 0 = OCP fp8 e4m3fn (above); 1 = int8 (two's complement), w = w8_scale[n] * int8 with the same per-row
    * power-of-two scale - |int8| <= 127 has 7 significant bits, so the dequantised weight is again exactly a bf16 number and the
    * int8 tensor is a lossless encoding of the bf16 matrix the other kernels stream (the weight-only 8-bit format in the role of
@@ -198,7 +208,6 @@ typedef struct ChattsLinearArgs {
 } ChattsLinearArgs;
 #define CHATTS_W8_FP8 0
 #define CHATTS_W8_INT8 1
-#define CHATTS_TILE_COUNTERS 4096
 size_t chatts_linear_workspace(int m, int n, int k);
 /* hi = bf16(x) (RNE), lo = bf16(x - hi): the operand split of the bf16x2 GEMM, done once per activation matrix. */
 int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, chatts_bf16* lo, int ld_planes,
@@ -313,16 +322,6 @@ int chatts_attention_decode_batched(const float* qkv_raw, int batch, int n_q, in
                                     const float* sin_tab, int pos, const int32_t* pos_dev,
                                     const ChattsKvCache* cache, size_t seq_stride, float* out, int n_splits,
                                     void* workspace, size_t workspace_bytes, chatts_stream_t stream);
-/* The same in ONE launch: `arrive` = n_kv * batch int32 words in device memory (<= CHATTS_TILE_COUNTERS; zero before the first use,
- * left zero by every completed call, not shared between streams).  The slot waves publish their partials write-through and draw a
- * ticket; the last min(n_q / n_kv, slots) arrivers of a (sequence, kv head) merge the group's heads and write the output rows - the
- * second launch of the form above (its merge kernel) disappears.  Same weights, the weighted sums in another order (<= 1e-6 relative). */
-int chatts_attention_decode_batched_fold(const float* qkv_raw, int batch, int n_q, int n_kv, const float* q_norm_w,
-                                         const float* k_norm_w, float norm_eps, const float* cos_tab,
-                                         const float* sin_tab, int pos, const int32_t* pos_dev,
-                                         const ChattsKvCache* cache, size_t seq_stride, float* out, int n_splits,
-                                         void* workspace, size_t workspace_bytes, int32_t* arrive, chatts_stream_t stream);
-
 /* logits [V] float32 -> *token (first index of the maximum, like torch.argmax); optionally also
  * appends the token to out_tokens[*step_dev] and increments *step_dev and *pos_dev (decode loop
  * state kept on the device so that a hipGraph of one decode step is replayable). */
@@ -425,6 +424,15 @@ int64_t chatts_tp_max_elems(const ChattsTpComm*);
 int chatts_tp_status(ChattsTpComm*);
 /* zero the local buffer and the call counter (all ranks, then a host barrier, before re-using a comm after an error) */
 int chatts_tp_reset(ChattsTpComm*, chatts_stream_t stream);
+/* The exchange-carrying projections (ChattsLinearArgs.tp_reduce) do not advance the device-resident call counter themselves: the host
+ * counts them (their epoch = counter + 1 + number issued since the last advancing collective) and the next stand-alone collective
+ * advances the counter for all of them.  chatts_tp_flush_epochs makes a sequence that ENDS with such projections self-contained: it
+ * enqueues a one-thread kernel that adds the pending count to the device counter and zeroes the host count (no-op when nothing is
+ * pending; every rank must call it at the same point).  chatts_decoder_prefill_last does so itself; a captured decode step requires a
+ * flushed communicator (chatts_decoder_decode_step* return CHATTS_E_BADARG otherwise), because its epochs are baked in relative to
+ * the counter at replay time.  chatts_tp_pending: the host count (0 = flushed). */
+int chatts_tp_flush_epochs(ChattsTpComm*, chatts_stream_t stream);
+int chatts_tp_pending(const ChattsTpComm*);
 /* out[i] = (resid ? resid[i] : 0) + sum over ranks of in[i], ranks added in rank order; n <= max_elems; out may alias resid */
 int chatts_allreduce(ChattsTpComm*, const float* in, float* out, const float* resid, int64_t n, chatts_stream_t stream);
 /* x[i] += sum over ranks of in[i] for PREFILL-sized vectors ([T, H] partial sums, SURVEY.md section 5.8 "large"): a two-shot
@@ -529,7 +537,6 @@ typedef struct ChattsDecoderBuffers {
   int kv_block_size;
   int kv_table_stride;
   int kv_pool_blocks;
-  int32_t* tile_counters;  /* optional: CHATTS_TILE_COUNTERS zeroed int32 (ChattsLinearArgs.tile_counters) for the batched-decode projections */
 } ChattsDecoderBuffers;
 
 typedef struct ChattsDecoder ChattsDecoder;  /* opaque; host memory only */

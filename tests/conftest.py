@@ -43,3 +43,27 @@ def _collect_gpu_garbage(request):
         torch.cuda.synchronize()
         gc.collect()
         torch.cuda.synchronize()
+
+
+@pytest.fixture(autouse=True)
+def _chatts_options_follow_the_environment(monkeypatch):
+    """The library never reads the environment (tuning options are set through chatts_set_option, chatts_amd/_lib.py); the tests keep
+    saying monkeypatch.setenv("CHATTS_<OPTION>", ...): every such change is mirrored into the option table, and every test starts from
+    the table the (clean) environment describes."""
+    from chatts_amd import _lib
+    _lib.sync_env()                      # (no-op until the library has been loaded)
+    real_set, real_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        real_set(name, value, *a, **k)
+        if name.startswith("CHATTS_"):
+            _lib.sync_env()
+
+    def delenv(name, *a, **k):
+        real_del(name, *a, **k)
+        if name.startswith("CHATTS_"):
+            _lib.sync_env()
+
+    monkeypatch.setattr(monkeypatch, "setenv", setenv, raising=False)
+    monkeypatch.setattr(monkeypatch, "delenv", delenv, raising=False)
+    yield

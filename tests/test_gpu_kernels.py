@@ -339,22 +339,19 @@ def test_gemm_dma_single_pass_speed_mode(lib, monkeypatch, epi, m, n, k):
 
 
 @pytest.mark.parametrize("sk", [1, 2, 3])
-def test_gemm_dma_equals_register_staged_bitwise(lib, sk, monkeypatch):
-    """Same products, same accumulation order: with the split-K factor pinned the register-staged kernel and the LDS-DMA kernel's
-    16x16x32 compute waves (CHATTS_GEMM_DMA32=0) agree bit for bit.  The round-3 compute waves (64 x 128 wave tiles on the 32x32x16
-    MFMA, the default) accumulate 16 instead of 32 products per instruction: same products, another float32 summation grouping -
-    they agree with both to float32 rounding (and with float64 to the tolerance of every other kernel: test_gemm_dma_parity)."""
+@pytest.mark.parametrize("tiles", [0, 1, 3])
+def test_gemm_ring_equals_register_staged_bitwise(lib, sk, tiles, monkeypatch):
+    """Same products, same accumulation order: with the split-K factor pinned the register-staged kernel and the prefill kernel
+    (gemm_ring_kernel: swapped MFMA operands, K walked in 32-deep half-stages, any number of M-tiles) agree bit for bit."""
     monkeypatch.setenv("CHATTS_GEMM_SK", str(sk))
     monkeypatch.setenv("CHATTS_GEMM_BM", "128")
-    for epi, (m, n, k) in ((_lib.EPI_RESID, (300, 640, 1536)), (_lib.EPI_SWIGLU, (257, 1024, 768))):
+    if tiles:
+        monkeypatch.setenv("CHATTS_GEMM_T", str(tiles))
+    for epi, (m, n, k) in ((_lib.EPI_RESID, (300, 640, 1536)), (_lib.EPI_SWIGLU, (257, 1024, 768)), (_lib.EPI_NONE, (144, 272, 384))):
         a, w, bias, resid, _ = _rand_problem(m, n, k, seed=sk + m, scale=2.0)
         r = resid if epi == _lib.EPI_RESID else None
-        monkeypatch.setenv("CHATTS_GEMM_DMA32", "0")
         ref = _linear(lib, a, w, bias, r, epi)
         assert torch.equal(_linear_planes(lib, a, w, bias, r, epi), ref)
-        monkeypatch.setenv("CHATTS_GEMM_DMA32", "1")
-        w32 = _linear_planes(lib, a, w, bias, r, epi)
-        assert not torch.isnan(w32).any() and rel_err(w32.cpu().numpy(), ref.cpu().numpy()) < 2e-6
 
 
 @pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
@@ -693,57 +690,6 @@ def test_attention_decode_batched_equals_per_sequence(lib):
     assert torch.equal(kc_b[:, 0], kc0[:, 0]) and torch.equal(kc_b[:, 2], kc0[:, 2])
 
 
-@pytest.mark.parametrize("nq,nkv,splits", [(40, 8, 64), (5, 1, 64), (32, 8, 16), (10, 2, 3), (8, 8, 64)])
-def test_attention_decode_in_one_launch_equals_the_two_kernel_form(lib, nq, nkv, splits):
-    """chatts_attention_decode_batched_fold (the last arriving waves of a (sequence, kv head) merge its heads inside the launch) against
-    the two-launch form: same cache rows, outputs equal up to the order of the weighted sums; positions with fewer tiles than heads,
-    one tile, a parked sequence, slots walking several tiles; the arrival words are back at zero, and a second call on them (a replay)
-    gives the same bits as the first."""
-    max_ctx, B = 2048, 6
-    g = torch.Generator().manual_seed(nq * 131 + splits)
-    raw = torch.randn((B, (nq + 2 * nkv) * 128), generator=g).to(DEV)
-    kc0 = torch.randn((B, nkv, max_ctx, 128), generator=g).to(DEV)
-    vc0 = torch.randn((B, nkv, max_ctx, 128), generator=g).to(DEV)
-    pos = [0, 17, 47, 830, -1, 2047]
-    for b, p_ in enumerate(pos):
-        kc0[b, :, max(p_, 0):] = float("nan")
-        vc0[b, :, max(p_, 0):] = float("nan")
-    qn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV)
-    kn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV)
-    cos, sin = _rope_tables(max_ctx)
-    wsb = int(lib.chatts_attn_workspace(B, nq, splits))
-    pos_dev = torch.tensor(pos, dtype=torch.int32, device=DEV)
-    seq_stride = nkv * max_ctx * 128
-
-    def run(fold, words=None):
-        ws = torch.full((wsb // 4,), float("nan"), device=DEV)       # stale partials of another kernel must never be read
-        ka, va = kc0.clone(), vc0.clone()
-        ca = _lib.KvCache(k=ka.data_ptr(), v=va.data_ptr(), max_ctx=max_ctx)
-        out = torch.full((B, nq * 128), float("nan"), device=DEV)
-        args = (raw.data_ptr(), B, nq, nkv, qn.data_ptr(), kn.data_ptr(), 1e-6, cos.data_ptr(), sin.data_ptr(), 0, pos_dev.data_ptr(),
-                C.byref(ca), seq_stride, out.data_ptr(), splits, ws.data_ptr(), wsb)
-        if fold:
-            _lib.check(lib.chatts_attention_decode_batched_fold(*args, words.data_ptr(), st()))
-        else:
-            _lib.check(lib.chatts_attention_decode_batched(*args, st()))
-        torch.cuda.synchronize()
-        return out, ka, va
-
-    out_a, ka, va = run(False)
-    words = torch.zeros(_lib.TILE_COUNTERS, dtype=torch.int32, device=DEV)
-    out_b, kb, vb = run(True, words)
-    assert int(words.abs().sum()) == 0, "arrival words not re-armed"
-    out_c, _, _ = run(True, words)
-    assert int(words.abs().sum()) == 0
-    live = [b for b, p_ in enumerate(pos) if p_ >= 0]
-    assert not torch.isnan(out_b[live]).any()
-    assert torch.equal(out_b[4], torch.zeros_like(out_b[4])) and torch.equal(out_a[4], out_b[4])      # parked row: zeros in both forms
-    for b in live:
-        assert torch.equal(kb[b, :, :pos[b] + 1], ka[b, :, :pos[b] + 1]) and torch.equal(vb[b, :, :pos[b] + 1], va[b, :, :pos[b] + 1])
-        assert rel_err(out_b[b].cpu().numpy(), out_a[b].cpu().numpy()) < 1e-6, b
-    assert torch.equal(out_b, out_c)
-
-
 @pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
 @pytest.mark.parametrize("norm", [False, True])
 @pytest.mark.parametrize("n,k", [(1024, 512), (5120, 5120), (96, 2048), (5120, 13824), (2048, 16 * 17)])
@@ -884,45 +830,6 @@ def test_gemm_stream_fp8_eight_waves_equal_four_bitwise(lib, epi, m, n, k, sk, m
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("fp8", [False, True])
-@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
-@pytest.mark.parametrize("m,n,k,sk", [(16, 5120, 13824, 6), (16, 7168, 5120, 4), (11, 5120, 5120, 6), (16, 27648, 5120, 2)])
-def test_gemm_stream_in_launch_split_k_epilogue_bitwise(lib, epi, m, n, k, sk, fp8, monkeypatch):
-    """ChattsLinearArgs.tile_counters: the last workgroup of a tile sums the split-K slabs and applies the epilogue inside the GEMM
-    launch == the separate epilogue launch, bit for bit; repeated launches (the counters re-arm themselves) stay identical."""
-    from chatts_amd.modeling import quantize_fp8_rows
-    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
-    q, scale, deq = quantize_fp8_rows(w)
-    hi, lo = _split_planes(lib, a)
-    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
-    wsb = max(int(lib.chatts_linear_workspace(m, n, k)), 8 * m * n * 4)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
-    cnt = torch.zeros(_lib.TILE_COUNTERS, dtype=torch.int32, device=DEV)
-    monkeypatch.setenv("CHATTS_GEMM_SK", str(sk))
-    monkeypatch.setenv("CHATTS_GEMM_FIXUP", "1")         # opt-in (measured slower than the launch it saves)
-
-    def run(counters):
-        out = torch.full((m, ncols), float("nan"), device=DEV)
-        r = resid.clone()
-        la = _lib.LinearArgs(a=None, w=deq.data_ptr(), bias=bias.data_ptr(), resid=r.data_ptr() if epi == _lib.EPI_RESID else None,
-                             c=out.data_ptr(), norm_w=None, norm_eps=0.0, m=m, n=n, k=k, lda=k, ldw=k, ldc=ncols, epilogue=epi,
-                             workspace=ws.data_ptr(), workspace_bytes=wsb, a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=k,
-                             tile_counters=cnt.data_ptr() if counters else None)
-        if fp8:
-            la.w8, la.w8_scale, la.ldw8 = q.data_ptr(), scale.data_ptr(), k
-        _lib.check(lib.chatts_linear(la, st()))
-        torch.cuda.synchronize()
-        return out
-
-    want = run(False)
-    assert not torch.isnan(want).any()
-    for _ in range(3):
-        ws.fill_(0xFF)                                   # stale slabs from the previous launch must not matter
-        got = run(True)
-        assert torch.equal(got, want)
-        assert int(cnt.abs().sum()) == 0                 # every counter re-armed
-
-
 @pytest.mark.parametrize("m,n,k", [(16, 5120, 5120), (300, 5120, 1536), (16, 5120, 64), (7, 256, 512)])
 @pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID])
 def test_linear_post_norm_planes_equal_separate_rmsnorm(lib, m, n, k, epi):
@@ -1017,52 +924,6 @@ def test_gemv_int4_parity(lib, epi, norm, n, k, gs):
     # and the bf16 GEMV on the dequantised matrix agrees to summation order
     out2 = _linear(lib, a, deq, bias, resid if epi == _lib.EPI_RESID else None, epi, nw if norm else None)
     assert rel_err(out.cpu().numpy(), out2.cpu().numpy()) < 1e-5
-
-
-@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID])
-@pytest.mark.parametrize("m,n,k", [(798, 5120, 5120), (798, 7168, 5120), (798, 5120, 13824), (300, 2080, 640), (513, 768, 1024),
-                                   (1024, 4096, 4096), (260, 256, 2048)])
-def test_gemm_dma_stream_k_parity(lib, monkeypatch, epi, m, n, k):
-    """Stream-K decomposition of the LDS-DMA GEMM (every CU gets the same number of K-steps; a tile collects 2..4 pieces as
-    split-K slabs): forced on, against float64 and against the uniform split - ragged M / N tiles, K from 10 to 216 steps."""
-    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi, scale=3.0)
-    r = resid if epi == _lib.EPI_RESID else None
-    monkeypatch.setenv("CHATTS_GEMM_STREAMK", "0")
-    base = _linear_planes(lib, a, w, bias, r, epi, with_a=False, ld=k + 64)
-    monkeypatch.setenv("CHATTS_GEMM_STREAMK", "1")
-    out = _linear_planes(lib, a, w, bias, r, epi, with_a=False, ld=k + 64)
-    want = _ref_linear(a, w, bias, resid, epi)
-    assert not torch.isnan(out).any()
-    assert rel_err(out.cpu().numpy(), want) < 2e-5
-    assert rel_err(out.cpu().numpy(), base.cpu().numpy()) < 1e-5
-
-
-def test_gemm_dma_stream_k_post_norm_fused_epilogue(lib, monkeypatch):
-    """the row-wise split-K epilogue that also writes the consumer's RMSNorm planes sums the slabs each tile really has"""
-    m, n, k = 798, 5120, 5120
-    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=11, scale=2.0)
-    g = torch.Generator().manual_seed(3)
-    nw = (1 + 0.1 * torch.randn(n, generator=g)).to(DEV)
-    hi, lo = _split_planes(lib, a)
-    outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CHATTS_GEMM_STREAMK", mode)
-        wsb = int(lib.chatts_linear_workspace(m, n, k))
-        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
-        out = torch.full((m, n), float("nan"), device=DEV)
-        phi = torch.empty((m, n), dtype=torch.bfloat16, device=DEV)
-        plo = torch.empty((m, n), dtype=torch.bfloat16, device=DEV)
-        la = _lib.LinearArgs(a=None, w=w.data_ptr(), bias=None, resid=resid.data_ptr(), c=out.data_ptr(), norm_w=None, norm_eps=0.0, m=m,
-                             n=n, k=k, lda=k, ldw=k, ldc=n, epilogue=_lib.EPI_RESID, workspace=ws.data_ptr(), workspace_bytes=wsb,
-                             a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=k, post_norm_w=nw.data_ptr(), post_norm_eps=1e-6,
-                             post_hi=phi.data_ptr(), post_lo=plo.data_ptr(), ld_post=n)
-        _lib.check(lib.chatts_linear(la, st()))
-        torch.cuda.synchronize()
-        outs[mode] = (out, phi.float() + plo.float())
-    want = _ref_linear(a, w, None, resid, _lib.EPI_RESID)
-    assert rel_err(outs["1"][0].cpu().numpy(), want) < 2e-5
-    assert rel_err(outs["1"][0].cpu().numpy(), outs["0"][0].cpu().numpy()) < 1e-5
-    assert rel_err(outs["1"][1].cpu().numpy(), outs["0"][1].cpu().numpy()) < 1e-4
 
 
 @pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID])
@@ -1311,41 +1172,6 @@ def test_gemv_ksplit_at_tensor_parallel_shard_shapes(lib, ks, monkeypatch):
         assert rel_err(out.cpu().numpy(), want) < 2e-5, (epi, n, k)
         again = _linear(lib, a, w, None if nob else bias, resid if nob else None, epi, nw if norm else None)
         assert torch.equal(out, again)
-
-
-@pytest.mark.parametrize("n_q,n_kv,norm", [(40, 8, False), (5, 1, False), (32, 8, True), (8, 2, False)])
-def test_attention_decode_workgroup_form_equals_the_two_kernel_form(lib, n_q, n_kv, norm, monkeypatch):
-    """attn_decode_wg_kernel (one workgroup per (kv head, sequence), partials merged in LDS, no second launch) == attn_decode_kernel +
-    attn_decode_combine_kernel at the same slot count, bit for bit: outputs and the K / V rows written, batched (parked slot included)
-    and single sequence, positions that leave slots empty and positions that give every wave several tiles."""
-    import ctypes as C
-    d, max_ctx, B = 128, 1024, 5
-    nwv = 16 if n_q // n_kv <= 5 else 8
-    g = torch.Generator().manual_seed(n_q)
-    qkv = torch.randn((B, (n_q + 2 * n_kv) * d), generator=g).to(DEV)
-    kc0 = torch.randn((B, n_kv, max_ctx, d), generator=g).to(DEV)
-    vc0 = torch.randn((B, n_kv, max_ctx, d), generator=g).to(DEV)
-    pos = torch.tensor([3, 200, -1, 1000, 37], dtype=torch.int32, device=DEV)        # slot 2 is parked
-    qn = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV) if norm else None
-    kn = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV) if norm else None
-    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, dtype=torch.float64) / 64))
-    ang = torch.arange(max_ctx, dtype=torch.float64)[:, None] * inv[None]
-    cos, sin = torch.cos(ang).float().to(DEV).contiguous(), torch.sin(ang).float().to(DEV).contiguous()
-    ws = torch.zeros(int(lib.chatts_attn_workspace(B, n_q, 64)) + 256, dtype=torch.uint8, device=DEV)
-    runs = {}
-    for mode in ("0", "2"):
-        monkeypatch.setenv("CHATTS_ATTN_WG", mode)
-        kc, vc = kc0.clone(), vc0.clone()
-        out = torch.full((B, n_q * d), float("nan"), device=DEV)
-        cache = _lib.KvCache(k=kc.data_ptr(), v=vc.data_ptr(), max_ctx=max_ctx, block_table=None, block_size=0, table_stride=0)
-        _lib.check(lib.chatts_attention_decode_batched(qkv.data_ptr(), B, n_q, n_kv, _lib.ptr(qn), _lib.ptr(kn), 1e-6, cos.data_ptr(),
-                                                       sin.data_ptr(), 0, pos.data_ptr(), C.byref(cache), n_kv * max_ctx * d, out.data_ptr(),
-                                                       nwv, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
-        torch.cuda.synchronize()
-        runs[mode] = (out, kc, vc)
-    for a, b in zip(runs["0"], runs["2"]):
-        assert torch.equal(a, b)
-    assert not torch.isnan(runs["2"][0]).any() and torch.count_nonzero(runs["2"][0][2]) == 0      # the parked row is written as zeros
 
 
 def _fp8_ref_quant(x, norm_w=None, eps=1e-6):

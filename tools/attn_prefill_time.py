@@ -21,6 +21,7 @@ st = torch.cuda.current_stream()
 ref = None
 for mode in ("0", "1"):
     os.environ["CHATTS_ATTN_BF16X3"] = mode
+    _lib.sync_env()
     for NS in (1, 2):
         wsb = int(lib.chatts_attn_workspace(T, nq, NS))
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
@@ -53,6 +54,7 @@ for _ in range(20):
 e1.record(st)
 torch.cuda.synchronize()
 os.environ["CHATTS_ATTN_BF16X3"] = "1"
+_lib.sync_env()
 ws16 = torch.empty(16, dtype=torch.uint8, device=DEV)
 _lib.check(lib.chatts_attention(qkv.data_ptr(), T, nq, nkv, 0, None, C.byref(cache), split_out.data_ptr(), 1, ws16.data_ptr(), 16, st.cuda_stream))
 torch.cuda.synchronize()

@@ -1,5 +1,5 @@
-"""Interleaved A/B of the prefill projections at the ChatTS-14B chunk shapes: round-4 LDS-DMA kernel (CHATTS_GEMM_RING=0) against the
-round-5 ring kernel, R rounds, each round runs every arm once per shape (median and min over the rounds; the epilogue launch of a
+"""Interleaved A/B of the prefill projections at the ChatTS-14B chunk shapes between option settings of the prefill kernel (round 5
+ran it between the round-4 LDS-DMA kernel and gemm_ring_kernel: profiles/r5_gemm_ab_ring_first.txt), R rounds, each round runs every arm once per shape (median and min over the rounds; the epilogue launch of a
 split-K projection is inside the timed region, as in the decoder).
     python tools/gemm_ab.py [M] [rounds]"""
 import os
@@ -18,10 +18,10 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 798
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 SHAPES = {"qkv": (7168, 5120, _lib.EPI_NONE), "o": (5120, 5120, _lib.EPI_RESID), "gate_up": (27648, 5120, _lib.EPI_SWIGLU),
           "down": (5120, 13824, _lib.EPI_RESID)}
-ARMS = {"round4": {"RING": 0}, "ring": {"RING": 1}}
+ARMS = {"auto": {}}
 for extra in sys.argv[3:]:          # e.g. ring_T6=T:6  or  ring_o=T:6,SK:2
     name, spec = extra.split("=")
-    ARMS[name] = {"RING": 1, **{a: int(b) for a, b in (kv.split(":") for kv in spec.split(","))}}
+    ARMS[name] = {**{a: int(b) for a, b in (kv.split(":") for kv in spec.split(","))}}
 
 
 def setenv(env):
@@ -29,6 +29,7 @@ def setenv(env):
         if kk.startswith("CHATTS_GEMM_"):
             del os.environ[kk]
     os.environ.update({"CHATTS_GEMM_" + a: str(b) for a, b in env.items()})
+    _lib.sync_env()
 
 
 cases = {}

@@ -1,4 +1,4 @@
-"""Prefill GEMM: time against K at a fixed tile count -> per-K-step cost s and per-tile fixed cost F of gemm_dma_kernel
+"""Prefill GEMM: time against K at a fixed tile count -> per-K-step cost s and per-tile fixed cost F of the prefill kernel
 (T = rounds * (F + nk * s)).  256 tiles = one full round on 256 CUs; the gate_up shape = 2.95 rounds.
     python tools/gemm_ksweep.py"""
 import os
@@ -14,6 +14,7 @@ lib = _lib.load()
 DEV = "cuda"
 st = torch.cuda.current_stream()
 os.environ["CHATTS_GEMM_SK"] = "1"
+_lib.sync_env()
 
 
 def timed(fn, reps=5):

@@ -1,5 +1,6 @@
-"""The round-5 prefill GEMM (gemm_ring_kernel) against float64 and against the round-4 LDS-DMA kernel: values, bit-equality at equal
-split-K, and time - over the ChatTS-14B / 8B projection shapes, several M and (T, split-K) choices.
+"""The prefill GEMM (gemm_ring_kernel) against float64 and against the register-staged kernel on the float32 operand: values,
+bit-equality at equal split-K, and time - over the ChatTS-14B / 8B projection shapes, several M and (T, split-K) choices.
+(Round 5 ran it against the round-4 LDS-DMA kernel it replaced: profiles/r5_ring_check_first.txt.)
     python tools/gemm_ring_check.py [quick]"""
 import os
 import sys
@@ -22,6 +23,7 @@ def setenv(**env):
         if kk.startswith("CHATTS_GEMM_"):
             del os.environ[kk]
     os.environ.update({"CHATTS_GEMM_" + a: str(b) for a, b in env.items()})
+    _lib.sync_env()
 
 
 def timed(fn, reps=5):
@@ -43,6 +45,7 @@ class Case:
         self.M, self.n, self.k, self.epi, self.planes_out, self.post_norm = M, n, k, epi, planes_out, post_norm
         self.ws = [(torch.randn((n, k), device=DEV) * 0.02).to(torch.bfloat16) for _ in range(3)]
         a = torch.randn((M, k), device=DEV)
+        self.a = a
         self.hi = a.to(torch.bfloat16)
         self.lo = (a - self.hi.float()).to(torch.bfloat16)
         self.ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
@@ -58,12 +61,13 @@ class Case:
         self.wsb = max(int(lib.chatts_linear_workspace(M, n, k)), 16 * M * n * 4)
         self.wsp = torch.empty(self.wsb, dtype=torch.uint8, device=DEV)
 
-    def run(self, w=None):
+    def run(self, w=None, planes=True):
         w = self.ws[0] if w is None else w
-        la = _lib.LinearArgs(a=None, w=w.data_ptr(), bias=_lib.ptr(self.bias), resid=self.resid.data_ptr() if self.epi == _lib.EPI_RESID else None,
+        la = _lib.LinearArgs(a=None if planes else self.a.data_ptr(), w=w.data_ptr(), bias=_lib.ptr(self.bias), resid=self.resid.data_ptr() if self.epi == _lib.EPI_RESID else None,
                              c=self.out.data_ptr(), norm_w=None, norm_eps=0.0, m=self.M, n=self.n, k=self.k, lda=self.k, ldw=self.k,
                              ldc=self.ncols, epilogue=self.epi, workspace=self.wsp.data_ptr(), workspace_bytes=self.wsb)
-        la.a_hi, la.a_lo, la.ld_planes = self.hi.data_ptr(), self.lo.data_ptr(), self.k
+        if planes:
+            la.a_hi, la.a_lo, la.ld_planes = self.hi.data_ptr(), self.lo.data_ptr(), self.k
         if self.planes_out:
             la.c = None
             la.c_hi, la.c_lo, la.ld_cplanes = self.phi.data_ptr(), self.plo.data_ptr(), self.ncols
@@ -96,18 +100,18 @@ class Case:
 
 
 def check(tag, c, envs_ring, bits_vs_old=True):
-    setenv(RING=0)
+    setenv()
     c.out.zero_(); c.phi.zero_(); c.plo.zero_()
-    c.run()
+    c.run(planes=False)
     old = c.result()
-    t_old = timed(lambda: [c.run(w) for w in c.ws]) / len(c.ws)
+    t_old = timed(lambda: [c.run(w, planes=False) for w in c.ws]) / len(c.ws)
     ref = c.reference()
     tol = 3e-5 if not c.planes_out else 2e-4      # planes carry 16 mantissa bits
     e_old = ((old.double() - ref).norm() / ref.norm()).item()
-    print(f"== {tag}: M={c.M} N={c.n} K={c.k}  round-4 kernel {t_old:8.1f} us  rel err {e_old:.2e}")
+    print(f"== {tag}: M={c.M} N={c.n} K={c.k}  register-staged kernel {t_old:8.1f} us  rel err {e_old:.2e}")
     ok = True
     for env in envs_ring:
-        setenv(RING=1, **env)
+        setenv(**env)
         c.out.fill_(float("nan")); c.phi.zero_(); c.plo.zero_()
         c.run()
         new = c.result()
@@ -119,7 +123,7 @@ def check(tag, c, envs_ring, bits_vs_old=True):
         ok = ok and finite and e_new < tol
         et = " ".join(f"{a}={b}" for a, b in env.items()) or "auto"
         print(f"   ring {et:12s} {t_new:8.1f} us  ({t_old / t_new:4.2f}x)  {2.0 * c.M * c.n * c.k / t_new / 1e6:6.0f} TF useful  rel err {e_new:.2e}  "
-              f"bit-equal to round 4: {same}{flag}")
+              f"bit-equal to the register-staged kernel: {same}{flag}")
     return ok
 
 

@@ -23,6 +23,7 @@ def bench(name, env):
         if kk.startswith("CHATTS_GEMM_"):
             del os.environ[kk]
     os.environ.update({a: str(b) for a, b in env.items()})
+    _lib.sync_env()
     ws = [torch.randint(-3000, 3000, (n, k), dtype=torch.int16, device=DEV).view(torch.bfloat16) for _ in range(4)]
     a = torch.randn((M, k), device=DEV)
     ncols = n // 2 if epi == _lib.EPI_SWIGLU else n

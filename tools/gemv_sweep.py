@@ -34,6 +34,7 @@ def bench(name, env, reps=3):
         if kk.startswith("CHATTS_GEMV_"):
             del os.environ[kk]
     os.environ.update({k2: str(v) for k2, v in env.items()})
+    _lib.sync_env()
     st = torch.cuda.current_stream()
 
     def run():

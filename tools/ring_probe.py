@@ -19,7 +19,11 @@ DEV = "cuda"
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 798
 SHAPES = {"qkv": (7168, 5120, _lib.EPI_NONE), "o": (5120, 5120, _lib.EPI_RESID), "gate_up": (27648, 5120, _lib.EPI_SWIGLU),
           "down": (5120, 13824, _lib.EPI_RESID)}
-VARIANTS = {"qkv": [{}, {"T": 7}], "o": [{}, {"T": 6, "SK": 1}], "gate_up": [{}, {"T": 6}], "down": [{}]}
+VARIANTS = {"qkv": [{}], "o": [{}], "down": [{}],
+            # ablations (timing only, results are garbage): 1 = no LDS-DMA, 2 = no fragment reads in the loop, 4 = no MFMAs
+            "gate_up": [{}, {"ABLATE": 1}, {"ABLATE": 2}, {"ABLATE": 3}, {"ABLATE": 4}, {"ABLATE": 5}, {"ABLATE": 6}, {"ABLATE": 7}, {}]}
+if len(sys.argv) > 2 and sys.argv[2] == "noablate":
+    VARIANTS["gate_up"] = [{}]
 st = torch.cuda.current_stream()
 NREC = 4096
 
@@ -37,6 +41,7 @@ for name, (n, k, epi) in SHAPES.items():
             if kk.startswith("CHATTS_GEMM_"):
                 del os.environ[kk]
         os.environ.update({"CHATTS_GEMM_" + a: str(b) for a, b in env.items()})
+        _lib.sync_env()
         w = (torch.randn((n, k), device=DEV) * 0.02).to(torch.bfloat16)
         a = torch.randn((M, k), device=DEV)
         hi = a.to(torch.bfloat16)

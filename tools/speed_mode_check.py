@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from chatts_amd import config as cfgmod  # noqa: E402
+from chatts_amd import _lib, config as cfgmod  # noqa: E402
 from chatts_amd.modeling import ChatTSForCausalLM  # noqa: E402
 
 
@@ -27,8 +27,10 @@ def main():
     for mode in ("bf16x2", "bf16", "bf16x2"):
         if mode == "bf16":
             os.environ["CHATTS_GEMM_PRECISION"] = "bf16"
+            _lib.sync_env()
         else:
             os.environ.pop("CHATTS_GEMM_PRECISION", None)
+            _lib.sync_env()
         ttft = []
         for _ in range(runs):
             torch.cuda.synchronize()

@@ -25,6 +25,7 @@ def setenv(env):
         if kk.startswith("CHATTS_GEMM_"):
             del os.environ[kk]
     os.environ.update({a: str(b) for a, b in env.items()})
+    _lib.sync_env()
 
 
 for name, (n, k, epi) in SHAPES.items():

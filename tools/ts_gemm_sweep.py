@@ -18,6 +18,7 @@ def run(P, K, N, env, planes=True, nbuf=12, reps=5):
         if k.startswith("CHATTS_GEMM_"):
             del os.environ[k]
     os.environ.update({k: str(v) for k, v in env.items()})
+    _lib.sync_env()
     ws = [torch.randint(-3000, 3000, (N, K), dtype=torch.int16, device=DEV).view(torch.bfloat16) for _ in range(nbuf)]
     a = torch.randn((P, K), device=DEV)
     hi = a.to(torch.bfloat16)
