@@ -188,7 +188,7 @@ def roofline_gate_up(model, reps=2, m=1):
 
 
 def prefill_mfma_gate_up(model, T, reps=1):
-    """The prefill's dominant GEMM (gate_up, M = prompt tokens, LDS-DMA kernel on bf16 planes) between two HIP events on
+    """The prefill's dominant GEMM (gate_up, M = prompt tokens, gemm_ring_kernel on bf16 planes) between two HIP events on
     the launching stream, over every layer's weights: MFMA-issued flops = 2 passes (hi, lo) x 2 M N K."""
     import torch
     from chatts_amd import _lib
@@ -223,11 +223,13 @@ def prefill_mfma_gate_up(model, T, reps=1):
     launches = reps * len(model.layers)
     avg_s = e0.elapsed_time(e1) * 1e-3 / launches
     issued = 2 * 2.0 * T * n * H
-    return {"kernel": "gemm_dma_kernel (gate_up_proj + SwiGLU, M = prompt tokens)", "bound": "mfma", "avg_us": avg_s * 1e6,
+    return {"kernel": "gemm_ring_kernel (gate_up_proj + SwiGLU, M = prompt tokens)", "bound": "mfma", "avg_us": avg_s * 1e6,
             "achieved": issued / avg_s / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": issued / avg_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, "useful_tflops": issued / 2 / avg_s / 1e12,
             "launches_timed": launches,
-            "note": "MFMA-issued flops (bf16x2: two passes per product); rows padded to 128 are not counted"}
+            "note": "MFMA-issued flops (bf16x2: two passes per product) of the BEST projection timed alone; the whole prefill is prefill_e2e. "
+                    "With these operand statistics the matrix pipe alone sustains 2.09 PF at a power-bound 2.07 GHz "
+                    "(profiles/r5_mfma_power_probe.txt), this kernel's clock under load is 1.6-1.9 GHz (profiles/r5_ring_probe_first.txt)"}
 
 
 def ts_encoder_roofline(model, ser, lengths, reps=20):
@@ -640,6 +642,16 @@ def main():
 
     # TTFT + warm-up run twice at most: under TP a peer-to-peer exchange that stalls on this node (bounded spins, status word) is
     # replaced by the host-driven RCCL path on every rank and the stage is repeated - the line then says tp_exchange = rccl
+    # first-run-readiness for a multi-GPU node: which device each rank sits on, whether it can reach its peers (hipDeviceCanAccessPeer as
+    # torch reports it) and, at the end, the exchange's status word - so that a fallback or a stall is explained by the record itself
+    tp_devices = None
+    if world > 1:
+        n_dev = torch.cuda.device_count()
+        mine = {"rank": rank, "device": dev_index, "device_count": n_dev,
+                "can_access_peer": [bool(torch.cuda.can_device_access_peer(dev_index, d)) if d != dev_index else True for d in range(n_dev)]}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        tp_devices = gathered
     tp_exchange = None if world == 1 else ("p2p over IPC-mapped buffers (csrc/tp.hip): decode exchanges inside the o_proj / down_proj GEMV launches, prefill sums = two-shot "
                                                           "bulk kernel inside chatts_decoder_prefill" if model._tp is not None else "rccl, host-driven")
     if world > 1 and model._tp is not None and rank == 0 and os.environ.get("CHATTS_BENCH_INJECT_P2P_STALL"):
@@ -708,6 +720,12 @@ def main():
     tok_s = args.steps / dt
     ms_step = dt / args.steps * 1e3
 
+    tp_status = None
+    if world > 1:
+        st_word = model._tp.status() if getattr(model, "_tp", None) is not None else -1          # -1: no p2p exchange attached (host-driven sums)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, int(st_word))
+        tp_status = gathered
     roof = roofline_gate_up(model)
     traffic, traffic_note, pmc = None, None, None     # HBM bytes per launch from the separate rocprofv3 --pmc pass (TP=1 shape only)
     try:
@@ -731,6 +749,7 @@ def main():
                    "model": args.model, "prompt_tokens": T, "ts_patches": sum((L + 15) // 16 for L in lengths),
                    "parallelism": f"tp{world}", "batch": 1, "decode_graph": model.graph_capturable(), "kv_block": model.kv_block_size or None,
                    "tp_exchange": tp_exchange, "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+                   "tp_devices": tp_devices, "tp_status": tp_status,
                    "precision": ("bf16 weights; f32 activations, KV cache and accumulation (bf16x2 MFMA split in "
                                  "prefill, exact f32 FMA in decode)") if model.precision == "bf16x2" else
                                 ("SPEED MODE precision=bf16 - NOT the parity-grade line: prefill GEMMs multiply bf16-rounded activations "
@@ -759,6 +778,15 @@ def main():
         result["prefill_roofline"] = prefill_mfma_gate_up(model, T)
     except Exception as e:
         result["prefill_roofline"] = {"error": f"{type(e).__name__}: {e}"}
+    # the prefill END TO END: useful flops of the prompt (2 x decoder parameters streamed per token on this rank; attention and the
+    # lm_head of the last row left out) over the measured TTFT (processor + TS encoder + merge + prefill + first token) - the figure
+    # that says how far the whole prefill is from the matrix pipe, not its best kernel
+    params = sum(lw[k].numel() for lw in model.layers for k in ("qkv", "o", "gate_up", "down") if k in lw)
+    useful = 2.0 * T * params
+    result["prefill_e2e"] = {"useful_tflops": useful / (ttft * 1e-3) / 1e12, "frac_of_bf16_peak": useful / (ttft * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                             "issued_frac_of_bf16_peak": (2.0 if model.precision == "bf16x2" else 1.0) * useful / (ttft * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                             "ttft_ms": ttft, "prompt_tokens": T,
+                             "note": "issued = useful x 2 in the parity-grade bf16x2 mode (hi and lo pass of every product)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(model, T, ser=ser)

@@ -114,6 +114,7 @@ SIGNATURES = {
     "chatts_ts_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, C.POINTER(TsWeights), c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "chatts_linear_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "chatts_gemv_ksplit": (c_int, [c_int, c_int, c_int, c_int]),
     "chatts_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
     "chatts_quantize_rows_fp8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "chatts_linear_fp8": (c_int, [C.POINTER(LinearFp8Args), c_void_p]),

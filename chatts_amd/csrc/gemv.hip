@@ -624,6 +624,31 @@ void gemv_default_geometry(int n, int k, int epilogue, int cus, int* nw_out, int
   *occ_out = occ_auto;
 }
 
+// Waves per row group of the bf16 GEMV (1 = the whole-K kernel): a pure function of the shape, so that a host-side test can pin which
+// shapes take which kernel (tests/test_host_logic.py: every TP = 1 projection of the supported models resolves to 1 - the K-split form
+// sums a row in another order - and the TP = 8 shard shapes to > 1).
+//   tasks = row groups (2 rows, or one gate / up pair), nchunks = K / 512, w_bytes = N K 2.
+int gemv_pick_ksplit(int tasks, int nchunks, bool norm, double w_bytes, int cus) {
+  if (nchunks < 4) return 1;
+  int ks = 1;
+  const double per_cu = (double)tasks / cus;
+  const int rounds = (nchunks + 1) / 2;                   // chunk pairs of a row: a wave should keep at least one
+  if (per_cu < 6.0) {
+    // the row groups alone leave the chip nearly empty - fewer than ~6 waves per CU
+    ks = (int)(12.0 / (per_cu > 0.25 ? per_cu : 0.25) + 0.999);
+    if (ks > rounds) ks = rounds;
+    if (ks > 8) ks = 8;
+  } else if (norm && per_cu < 16.0 && w_bytes < 48e6) {
+    // a SHARD-sized matrix whose row groups alone half-fill the chip (gate_up of a TP = 8 rank: 35 MB, 13.5 waves per CU): every wave
+    // still walks K / 1024 dependent round trips; one chunk pair per wave measured 1.2 us per launch better (profiles/r4_tp_shard_step*).
+    // The 48 MB bound keeps every TP = 1 shape (o_proj: 52 MB, 10 waves per CU; the 8B qkv: 50.3 MB) on the whole-K kernel; `norm`
+    // restricts the rule to the column-parallel projections (qkv, gate_up: RMSNorm in the prologue) - the row-parallel ones (o_proj,
+    // down_proj) must sum a row in the same order whether or not they carry the exchange (tp_reduce), which the K-split form does not do.
+    ks = rounds > 8 ? 8 : rounds;
+  }
+  return ks;
+}
+
 int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   GemvParams p;
   p.tp = TpParams{};
@@ -719,21 +744,7 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
   // row is long enough to split.  Every TP = 1 shape of the supported models has >= 10 waves per CU and keeps the whole-K kernel.
   p.ks = 1;
   if (!a->tp_reduce && rows == 2 && unr == 2 && nchunks >= 4) {
-    int ks = 1;
-    const double per_cu = (double)p.tasks / cus;
-    const int rounds = (nchunks + 1) / 2;                   // chunk pairs of a row: a wave should keep at least one
-    if (per_cu < 6.0) {
-      ks = (int)(12.0 / (per_cu > 0.25 ? per_cu : 0.25) + 0.999);
-      if (ks > rounds) ks = rounds;
-      if (ks > 8) ks = 8;
-    } else if (norm && per_cu < 16.0 && (double)a->n * a->k * 2.0 < 48e6) {
-      // a SHARD-sized matrix whose row groups alone half-fill the chip (gate_up of a TP = 8 rank: 35 MB, 13.5 waves per CU): every wave
-      // still walks K / 1024 dependent round trips; one chunk pair per wave measured 1.2 us per launch better (profiles/r4_tp_shard_step*).
-      // The 48 MB bound keeps every TP = 1 shape (o_proj: 52 MB, 10 waves per CU) on the whole-K kernel; `norm` restricts the rule to
-      // the column-parallel projections (qkv, gate_up: RMSNorm in the prologue) - the row-parallel ones (o_proj, down_proj) must sum
-      // a row in the same order whether or not they carry the exchange (tp_reduce), which the K-split form does not implement.
-      ks = rounds > 8 ? 8 : rounds;
-    }
+    int ks = gemv_pick_ksplit(p.tasks, nchunks, norm, (double)a->n * a->k * 2.0, cus);
     ks = opt_get(OPT_GEMV_KS, ks);
     if (ks > 16) ks = 16;
     if (ks > 1) {
@@ -773,3 +784,13 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
 }
 
 }  // namespace chatts
+
+// host-only query (no device touched): the K-split factor the bf16 decode GEMV picks for a shape on this device - see gemv_pick_ksplit
+extern "C" int chatts_gemv_ksplit(int n, int k, int epilogue, int has_norm) {
+  if (n <= 0 || k <= 0) return -1;
+  const int swiglu = epilogue == CHATTS_EPI_SWIGLU;
+  const int units = swiglu ? n / 2 : n, upt = swiglu ? 1 : 2;
+  const int cus = chatts::device_cus() > 0 ? chatts::device_cus() : 256;
+  return chatts::gemv_pick_ksplit((units + upt - 1) / upt, (k + 511) / 512, has_norm != 0, (double)n * k * 2.0, cus);
+}
+

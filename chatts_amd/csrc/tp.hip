@@ -201,7 +201,8 @@ __device__ __forceinline__ bool wait_flag(uint32_t* f, uint32_t epoch, uint32_t*
   }
 }
 
-__global__ __launch_bounds__(256) void tp_allreduce_bulk_kernel(TpParams p, const float* __restrict__ in, float* x, int64_t n) {
+constexpr int kBulkThreads = 512;      // one f32x4 position per thread and pass at the 798 x 5120 / 8-rank shape with 256 workgroups
+__global__ __launch_bounds__(kBulkThreads) void tp_allreduce_bulk_kernel(TpParams p, const float* __restrict__ in, float* x, int64_t n) {
   const uint32_t epoch = tp_epoch(p);
   const int W = p.world, b = blockIdx.x, tid = threadIdx.x;
   // slice s = elements [s * slice, (s + 1) * slice) of the vector (multiples of 4 floats); workgroup b owns [lo, hi) of every slice
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void tp_allreduce_bulk_kernel(TpParams p, cons
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   // 1. scatter my partial: slice s goes to rank s (loop-back: into my own "from q" area, zeros for the absent peers).  All W loads of
   //    a thread's position are issued before the first store: W independent requests in flight per lane.
-  for (int64_t i = lo + tid * 4; i < hi; i += 256 * 4) {
+  for (int64_t i = lo + tid * 4; i < hi; i += kBulkThreads * 4) {
     f32x4 v[kMaxWorld];
 #pragma unroll
     for (int k = 0; k < kMaxWorld; ++k) {
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void tp_allreduce_bulk_kernel(TpParams p, cons
   if (tid < W) (void)wait_flag(mine.flags + (size_t)tid * kBulkMaxBlocks + b, epoch, &p.ctr[2]);     // (a timeout raises the status bit)
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  for (int64_t i = lo + tid * 4; i < hi; i += 256 * 4) {
+  for (int64_t i = lo + tid * 4; i < hi; i += kBulkThreads * 4) {
     f32x4 c[kMaxWorld];
 #pragma unroll
     for (int src = 0; src < kMaxWorld; ++src)
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void tp_allreduce_bulk_kernel(TpParams p, cons
   if (tid < W) (void)wait_flag(mine.flags + (size_t)(kMaxWorld + tid) * kBulkMaxBlocks + b, epoch, &p.ctr[2]);
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  for (int64_t i = lo + tid * 4; i < hi; i += 256 * 4) {          // (all W slices of a position: 2 W independent loads in flight per lane)
+  for (int64_t i = lo + tid * 4; i < hi; i += kBulkThreads * 4) {          // (all W slices of a position: 2 W independent loads in flight per lane)
     f32x4 r[kMaxWorld], xv[kMaxWorld];
 #pragma unroll
     for (int s = 0; s < kMaxWorld; ++s) {
@@ -563,14 +564,17 @@ extern "C" int chatts_allreduce_bulk(ChattsTpComm* c, const float* in, float* x,
                  (long long)n, (long long)chatts_tp_bulk_elems(c));
   CHATTS_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)x % 16) == 0, CHATTS_E_SHAPE, "allreduce_bulk: pointers must be 16-byte aligned");
   if (n == 0) return CHATTS_OK;
-  // one workgroup per ~8 KB of a slice, at most kBulkMaxBlocks (every rank computes the same grid from n: the flags are per workgroup)
+  // one workgroup per ~8 KB of a slice, at most kBulkMaxBlocks = one per CU (every rank computes the same grid from n: the flags are per
+  // workgroup).  Round 5: 256 x 512 threads instead of 128 x 256 - every pass is a latency chain of W uncached 16-byte requests per
+  // thread, and at [798, 5120] / 8 ranks a thread now makes ONE trip per pass instead of four (51 -> see profiles/r5_tp_shard_step.json).
+  // TP_BULK_BLOCKS lowers the bound for several ranks emulated on ONE device (their waiting grids must be resident together).
   const int64_t slice = ((n + c->p.world - 1) / c->p.world + 3) / 4 * 4;
   int64_t blocks = (slice + 2047) / 2048;
-  const int cap = opt_get(OPT_TP_BULK_BLOCKS, 128);
+  const int cap = opt_get(OPT_TP_BULK_BLOCKS, kBulkMaxBlocks);
   if (blocks > cap) blocks = cap;
   if (blocks > kBulkMaxBlocks) blocks = kBulkMaxBlocks;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(tp_allreduce_bulk_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), tp_issue(c, true), in, x, n);
+  hipLaunchKernelGGL(tp_allreduce_bulk_kernel, dim3((unsigned)blocks), dim3(kBulkThreads), 0, as_stream(stream), tp_issue(c, true), in, x, n);
   CHATTS_CHECK_LAUNCH("tp_allreduce_bulk");
   return CHATTS_OK;
 }

@@ -56,8 +56,13 @@ class Request:
 class Engine:
     """add_request() / step() like vLLM's LLMEngine.  `on_tokens(request, new_token_ids, finished)` is called from step()."""
 
-    def __init__(self, model, processor, sync_every=4, prefill_chunk_tokens=None):
+    def __init__(self, model, processor, sync_every=4, prefill_chunk_tokens=None, greedy_return_steps=256):
         self.model, self.processor = model, processor
+        # per-slot sampling: scheduler iterations without any sampling request (running or waiting) after which the step goes back from the
+        # per-row sampler to the plain argmax tail (a graph re-capture); 0 = stay in per-row mode once entered.  Every rank of a
+        # tensor-parallel group counts the same iterations (followers replay the leader's), so all of them switch together.
+        self.greedy_return_steps = max(0, int(greedy_return_steps))
+        self._greedy_iters = 0
         self.sync_every = max(1, int(sync_every))       # decode steps between device->host token reads
         # chunked-prefill scheduling (vLLM: enable_chunked_prefill / max_num_batched_tokens): while other sequences are decoding, a
         # long prompt is prefilled this many rows per scheduler iteration, each followed by one decode step of the running batch,
@@ -123,8 +128,16 @@ class Engine:
                           (self.prefilling is not None and self.prefilling[0].sampling_key) or
                           any(q.sampling_key for q in self.waiting)) else None
         if want is None and self.active_key == "rows":
-            return          # stay in per-row mode once entered: greedy rows already take the argmax token there, and every switch drops
-                            # both captured hipGraphs (re-capture + a warm eager step on all ranks) - alternating traffic would stall
+            # Hysteresis instead of either extreme.  Every switch drops both captured hipGraphs (re-capture + a warm eager step on all
+            # ranks), so alternating traffic must not flip the mode per request; but staying in per-row mode for good would leave later
+            # greedy traffic on the sampler path (under TP: a full-vocabulary all-gather + the sampler kernel per step instead of the
+            # 2-word tp_argmax).  So: back to the argmax tail after `greedy_return_steps` consecutive iterations without any sampling
+            # request running or waiting (0 = never switch back).
+            self._greedy_iters = getattr(self, "_greedy_iters", 0) + 1
+            if not self.greedy_return_steps or self._greedy_iters < self.greedy_return_steps:
+                return
+        if want == "rows":
+            self._greedy_iters = 0
         if want != self.active_key:
             self._apply_sampling(want)
 

@@ -346,6 +346,10 @@ class ChatTSForCausalLM:
         for m in range(2, self.max_batch + 1):     # batched lm_head
             ws_bytes = max(ws_bytes, int(lib.chatts_linear_workspace(m, plan.vocab, H)))
         ws_bytes = max(ws_bytes, int(lib.chatts_attn_workspace(self.max_batch, plan.nq, self.n_splits)) + 256)
+        # the prefill attention's K / V planes (kv_planes_kernel: 32 KB per (kv head, 32-key tile)) for a sequence of max_ctx positions:
+        # with the workspace sized for them the planes kernel is taken at EVERY chunk position, so the same prompt never changes
+        # kernel (and summation order) with where a chunk starts
+        ws_bytes = max(ws_bytes, ((self.max_ctx + 31) // 32) * plan.nkv * 4 * 32 * d * 2 + 256)
         MB = self.max_batch
         f32 = dict(dtype=torch.float32, device=dev)
         qkv_n = (plan.nq + 2 * plan.nkv) * d

@@ -104,6 +104,10 @@ class TimeSeriesEmbedding:
         ~1e-2 from the default.  Fewer patches than 64 keep the default path (weight-streaming bound: nothing to gain)."""
         if precision not in ("bf16x2", "fp8"):
             raise ValueError("TimeSeriesEmbedding precision must be 'bf16x2' or 'fp8'")
+        if precision == "fp8" and self.hidden_size % 128 != 0:
+            # layers after the first quantise their activations with row length H but multiply over ceil128(H): the pad bytes of the
+            # e4m3 buffer would be uninitialised (NaN x 0 = NaN) - the fp8 GEMM's K-step is 128, so H must be whole steps
+            raise ValueError(f"TimeSeriesEmbedding precision='fp8' needs hidden_size % 128 == 0 (got {self.hidden_size})")
         self.precision = precision
         self._w8 = None
 

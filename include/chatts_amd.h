@@ -209,6 +209,10 @@ typedef struct ChattsLinearArgs {
 #define CHATTS_W8_FP8 0
 #define CHATTS_W8_INT8 1
 size_t chatts_linear_workspace(int m, int n, int k);
+/* Host-only query (no device work): how many waves share a row group of the M == 1 bf16 GEMV for this shape on the current device
+ * (1 = the whole-K kernel every TP = 1 projection of the supported models runs; > 1 = the K-split form of shard-sized column-parallel
+ * projections, which sums a row in another order).  Lets a host-side test pin which shapes take which kernel. */
+int chatts_gemv_ksplit(int n, int k, int epilogue, int has_norm);
 /* hi = bf16(x) (RNE), lo = bf16(x - hi): the operand split of the bf16x2 GEMM, done once per activation matrix. */
 int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, chatts_bf16* lo, int ld_planes,
                         chatts_stream_t stream);

@@ -492,19 +492,19 @@ def test_rope_kv_write(lib, qk_norm):
 
 
 def _ref_attention(q, kc, vc, pos0):
-    """q [T,nq,128] (rotated), caches [nkv, ctx, 128]; float64 eager attention with causal mask."""
+    """q [T,nq,128] (rotated), caches [nkv, ctx, 128]; float64 eager attention with causal mask (one masked matrix product per head)."""
     T, nq, _ = q.shape
     nkv = kc.shape[0]
     g = nq // nkv
+    n_keys = pos0 + T
     out = torch.zeros((T, nq, 128), dtype=torch.float64)
-    for t in range(T):
-        pos = pos0 + t
-        for h in range(nq):
-            k = kc[h // g, :pos + 1].double()
-            v = vc[h // g, :pos + 1].double()
-            s = (k @ q[t, h].double()) / np.sqrt(128.0)
-            p = torch.softmax(s, dim=0)
-            out[t, h] = p @ v
+    future = torch.arange(n_keys)[None, :] > (pos0 + torch.arange(T))[:, None]          # key j is visible to row t iff j <= pos0 + t
+    for h in range(nq):
+        k = kc[h // g, :n_keys].double()
+        v = vc[h // g, :n_keys].double()
+        s = (q[:, h].double() @ k.t()) / np.sqrt(128.0)
+        s = s.masked_fill(future, float("-inf"))
+        out[:, h] = torch.softmax(s, dim=1) @ v
     return out
 
 

@@ -173,3 +173,21 @@ def test_config_ts_key_aliases_and_scalar_eos():
     assert c.ts["max_sequence_length"] == 8192 and c.eos_token_id == [151645]
     c = cfgmod.ChatTSConfig(ts={"max_length": 4096})
     assert c.ts["max_sequence_length"] == 4096
+
+
+def test_decode_gemv_kernel_choice_is_pinned_by_shape():
+    """Every TP = 1 projection of ChatTS-14B and ChatTS-8B runs the whole-K decode GEMV (the kernel the full-depth parity runs were
+    recorded with; the K-split form sums a row in another order), the column-parallel projections of a TP = 8 rank take the K-split
+    form (chatts_gemv_ksplit: the launcher's own decision function, evaluated on the host for 256 CUs)."""
+    lib = _lib.load()
+    NONE, RESID, SWIGLU = _lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU
+    tp1 = {"14b": [(7168, 5120, NONE, 1), (5120, 5120, RESID, 0), (27648, 5120, SWIGLU, 1), (5120, 13824, RESID, 0), (152064, 5120, NONE, 1)],
+           "8b": [(6144, 4096, NONE, 1), (4096, 4096, RESID, 0), (24576, 4096, SWIGLU, 1), (4096, 12288, RESID, 0), (151936, 4096, NONE, 1)]}
+    for model, shapes in tp1.items():
+        for n, k, epi, norm in shapes:
+            assert lib.chatts_gemv_ksplit(n, k, epi, norm) == 1, (model, n, k)
+    # one rank of TP = 8 (14B): qkv 896 x 5120 and gate_up 3456 x 5120 split K; the row-parallel o / down run the whole-K kernel
+    # only when they carry the exchange (tp_reduce) - their shape alone would split, which the decoder never asks for under TP
+    assert lib.chatts_gemv_ksplit(896, 5120, NONE, 1) > 1
+    assert lib.chatts_gemv_ksplit(3456, 5120, SWIGLU, 1) > 1
+
