@@ -1,4 +1,5 @@
 // api.hip - error string, device query, synthetic-weight fill.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <string.h>
 
@@ -34,6 +35,29 @@ int opt_get(ChattsOpt o, int dflt) {
   if (!__atomic_load_n(&g_opts_ready, __ATOMIC_ACQUIRE)) return dflt;
   const int v = __atomic_load_n(&g_opts[o], __ATOMIC_RELAXED);
   return v == kOptUnset ? dflt : v;
+}
+
+// roctx ranges (see common.h): resolved once; a missing library leaves both pointers null
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+static roctx_push_fn g_roctx_push = nullptr;
+static roctx_pop_fn g_roctx_pop = nullptr;
+static int g_roctx_state = 0;      // 0 = not tried, 1 = resolved, 2 = unavailable
+static void roctx_resolve() {
+  if (__atomic_load_n(&g_roctx_state, __ATOMIC_ACQUIRE) != 0) return;
+  void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+  if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
+  roctx_push_fn pu = h ? reinterpret_cast<roctx_push_fn>(dlsym(h, "roctxRangePushA")) : nullptr;
+  roctx_pop_fn po = h ? reinterpret_cast<roctx_pop_fn>(dlsym(h, "roctxRangePop")) : nullptr;
+  if (pu && po) { g_roctx_push = pu; g_roctx_pop = po; __atomic_store_n(&g_roctx_state, 1, __ATOMIC_RELEASE); }
+  else __atomic_store_n(&g_roctx_state, 2, __ATOMIC_RELEASE);
+}
+void stage_push(const char* name) {
+  roctx_resolve();
+  if (__atomic_load_n(&g_roctx_state, __ATOMIC_ACQUIRE) == 1) (void)g_roctx_push(name);
+}
+void stage_pop() {
+  if (__atomic_load_n(&g_roctx_state, __ATOMIC_ACQUIRE) == 1) (void)g_roctx_pop();
 }
 
 int device_cus() {

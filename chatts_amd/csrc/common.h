@@ -156,6 +156,19 @@ __device__ __forceinline__ void rope_kv_head(float a, float b, int h, int pos, i
 
 inline hipStream_t as_stream(chatts_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- stage ranges for traces (api.hip): roctx push / pop around the host-side enqueue of a stage, resolved with dlopen at first use
+// (librocprofiler-sdk-roctx.so; absent library = no-ops), so that `rocprofv3 --marker-trace --kernel-trace` reads by stage - ts_encode,
+// prefill, layer.attn / layer.mlp, decode_step, logits, select_tokens - instead of by kernel name.  Ranges mark where work is ENQUEUED;
+// a captured decode step shows its range at capture time only.
+void stage_push(const char* name);
+void stage_pop();
+struct StageRange {
+  explicit StageRange(const char* name) { stage_push(name); }
+  ~StageRange() { stage_pop(); }
+  StageRange(const StageRange&) = delete;
+  StageRange& operator=(const StageRange&) = delete;
+};
+
 // ---- tuning options (chatts_set_option, api.hip) ---------------------------------------------------------------------------------
 // A fixed table of named integers, process-wide, all UNSET by default = the shipped, measured-best choice.  The entry points read
 // the table (one relaxed load); nothing in the library reads the environment.  The host sets an option explicitly (A/B runs, the

@@ -241,6 +241,7 @@ extern "C" int chatts_decoder_select_tokens(ChattsDecoder* d, const float* logit
                                             int32_t* pos_dev, int pos_limit, const ChattsSamplingArgs* override_sa,
                                             chatts_stream_t stream) {
   CHATTS_REQUIRE(d && logits && token && batch >= 1, CHATTS_E_BADARG, "decoder_select_tokens: bad arguments");
+  StageRange stage("chatts.select_tokens");
   const ChattsDecoderConfig& c = d->cfg;
   const ChattsSamplingArgs* sa = override_sa ? override_sa : (d->sampling ? &d->sa : nullptr);
   if (c.tp_world <= 1) {
@@ -347,6 +348,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
                  "decoder_layer_part: bad arguments");
   CHATTS_REQUIRE(t >= 1 && t <= d->b.t_max, CHATTS_E_SHAPE, "decoder_layer_part: t=%d exceeds buffers (%d)", t, d->b.t_max);
   if (d->prefill_fp8 && t >= 16) return layer_part_fp8(d, layer, part, t, pos0, pos0_dev, stream);      // speed mode, prefill chunks only
+  StageRange stage(part == 0 ? "chatts.layer.attn" : "chatts.layer.mlp");
   const ChattsDecoderConfig& c = d->cfg;
   const ChattsLayerWeights& lw = d->layers[layer];
   const bool tp = c.tp_world > 1;
@@ -480,6 +482,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   const int maxb = d->b.max_batch > 0 ? d->b.max_batch : 1;
   CHATTS_REQUIRE(batch >= 1 && batch <= maxb && batch <= d->b.t_max, CHATTS_E_SHAPE,
                  "decoder_layer_part_batched: batch %d exceeds max_batch %d", batch, maxb);
+  StageRange stage(part == 0 ? "chatts.layer.attn" : "chatts.layer.mlp");
   const ChattsDecoderConfig& c = d->cfg;
   const ChattsLayerWeights& lw = d->layers[layer];
   const bool tp = c.tp_world > 1;
@@ -572,6 +575,7 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
                                                   int64_t out_stride, float* logits_all, int n_splits,
                                                   chatts_stream_t stream) {
   CHATTS_REQUIRE(d && pos_dev && step_dev && token_dev && logits_all, CHATTS_E_BADARG, "decode_step_batched: null argument");
+  StageRange stage("chatts.decode_step_batched");
   const bool tp = d->cfg.tp_world > 1;
   CHATTS_REQUIRE(!tp || d->tp, CHATTS_E_BADARG, "decode_step_batched: tp_world = %d but no exchange attached (chatts_decoder_set_tp)",
                  d->cfg.tp_world);
@@ -617,6 +621,7 @@ extern "C" int chatts_decoder_prefill(ChattsDecoder* d, int t, int pos0, chatts_
   CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_prefill: null decoder");
   CHATTS_REQUIRE(t >= 1 && t <= d->b.t_max, CHATTS_E_SHAPE, "decoder_prefill: t=%d exceeds buffers (%d)", t, d->b.t_max);
   CHATTS_REQUIRE_TP_BULK(d, t, "decoder_prefill");
+  StageRange stage("chatts.prefill");
   const bool tp = d->cfg.tp_world > 1;
   d->chain = true;
   d->normed = false;
@@ -684,6 +689,7 @@ extern "C" int chatts_decoder_prefill_last(ChattsDecoder* d, int t, int pos0, ch
   CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_prefill_last: null decoder");
   CHATTS_REQUIRE(t >= 1 && t <= d->b.t_max, CHATTS_E_SHAPE, "decoder_prefill_last: t=%d exceeds buffers (%d)", t, d->b.t_max);
   CHATTS_REQUIRE_TP_BULK(d, t, "decoder_prefill_last");
+  StageRange stage("chatts.prefill_last");
   const bool tp = d->cfg.tp_world > 1;
   d->chain = true;
   d->normed = false;
@@ -787,6 +793,7 @@ extern "C" int chatts_decoder_prefill_packed(ChattsDecoder* d, const ChattsPrefi
     t += sg.t;
   }
   CHATTS_REQUIRE(t <= d->b.t_max, CHATTS_E_SHAPE, "decoder_prefill_packed: %d rows exceed buffers (%d)", t, d->b.t_max);
+  StageRange stage("chatts.prefill_packed");
   d->chain = true;
   d->normed = false;
   int rc = CHATTS_OK;
@@ -801,6 +808,7 @@ extern "C" int chatts_decoder_prefill_packed(ChattsDecoder* d, const ChattsPrefi
 
 extern "C" int chatts_decoder_logits(ChattsDecoder* d, int row, chatts_stream_t stream) {
   CHATTS_REQUIRE(d && row >= 0 && row < d->b.t_max, CHATTS_E_BADARG, "decoder_logits: bad row");
+  StageRange stage("chatts.logits");
   const ChattsDecoderConfig& c = d->cfg;
   ChattsLinearArgs la{};
   la.a = d->b.x + (size_t)row * c.hidden; la.w = d->w.lm_head; la.c = d->b.logits;
@@ -814,6 +822,7 @@ extern "C" int chatts_decoder_decode_step(ChattsDecoder* d, int32_t* pos_dev, in
                                           float* token_logit_dev, int64_t* out_tokens, int n_splits,
                                           chatts_stream_t stream) {
   CHATTS_REQUIRE(d && pos_dev && step_dev && token_dev, CHATTS_E_BADARG, "decode_step: null argument");
+  StageRange stage("chatts.decode_step");
   const bool tp = d->cfg.tp_world > 1;
   CHATTS_REQUIRE(!tp || d->tp, CHATTS_E_BADARG, "decode_step: tp_world = %d but no exchange attached (chatts_decoder_set_tp)", d->cfg.tp_world);
   CHATTS_REQUIRE(!tp || chatts_tp_pending(d->tp) == 0, CHATTS_E_BADARG, "decode_step: the exchange has %d collectives whose epochs were never settled "

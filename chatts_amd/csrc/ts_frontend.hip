@@ -199,6 +199,7 @@ extern "C" int chatts_ts_encode(const float* series, const int32_t* row_off, con
                                 float* h1, float* out, void* workspace, size_t workspace_bytes, chatts_stream_t stream) {
   CHATTS_REQUIRE(w != nullptr && w->num_layers >= 1 && w->num_layers <= 8, CHATTS_E_BADARG, "ts_encode: bad weights");
   if (total_patches == 0) return CHATTS_OK;
+  StageRange stage("chatts.ts_encode");
   CHATTS_REQUIRE(feat && out && (w->num_layers < 2 || h0) && (w->num_layers < 3 || h1), CHATTS_E_BADARG,
                  "ts_encode: null buffer");
   ChattsPatchifyArgs pa{};
