@@ -367,12 +367,12 @@ def workload_key(args):
 
 def parity_reference(args):
     """The committed FULL-DEPTH oracle run of this workload (tools/parity_full_depth.py: CPU float32 oracle, all layers, same
-    inputs, seed 0), or None.  Files are keyed by the workload; the newest round's run wins (round 4 re-ran the headline and the 8B
-    line on the code that changed the decode attention's summation order, the greedy tail and the qkv epilogue in round 3)."""
+    inputs, seed 0), or None.  Files are keyed by the workload; the newest round's run wins (round 5 re-ran every workload on the
+    rebuilt prefill GEMM, whose split-K choices - and with them the summation order of o_proj / down_proj - changed)."""
     key = workload_key(args)
     if key is None:
         return None, None
-    cands = [os.path.join(ROOT, "profiles", f"r4_parity_{key}_full.json"), os.path.join(ROOT, "profiles", f"r3_parity_{key}_full.json")]
+    cands = [os.path.join(ROOT, "profiles", f"r{rnd}_parity_{key}_full.json") for rnd in (5, 4, 3)]
     if args.weights == "bf16" and args.batch <= 1 and getattr(args, "lengths", "uniform") == "uniform":
         cands.append(os.path.join(ROOT, "profiles", f"r2_parity_{key.split('_')[0]}_full.json"))
     for path in cands:

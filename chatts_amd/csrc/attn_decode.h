@@ -348,22 +348,24 @@ __device__ __forceinline__ void attn_combine_wave(const AttnParams& p, const int
   const int pos = p.pos0_dev ? p.pos0_dev[seq] : p.pos0;
   const int ntiles = pos < 0 ? 0 : pos / kDTile + 1;         // parked slot: no partials exist, the row is written as zeros
   const int ns = ntiles < p.n_splits ? ntiles : p.n_splits;
+  // every load of this wave is requested before the first use (round 5): (m, l) of the slots and all <= 64 partial rows of this lane's
+  // dim travel in ONE memory round trip instead of three dependent ones (the weights do not decide WHAT is loaded, only how it is summed)
   float m = -INFINITY, l = 0.f;
   if (lane < ns) { m = part_ml[(base + lane) * 2]; l = part_ml[(base + lane) * 2 + 1]; }
+  float o[kMaxSlots];
+#pragma unroll
+  for (int u = 0; u < kMaxSlots; ++u) {
+    const int sidx = u < ns ? u : (ns > 0 ? ns - 1 : 0);      // (clamped: its weight is 0)
+    o[u] = (u < 32 || ns > 32) ? part_o[(base + sidx) * kHeadDim + d] : 0.f;
+  }
   const float M = wave_max(m);
   const float w = lane < ns ? expf(m - M) : 0.f;
   const float den = wave_sum(w * l);
   float num = 0.f;
-  for (int s0 = 0; s0 < ns; s0 += 32) {       // 32 independent loads in flight per lane: at most two dependent rounds for 64 slots
-    float o[32];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      const int s = s0 + u < ns ? s0 + u : ns - 1;
-      o[u] = part_o[(base + s) * kHeadDim + d];
-    }
-#pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      const float ws = __shfl(w, (s0 + u) & 63, 64);     // 0 for slots >= ns
+  for (int u = 0; u < kMaxSlots; ++u) {
+    if (u < 32 || ns > 32) {                                   // (same fmaf chain over the slots in ascending order as before)
+      const float ws = __shfl(w, u, 64);                       // 0 for slots >= ns
       num = fmaf(ws, o[u], num);
     }
   }

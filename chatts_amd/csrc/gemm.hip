@@ -610,6 +610,76 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
   }
 }
 
+// The same kernel with every memory round trip of a thread taken ONCE (round 5): sk <= 4 slabs, rows of <= 1024 kIt columns.  The kernel
+// above walks a row in kIt dependent iterations - slab loads, wait, store - and then re-reads its own stores for the planes: ~2 kIt round
+// trips per workgroup, 16.5 us per 798 x 5120 epilogue (two per layer in a prefill chunk).  Here a thread requests all slabs, the residual,
+// bias and norm weights of all its kIt column groups up front, keeps the row values in registers, and writes c and the planes from them.
+// Same sums in the same order (split order per element, the row's sum of squares in column-group order per thread): bit-identical.
+template <int kIt>
+__global__ __launch_bounds__(256) void splitk_epilogue_norm_reg_kernel(const float* __restrict__ ws, int sk, int m, int n,
+                                                                      const float* __restrict__ bias, const float* __restrict__ resid,
+                                                                      float* __restrict__ c, int ldc, int epilogue,
+                                                                      const float* __restrict__ scale, const float* __restrict__ norm_w,
+                                                                      float eps, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int ldp) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const size_t plane = (size_t)m * n;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 t[kIt][4], rs[kIt], gw[kIt], sc4[kIt], b4[kIt];
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int col = threadIdx.x * 4 + it * 1024;
+    const bool live = col < n;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      t[it][s] = live ? *reinterpret_cast<const f32x4*>(ws + (s < sk ? s : sk - 1) * plane + (size_t)row * n + col) : zero;
+    rs[it] = (live && epilogue == CHATTS_EPI_RESID) ? *reinterpret_cast<const f32x4*>(resid + (size_t)row * ldc + col) : zero;
+    gw[it] = live ? *reinterpret_cast<const f32x4*>(norm_w + col) : zero;
+    sc4[it] = (live && scale) ? *reinterpret_cast<const f32x4*>(scale + col) : zero;
+    b4[it] = (live && bias) ? *reinterpret_cast<const f32x4*>(bias + col) : zero;
+  }
+  f32x4 keep[kIt];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int col = threadIdx.x * 4 + it * 1024;
+    f32x4 v = zero;
+    if (col < n) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (s < sk) { v.x += t[it][s].x; v.y += t[it][s].y; v.z += t[it][s].z; v.w += t[it][s].w; }
+      if (scale) { v.x *= sc4[it].x; v.y *= sc4[it].y; v.z *= sc4[it].z; v.w *= sc4[it].w; }
+      if (bias) { v.x += b4[it].x; v.y += b4[it].y; v.z += b4[it].z; v.w += b4[it].w; }
+      if (epilogue == CHATTS_EPI_RESID) { v.x = rs[it].x + v.x; v.y = rs[it].y + v.y; v.z = rs[it].z + v.z; v.w = rs[it].w + v.w; }
+      *reinterpret_cast<f32x4*>(c + (size_t)row * ldc + col) = v;
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;        // same accumulation pattern as rmsnorm_kernel
+    }
+    keep[it] = v;
+  }
+  ss = block_sum<4>(ss, red);
+  const float rstd = rsqrtf(ss / (float)n + eps);
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int col = threadIdx.x * 4 + it * 1024;
+    if (col >= n) continue;
+    const f32x4 v = keep[it], g = gw[it];
+    const float o[4] = {g.x * (v.x * rstd), g.y * (v.y * rstd), g.z * (v.z * rstd), g.w * (v.w * rstd)};
+    {
+#pragma clang fp contract(off)   // lo must be the split of the ROUNDED product, as in rmsnorm_kernel<true>
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      bf16x4_t hv, lv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const __bf16 h = (__bf16)o[j];
+        hv[j] = h;
+        lv[j] = (__bf16)(o[j] - (float)h);
+      }
+      *reinterpret_cast<bf16x4_t*>(hi + (size_t)row * ldp + col) = hv;
+      *reinterpret_cast<bf16x4_t*>(lo + (size_t)row * ldp + col) = lv;
+    }
+  }
+}
+
 // The same kernel for FEW rows (batched decode, M <= 16): one workgroup per row leaves the chip idle (16 workgroups), so gridDim.y = Q
 // workgroups share a row.  Each of them sums the slabs of the WHOLE row - it needs the row's sum of squares, and forming it with the same
 // thread-to-column mapping as above keeps every bit - but stores c and the planes only for its own 256 / Q threads' columns.  The
@@ -924,8 +994,27 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
       CHATTS_CHECK_LAUNCH("splitk_epilogue_norm_q");
       return CHATTS_OK;
     }
-    hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(a->m), dim3(256), 0, s, reinterpret_cast<const float*>(a->workspace), sk,
-                       a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue, a->w8 ? a->w8_scale : nullptr, a->post_norm_w,
+    const float* ws_f = reinterpret_cast<const float*>(a->workspace);
+    const float* sc = a->w8 ? a->w8_scale : nullptr;
+    const int its = (a->n + 1023) / 1024;
+    if (sk <= 4 && its <= 8 && opt_get(OPT_EPI_NORM_REG, 1) != 0) {      // all round trips of a thread at once (bit-identical; 13.5)
+#define CHATTS_EPI_REG(K) hipLaunchKernelGGL((splitk_epilogue_norm_reg_kernel<K>), dim3(a->m), dim3(256), 0, s, ws_f, sk, a->m, a->n, a->bias, \
+                                             a->resid, a->c, a->ldc, a->epilogue, sc, a->post_norm_w, a->post_norm_eps, a->post_hi, a->post_lo, a->ld_post)
+      switch (its) {
+        case 1: CHATTS_EPI_REG(1); break;
+        case 2: CHATTS_EPI_REG(2); break;
+        case 3: CHATTS_EPI_REG(3); break;
+        case 4: CHATTS_EPI_REG(4); break;
+        case 5: CHATTS_EPI_REG(5); break;
+        case 6: CHATTS_EPI_REG(6); break;
+        default: CHATTS_EPI_REG(8); break;
+      }
+#undef CHATTS_EPI_REG
+      CHATTS_CHECK_LAUNCH("splitk_epilogue_norm_reg");
+      return CHATTS_OK;
+    }
+    hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(a->m), dim3(256), 0, s, ws_f, sk,
+                       a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue, sc, a->post_norm_w,
                        a->post_norm_eps, a->post_hi, a->post_lo, a->ld_post);
     CHATTS_CHECK_LAUNCH("splitk_epilogue_norm");
     return CHATTS_OK;

@@ -201,8 +201,18 @@ __device__ __forceinline__ bool wait_flag(uint32_t* f, uint32_t epoch, uint32_t*
   }
 }
 
-constexpr int kBulkThreads = 512;      // one f32x4 position per thread and pass at the 798 x 5120 / 8-rank shape with 256 workgroups
-__global__ __launch_bounds__(kBulkThreads) void tp_allreduce_bulk_kernel(TpParams p, const float* __restrict__ in, float* x, int64_t n) {
+// What a workgroup does between its stores into the peers' areas and the flag that publishes them.  The areas are UNCACHED memory
+// (chatts_tp_buffer_alloc: hipDeviceMallocUncached, mapped the same way by every peer), so the stores themselves never sit in a cache:
+// they are complete - at the remote memory - when `s_waitcnt vmcnt(0)` returns.  __threadfence_system() adds a write-back of EVERY dirty
+// line of this XCD's L2 (buffer_wbl2 sc0 sc1), among them the 16 MB of partial sums the projection in front of this kernel has just
+// left there: TP_BULK_FENCE=1 selects it (the round-4 form), the default drains the stores only.
+__device__ __forceinline__ void bulk_release(int light) {
+  if (light) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else __threadfence_system();
+}
+// (kBulkThreads threads per workgroup: 256 is the measured choice, see chatts_allreduce_bulk)
+template <int kBulkThreads>
+__global__ __launch_bounds__(kBulkThreads) void tp_allreduce_bulk_kernel(TpParams p, const float* __restrict__ in, float* x, int64_t n, int light_fence) {
   const uint32_t epoch = tp_epoch(p);
   const int W = p.world, b = blockIdx.x, tid = threadIdx.x;
   // slice s = elements [s * slice, (s + 1) * slice) of the vector (multiples of 4 floats); workgroup b owns [lo, hi) of every slice
@@ -210,30 +220,41 @@ __global__ __launch_bounds__(kBulkThreads) void tp_allreduce_bulk_kernel(TpParam
   const int64_t per = ((slice + gridDim.x - 1) / gridDim.x + 3) / 4 * 4;
   const int64_t lo = (int64_t)b * per, hi = lo + per < slice ? lo + per : slice;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  // 1. scatter my partial: slice s goes to rank s (loop-back: into my own "from q" area, zeros for the absent peers).  All W loads of
-  //    a thread's position are issued before the first store: W independent requests in flight per lane.
-  for (int64_t i = lo + tid * 4; i < hi; i += kBulkThreads * 4) {
-    f32x4 v[kMaxWorld];
+  // 1. scatter my partial: slice s goes to rank s (loop-back: into my own "from q" area, zeros for the absent peers).  Every pass of
+  //    this kernel is a chain of round trips to uncached memory, so a thread requests ALL of its positions at once - kU positions x W
+  //    loads in flight per lane - before the first store (round 5: one position at a time was 4 dependent trips per pass at [798, 5120]).
+  constexpr int kU = kBulkThreads >= 1024 ? 1 : (kBulkThreads >= 512 ? 2 : 4);
+  for (int64_t i0 = lo + tid * 4; i0 < hi; i0 += (int64_t)kU * kBulkThreads * 4) {
+    f32x4 v[kU][kMaxWorld];
 #pragma unroll
-    for (int k = 0; k < kMaxWorld; ++k) {
-      const int s = (p.rank + k) % W;
-      const int64_t g = (int64_t)(p.loopback ? p.rank : s) * slice + i;
-      v[k] = zero;
-      if (k < W && !(p.loopback && s != p.rank)) {
-        if (g + 3 < n) v[k] = *reinterpret_cast<const f32x4*>(in + g);
-        else { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; ++e) if (g + e < n) t[e] = in[g + e]; v[k] = (f32x4){t[0], t[1], t[2], t[3]}; }
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + (int64_t)u * kBulkThreads * 4;
+#pragma unroll
+      for (int k = 0; k < kMaxWorld; ++k) {
+        const int s = (p.rank + k) % W;
+        const int64_t g = (int64_t)(p.loopback ? p.rank : s) * slice + i;
+        v[u][k] = zero;
+        if (i < hi && k < W && !(p.loopback && s != p.rank)) {
+          if (g + 3 < n) v[u][k] = *reinterpret_cast<const f32x4*>(in + g);
+          else { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; ++e) if (g + e < n) t[e] = in[g + e]; v[u][k] = (f32x4){t[0], t[1], t[2], t[3]}; }
+        }
       }
     }
 #pragma unroll
-    for (int k = 0; k < kMaxWorld; ++k) {
-      if (k < W) {
-        const int s = (p.rank + k) % W;
-        const BulkView dst = bulk_view(p, p.loopback ? p.rank : s, epoch);
-        *reinterpret_cast<f32x4*>(dst.scatter + (size_t)(p.loopback ? s : p.rank) * p.slice_cap + i) = v[k];
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + (int64_t)u * kBulkThreads * 4;
+      if (i >= hi) continue;
+#pragma unroll
+      for (int k = 0; k < kMaxWorld; ++k) {
+        if (k < W) {
+          const int s = (p.rank + k) % W;
+          const BulkView dst = bulk_view(p, p.loopback ? p.rank : s, epoch);
+          *reinterpret_cast<f32x4*>(dst.scatter + (size_t)(p.loopback ? s : p.rank) * p.slice_cap + i) = v[u][k];
+        }
       }
     }
   }
-  __threadfence_system();
+  bulk_release(light_fence);
   __syncthreads();
   if (tid < W) {
     const int s = (p.rank + tid) % W;
@@ -245,25 +266,34 @@ __global__ __launch_bounds__(kBulkThreads) void tp_allreduce_bulk_kernel(TpParam
   if (tid < W) (void)wait_flag(mine.flags + (size_t)tid * kBulkMaxBlocks + b, epoch, &p.ctr[2]);     // (a timeout raises the status bit)
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  for (int64_t i = lo + tid * 4; i < hi; i += kBulkThreads * 4) {
-    f32x4 c[kMaxWorld];
+  for (int64_t i0 = lo + tid * 4; i0 < hi; i0 += (int64_t)kU * kBulkThreads * 4) {
+    f32x4 c[kU][kMaxWorld];
 #pragma unroll
-    for (int src = 0; src < kMaxWorld; ++src)
-      c[src] = src < W ? *reinterpret_cast<const f32x4*>(mine.scatter + (size_t)src * p.slice_cap + i) : zero;      // W loads in flight
-    f32x4 sum = c[0];
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + (int64_t)u * kBulkThreads * 4;
 #pragma unroll
-    for (int src = 1; src < kMaxWorld; ++src)
-      if (src < W) { sum.x += c[src].x; sum.y += c[src].y; sum.z += c[src].z; sum.w += c[src].w; }                    // rank order
+      for (int src = 0; src < kMaxWorld; ++src)
+        c[u][src] = (src < W && i < hi) ? *reinterpret_cast<const f32x4*>(mine.scatter + (size_t)src * p.slice_cap + i) : zero;      // kU W loads in flight
+    }
 #pragma unroll
-    for (int k = 0; k < kMaxWorld; ++k) {
-      if (k < W) {
-        const int q = (p.rank + k) % W;
-        const BulkView dst = bulk_view(p, p.loopback ? p.rank : q, epoch);
-        *reinterpret_cast<f32x4*>(dst.gather + (size_t)(p.loopback ? q : p.rank) * p.slice_cap + i) = (p.loopback && q != p.rank) ? zero : sum;
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + (int64_t)u * kBulkThreads * 4;
+      if (i >= hi) continue;
+      f32x4 sum = c[u][0];
+#pragma unroll
+      for (int src = 1; src < kMaxWorld; ++src)
+        if (src < W) { sum.x += c[u][src].x; sum.y += c[u][src].y; sum.z += c[u][src].z; sum.w += c[u][src].w; }                  // rank order
+#pragma unroll
+      for (int k = 0; k < kMaxWorld; ++k) {
+        if (k < W) {
+          const int q = (p.rank + k) % W;
+          const BulkView dst = bulk_view(p, p.loopback ? p.rank : q, epoch);
+          *reinterpret_cast<f32x4*>(dst.gather + (size_t)(p.loopback ? q : p.rank) * p.slice_cap + i) = (p.loopback && q != p.rank) ? zero : sum;
+        }
       }
     }
   }
-  __threadfence_system();
+  bulk_release(light_fence);
   __syncthreads();
   if (tid < W) {
     const int q = (p.rank + tid) % W;
@@ -275,25 +305,35 @@ __global__ __launch_bounds__(kBulkThreads) void tp_allreduce_bulk_kernel(TpParam
   if (tid < W) (void)wait_flag(mine.flags + (size_t)(kMaxWorld + tid) * kBulkMaxBlocks + b, epoch, &p.ctr[2]);
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  for (int64_t i = lo + tid * 4; i < hi; i += kBulkThreads * 4) {          // (all W slices of a position: 2 W independent loads in flight per lane)
-    f32x4 r[kMaxWorld], xv[kMaxWorld];
+  constexpr int kU3 = kU > 1 ? kU / 2 : 1;                                          // (two positions x 2 W loads: the gathered slices and x)
+  for (int64_t i0 = lo + tid * 4; i0 < hi; i0 += (int64_t)kU3 * kBulkThreads * 4) {
+    f32x4 r[kU3][kMaxWorld], xv[kU3][kMaxWorld];
 #pragma unroll
-    for (int s = 0; s < kMaxWorld; ++s) {
-      const int64_t g = (int64_t)s * slice + i;
-      r[s] = s < W ? *reinterpret_cast<const f32x4*>(mine.gather + (size_t)s * p.slice_cap + i) : zero;
-      xv[s] = (s < W && g + 3 < n) ? *reinterpret_cast<const f32x4*>(x + g) : zero;
+    for (int u = 0; u < kU3; ++u) {
+      const int64_t i = i0 + (int64_t)u * kBulkThreads * 4;
+#pragma unroll
+      for (int s = 0; s < kMaxWorld; ++s) {
+        const int64_t g = (int64_t)s * slice + i;
+        r[u][s] = (s < W && i < hi) ? *reinterpret_cast<const f32x4*>(mine.gather + (size_t)s * p.slice_cap + i) : zero;
+        xv[u][s] = (s < W && i < hi && g + 3 < n) ? *reinterpret_cast<const f32x4*>(x + g) : zero;
+      }
     }
 #pragma unroll
-    for (int s = 0; s < kMaxWorld; ++s) {
-      const int64_t g = (int64_t)s * slice + i;
-      if (s >= W || g >= n) continue;
-      if (g + 3 < n) {
-        f32x4 v = xv[s];
-        v.x += r[s].x; v.y += r[s].y; v.z += r[s].z; v.w += r[s].w;
-        *reinterpret_cast<f32x4*>(x + g) = v;
-      } else {
-        const float t[4] = {r[s].x, r[s].y, r[s].z, r[s].w};
-        for (int e = 0; e < 4; ++e) if (g + e < n) x[g + e] += t[e];
+    for (int u = 0; u < kU3; ++u) {
+      const int64_t i = i0 + (int64_t)u * kBulkThreads * 4;
+      if (i >= hi) continue;
+#pragma unroll
+      for (int s = 0; s < kMaxWorld; ++s) {
+        const int64_t g = (int64_t)s * slice + i;
+        if (s >= W || g >= n) continue;
+        if (g + 3 < n) {
+          f32x4 v = xv[u][s];
+          v.x += r[u][s].x; v.y += r[u][s].y; v.z += r[u][s].z; v.w += r[u][s].w;
+          *reinterpret_cast<f32x4*>(x + g) = v;
+        } else {
+          const float t[4] = {r[u][s].x, r[u][s].y, r[u][s].z, r[u][s].w};
+          for (int e = 0; e < 4; ++e) if (g + e < n) x[g + e] += t[e];
+        }
       }
     }
   }
@@ -564,17 +604,24 @@ extern "C" int chatts_allreduce_bulk(ChattsTpComm* c, const float* in, float* x,
                  (long long)n, (long long)chatts_tp_bulk_elems(c));
   CHATTS_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)x % 16) == 0, CHATTS_E_SHAPE, "allreduce_bulk: pointers must be 16-byte aligned");
   if (n == 0) return CHATTS_OK;
-  // one workgroup per ~8 KB of a slice, at most kBulkMaxBlocks = one per CU (every rank computes the same grid from n: the flags are per
-  // workgroup).  Round 5: 256 x 512 threads instead of 128 x 256 - every pass is a latency chain of W uncached 16-byte requests per
-  // thread, and at [798, 5120] / 8 ranks a thread now makes ONE trip per pass instead of four (51 -> see profiles/r5_tp_shard_step.json).
-  // TP_BULK_BLOCKS lowers the bound for several ranks emulated on ONE device (their waiting grids must be resident together).
+  // one workgroup per ~8 KB of a slice, at most 128 (every rank computes the same grid from n: the flags are per workgroup).  Round 5
+  // tried 256 workgroups x 512 threads (one trip per thread and pass instead of four): 102 us against 51 us per [798, 5120] sum on a
+  // loop-back TP = 8 rank - the kernel is paced by its per-workgroup fences and flag round trips (two __threadfence_system() and 2 W
+  // system-scope flags each), not by the three passes; profiles/r5_tp_bulk_sweep.txt has the (workgroups, threads) grid.
+  // TP_BULK_BLOCKS also lowers the bound for several ranks emulated on ONE device (their waiting grids must be resident together).
   const int64_t slice = ((n + c->p.world - 1) / c->p.world + 3) / 4 * 4;
   int64_t blocks = (slice + 2047) / 2048;
-  const int cap = opt_get(OPT_TP_BULK_BLOCKS, kBulkMaxBlocks);
+  const int cap = opt_get(OPT_TP_BULK_BLOCKS, 128);
   if (blocks > cap) blocks = cap;
   if (blocks > kBulkMaxBlocks) blocks = kBulkMaxBlocks;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(tp_allreduce_bulk_kernel, dim3((unsigned)blocks), dim3(kBulkThreads), 0, as_stream(stream), tp_issue(c, true), in, x, n);
+  const TpParams tp = tp_issue(c, true);
+  const int light = opt_get(OPT_TP_BULK_FENCE, 0) == 0;
+  switch (opt_get(OPT_TP_BULK_THREADS, 256)) {
+    case 1024: hipLaunchKernelGGL(tp_allreduce_bulk_kernel<1024>, dim3((unsigned)blocks), dim3(1024), 0, as_stream(stream), tp, in, x, n, light); break;
+    case 512: hipLaunchKernelGGL(tp_allreduce_bulk_kernel<512>, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), tp, in, x, n, light); break;
+    default: hipLaunchKernelGGL(tp_allreduce_bulk_kernel<256>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), tp, in, x, n, light); break;
+  }
   CHATTS_CHECK_LAUNCH("tp_allreduce_bulk");
   return CHATTS_OK;
 }

@@ -864,6 +864,41 @@ def test_linear_post_norm_planes_equal_separate_rmsnorm(lib, m, n, k, epi):
     assert not torch.isnan(h2[:, :n].float()).any() and torch.isnan(h2[:, n:].float()).all()
 
 
+@pytest.mark.parametrize("sk", [2, 3, 4])
+@pytest.mark.parametrize("m,n,k,epi", [(798, 5120, 5120, _lib.EPI_RESID), (300, 5120, 1536, _lib.EPI_NONE), (130, 2080, 2048, _lib.EPI_RESID),
+                                       (200, 6144, 1024, _lib.EPI_RESID)])
+def test_post_norm_epilogue_with_all_round_trips_at_once_is_bitwise_the_walking_one(lib, monkeypatch, sk, m, n, k, epi):
+    """splitk_epilogue_norm_reg_kernel (every slab / residual / weight load of a thread issued up front, the row kept in registers) ==
+    splitk_epilogue_norm_kernel (EPI_NORM_REG=0: walks the row, re-reads its stores): c and both planes bit for bit, rows that are not a
+    multiple of 1024 columns, 2 .. 4 slabs, with and without the residual."""
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + sk, scale=2.0)
+    g = torch.Generator().manual_seed(5)
+    nw = (1 + 0.1 * torch.randn(n, generator=g)).to(DEV)
+    hi, lo = _split_planes(lib, a)
+    monkeypatch.setenv("CHATTS_GEMM_SK", str(sk))
+    wsb = max(int(lib.chatts_linear_workspace(m, n, k)), 4 * m * n * 4)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    runs = []
+    for reg in ("0", "1"):
+        monkeypatch.setenv("CHATTS_EPI_NORM_REG", reg)
+        out = torch.full((m, n), float("nan"), device=DEV)
+        r = resid.clone() if epi == _lib.EPI_RESID else None
+        phi = torch.full((m, n + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+        plo = torch.full((m, n + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+        la = _lib.LinearArgs(a=None, w=w.data_ptr(), bias=bias.data_ptr(), resid=_lib.ptr(r), c=out.data_ptr(), norm_w=None,
+                             norm_eps=0.0, m=m, n=n, k=k, lda=k, ldw=k, ldc=n, epilogue=epi, workspace=ws.data_ptr(),
+                             workspace_bytes=wsb, a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=k)
+        la.post_norm_w, la.post_norm_eps, la.post_hi, la.post_lo, la.ld_post = nw.data_ptr(), 1e-6, phi.data_ptr(), plo.data_ptr(), n + 8
+        _lib.check(lib.chatts_linear(la, st()))
+        torch.cuda.synchronize()
+        runs.append((out, phi, plo))
+    (o0, h0, l0), (o1, h1, l1) = runs
+    assert not torch.isnan(o1).any() and torch.equal(o0, o1)
+    assert torch.equal(h0[:, :n], h1[:, :n]) and torch.equal(l0[:, :n], l1[:, :n]) and torch.isnan(h1[:, n:].float()).all()
+    want = _ref_linear(a, w, bias, resid, epi)
+    assert rel_err(o1.cpu().numpy(), want) < 2e-5
+
+
 def test_ts_normalise_on_device_matches_the_reference_vectors(lib, golden):
     """chatts_ts_normalise (GPU-side normalisation statistics) against the vectors the REFERENCE's
     sp_encoding produced (tests/golden/sp_encoding.npz): identical prompt prefixes (the %.4f text), statistics within one

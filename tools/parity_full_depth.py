@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--length", type=int, default=256)
     ap.add_argument("--lengths", default="uniform", choices=["uniform", "mixed"])
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"])
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "int8", "int4"])
     ap.add_argument("--oracle-slots", default="0", help="--batch > 1: cache slots the oracle recomputes (comma separated)")
     ap.add_argument("--new", type=int, default=9, help="first token + decode steps compared")
     ap.add_argument("--layers", type=int, default=None)

@@ -18,8 +18,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.environ.get("PMC_TRAFFIC_OUT") or os.path.join(ROOT, "profiles", "pmc_traffic.json")      # (a GPU-box job writes under gpurun_out/)
 GEMV_FILES = ["chatts_amd/csrc/gemv.hip", "chatts_amd/csrc/gemv_common.h", "chatts_amd/csrc/tp_common.h", "chatts_amd/csrc/common.h"]
-TS_FILES = ["chatts_amd/csrc/gemm.hip", "chatts_amd/csrc/ts_frontend.hip", "chatts_amd/csrc/common.h"]
-BATCHED_FILES = ["chatts_amd/csrc/gemm.hip", "chatts_amd/csrc/attention.hip", "chatts_amd/csrc/attn_decode.h", "chatts_amd/csrc/common.h"]
+TS_FILES = ["chatts_amd/csrc/gemm.hip", "chatts_amd/csrc/gemm_ring.hip", "chatts_amd/csrc/gemm_common.h", "chatts_amd/csrc/ts_frontend.hip",
+            "chatts_amd/csrc/common.h"]
+BATCHED_FILES = ["chatts_amd/csrc/gemm.hip", "chatts_amd/csrc/gemm_common.h", "chatts_amd/csrc/attention.hip", "chatts_amd/csrc/attn_decode.h",
+                 "chatts_amd/csrc/common.h"]
 
 
 def code_digest(files):

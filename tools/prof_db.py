@@ -30,5 +30,30 @@ def main():
             print(f"{n:6d} {val:14.1f} {dur:9.2f} {grid:9d} {wg:5d}  {cname:10s}  {name[:100]}")
 
 
+def regions(path):
+    """roctx stage ranges (chatts.* - csrc/api.hip stage_push / stage_pop) of a --marker-trace run: host-side ENQUEUE time per stage"""
+    import json
+    cur = sqlite3.connect(path).cursor()
+    try:
+        rows = cur.execute("select extdata, duration from regions where category like 'MARKER%'").fetchall()
+    except sqlite3.Error:
+        return
+    agg = {}
+    for ext, dur in rows:
+        try:
+            name = json.loads(ext).get("message", "?")
+        except Exception:
+            name = "?"
+        a = agg.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += dur / 1000.0
+    if agg:
+        print("\n# roctx stage ranges (host-side enqueue time; names from csrc: chatts.<stage>)")
+        print(f"{'calls':>6} {'avg_us':>10} {'total_ms':>9}  range")
+        for name, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print(f"{n:6d} {tot / n:10.1f} {tot / 1000.0:9.2f}  {name}")
+
+
 if __name__ == "__main__":
     main()
+    regions(sys.argv[1])
