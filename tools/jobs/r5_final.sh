@@ -42,6 +42,7 @@ timeout 300 python bench.py --weights fp8 --steps 32 --warmup 8 --no-cpu-baselin
 timeout 300 python bench.py --weights int8 --steps 32 --warmup 8 --no-cpu-baseline > $O/r5_bench_int8_weights.json 2> $O/int8.err
 timeout 300 python bench.py --weights int4 --steps 32 --warmup 8 --no-cpu-baseline > $O/r5_bench_int4_weights.json 2> $O/int4.err
 timeout 600 python tools/tp_shard_step.py --worlds 1,2,4,8 --out $O/r5_tp_shard_step.json > /dev/null 2> $O/tp_shard_step.err
+CHATTS_TP_BULK_FENCE=1 timeout 300 python tools/tp_shard_step.py --worlds 8 --out $O/r5_tp_shard_step_w8_threadfence.json > /dev/null 2> $O/tp_shard_step_fence.err
 rm -rf /tmp/kt8
 timeout 300 rocprofv3 --kernel-trace -d /tmp/kt8 -o p -- python tools/tp_shard_step.py --worlds 8 --steps 8 --out $O/tp8_traced.json > $O/tp8_trace.log 2>&1
 (echo "## rocprofv3 --kernel-trace -- python tools/tp_shard_step.py --worlds 8 --steps 8   (one rank of TP = 8, loop-back exchange, MI355X, round 5, final code)"; python tools/prof_db.py $(find /tmp/kt8 -name "*.db" | head -1)) > $O/r5_tp8_shard_kernel_trace.txt
@@ -57,3 +58,4 @@ except Exception as e:
     print(sys.argv[1], "ERR", e)
 PY
 done
+timeout 1200 python -m pytest tests/ -q -m gpu --durations=15 > $O/pytest_gpu_full.txt 2>&1; tail -22 $O/pytest_gpu_full.txt

@@ -31,6 +31,14 @@ PY
   rc=$?; fi
   say $rc "bench.py --gpus $W (TP=$W decode graph + p2p exchange, oracle tokens)" "$O/4_bench_tp$W.err"
 done
+# 4b. if step 4 ran but parity_checked came out false: repeat it with the conservative release of the prefill-sized all-reduce
+#     (CHATTS_TP_BULK_FENCE=1: __threadfence_system() before the flags instead of draining the stores to the uncached exchange areas -
+#     DESIGN.md section 13.4; both forms pass every single-device test, neither has crossed a link)
+for W in 2 "$N"; do
+  [ "$W" -le "$N" ] || continue
+  CHATTS_TP_BULK_FENCE=1 timeout 900 python bench.py --gpus "$W" --no-cpu-baseline --steps 16 --warmup 4 > "$O/4b_bench_tp${W}_fence.json" 2> "$O/4b_bench_tp${W}_fence.err"
+  say $? "bench.py --gpus $W with TP_BULK_FENCE=1 (compare ttft_ms / parity_checked with step 4)" "$O/4b_bench_tp${W}_fence.err"
+done
 # 5. the plain-Python call shape of the reference (demo/demo_vllm.py:30): LLM(tensor_parallel_size=2) spawns its follower
 timeout 300 python tools/llm_tp_spawn_check.py > "$O/5_llm_spawn.json" 2> "$O/5_llm_spawn.err"; say $? "LLM(tensor_parallel_size=2) from one process" "$O/5_llm_spawn.err"
 # 6. the TP server under its own launcher (leader announces engine iterations, followers replay)
