@@ -257,7 +257,7 @@ def ts_encoder_roofline(model, ser, lengths, reps=20):
     flops = 2.0 * P * sum(enc.layer_in_features(l) * H for l in range(enc.num_layers))
     hbm_floor_us, mfma_floor_us = byts / HBM_PEAK_GBS / 1e3, 2 * flops / MFMA_BF16_PEAK_TFLOPS / 1e6     # bf16x2: two MFMA passes
     bound = "hbm" if hbm_floor_us >= mfma_floor_us else "mfma"
-    res = {"kernel": "chatts_ts_encode (ts_patchify + 5 x gemm_{stream,dma}_kernel on bf16 planes, GELU fused)", "patches": P,
+    res = {"kernel": "chatts_ts_encode (ts_patchify + 5 x gemm_{stream,ring}_kernel on bf16 planes, GELU fused)", "patches": P,
            "bound": bound, "avg_us": avg_s * 1e6, "bytes_per_call": byts, "flops_per_call": flops, "calls_timed": reps}
     if bound == "hbm":
         res.update(achieved=byts / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=byts / avg_s / 1e9 / HBM_PEAK_GBS)
