@@ -28,13 +28,13 @@ namespace chatts {
 // ---------------------------------------------------------------------------------------------------
 // decode: grid (n_kv, n_slots), 64 threads.  Slot s walks tiles s, s + n_slots, ... of 16 keys.
 // ---------------------------------------------------------------------------------------------------
-template <int GMAX>
-__global__ __launch_bounds__(64) void attn_decode_kernel(AttnParams p) {
+template <int GMAX, bool EXACT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void attn_decode_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) float q_s[GMAX * kHeadDim];
   __shared__ __attribute__((aligned(16))) float knew_s[kHeadDim];
   __shared__ __attribute__((aligned(16))) float vnew_s[kHeadDim];
-  attn_decode_wave<GMAX>(p, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, q_s, knew_s, vnew_s, p.part_o, p.part_ml,
-                         (size_t)blockIdx.z * p.n_q + blockIdx.x * (p.n_q / p.n_kv));
+  attn_decode_wave<GMAX, true, EXACT>(p, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, q_s, knew_s, vnew_s, p.part_o, p.part_ml,
+                                      (size_t)blockIdx.z * p.n_q + blockIdx.x * (EXACT ? GMAX : p.n_q / p.n_kv));
 }
 
 // out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots): attn_combine_wave
@@ -1100,11 +1100,19 @@ int attention_decode_batched_impl(const float* qkv_raw, int batch, int n_q, int 
   const int rc = bind_workspace(p, workspace, workspace_bytes);
   if (rc) return rc;
   const dim3 grid(n_kv, n_splits, batch);
-  switch (n_q / n_kv) {       // registers sized for the group (every head's arithmetic is the same in all instantiations)
-    case 1: case 2: case 3: case 4: hipLaunchKernelGGL(attn_decode_kernel<4>, grid, dim3(64), 0, as_stream(stream), p); break;
-    case 5: hipLaunchKernelGGL(attn_decode_kernel<5>, grid, dim3(64), 0, as_stream(stream), p); break;
-    case 6: hipLaunchKernelGGL(attn_decode_kernel<6>, grid, dim3(64), 0, as_stream(stream), p); break;
-    default: hipLaunchKernelGGL(attn_decode_kernel<kMaxGroup>, grid, dim3(64), 0, as_stream(stream), p); break;
+  // registers sized for the group (every head's arithmetic is the same in all instantiations); the groups of the shipped models
+  // (Qwen2.5-14B: 5, Qwen3-8B: 4) get the form with the head count known to the compiler (a group of 8 spills in that form: not
+  // built); option ATTN_EXACT=0: the run-time form
+  const bool exact = opt_get(OPT_ATTN_EXACT, 1) != 0;
+  const dim3 wave(64);
+  switch (n_q / n_kv) {
+    case 4: if (exact) { hipLaunchKernelGGL((attn_decode_kernel<4, true>), grid, wave, 0, as_stream(stream), p); break; }
+    case 1: case 2: case 3: hipLaunchKernelGGL((attn_decode_kernel<4, false>), grid, wave, 0, as_stream(stream), p); break;
+    case 5: if (exact) hipLaunchKernelGGL((attn_decode_kernel<5, true>), grid, wave, 0, as_stream(stream), p);
+            else hipLaunchKernelGGL((attn_decode_kernel<5, false>), grid, wave, 0, as_stream(stream), p);
+            break;
+    case 6: hipLaunchKernelGGL((attn_decode_kernel<6, false>), grid, wave, 0, as_stream(stream), p); break;
+    default: hipLaunchKernelGGL((attn_decode_kernel<kMaxGroup, false>), grid, wave, 0, as_stream(stream), p); break;
   }
   CHATTS_CHECK_LAUNCH("attn_decode");
   hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(n_q, batch), dim3(128), 0, as_stream(stream), p);

@@ -147,12 +147,15 @@ __device__ __forceinline__ bool attn_decode_preload(const AttnParams& p, const i
 // GMAX: query heads of the group this wave handles at most; it takes heads g0 .. g0 + gn - 1 of kv head hk's group (the stand-alone
 // kernel: all of them, GMAX = kMaxGroup; the persistent step splits a group over two waves).  Heads are independent of each
 // other, so the split does not change a single operation of any head.  The wave with g0 == 0 stores the new K / V row.
-template <int GMAX, bool PF>
+// EXACT (round 5): the group IS GMAX heads - `g < gn` is decided by the compiler and the tile body is one straight-line block (the
+// run-time form compiled to ~400 basic blocks, every head's every step behind a scalar branch, no load / FMA interleaving across them).
+template <int GMAX, bool PF, bool EXACT>
 __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
-                                                   AttnTileRegs& t, float* q_s, float* knew_s, float* vnew_s, const int g0, const int gn,
+                                                   AttnTileRegs& t, float* q_s, float* knew_s, float* vnew_s, const int g0, const int gn_rt,
                                                    float* part_o, float* part_ml, const size_t head_base) {
+  const int gn = EXACT ? GMAX : gn_rt;
   const int NS = p.n_splits;
-  const int G = p.n_q / p.n_kv;
+  const int G = EXACT ? GMAX : p.n_q / p.n_kv;
   const int pos = t.pos;
   const int ntiles = pos / kDTile + 1;
   const int qkv_n = (p.n_q + 2 * p.n_kv) * kHeadDim;
@@ -242,6 +245,9 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
           db[g] = fmaf(kvb[4 + i].w, qv.w, db[g]);
         }
       }
+      // EXACT: keep the q fragments of one 32-dim slice live at a time (unfenced, the scheduler hoists all GMAX x 4 LDS reads of the
+      // tile to its top and the kernel no longer fits the 256 registers of two waves per SIMD)
+      if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
     }
     float pa[GMAX], pb[GMAX];
 #pragma unroll
@@ -329,13 +335,13 @@ __device__ __forceinline__ void attn_decode_finish(const AttnParams& p, const in
 
 
 // GMAX >= the group size: the per-head registers are sized by it (a Qwen2-14B group of 5 in registers for 8 costs the third wave per SIMD)
-template <int GMAX = kMaxGroup, bool PF = true>
+template <int GMAX = kMaxGroup, bool PF = true, bool EXACT = false>
 __device__ __forceinline__ void attn_decode_wave(const AttnParams& p, const int hk, const int slot, const int seq, const int lane,
                                                  float* q_s, float* knew_s, float* vnew_s, float* part_o, float* part_ml,
                                                  const size_t head_base) {
   AttnTileRegs t;
   if (!attn_decode_preload(p, hk, slot, seq, lane, t)) return;
-  attn_decode_finish<GMAX, PF>(p, hk, slot, seq, lane, t, q_s, knew_s, vnew_s, 0, p.n_q / p.n_kv, part_o, part_ml, head_base);
+  attn_decode_finish<GMAX, PF, EXACT>(p, hk, slot, seq, lane, t, q_s, knew_s, vnew_s, 0, p.n_q / p.n_kv, part_o, part_ml, head_base);
 }
 
 // out[h] = sum_s e^{m_s - M} o_s / sum_s e^{m_s - M} l_s over the slots that saw keys (<= 64 slots).  One workgroup

@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_reg_kernel(const flo
 // thread-to-column mapping as above keeps every bit - but stores c and the planes only for its own 256 / Q threads' columns.  The
 // re-read of the slabs by Q workgroups is L2 traffic (Q x sk x M x N x 4 bytes: 16 MB at Q = 8, sk = 6, 16 x 5120).  Because a
 // workgroup reads resid columns that another one updates, c must NOT alias resid here (the batched decoder ping-pongs x / xn).
-template <int kMaxIt>
+template <int kMaxIt, int kG>
 __global__ __launch_bounds__(256) void splitk_epilogue_norm_q_kernel(const float* __restrict__ ws, int sk, int m, int n,
                                                                     const float* __restrict__ bias, const float* __restrict__ resid,
                                                                     float* __restrict__ c, int ldc, int epilogue,
@@ -698,29 +698,57 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_q_kernel(const float
   const size_t plane = (size_t)m * n;
   f32x4 keep[kMaxIt];
   float ss = 0.f;
+  // Column groups are taken kG at a time (kG = 3 since round 5, option EPI_NORM_Q_GROUPS; 1 = the round-3 walk): all slabs (sk <= 8;
+  // the clamp re-reads the last slab and the value is dropped), the residual and the scale / bias of kG groups are requested before
+  // the first is summed - two dependent round trips for a 5120-wide row instead of five; with 16 workgroups' worth of rows there is no
+  // other wave to hide a chain of trips behind.  Clamped addresses instead of branches inside a batch: a group past the row end
+  // loads column 0 and is dropped; a batch that starts past the row end is skipped whole.
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g0 = 0; g0 < kMaxIt; g0 += kG) {
+    if (g0 * 1024 >= n) {
+#pragma unroll
+      for (int u = 0; u < kG; ++u)
+        if (g0 + u < kMaxIt) keep[g0 + u] = zero;
+      continue;
+    }
+    f32x4 t8[kG][8], tr[kG], tsc[kG], tb[kG];
+#pragma unroll
+    for (int u = 0; u < kG; ++u) {
+      const int it = g0 + u;
+      const int col = threadIdx.x * 4 + it * 1024;
+      const int cc = (it < kMaxIt && col < n) ? col : 0;
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        t8[u][s] = *reinterpret_cast<const f32x4*>(ws + (s < sk ? s : sk - 1) * plane + (size_t)row * n + cc);
+      tr[u] = epilogue == CHATTS_EPI_RESID ? *reinterpret_cast<const f32x4*>(resid + (size_t)row * ldc + cc) : zero;
+      tsc[u] = scale ? *reinterpret_cast<const f32x4*>(scale + cc) : zero;
+      tb[u] = bias ? *reinterpret_cast<const f32x4*>(bias + cc) : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < kG; ++u) {
+      const int it = g0 + u;
+      if (it >= kMaxIt) continue;
+      const int col = threadIdx.x * 4 + it * 1024;
+      f32x4 v = zero;
+      if (col < n) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          if (s < sk) { v.x += t8[u][s].x; v.y += t8[u][s].y; v.z += t8[u][s].z; v.w += t8[u][s].w; }
+        if (scale) { v.x *= tsc[u].x; v.y *= tsc[u].y; v.z *= tsc[u].z; v.w *= tsc[u].w; }
+        if (bias) { v.x += tb[u].x; v.y += tb[u].y; v.z += tb[u].z; v.w += tb[u].w; }
+        if (epilogue == CHATTS_EPI_RESID) { v.x = tr[u].x + v.x; v.y = tr[u].y + v.y; v.z = tr[u].z + v.z; v.w = tr[u].w + v.w; }
+        if (mine) *reinterpret_cast<f32x4*>(c + (size_t)row * ldc + col) = v;
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;        // same accumulation pattern as rmsnorm_kernel
+      }
+      keep[it] = v;
+    }
+  }
+  f32x4 gw[kMaxIt];                                  // the norm weights travel while the workgroup reduces
 #pragma unroll
   for (int it = 0; it < kMaxIt; ++it) {
     const int col = threadIdx.x * 4 + it * 1024;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (col < n) {
-      // all slabs of this column group requested at once (sk <= 8, the clamp re-reads the last slab and the value is dropped): with
-      // 16 workgroups' worth of rows there is no other wave to hide a chain of sk dependent round trips behind
-      f32x4 t8[8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-        t8[s] = *reinterpret_cast<const f32x4*>(ws + (s < sk ? s : sk - 1) * plane + (size_t)row * n + col);
-      f32x4 tr = {0.f, 0.f, 0.f, 0.f};
-      if (epilogue == CHATTS_EPI_RESID) tr = *reinterpret_cast<const f32x4*>(resid + (size_t)row * ldc + col);
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-        if (s < sk) { v.x += t8[s].x; v.y += t8[s].y; v.z += t8[s].z; v.w += t8[s].w; }
-      if (scale) { const f32x4 t = *reinterpret_cast<const f32x4*>(scale + col); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
-      if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + col); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-      if (epilogue == CHATTS_EPI_RESID) { v.x = tr.x + v.x; v.y = tr.y + v.y; v.z = tr.z + v.z; v.w = tr.w + v.w; }
-      if (mine) *reinterpret_cast<f32x4*>(c + (size_t)row * ldc + col) = v;
-      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;        // same accumulation pattern as rmsnorm_kernel
-    }
-    keep[it] = v;
+    gw[it] = (kG > 1 && mine && col < n) ? *reinterpret_cast<const f32x4*>(norm_w + col) : zero;
   }
   ss = block_sum<4>(ss, red);
   const float rstd = rsqrtf(ss / (float)n + eps);
@@ -730,7 +758,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_q_kernel(const float
     const int col = threadIdx.x * 4 + it * 1024;
     if (col >= n) continue;
     const f32x4 v = keep[it];
-    const f32x4 g = *reinterpret_cast<const f32x4*>(norm_w + col);
+    const f32x4 g = kG > 1 ? gw[it] : *reinterpret_cast<const f32x4*>(norm_w + col);
     const float o[4] = {g.x * (v.x * rstd), g.y * (v.y * rstd), g.z * (v.z * rstd), g.w * (v.w * rstd)};
     {
 #pragma clang fp contract(off)   // lo must be the split of the ROUNDED product, as in rmsnorm_kernel<true>
@@ -988,9 +1016,14 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
     const int qsplit = opt_get(OPT_EPI_NORM_Q, 8);
     if (a->m <= 16 && qsplit > 1 && qsplit <= 256 && sk <= 8 && a->n <= 8192 && a->n % 4 == 0 &&
         (a->epilogue != CHATTS_EPI_RESID || a->c != a->resid)) {          // few rows: Q workgroups per row (c must not alias resid)
-      hipLaunchKernelGGL((splitk_epilogue_norm_q_kernel<8>), dim3(a->m, qsplit), dim3(256), 0, s,
-                         reinterpret_cast<const float*>(a->workspace), sk, a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue,
-                         a->w8 ? a->w8_scale : nullptr, a->post_norm_w, a->post_norm_eps, a->post_hi, a->post_lo, a->ld_post);
+      if (opt_get(OPT_EPI_NORM_Q_GROUPS, 3) == 1)
+        hipLaunchKernelGGL((splitk_epilogue_norm_q_kernel<8, 1>), dim3(a->m, qsplit), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(a->workspace), sk, a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue,
+                           a->w8 ? a->w8_scale : nullptr, a->post_norm_w, a->post_norm_eps, a->post_hi, a->post_lo, a->ld_post);
+      else
+        hipLaunchKernelGGL((splitk_epilogue_norm_q_kernel<8, 3>), dim3(a->m, qsplit), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(a->workspace), sk, a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue,
+                           a->w8 ? a->w8_scale : nullptr, a->post_norm_w, a->post_norm_eps, a->post_hi, a->post_lo, a->ld_post);
       CHATTS_CHECK_LAUNCH("splitk_epilogue_norm_q");
       return CHATTS_OK;
     }

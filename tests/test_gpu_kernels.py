@@ -690,6 +690,76 @@ def test_attention_decode_batched_equals_per_sequence(lib):
     assert torch.equal(kc_b[:, 0], kc0[:, 0]) and torch.equal(kc_b[:, 2], kc0[:, 2])
 
 
+@pytest.mark.parametrize("group", [4, 5])
+@pytest.mark.parametrize("qk_norm", [False, True])
+def test_attention_decode_with_the_group_size_compiled_in_is_bitwise_the_run_time_form(lib, monkeypatch, group, qk_norm):
+    """attn_decode_kernel<G, EXACT> (round 5: `g < gn` decided by the compiler, one straight-line tile body) == the run-time form
+    (ATTN_EXACT=0): outputs and the new cache rows bit for bit, for slots of one tile and of several (the prefetching ping-pong),
+    positions at tile edges, a parked sequence."""
+    nkv, max_ctx, B = 2, 640, 6
+    nq = nkv * group
+    g = torch.Generator().manual_seed(group * 3 + qk_norm)
+    raw = torch.randn((B, (nq + 2 * nkv) * 128), generator=g).to(DEV)
+    kc0 = torch.randn((B, nkv, max_ctx, 128), generator=g).to(DEV)
+    vc0 = torch.randn((B, nkv, max_ctx, 128), generator=g).to(DEV)
+    qn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV) if qk_norm else None
+    kn = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV) if qk_norm else None
+    cos, sin = _rope_tables(max_ctx)
+    pos_dev = torch.tensor([0, 15, 16, 333, 639, -1], dtype=torch.int32, device=DEV)
+    for splits in (1, 3, 16, 40):
+        wsb = int(lib.chatts_attn_workspace(B, nq, splits))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        runs = []
+        for exact in ("0", "1"):
+            monkeypatch.setenv("CHATTS_ATTN_EXACT", exact)
+            kc, vc = kc0.clone(), vc0.clone()
+            cache = _lib.KvCache(k=kc.data_ptr(), v=vc.data_ptr(), max_ctx=max_ctx)
+            out = torch.full((B, nq * 128), float("nan"), device=DEV)
+            _lib.check(lib.chatts_attention_decode_batched(raw.data_ptr(), B, nq, nkv, _lib.ptr(qn), _lib.ptr(kn), 1e-6, cos.data_ptr(),
+                                                           sin.data_ptr(), 0, pos_dev.data_ptr(), C.byref(cache), nkv * max_ctx * 128,
+                                                           out.data_ptr(), splits, ws.data_ptr(), wsb, st()))
+            torch.cuda.synchronize()
+            runs.append((out, kc, vc))
+        (o0, k0, v0), (o1, k1, v1) = runs
+        assert not torch.isnan(o1[:5]).any() and torch.equal(o0[:5], o1[:5])
+        assert torch.equal(k0, k1) and torch.equal(v0, v1)
+        assert torch.equal(k1[5], kc0[5]) and not torch.equal(k1[3], kc0[3])
+
+
+@pytest.mark.parametrize("sk", [2, 5, 8])
+@pytest.mark.parametrize("m,n,k,epi", [(16, 5120, 5120, _lib.EPI_RESID), (16, 8192, 2048, _lib.EPI_NONE), (7, 2080, 2048, _lib.EPI_RESID),
+                                       (3, 3072, 1024, _lib.EPI_RESID), (16, 4112, 1024, _lib.EPI_NONE)])
+def test_few_row_post_norm_epilogue_three_column_groups_per_trip_is_bitwise_one_per_trip(lib, monkeypatch, sk, m, n, k, epi):
+    """splitk_epilogue_norm_q_kernel<8, 3> (round 5: slabs / residual of three 1024-column groups requested together) == <8, 1>
+    (EPI_NORM_Q_GROUPS=1): c and both planes bit for bit, rows that end inside a batch of groups, at its edge, and past 7 groups."""
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + sk, scale=2.0)
+    g = torch.Generator().manual_seed(7)
+    nw = (1 + 0.1 * torch.randn(n, generator=g)).to(DEV)
+    hi, lo = _split_planes(lib, a)
+    monkeypatch.setenv("CHATTS_GEMM_SK", str(sk))
+    wsb = max(int(lib.chatts_linear_workspace(m, n, k)), 8 * m * n * 4)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    runs = []
+    for groups in ("1", "3"):
+        monkeypatch.setenv("CHATTS_EPI_NORM_Q_GROUPS", groups)
+        out = torch.full((m, n), float("nan"), device=DEV)
+        r = resid.clone() if epi == _lib.EPI_RESID else None
+        phi = torch.full((m, n + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+        plo = torch.full((m, n + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+        la = _lib.LinearArgs(a=None, w=w.data_ptr(), bias=bias.data_ptr(), resid=_lib.ptr(r), c=out.data_ptr(), norm_w=None,
+                             norm_eps=0.0, m=m, n=n, k=k, lda=k, ldw=k, ldc=n, epilogue=epi, workspace=ws.data_ptr(),
+                             workspace_bytes=wsb, a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=k)
+        la.post_norm_w, la.post_norm_eps, la.post_hi, la.post_lo, la.ld_post = nw.data_ptr(), 1e-6, phi.data_ptr(), plo.data_ptr(), n + 8
+        _lib.check(lib.chatts_linear(la, st()))
+        torch.cuda.synchronize()
+        runs.append((out, phi, plo))
+    (o0, h0, l0), (o1, h1, l1) = runs
+    assert not torch.isnan(o1).any() and torch.equal(o0, o1)
+    assert torch.equal(h0[:, :n], h1[:, :n]) and torch.equal(l0[:, :n], l1[:, :n]) and torch.isnan(h1[:, n:].float()).all()
+    want = _ref_linear(a, w, bias, resid, epi)
+    assert rel_err(o1.cpu().numpy(), want) < 2e-5
+
+
 @pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
 @pytest.mark.parametrize("norm", [False, True])
 @pytest.mark.parametrize("n,k", [(1024, 512), (5120, 5120), (96, 2048), (5120, 13824), (2048, 16 * 17)])
