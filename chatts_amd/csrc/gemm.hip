@@ -514,17 +514,19 @@ __global__ __launch_bounds__(256) void splitk_epilogue_v4_kernel(const float* __
   f32x4 t8[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) t8[s] = *reinterpret_cast<const f32x4*>(ws + (s < sk ? s : sk - 1) * plane + at);
-  f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 r4 = {0.f, 0.f, 0.f, 0.f}, s4 = r4, b4 = r4;            // residual, scale, bias: requested with the slabs (one round trip)
   if (epilogue == CHATTS_EPI_RESID) r4 = *reinterpret_cast<const f32x4*>(resid + (size_t)row * ldc + col);
+  if (scale) s4 = *reinterpret_cast<const f32x4*>(scale + col);
+  if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + col);
   float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 8; ++s)
     if (s < sk) { v[0] += t8[s].x; v[1] += t8[s].y; v[2] += t8[s].z; v[3] += t8[s].w; }
-  const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+  const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, sc[4] = {s4.x, s4.y, s4.z, s4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (scale) v[j] *= scale[col + j];
-    if (bias) v[j] += bias[col + j];
+    if (scale) v[j] *= sc[j];
+    if (bias) v[j] += bb[j];
     if (epilogue == CHATTS_EPI_GELU) v[j] = gelu_erf_f(v[j]);
     if (epilogue == CHATTS_EPI_RESID) v[j] = rr[j] + v[j];
   }
@@ -1062,7 +1064,8 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
     return CHATTS_OK;
   }
   if (sk > 1 && sk <= 8 && a->epilogue != CHATTS_EPI_SWIGLU && a->n % 4 == 0 && a->ldc % 4 == 0 &&
-      ((uintptr_t)a->c % 16) == 0 && ((uintptr_t)a->resid % 16) == 0 && opt_get(OPT_EPI_V4, 1) != 0) {
+      ((uintptr_t)a->c % 16) == 0 && ((uintptr_t)a->resid % 16) == 0 && ((uintptr_t)a->bias % 16) == 0 &&
+      (!a->w8 || ((uintptr_t)a->w8_scale % 16) == 0) && opt_get(OPT_EPI_V4, 1) != 0) {
     const size_t total = (size_t)a->m * (a->n / 4);
     hipLaunchKernelGGL(splitk_epilogue_v4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float*>(a->workspace), sk, a->m, a->n, a->bias, a->resid, a->c, a->ldc, a->epilogue,

@@ -611,7 +611,8 @@ extern "C" int chatts_allreduce_bulk(ChattsTpComm* c, const float* in, float* x,
   // TP_BULK_BLOCKS also lowers the bound for several ranks emulated on ONE device (their waiting grids must be resident together).
   const int64_t slice = ((n + c->p.world - 1) / c->p.world + 3) / 4 * 4;
   int64_t blocks = (slice + 2047) / 2048;
-  const int cap = opt_get(OPT_TP_BULK_BLOCKS, 128);
+  // cap 256 since the light release (round 5): W = 8 is flat from 128 to 256 workgroups (38.5 / 38.7 us), W = 2 gains 10 us (51.6 -> 41.6)
+  const int cap = opt_get(OPT_TP_BULK_BLOCKS, 256);
   if (blocks > cap) blocks = cap;
   if (blocks > kBulkMaxBlocks) blocks = kBulkMaxBlocks;
   if (blocks < 1) blocks = 1;
