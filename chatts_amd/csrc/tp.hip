@@ -611,13 +611,14 @@ extern "C" int chatts_allreduce_bulk(ChattsTpComm* c, const float* in, float* x,
   // TP_BULK_BLOCKS also lowers the bound for several ranks emulated on ONE device (their waiting grids must be resident together).
   const int64_t slice = ((n + c->p.world - 1) / c->p.world + 3) / 4 * 4;
   int64_t blocks = (slice + 2047) / 2048;
-  // cap 256 since the light release (round 5): W = 8 is flat from 128 to 256 workgroups (38.5 / 38.7 us), W = 2 gains 10 us (51.6 -> 41.6)
-  const int cap = opt_get(OPT_TP_BULK_BLOCKS, 256);
+  // cap 256 with the light release (round 5): W = 8 is flat from 128 to 256 workgroups (38.5 / 38.7 us), W = 2 gains 10 us (51.6 -> 41.6);
+  // with the system-scope fence every workgroup costs, and 128 is its minimum (50.4 us against 65.6 at 256)
+  const int light = opt_get(OPT_TP_BULK_FENCE, 0) == 0;
+  const int cap = opt_get(OPT_TP_BULK_BLOCKS, light ? 256 : 128);
   if (blocks > cap) blocks = cap;
   if (blocks > kBulkMaxBlocks) blocks = kBulkMaxBlocks;
   if (blocks < 1) blocks = 1;
   const TpParams tp = tp_issue(c, true);
-  const int light = opt_get(OPT_TP_BULK_FENCE, 0) == 0;
   switch (opt_get(OPT_TP_BULK_THREADS, 256)) {
     case 1024: hipLaunchKernelGGL(tp_allreduce_bulk_kernel<1024>, dim3((unsigned)blocks), dim3(1024), 0, as_stream(stream), tp, in, x, n, light); break;
     case 512: hipLaunchKernelGGL(tp_allreduce_bulk_kernel<512>, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), tp, in, x, n, light); break;
