@@ -604,7 +604,7 @@ extern "C" int chatts_allreduce_bulk(ChattsTpComm* c, const float* in, float* x,
                  (long long)n, (long long)chatts_tp_bulk_elems(c));
   CHATTS_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)x % 16) == 0, CHATTS_E_SHAPE, "allreduce_bulk: pointers must be 16-byte aligned");
   if (n == 0) return CHATTS_OK;
-  // one workgroup per ~8 KB of a slice, at most 128 (every rank computes the same grid from n: the flags are per workgroup).  Round 5
+  // one workgroup per ~8 KB of a slice, capped below (every rank computes the same grid from n: the flags are per workgroup).  Round 5
   // tried 256 workgroups x 512 threads (one trip per thread and pass instead of four): 102 us against 51 us per [798, 5120] sum on a
   // loop-back TP = 8 rank - the kernel is paced by its per-workgroup fences and flag round trips (two __threadfence_system() and 2 W
   // system-scope flags each), not by the three passes; profiles/r5_tp_bulk_sweep.txt has the (workgroups, threads) grid.
