@@ -191,3 +191,51 @@ def test_decode_gemv_kernel_choice_is_pinned_by_shape():
     assert lib.chatts_gemv_ksplit(896, 5120, NONE, 1) > 1
     assert lib.chatts_gemv_ksplit(3456, 5120, SWIGLU, 1) > 1
 
+
+
+def test_tuning_options_table_set_get_unset_and_the_environment_mirror(monkeypatch):
+    """chatts_set_option / _unset_option / _get_option / _option_name (include/chatts_amd.h): the table is host code - every name the
+    header documents exists, unknown names are refused with a message, a leading CHATTS_ is ignored, unset(NULL) clears everything, and
+    the Python binding mirrors CHATTS_<NAME> variables into it (the library itself never reads the environment)."""
+    lib = _lib.load()
+    names = _lib.option_names()
+    assert len(names) == len(set(names)) and "GEMM_SK" in names and "ATTN_EXACT" in names and "TP_BULK_FENCE" in names
+    hdr = open(os.path.join(ROOT, "include", "chatts_amd.h")).read()
+    doc = hdr[hdr.index("Names (a leading"):hdr.index("int chatts_set_option")]
+    documented = set(re.findall(r"\b([A-Z][A-Z0-9]*(?:_[A-Z0-9]+)+)\b", doc)) - {"CHATTS_", "DESIGN"}
+    probes = {"GEMM_ABLATE"}                                   # diagnostic builds only (tools/build_variant.py probe)
+    assert documented - {"CHATTS_"} <= set(names), documented - set(names)
+    assert set(names) - documented <= probes, set(names) - documented
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    sec = design[design.index("## 11. Tuning options"):design.index("## 12. ")]
+    for n in set(names) - probes:                               # DESIGN.md section 11 says what each one selects
+        assert n in sec or n.rsplit("_", 1)[0] + " / _" in sec or ("GEMV_" in n and "GEMV_ROWS / _UNR" in sec), n
+    try:
+        _lib.set_option("GEMM_SK", 3)
+        assert _lib.get_option("GEMM_SK") == 3 and _lib.get_option("CHATTS_GEMM_SK") == 3
+        _lib.set_option("CHATTS_GEMM_T", 7)
+        assert _lib.get_option("GEMM_T") == 7
+        _lib.set_option("GEMM_SK", None)
+        assert _lib.get_option("GEMM_SK") is None and _lib.get_option("GEMM_T") == 7
+        assert lib.chatts_set_option(b"NO_SUCH_KNOB", 1) == _lib.E_BADARG and b"NO_SUCH_KNOB" in lib.chatts_last_error()
+        assert lib.chatts_set_option(None, 1) == _lib.E_BADARG
+        v, isset = ctypes.c_int(5), ctypes.c_int(5)
+        assert lib.chatts_get_option(b"NO_SUCH_KNOB", ctypes.byref(v), ctypes.byref(isset)) == _lib.E_BADARG
+        assert lib.chatts_unset_option(None) == 0 and _lib.get_option("GEMM_T") is None
+        with _lib.options(EPI_V4=0, ATTN_EXACT=0):
+            assert _lib.get_option("EPI_V4") == 0 and _lib.get_option("ATTN_EXACT") == 0
+        assert _lib.get_option("EPI_V4") is None and _lib.get_option("ATTN_EXACT") is None
+        # the environment reaches the table only through sync_env (tests/conftest.py calls it on every monkeypatch.setenv)
+        monkeypatch.setenv("CHATTS_TP_BULK_BLOCKS", "64")
+        monkeypatch.setenv("CHATTS_GEMM_PRECISION", "bf16")   # alias of 1
+        assert _lib.get_option("TP_BULK_BLOCKS") == 64 and _lib.get_option("GEMM_PRECISION") == 1
+        monkeypatch.delenv("CHATTS_TP_BULK_BLOCKS")
+        assert _lib.get_option("TP_BULK_BLOCKS") is None
+        monkeypatch.setenv("CHATTS_GEMM_SK", "three")
+    except RuntimeError as e:
+        assert "integers" in str(e)
+        monkeypatch.delenv("CHATTS_GEMM_SK")
+    else:
+        raise AssertionError("a non-integer option value must be refused")
+    finally:
+        lib.chatts_unset_option(None)
