@@ -29,7 +29,7 @@ class TsWeights(C.Structure):
                 ("b", c_void_p * 8)]
 
 
-ABI_VERSION = 8            # CHATTS_ABI_VERSION of include/chatts_amd.h this binding was written against (checked by load())
+ABI_VERSION = 9            # CHATTS_ABI_VERSION of include/chatts_amd.h this binding was written against (checked by load())
 W8_FP8, W8_INT8 = 0, 1     # ChattsLinearArgs.w8_format
 
 
@@ -49,6 +49,17 @@ class LinearFp8Args(C.Structure):
     _fields_ = [("a8", c_void_p), ("a_scale", c_void_p), ("w8", c_void_p), ("w_scale", c_void_p), ("bias", c_void_p), ("resid", c_void_p),
                 ("c", c_void_p), ("m", c_int), ("n", c_int), ("k", c_int), ("lda8", c_int), ("ldw8", c_int), ("ldc", c_int),
                 ("epilogue", c_int)]
+
+
+class LinearF16qArgs(C.Structure):
+    """ChattsLinearF16qArgs: the prefill projection on f16q planes (csrc/gemm_f16q.hip)"""
+    _fields_ = [("a_hi", c_void_p), ("a_lo8", c_void_p), ("a_scale", c_void_p), ("ld_a", c_int), ("ld_scale", c_int),
+                ("w16", c_void_p), ("w8", c_void_p), ("w8_exp", c_void_p), ("ldw", c_int),
+                ("bias", c_void_p), ("resid", c_void_p), ("c", c_void_p), ("m", c_int), ("n", c_int), ("k", c_int), ("ldc", c_int),
+                ("epilogue", c_int), ("c_hi", c_void_p), ("c_lo8", c_void_p), ("c_scale", c_void_p), ("ld_cplanes", c_int),
+                ("ld_cscale", c_int), ("post_norm_w", c_void_p), ("post_norm_eps", c_float), ("post_hi", c_void_p),
+                ("post_lo8", c_void_p), ("post_scale", c_void_p), ("ld_post", c_int), ("ld_pscale", c_int),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
 
 
 class KvCache(C.Structure):
@@ -118,6 +129,11 @@ SIGNATURES = {
     "chatts_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
     "chatts_quantize_rows_fp8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "chatts_linear_fp8": (c_int, [C.POINTER(LinearFp8Args), c_void_p]),
+    "chatts_split_f16q": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "chatts_weights_f16q": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "chatts_rmsnorm_f16q": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "chatts_linear_f16q_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "chatts_linear_f16q": (c_int, [C.POINTER(LinearF16qArgs), c_void_p]),
     "chatts_decoder_set_prefill_fp8": (c_int, [c_void_p, c_int]),
     "chatts_split_bf16x2": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "chatts_embed_merge": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64,

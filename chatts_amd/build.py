@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libchatts_amd.so")
-SOURCES = ["api.hip", "ts_frontend.hip", "gemv.hip", "gemm.hip", "gemm_ring.hip", "gemm_fp8.hip", "elementwise.hip", "sampler.hip", "attention.hip", "tp.hip", "decoder.hip"]
+SOURCES = ["api.hip", "ts_frontend.hip", "gemv.hip", "gemm.hip", "gemm_ring.hip", "gemm_f16q.hip", "gemm_fp8.hip", "elementwise.hip", "sampler.hip", "attention.hip", "tp.hip", "decoder.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file extra flags (none at the moment)
 EXTRA_FLAGS = {}

@@ -31,6 +31,7 @@ extern "C" {
 
 typedef void* chatts_stream_t; /* hipStream_t */
 typedef uint16_t chatts_bf16;  /* raw bfloat16 bits */
+typedef uint16_t chatts_f16;   /* raw IEEE binary16 bits */
 typedef struct ChattsTpComm ChattsTpComm;     /* tensor-parallel exchange (section below); opaque, host memory only */
 
 const char* chatts_last_error(void);
@@ -43,8 +44,11 @@ const char* chatts_last_error(void);
  *     chatts_decoder_mega_* is gone - built and measured slower than the captured multi-kernel step in round 3);
  *  8: chatts_set_option / chatts_unset_option / chatts_get_option / chatts_option_name (tuning knobs: the library no longer reads the
  *     environment); ChattsLinearArgs.tile_counters, ChattsDecoderBuffers.tile_counters and CHATTS_TILE_COUNTERS removed (the in-launch
- *     split-K fix-up they served was measured slower twice); chatts_tp_flush_epochs. */
-#define CHATTS_ABI_VERSION 8
+ *     split-K fix-up they served was measured slower twice); chatts_tp_flush_epochs;
+ *  9: the f16q operand format of the prefill projections (chatts_split_f16q / chatts_weights_f16q / chatts_rmsnorm_f16q /
+ *     chatts_linear_f16q, ChattsLayerWeights.*16 / *q8 / *q8_exp, ChattsDecoderBuffers.planes*_scale, chatts_decoder_set_prefill_f16q);
+ *     the tensor-parallel exchange's release form per communicator (chatts_tp_cross_device / chatts_tp_set_bulk_release / chatts_tp_bulk_release). */
+#define CHATTS_ABI_VERSION 9
 int chatts_abi_version(void);
 /* Number of CUs of the current device (grid sizing), or <0. */
 int chatts_device_cus(void);
@@ -56,7 +60,7 @@ int chatts_device_cus(void);
  * GEMM_BM GEMM_PRECISION (1 = the bf16 speed mode) GEMM_PLANES_MIN_M GEMM_STREAM GEMM_STREAM_STAGES GEMM_STREAM_WAVES GEMM_STREAM_MB
  * GEMM_STREAM_MB_WAVES EPI_V4 EPI_NORM_Q EPI_NORM_Q_GROUPS EPI_NORM_REG POST_NORM_SMALL_M ROPE_FUSE ATTN_BF16X3 ATTN_EXACT ATTN_PLANES ATTN_XCD ATTN_ROWS ATTN_KSPLIT ARGMAX_2STAGE
  * TS_F32_PATH KV_ROUND TP_FUSE TP_FUSE_BLOCKS TP_BULK_BLOCKS TP_BULK_THREADS TP_BULK_FENCE TP_AR_BLOCKS GEMV_ROWS GEMV_UNR GEMV_NW GEMV_OCC GEMV_BLOCKS GEMV_LDSPAD GEMV_KS
- * FP8_BM FP8_ORDER (DESIGN.md section 11 says what each selects and where it was measured).  A set / unset is a relaxed atomic store: safe
+ * FP8_BM FP8_ORDER F16Q_STAGGER F16Q_MIN_M (DESIGN.md section 11 says what each selects and where it was measured).  A set / unset is a relaxed atomic store: safe
  * beside running calls, which see either value.  chatts_unset_option(NULL) clears all.  chatts_option_name(i) enumerates (NULL at the end). */
 int chatts_set_option(const char* name, int value);
 int chatts_unset_option(const char* name);
@@ -223,6 +227,56 @@ int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, 
  *                           otherwise gemm_bf16x2_kernel (register-staged LDS tiles);
  *           all MFMA paths: v_mfma_f32_16x16x32_bf16 with the bf16x2 split of A. */
 int chatts_linear(const ChattsLinearArgs* args, chatts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The f16q operand format of the prefill projections (round 6; csrc/f16q.h, csrc/gemm_f16q.hip).  No reference twin: the reference
+ * multiplies fp16 x fp16 inside vLLM / flash-attn kernels (NOT IN REFERENCE); this is HOW the float32-grade projection
+ * (oracle: float32 matmul, oracle/qwen_decoder.py) is issued to the CDNA4 matrix pipes at 1.5 instead of 2 pass-equivalents per product.
+ *   x = hi + lo,  hi = f16_rne(clamp(x, +-65504)) [M, ld_planes],  lo = x - hi (exact) stored as OCP e4m3fn q = rne(lo * 2^-E) [M, ld_planes],
+ *   E + 127 = one e8m0 byte per row and 128 consecutive K-values [M, ld_scale]: the smallest power of two with max|lo| / 2^E <= 448 (127 for
+ *   an all-zero block).  Weights: an f16 copy of the bf16 matrix (exact for 2^-17 <= |w| <= 65504) and an e4m3 copy with ONE power-of-two
+ *   scale per row (byte E + 127, the same rule over the row).  C = epilogue(hi . W16^T + (q 2^E) . (W8 2^Ew)^T), float32 accumulate.
+ * chatts_split_f16q: float32 [M, K] -> planes (K % 128 == 0).  chatts_weights_f16q: bf16 [N, K] -> (w16, w8, w8_exp), ld_out % 16 == 0.
+ * chatts_rmsnorm_f16q: chatts_rmsnorm's arithmetic with the row written as planes.  chatts_linear_f16q: the GEMM (M >= 1; meant for
+ * prefill chunks); epilogues of chatts_linear; SWIGLU may write its result as planes (c_hi / c_lo8 / c_scale: the next projection's
+ * operand) instead of float32 c; EPI_NONE / EPI_RESID may additionally write RMSNorm(c) as planes (post_*), fused into the split-K
+ * epilogue when there is one.  Workspace: chatts_linear_f16q_workspace(m, n, k) bytes.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ChattsLinearF16qArgs {
+  const chatts_f16* a_hi;    /* [M, ld_a] */
+  const uint8_t* a_lo8;      /* [M, ld_a] e4m3 */
+  const uint8_t* a_scale;    /* [M, ld_scale] e8m0 */
+  int ld_a, ld_scale;
+  const chatts_f16* w16;     /* [N, ldw] */
+  const uint8_t* w8;         /* [N, ldw] e4m3 */
+  const uint8_t* w8_exp;     /* [N] e8m0 */
+  int ldw;
+  const float* bias;         /* [N] or NULL (SWIGLU: interleaved like the rows) */
+  const float* resid;        /* EPI_RESID: [M, ldc] */
+  float* c;                  /* [M, ldc] (SWIGLU: [M, N / 2]); may be NULL when c_hi is set */
+  int m, n, k, ldc, epilogue;
+  chatts_f16* c_hi;          /* optional (SWIGLU only): the result as f16q planes [M, ld_cplanes], scales [M, ld_cscale] */
+  uint8_t* c_lo8;
+  uint8_t* c_scale;
+  int ld_cplanes, ld_cscale;
+  const float* post_norm_w;  /* optional (EPI_NONE / EPI_RESID): RMSNorm(c) with this weight as f16q planes */
+  float post_norm_eps;
+  chatts_f16* post_hi;
+  uint8_t* post_lo8;
+  uint8_t* post_scale;
+  int ld_post, ld_pscale;
+  void* workspace;
+  size_t workspace_bytes;
+} ChattsLinearF16qArgs;
+int chatts_split_f16q(const float* x, int m, int k, int ldx, chatts_f16* hi, uint8_t* lo8, uint8_t* scale, int ld_planes, int ld_scale,
+                      chatts_stream_t stream);
+int chatts_weights_f16q(const chatts_bf16* w, int n, int k, int ldw, chatts_f16* w16, uint8_t* w8, uint8_t* w8_exp, int ld_out,
+                        chatts_stream_t stream);
+int chatts_rmsnorm_f16q(const float* x, const float* w, chatts_f16* hi, uint8_t* lo8, uint8_t* scale, int ld_planes, int ld_scale, int t,
+                        int hidden, float eps, chatts_stream_t stream);
+size_t chatts_linear_f16q_workspace(int m, int n, int k);
+int chatts_linear_f16q(const ChattsLinearF16qArgs* a, chatts_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * SPEED MODE, not parity grade: fp8 x fp8 projections on the CDNA4 block-scaled matrix pipe (v_mfma_scale_f32_16x16x128_f8f6f4 with

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.chatts_abi_version() == 8
+    assert lib.chatts_abi_version() == 9
     # host-only validation paths: negative codes + message, no device touched
     assert lib.chatts_linear(None, None) == _lib.E_BADARG
     assert b"null args" in lib.chatts_last_error()
