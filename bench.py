@@ -206,10 +206,11 @@ def prefill_mfma_gate_up(model, T, reps=1):
     ws = torch.empty(wsb, dtype=torch.uint8, device=model.device)
 
     def sweep():
-        for lw in model.layers:
+        for i, lw in enumerate(model.layers):
             la = _lib.LinearArgs(a=None, w=lw["gate_up"].data_ptr(), bias=None, resid=None, c=out.data_ptr(), norm_w=None,
                                  norm_eps=0.0, m=T, n=n, k=H, lda=H, ldw=H, ldc=plan.inter, epilogue=_lib.EPI_SWIGLU,
                                  workspace=ws.data_ptr(), workspace_bytes=wsb, a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=H)
+            la.w_tiled = _lib.ptr(model._tiled[i].get("gate_up")) if i < len(model._tiled) else None      # as the decoder calls it
             _lib.check(lib.chatts_linear(la, stream.cuda_stream))
 
     sweep()
@@ -773,7 +774,8 @@ def main():
                                  "prefill, exact f32 FMA in decode)") if model.precision == "bf16x2" else
                                 ("SPEED MODE precision=bf16 - NOT the parity-grade line: prefill GEMMs multiply bf16-rounded activations "
                                  "(one MFMA pass), logits ~3e-2 of the default mode (profiles/r2_speed_mode_14b.json); decode as in the default"),
-                   "first_tokens": toks[:8]},
+                   "first_tokens": toks[:8],
+                   "weight_bytes_decode_stream": step_bytes, "weight_bytes_tiled_prefill_copies": model.tiled_weight_bytes_local()},
         "ttft_ms_p50": ttft, "ts_encode_ms_p50": median(enc_ms),
         "decode_hbm_gbs_per_gpu": step_bytes / (dt / args.steps) / 1e9,
         "decode_hbm_frac_of_8TBs": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,

@@ -42,7 +42,7 @@ class LinearArgs(C.Structure):
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("ld_cplanes", c_int),
                 ("post_norm_w", c_void_p), ("post_norm_eps", c_float), ("post_hi", c_void_p), ("post_lo", c_void_p), ("ld_post", c_int),
                 ("w4", c_void_p), ("w4_sz", c_void_p), ("ldw4", c_int), ("w4_group", c_int),
-                ("w8_format", c_int), ("tp_reduce", c_void_p)]
+                ("w8_format", c_int), ("tp_reduce", c_void_p), ("w_tiled", c_void_p), ("planes_tiled", c_int)]
 
 
 class LinearFp8Args(C.Structure):
@@ -74,7 +74,8 @@ class LayerWeights(C.Structure):
                 ("o8_scale", c_void_p), ("gate_up8", c_void_p), ("gate_up8_scale", c_void_p), ("down8", c_void_p),
                 ("down8_scale", c_void_p),
                 ("qkv4", c_void_p), ("qkv4_sz", c_void_p), ("o4", c_void_p), ("o4_sz", c_void_p), ("gate_up4", c_void_p),
-                ("gate_up4_sz", c_void_p), ("down4", c_void_p), ("down4_sz", c_void_p), ("w4_group", c_int)]
+                ("gate_up4_sz", c_void_p), ("down4", c_void_p), ("down4_sz", c_void_p), ("w4_group", c_int),
+                ("qkv_t", c_void_p), ("o_t", c_void_p), ("gate_up_t", c_void_p), ("down_t", c_void_p)]
 
 
 class PrefillSegment(C.Structure):
@@ -135,6 +136,8 @@ SIGNATURES = {
     "chatts_linear_f16q_workspace": (c_size_t, [c_int, c_int, c_int]),
     "chatts_linear_f16q": (c_int, [C.POINTER(LinearF16qArgs), c_void_p]),
     "chatts_decoder_set_prefill_fp8": (c_int, [c_void_p, c_int]),
+    "chatts_tile_bf16_elems": (c_size_t, [c_int, c_int]),
+    "chatts_tile_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "chatts_split_bf16x2": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "chatts_embed_merge": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -359,7 +359,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     const int qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim;
     // RMSNorm -> QKV (+bias).  Decode: norm fused in the GEMV prologue; prefill: separate kernel.
     la = ChattsLinearArgs{};
-    la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = t; la.n = qkv_n; la.k = H;
+    la.w = lw.qkv; la.w_tiled = lw.qkv_t; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = t; la.n = qkv_n; la.k = H;
     la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if (t == 1) {
@@ -406,7 +406,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
     }
     // o_proj (+ residual, or partial sum for the TP all-reduce)
     la = ChattsLinearArgs{};
-    la.a = d->b.attn; la.w = lw.o; la.m = t; la.n = H; la.k = c.n_q * kHeadDim;
+    la.a = d->b.attn; la.w = lw.o; la.w_tiled = lw.o_t; la.m = t; la.n = H; la.k = c.n_q * kHeadDim;
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if (t == 1) {
@@ -429,7 +429,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   }
   // part 1: RMSNorm -> gate_up + SwiGLU -> down (+ residual / partial)
   la = ChattsLinearArgs{};
-  la.w = lw.gate_up; la.c = d->b.act; la.m = t; la.n = 2 * c.inter; la.k = H;
+  la.w = lw.gate_up; la.w_tiled = lw.gate_up_t; la.c = d->b.act; la.m = t; la.n = 2 * c.inter; la.k = H;
   la.lda = H; la.ldw = H; la.ldc = c.inter; la.epilogue = CHATTS_EPI_SWIGLU;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if (t == 1) {
@@ -443,7 +443,7 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
   if (act_planes) { la.c = nullptr; la.c_hi = d->b.planes2_hi; la.c_lo = d->b.planes2_lo; la.ld_cplanes = c.inter; }
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
   la = ChattsLinearArgs{};
-  la.a = d->b.act; la.w = lw.down; la.m = t; la.n = H; la.k = c.inter;
+  la.a = d->b.act; la.w = lw.down; la.w_tiled = lw.down_t; la.m = t; la.n = H; la.k = c.inter;
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if (t == 1) {
@@ -492,7 +492,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   if (part == 0) {
     const int qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim;
     la = ChattsLinearArgs{};
-    la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = batch; la.n = qkv_n; la.k = H;
+    la.w = lw.qkv; la.w_tiled = lw.qkv_t; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = batch; la.n = qkv_n; la.k = H;
     la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
     la.w8 = lw.qkv8; la.w8_scale = lw.qkv8_scale; la.ldw8 = H; la.w8_format = d->cfg.w8_format;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
@@ -505,7 +505,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
                                             attn_planes ? d->b.planes_lo : nullptr, n_splits, d->b.workspace, d->b.workspace_bytes,
                                             stream)) != 0) return rc;
     la = ChattsLinearArgs{};
-    la.a = d->b.attn; la.w = lw.o; la.m = batch; la.n = H; la.k = c.n_q * kHeadDim;
+    la.a = d->b.attn; la.w = lw.o; la.w_tiled = lw.o_t; la.m = batch; la.n = H; la.k = c.n_q * kHeadDim;
     la.lda = la.k; la.ldw = la.k; la.ldc = H;
     la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k; la.w8_format = d->cfg.w8_format;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
@@ -525,7 +525,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
     return chatts_linear(&la, stream);
   }
   la = ChattsLinearArgs{};
-  la.w = lw.gate_up; la.c = d->b.act; la.m = batch; la.n = 2 * c.inter; la.k = H;
+  la.w = lw.gate_up; la.w_tiled = lw.gate_up_t; la.c = d->b.act; la.m = batch; la.n = 2 * c.inter; la.k = H;
   la.lda = H; la.ldw = H; la.ldc = c.inter; la.epilogue = CHATTS_EPI_SWIGLU;
   la.w8 = lw.gate_up8; la.w8_scale = lw.gate_up8_scale; la.ldw8 = H; la.w8_format = d->cfg.w8_format;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
@@ -534,7 +534,7 @@ extern "C" int chatts_decoder_layer_part_batched(ChattsDecoder* d, int layer, in
   if (act_planes) { la.c = nullptr; la.c_hi = d->b.planes2_hi; la.c_lo = d->b.planes2_lo; la.ld_cplanes = c.inter; }
   if ((rc = chatts_linear(&la, stream)) != 0) return rc;
   la = ChattsLinearArgs{};
-  la.a = d->b.act; la.w = lw.down; la.m = batch; la.n = H; la.k = c.inter;
+  la.a = d->b.act; la.w = lw.down; la.w_tiled = lw.down_t; la.m = batch; la.n = H; la.k = c.inter;
   la.lda = c.inter; la.ldw = c.inter; la.ldc = H;
   la.w8 = lw.down8; la.w8_scale = lw.down8_scale; la.ldw8 = c.inter; la.w8_format = d->cfg.w8_format;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
@@ -648,7 +648,7 @@ static int layer_last_row(ChattsDecoder* d, int layer, int t, int pos0, chatts_s
   const int H = c.hidden, qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim;
   int rc;
   ChattsLinearArgs la{};
-  la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = t; la.n = qkv_n; la.k = H;
+  la.w = lw.qkv; la.w_tiled = lw.qkv_t; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = t; la.n = qkv_n; la.k = H;
   la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
@@ -669,7 +669,7 @@ static int layer_last_row(ChattsDecoder* d, int layer, int t, int pos0, chatts_s
     CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "prefill_last: row copy: %s", hipGetErrorString(e));
   }
   la = ChattsLinearArgs{};
-  la.a = d->b.attn; la.w = lw.o; la.m = 1; la.n = H; la.k = c.n_q * kHeadDim; la.lda = la.k; la.ldw = la.k; la.ldc = H;
+  la.a = d->b.attn; la.w = lw.o; la.w_tiled = lw.o_t; la.m = 1; la.n = H; la.k = c.n_q * kHeadDim; la.lda = la.k; la.ldw = la.k; la.ldc = H;
   la.w8 = lw.o8; la.w8_scale = lw.o8_scale; la.ldw8 = la.k; la.w8_format = d->cfg.w8_format;
   la.w4 = lw.o4; la.w4_sz = lw.o4_sz; la.ldw4 = la.k / 2; la.w4_group = lw.w4_group;
   la.c = d->b.x; la.resid = d->b.x; la.epilogue = CHATTS_EPI_RESID;
@@ -741,7 +741,7 @@ static int layer_part0_packed(ChattsDecoder* d, int layer, int t, const ChattsPr
     f.m = t; f.n = qkv_n; f.k = H; f.lda8 = H; f.ldw8 = H; f.ldc = qkv_n; f.epilogue = CHATTS_EPI_NONE;
     if ((rc = chatts_linear_fp8(&f, stream)) != 0) return rc;
   } else {
-    la.w = lw.qkv; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = t; la.n = qkv_n; la.k = H;
+    la.w = lw.qkv; la.w_tiled = lw.qkv_t; la.bias = lw.qkv_bias; la.c = d->b.qkv; la.m = t; la.n = qkv_n; la.k = H;
     la.lda = H; la.ldw = H; la.ldc = qkv_n; la.epilogue = CHATTS_EPI_NONE;
     la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
     if ((rc = norm_into(d, lw.input_norm, &la, stream)) != 0) return rc;
@@ -767,7 +767,7 @@ static int layer_part0_packed(ChattsDecoder* d, int layer, int t, const ChattsPr
     return chatts_linear_fp8(&f, stream);
   }
   la = ChattsLinearArgs{};
-  la.a = d->b.attn; la.w = lw.o; la.m = t; la.n = H; la.k = na; la.lda = na; la.ldw = na; la.ldc = H;
+  la.a = d->b.attn; la.w = lw.o; la.w_tiled = lw.o_t; la.m = t; la.n = H; la.k = na; la.lda = na; la.ldw = na; la.ldc = H;
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   if (t > 1 && planes_path(d, t, na)) {
     if ((rc = chatts_split_bf16x2(d->b.attn, t, na, na, d->b.planes_hi, d->b.planes_lo, na, stream)) != 0) return rc;

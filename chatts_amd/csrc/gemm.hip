@@ -937,6 +937,8 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
   const bool stream = use_stream(a);
   const bool ring = !stream && use_ring(a);
   RingGeom rg{};
+  CHATTS_REQUIRE(!a->planes_tiled || ring, CHATTS_E_SHAPE, "linear: tiled planes are the prefill kernel's operand format (M=%d K=%d take another kernel)", a->m, a->k);
+  CHATTS_REQUIRE(!ring || !a->w_tiled || (((uintptr_t)a->w_tiled % 16) == 0 && a->ldw == a->k), CHATTS_E_SHAPE, "linear: w_tiled needs 16-byte alignment and ldw == K");
   if (stream) {
     sk = pick_stream_sk(a->n, a->k, a->w8 != nullptr);
     bm = 16;
@@ -962,6 +964,7 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
   p.epilogue = a->epilogue; p.k_per_split = kps; p.direct = sk == 1;
   p.w8 = a->w8; p.w8_scale = a->w8_scale; p.ldw8 = a->ldw8; p.w8_format = a->w8_format;
   p.c_hi = a->c_hi; p.c_lo = a->c_lo; p.ldcp = a->ld_cplanes;
+  p.wt = ring ? a->w_tiled : nullptr; p.planes_tiled = a->planes_tiled;
   if (sk > 1) {
     const size_t need = (size_t)sk * a->m * a->n * sizeof(float);
     CHATTS_REQUIRE(a->workspace && a->workspace_bytes >= need, CHATTS_E_WORKSPACE,

@@ -22,6 +22,8 @@ struct GemmParams {
   uint16_t* c_hi;        // optional: the output goes out as bf16 hi / lo planes [M, ldcp] (the next GEMM's operand
   uint16_t* c_lo;        // format) instead of float32 c
   int ldcp;
+  const uint16_t* wt;    // optional (gemm_ring_kernel): W in the tiled layout of chatts_tile_bf16 - a 1 KB LDS-DMA piece is 1 KB of memory
+  int planes_tiled;      // a_hi / a_lo are in that layout too
 };
 
 __device__ __forceinline__ void store_planes(uint16_t* hi, uint16_t* lo, size_t off, float v) {

@@ -80,6 +80,10 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
     // A pieces q = 0 .. 2 f - 1 (q < f: hi plane fragment q, else lo plane fragment q - f) those with q % 4 == L.
     const int L = wave - kRingCompute;
     const int prow = lane >> 2, gchunk = (lane & 3) ^ ((lane >> 5) << 1);
+    // tiled operands (chatts_tile_bf16): piece (16-row block b, half-stage t) is the 1 KB at ((b * K / 32) + t) * 1 KB, already in LDS
+    // order - whole cache lines per request instead of 16 half lines (profiles/r6_feed_probe.txt)
+    const bool wtiled = p.wt != nullptr, atiled = p.planes_tiled != 0;
+    const int nkt = p.k >> 5, wstep = wtiled ? 1024 : 64, astep = atiled ? 1024 : 64;
     const char* src[9];
     int dst[9];
     int np = 0, nh_cur = 0, hh = 0, ucur = u0;
@@ -90,9 +94,16 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
       const int n0 = r.panel * kRingBN;
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
-        int wr = n0 + (L + 4 * h) * 16 + prow;
-        if (wr > p.n - 1) wr = p.n - 1;
-        src[h] = reinterpret_cast<const char*>(p.w + (size_t)wr * p.ldw + r.kbeg + gchunk * 8);
+        if (wtiled) {
+          int rb = (n0 >> 4) + L + 4 * h;
+          const int rbmax = ((p.n + 15) >> 4) - 1;
+          if (rb > rbmax) rb = rbmax;
+          src[h] = reinterpret_cast<const char*>(p.wt + ((size_t)rb * nkt + (r.kbeg >> 5)) * 512) + lane * 16;
+        } else {
+          int wr = n0 + (L + 4 * h) * 16 + prow;
+          if (wr > p.n - 1) wr = p.n - 1;
+          src[h] = reinterpret_cast<const char*>(p.w + (size_t)wr * p.ldw + r.kbeg + gchunk * 8);
+        }
         dst[h] = kRingWOff + (L + 4 * h) * 1024;
       }
       np = 4;
@@ -102,9 +113,13 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
         const int q = L + 4 * h;
         if (q < na) {
           const int plane = q >= r.f, frag = plane ? q - r.f : q;
-          int am = r.m0 + frag * 16 + prow;
-          if (am > p.m - 1) am = p.m - 1;
-          src[4 + h] = reinterpret_cast<const char*>((plane ? a_lo : a_hi) + (size_t)am * ldp + r.kbeg + gchunk * 8);
+          if (atiled) {
+            src[4 + h] = reinterpret_cast<const char*>((plane ? a_lo : a_hi) + ((size_t)((r.m0 >> 4) + frag) * nkt + (r.kbeg >> 5)) * 512) + lane * 16;
+          } else {
+            int am = r.m0 + frag * 16 + prow;
+            if (am > p.m - 1) am = p.m - 1;
+            src[4 + h] = reinterpret_cast<const char*>((plane ? a_lo : a_hi) + (size_t)am * ldp + r.kbeg + gchunk * 8);
+          }
           dst[4 + h] = plane * kRingAPlane + frag * 1024;
           np = 5 + h;
         }
@@ -114,10 +129,10 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
     auto issue = [&]() -> int {                                // request the next half-stage (if any); -> its piece count
       if (ucur >= uend) return 0;
       char* base = smem + (gi & (kRingSlots - 1)) * kRingHalf;
-      const size_t koff = (size_t)hh * 64;
+      const size_t koffw = (size_t)hh * wstep, koffa = (size_t)hh * astep;
 #pragma unroll
       for (int h = 0; h < 9; ++h)
-        if (h < np && !RABLATE(1)) __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + koff), (lptr_t)(base + dst[h]), 16, 0, 0);
+        if (h < np && !RABLATE(1)) __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + (h < 4 ? koffw : koffa)), (lptr_t)(base + dst[h]), 16, 0, 0);
       const int n = np;
       ++gi;
       if (++hh == nh_cur) {
@@ -327,7 +342,38 @@ int launch_ring(const GemmParams& p, const uint16_t* a_hi, const uint16_t* a_lo,
   return single ? launch_ring_t<true>(p, a_hi, a_lo, ldp, g, s) : launch_ring_t<false>(p, a_hi, a_lo, ldp, g, s);
 }
 
+// bf16 [rows, k] row-major -> the tiled layout: block (b = row / 16, t = k / 32) is 1 KB at ((b * k / 32) + t) * 1 KB; inside it the 16-byte
+// chunk at position l (0 .. 63) holds row 16 b + (l >> 2), K-values 32 t + 8 c .. + 7 with c = (l & 3) ^ ((l >> 5) << 1) - the order in
+// which the lanes of an LDS-DMA piece deposit a half-stage block (the header comment's swizzle).  Rows beyond the matrix repeat the last row.
+__global__ __launch_bounds__(256) void tile_bf16_kernel(const uint16_t* __restrict__ src, int rows, int k, int ld, uint16_t* __restrict__ dst) {
+  const int nkt = k >> 5;
+  const size_t chunks = (size_t)((rows + 15) >> 4) * nkt * 64;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (size_t)gridDim.x * 256) {
+    const int l = (int)(i & 63);
+    const size_t blk = i >> 6;
+    const int t = (int)(blk % nkt);
+    int row = (int)(blk / nkt) * 16 + (l >> 2);
+    if (row > rows - 1) row = rows - 1;
+    const int c = (l & 3) ^ ((l >> 5) << 1);
+    *reinterpret_cast<u32x4*>(dst + i * 8) = *reinterpret_cast<const u32x4*>(src + (size_t)row * ld + t * 32 + c * 8);
+  }
+}
+
 }  // namespace chatts
+
+extern "C" size_t chatts_tile_bf16_elems(int rows, int k) { return rows > 0 && k > 0 ? (size_t)((rows + 15) / 16) * 16 * k : 0; }
+
+extern "C" int chatts_tile_bf16(const chatts_bf16* src, int rows, int k, int ld, chatts_bf16* dst, chatts_stream_t stream) {
+  using namespace chatts;
+  CHATTS_REQUIRE(rows >= 0 && k > 0 && k % 32 == 0 && ld >= k && ld % 8 == 0, CHATTS_E_SHAPE, "tile_bf16: rows=%d k=%d ld=%d (K %% 32 == 0, ld %% 8 == 0)", rows, k, ld);
+  if (rows == 0) return CHATTS_OK;
+  CHATTS_REQUIRE(src && dst && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, CHATTS_E_BADARG, "tile_bf16: null / unaligned pointer");
+  const size_t chunks = chatts_tile_bf16_elems(rows, k) / 8;
+  const unsigned blocks = (unsigned)((chunks + 255) / 256 < 16384 ? (chunks + 255) / 256 : 16384);
+  hipLaunchKernelGGL(tile_bf16_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, rows, k, ld, dst);
+  CHATTS_CHECK_LAUNCH("tile_bf16");
+  return CHATTS_OK;
+}
 
 #ifdef CHATTS_GEMM_PROBE
 // diagnostic builds only (not in include/chatts_amd.h): copy the ring kernel's probe records to the host and clear them

@@ -12,6 +12,7 @@ streams and the RCCL process group.  There is no CPU/PyTorch fallback.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -98,7 +99,7 @@ class ChatTSForCausalLM:
 
     def __init__(self, config, device="cuda", comm=None, max_ctx=2048, max_prefill_tokens=2048, use_graph=True,
                  max_batch=1, weight_format="bf16", use_p2p=True, enable_prefix_caching=True, kv_block_size=None,
-                 kv_pool_blocks=None, precision=None):
+                 kv_pool_blocks=None, precision=None, prefill_tiled_weights=None):
         if not torch.cuda.is_available():
             raise RuntimeError("chatts_amd needs a ROCm GPU: there is no CPU fallback for the model")
         self.lib = _lib.load()
@@ -143,6 +144,13 @@ class ChatTSForCausalLM:
         self._gptq_codes = {}                    # HF module name -> (codes, scale, zero) of a GPTQ checkpoint, consumed by _load_with
         self.max_batch = int(max_batch)          # KV-cache slots for batched decode (continuous batching)
         self.t_max = int(max(min(max_prefill_tokens, self.max_ctx), self.max_batch))
+        # a second copy of the four projection matrices of every layer in the prefill kernel's tiled layout (chatts_tile_bf16: its LDS-DMA
+        # pieces then read consecutive memory; bit-identical results, prefill projections -4 %, profiles/r6_tiled_check.txt).  None = when
+        # a prefill chunk can reach that kernel (>= 96 rows) and CHATTS_TILED_WEIGHTS != 0; costs the bf16 weight bytes once more.
+        if prefill_tiled_weights is None:
+            prefill_tiled_weights = self.t_max >= 96 and os.environ.get("CHATTS_TILED_WEIGHTS", "1") != "0"
+        self.prefill_tiled_weights = bool(prefill_tiled_weights)
+        self._tiled = []                         # per layer: {projection: tiled copy}
         self.use_graph = use_graph
         self.use_p2p = use_p2p                   # TP: decode-sized exchanges through csrc/tp.hip instead of RCCL (chatts_amd/tp.py)
         self._tp = None                          # P2PExchange of this rank once attached
@@ -397,9 +405,24 @@ class ChatTSForCausalLM:
                 self._kv.reserve(sl, self.max_ctx)
                 self._kv.retire(sl)
                 self._push_kv_row(sl)
+        self._tiled = []
+        for lw in self.layers:
+            tiled = {}
+            if self.prefill_tiled_weights:
+                for name in ("qkv", "o", "gate_up", "down"):
+                    w = lw[name]
+                    rows, k = w.shape
+                    if k % 64 == 0 and w.is_contiguous():
+                        out = torch.empty(int(lib.chatts_tile_bf16_elems(rows, k)), dtype=torch.bfloat16, device=dev)
+                        _lib.check(lib.chatts_tile_bf16(w.data_ptr(), rows, k, k, out.data_ptr(), _lib.stream_ptr()))
+                        tiled[name] = out
+            self._tiled.append(tiled)
         arr = (_lib.LayerWeights * L)()
         for i, lw in enumerate(self.layers):
-            arr[i] = _lib.LayerWeights(input_norm=_lib.ptr(lw["input_norm"]), qkv=_lib.ptr(lw["qkv"]),
+            tl = self._tiled[i]
+            arr[i] = _lib.LayerWeights(qkv_t=_lib.ptr(tl.get("qkv")), o_t=_lib.ptr(tl.get("o")), gate_up_t=_lib.ptr(tl.get("gate_up")),
+                                       down_t=_lib.ptr(tl.get("down")),
+                                       input_norm=_lib.ptr(lw["input_norm"]), qkv=_lib.ptr(lw["qkv"]),
                                        qkv_bias=_lib.ptr(lw.get("qkv_bias")), q_norm=_lib.ptr(lw.get("q_norm")),
                                        k_norm=_lib.ptr(lw.get("k_norm")), o=_lib.ptr(lw["o"]),
                                        post_norm=_lib.ptr(lw["post_norm"]), gate_up=_lib.ptr(lw["gate_up"]),
@@ -495,6 +518,10 @@ class ChatTSForCausalLM:
         T = self._tensors
         head = (T["lm_head8"].numel() + T["lm_head8_scale"].numel() * 4) if "lm_head8" in T else T["lm_head"].numel() * 2
         return n + head + T["final_norm"].numel() * 4
+
+    def tiled_weight_bytes_local(self):
+        """Bytes of the prefill kernel's tiled weight copies on this rank (resident beside the tensors weight_bytes_local() counts)."""
+        return sum(t.numel() * t.element_size() for tl in self._tiled for t in tl.values())
 
     # ---------------------------------------------------------------------------------------------
     # vLLM-plugin-shaped hooks (same names/order as chatts_vllm.py:538-610)

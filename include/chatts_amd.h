@@ -209,6 +209,13 @@ typedef struct ChattsLinearArgs {
    * without the partial vector's round trip and without the stand-alone exchange launch.  n <= chatts_tp_max_elems(comm).  Every rank
    * must issue the same call (same N, same launch geometry) - like any collective. */
   ChattsTpComm* tp_reduce;
+  /* optional (prefill kernel only, i.e. planes given and M >= 96): the same bf16 matrix as `w` in the tiled layout of chatts_tile_bf16
+   * (ldw == K).  The prefill kernel is bound by its operand feed, and an LDS-DMA piece of 16 rows x 64 bytes uses half of each of the 16
+   * cache lines it touches (profiles/r6_feed_probe.txt: 18 B/clk/CU against 27-30 for 1 KB of consecutive memory).  Same products, same
+   * order: bit-identical results.  planes_tiled != 0: a_hi / a_lo are in that layout as well (ld_planes ignored; every kernel other than
+   * the prefill kernel refuses them). */
+  const chatts_bf16* w_tiled;
+  int planes_tiled;
 } ChattsLinearArgs;
 #define CHATTS_W8_FP8 0
 #define CHATTS_W8_INT8 1
@@ -220,6 +227,12 @@ int chatts_gemv_ksplit(int n, int k, int epilogue, int has_norm);
 /* hi = bf16(x) (RNE), lo = bf16(x - hi): the operand split of the bf16x2 GEMM, done once per activation matrix. */
 int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts_bf16* hi, chatts_bf16* lo, int ld_planes,
                         chatts_stream_t stream);
+/* bf16 [rows, ld] row-major (K % 32 == 0) -> the tiled layout the prefill kernel's LDS-DMA pieces read as consecutive memory:
+ * block (b = row / 16, t = k / 32) is the 1 KB at ((b * K / 32) + t) * 1 KB; inside it the 16-byte chunk at position l (0 .. 63) holds
+ * row 16 b + (l >> 2), K-values 32 t + 8 c .. 32 t + 8 c + 7 with c = (l & 3) ^ ((l >> 5) << 1).  Rows beyond the matrix (the last
+ * block of a ragged row count) repeat the last row.  dst holds chatts_tile_bf16_elems(rows, k) = ceil(rows / 16) * 16 * k elements. */
+size_t chatts_tile_bf16_elems(int rows, int k);
+int chatts_tile_bf16(const chatts_bf16* src, int rows, int k, int ld, chatts_bf16* dst, chatts_stream_t stream);
 /* Dispatch: M == 1       -> weight-streaming GEMV (gemv_ldsx_kernel: exact f32 VALU products, x staged in LDS, HBM-bound);
  *           2 <= M <= 16 -> with pre-split planes: gemm_stream_kernel (W and the A planes staged by whole-line LDS-DMA through a
  *                           4-deep ring, split-K over workgroups); with float32 A: the register-staged gemm_bf16x2_kernel;
@@ -537,6 +550,9 @@ typedef struct ChattsLayerWeights {
   const uint8_t* gate_up4; const float* gate_up4_sz;
   const uint8_t* down4; const float* down4_sz;
   int w4_group;
+  /* optional copies of the four bf16 matrices in the tiled layout of chatts_tile_bf16 (ChattsLinearArgs.w_tiled): the operand feed of the
+   * prefill kernel reads them as consecutive memory; every other kernel keeps streaming the row-major tensors.  NULL = row-major only. */
+  const chatts_bf16* qkv_t; const chatts_bf16* o_t; const chatts_bf16* gate_up_t; const chatts_bf16* down_t;
 } ChattsLayerWeights;
 
 typedef struct ChattsDecoderConfig {

@@ -338,6 +338,66 @@ def test_gemm_dma_single_pass_speed_mode(lib, monkeypatch, epi, m, n, k):
     assert 1e-4 < rel_err(out.cpu().numpy(), want_exact) < 2e-2          # the price of the mode: ~2^-9 per operand
 
 
+def _tile_ref(t):
+    """chatts_tile_bf16's layout restated with torch indexing (include/chatts_amd.h): block (b, t) = 1 KB, chunk position l holds row
+    16 b + (l >> 2), K-chunk (l & 3) ^ ((l >> 5) << 1); rows beyond the matrix repeat the last one."""
+    rows, k = t.shape
+    rb = (rows + 15) // 16
+    idx = torch.clamp(torch.arange(rb * 16, device=t.device), max=rows - 1)
+    x = t[idx].view(rb, 16, k // 32, 4, 8)
+    l = torch.arange(64, device=t.device)
+    return x.permute(0, 2, 1, 3, 4)[:, :, l >> 2, (l & 3) ^ ((l >> 5) << 1), :].reshape(-1)
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("m,n,k", [(96, 256, 64), (130, 416, 1024), (798, 2080, 640), (360, 7168, 5120), (200, 1024, 13824)])
+def test_gemm_ring_on_tiled_operands_is_bitwise_the_row_major_result(lib, epi, m, n, k):
+    """chatts_tile_bf16 + ChattsLinearArgs.w_tiled / planes_tiled: the prefill kernel's LDS-DMA pieces read 1 KB of consecutive memory
+    instead of 16 rows x 64 bytes.  The tiled layout equals its restatement; the products and their order are unchanged, so every output
+    is bit-identical to the row-major call (ragged M and N: the last 16-row block repeats the last row, its outputs are never stored)."""
+    a, w, bias, resid, _ = _rand_problem(m, n, k, seed=m + n + k + epi + 11, scale=3.0)
+    hi, lo = _split_planes(lib, a, None)
+
+    def tile(t):
+        out = torch.empty(int(lib.chatts_tile_bf16_elems(t.shape[0], t.shape[1])), dtype=torch.bfloat16, device=DEV)
+        _lib.check(lib.chatts_tile_bf16(t.data_ptr(), t.shape[0], t.shape[1], t.shape[1], out.data_ptr(), st()))
+        return out
+    wt, hit, lot = tile(w), tile(hi), tile(lo)
+    for src, got in ((w, wt), (hi, hit)):
+        assert torch.equal(_tile_ref(src).view(torch.int16), got.view(torch.int16))
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    wsb = int(lib.chatts_linear_workspace(m, n, k))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    outs = []
+    for mode in range(3):                       # row-major | W tiled | W and planes tiled
+        out = torch.full((m, ncols), float("nan"), dtype=torch.float32, device=DEV)
+        la = _lib.LinearArgs(a=None, w=w.data_ptr(), bias=_lib.ptr(bias), resid=_lib.ptr(resid if epi == _lib.EPI_RESID else None),
+                             c=out.data_ptr(), norm_w=None, norm_eps=0.0, m=m, n=n, k=k, lda=k, ldw=k, ldc=ncols, epilogue=epi,
+                             workspace=ws.data_ptr(), workspace_bytes=wsb, a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=k)
+        if mode >= 1:
+            la.w_tiled = wt.data_ptr()
+        if mode == 2:
+            la.a_hi, la.a_lo, la.planes_tiled = hit.data_ptr(), lot.data_ptr(), 1
+        _lib.check(lib.chatts_linear(la, st()))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert torch.equal(outs[0].view(torch.int32), outs[2].view(torch.int32))
+    assert rel_err(outs[1].cpu().numpy(), _ref_linear(a, w, bias, resid, epi)) < 2e-5
+
+
+def test_tiled_planes_are_refused_outside_the_prefill_kernel(lib):
+    a, w, bias, resid, _ = _rand_problem(8, 256, 256, seed=5, scale=1.0)
+    hi, lo = _split_planes(lib, a, None)
+    out = torch.zeros((8, 256), dtype=torch.float32, device=DEV)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    la = _lib.LinearArgs(a=a.data_ptr(), w=w.data_ptr(), c=out.data_ptr(), m=8, n=256, k=256, lda=256, ldw=256, ldc=256, epilogue=_lib.EPI_NONE,
+                         workspace=ws.data_ptr(), workspace_bytes=ws.numel(), a_hi=hi.data_ptr(), a_lo=lo.data_ptr(), ld_planes=256, planes_tiled=1)
+    assert lib.chatts_linear(la, st()) == _lib.E_SHAPE and b"tiled planes" in lib.chatts_last_error()
+    assert lib.chatts_tile_bf16(w.data_ptr(), 256, 250, 256, out.data_ptr(), st()) == _lib.E_SHAPE
+
+
 @pytest.mark.parametrize("sk", [1, 2, 3])
 @pytest.mark.parametrize("tiles", [0, 1, 3])
 def test_gemm_ring_equals_register_staged_bitwise(lib, sk, tiles, monkeypatch):
