@@ -659,12 +659,13 @@ def main():
     if world > 1 and model._tp is not None and rank == 0 and os.environ.get("CHATTS_BENCH_INJECT_P2P_STALL"):
         # test hook (tools/jobs/tp2_single_device.sh): rank 0 enters a collective alone - it times out and leaves the exchange broken
         model._tp.all_reduce(torch.ones(64, device=device))
-    # the prefill-sized sums release their stores with s_waitcnt vmcnt(0) (uncached exchange buffers) - measured and
-    # parity-tested with every rank on ONE device only.  First contact with real links: if the warm-up tokens differ from the committed
-    # oracle run, every rank switches to the system-scope fence of round 4 (TP_BULK_FENCE=1) and the stage is repeated; the line says so
+    # the release form of the prefill-sized sums is decided per communicator when the exchange is created (P2PExchange.first_contact:
+    # ranks on different devices use the system-scope fence unless >= 64 test sums validated the light form on these links); the line
+    # records that decision.  Second line of defence here: if the warm-up tokens still differ from the committed oracle run under the
+    # light form, every rank switches to the fence and the stage is repeated
     tp_release = None
     if world > 1 and model._tp is not None:
-        tp_release = "fence" if _lib.get_option("TP_BULK_FENCE") == 1 else "light"
+        tp_release = model._tp.release_note or model._tp.bulk_release()
     _, ref_run = parity_reference(args)
     ref_toks = ref_run.get("tokens_oracle") if ref_run else None
     for attempt in range(3):
@@ -712,9 +713,10 @@ def main():
             inject = attempt == 0 and bool(os.environ.get("CHATTS_BENCH_INJECT_RELEASE_MISMATCH"))     # test hook (tools/jobs/r5_tp_self_launch.sh)
             wrong = torch.tensor([float((k > 0 and got[:k] != ref_toks[:k]) or inject)], device=device)
             dist.all_reduce(wrong, op=dist.ReduceOp.MAX)
-            if wrong.item() == 0 or tp_release != "light":
+            if wrong.item() == 0 or model._tp.bulk_release() != "light":
                 break
-            log("[bench] tokens differ from the committed oracle run with the light release of the bulk sums: repeating with TP_BULK_FENCE=1")
+            log("[bench] tokens differ from the committed oracle run with the light release of the bulk sums: repeating with the fence")
+            model._tp.set_bulk_release("fence")
             _lib.set_option("TP_BULK_FENCE", 1)
             tp_release = "fence (the light release gave different tokens on this node)"
             continue

@@ -200,6 +200,10 @@ SIGNATURES = {
     "chatts_tp_rank": (c_int, [c_void_p]),
     "chatts_tp_world": (c_int, [c_void_p]),
     "chatts_tp_max_elems": (c_int64, [c_void_p]),
+    "chatts_tp_cross_device": (c_int, [c_void_p]),
+    "chatts_tp_set_cross_device": (c_int, [c_void_p, c_int]),
+    "chatts_tp_set_bulk_release": (c_int, [c_void_p, c_int]),
+    "chatts_tp_bulk_release": (c_int, [c_void_p]),
     "chatts_tp_status": (c_int, [c_void_p]),
     "chatts_tp_reset": (c_int, [c_void_p, c_void_p]),
     "chatts_tp_flush_epochs": (c_int, [c_void_p, c_void_p]),

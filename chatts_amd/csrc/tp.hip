@@ -358,7 +358,29 @@ struct ChattsTpComm {
   bool ipc = false;
   size_t bytes = 0;
   uint32_t pending = 0;              // collectives issued since the last counter bump (TpParams::idx of the next one)
+  // Release form of the bulk sums (bulk_release()).  The light form - s_waitcnt vmcnt(0) before the flags - has only ever run with every
+  // rank on ONE device; whether a store to a peer's uncached buffer is visible THERE when vmcnt returns is unproven across xGMI / PCIe.
+  // So: peers on other devices (or unknown) => the system-scope fence, until the host has validated the light form on these very
+  // links and says so (chatts_tp_set_bulk_release(c, 0): chatts_amd/tp.py's first-contact test).  The TP_BULK_FENCE option, when set,
+  // overrides both ways (A/B runs).
+  int cross_device = 0;              // some peer buffer lives on another device than ours (or its device could not be determined)
+  int shared_device = 0;             // several ranks' buffers on THIS device, not loop-back: their waiting grids must be resident together
+  int release_mode = -1;             // -1 = by cross_device, 0 = light, 1 = fence
 };
+static int ptr_device(const void* p) {
+  hipPointerAttribute_t a;
+  if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return a.device;
+}
+static void tp_classify_peers(ChattsTpComm* c) {
+  const int mine = ptr_device(c->p.peer[c->p.rank]);
+  for (int r = 0; r < c->p.world; ++r) {
+    if (r == c->p.rank) continue;
+    const int d = ptr_device(c->p.peer[r]);
+    if (mine < 0 || d < 0 || d != mine) c->cross_device = 1;
+    else c->shared_device = 1;
+  }
+}
 
 extern "C" size_t chatts_tp_buffer_bytes(int world, int64_t max_elems) {
   if (world < 1 || world > kMaxWorld || max_elems < 1) return 0;
@@ -488,6 +510,7 @@ extern "C" ChattsTpComm* chatts_tp_init(int rank, int world, void* local_buf, co
     c->opened[r] = ptr;
     c->p.peer[r] = reinterpret_cast<uint64_t*>(ptr);
   }
+  tp_classify_peers(c);
   return c;
 }
 
@@ -500,6 +523,7 @@ extern "C" ChattsTpComm* chatts_tp_init_local(int rank, int world, void* const* 
     c->p.peer[r] = reinterpret_cast<uint64_t*>(bufs[r]);
   }
   tp_bind_local(c, bufs[rank]);
+  tp_classify_peers(c);
   return c;
 }
 
@@ -533,6 +557,25 @@ extern "C" void chatts_tp_destroy(ChattsTpComm* c) {
   delete c;
 }
 
+extern "C" int chatts_tp_cross_device(const ChattsTpComm* c) { return c ? c->cross_device : -1; }
+extern "C" int chatts_tp_set_cross_device(ChattsTpComm* c, int cross) {
+  CHATTS_REQUIRE(c, CHATTS_E_BADARG, "tp_set_cross_device: null comm");
+  c->cross_device = cross ? 1 : 0;
+  return CHATTS_OK;
+}
+extern "C" int chatts_tp_set_bulk_release(ChattsTpComm* c, int mode) {
+  CHATTS_REQUIRE(c && mode >= -1 && mode <= 1, CHATTS_E_BADARG, "tp_set_bulk_release: comm / mode (-1 = by device, 0 = light, 1 = fence)");
+  c->release_mode = mode;
+  return CHATTS_OK;
+}
+// the form the next bulk sum uses: 1 = system-scope fence, 0 = light (drain only)
+extern "C" int chatts_tp_bulk_release(const ChattsTpComm* c) {
+  if (!c) return -1;
+  const int opt = opt_get(OPT_TP_BULK_FENCE, -1);
+  if (opt >= 0) return opt != 0;
+  if (c->release_mode >= 0) return c->release_mode;
+  return c->cross_device && !c->p.loopback;
+}
 extern "C" int chatts_tp_rank(const ChattsTpComm* c) { return c ? c->p.rank : -1; }
 extern "C" int chatts_tp_world(const ChattsTpComm* c) { return c ? c->p.world : -1; }
 extern "C" int64_t chatts_tp_max_elems(const ChattsTpComm* c) { return c ? c->p.max_elems : 0; }
@@ -613,8 +656,10 @@ extern "C" int chatts_allreduce_bulk(ChattsTpComm* c, const float* in, float* x,
   int64_t blocks = (slice + 2047) / 2048;
   // cap 256 with the light release (round 5): W = 8 is flat from 128 to 256 workgroups (38.5 / 38.7 us), W = 2 gains 10 us (51.6 -> 41.6);
   // with the system-scope fence every workgroup costs, and 128 is its minimum (50.4 us against 65.6 at 256)
-  const int light = opt_get(OPT_TP_BULK_FENCE, 0) == 0;
-  const int cap = opt_get(OPT_TP_BULK_BLOCKS, light ? 256 : 128);
+  const int light = chatts_tp_bulk_release(c) == 0;
+  // (several ranks on one device - the emulation every test of this box runs: W waiting grids + a persistent prefill GEMM of one 144 KB
+  //  workgroup per CU must be resident together, 64 workgroups per rank is what fits)
+  const int cap = opt_get(OPT_TP_BULK_BLOCKS, (c->shared_device && !c->p.loopback) ? 64 : (light ? 256 : 128));
   if (blocks > cap) blocks = cap;
   if (blocks > kBulkMaxBlocks) blocks = kBulkMaxBlocks;
   if (blocks < 1) blocks = 1;

@@ -46,8 +46,10 @@ const char* chatts_last_error(void);
  *     environment); ChattsLinearArgs.tile_counters, ChattsDecoderBuffers.tile_counters and CHATTS_TILE_COUNTERS removed (the in-launch
  *     split-K fix-up they served was measured slower twice); chatts_tp_flush_epochs;
  *  9: the f16q operand format of the prefill projections (chatts_split_f16q / chatts_weights_f16q / chatts_rmsnorm_f16q /
- *     chatts_linear_f16q, ChattsLayerWeights.*16 / *q8 / *q8_exp, ChattsDecoderBuffers.planes*_scale, chatts_decoder_set_prefill_f16q);
- *     the tensor-parallel exchange's release form per communicator (chatts_tp_cross_device / chatts_tp_set_bulk_release / chatts_tp_bulk_release). */
+ *     chatts_linear_f16q: an experiment kept for its numbers, NOT a decoder path - DESIGN.md section 14);
+ *     the tensor-parallel exchange's release form per communicator (chatts_tp_cross_device / chatts_tp_set_cross_device /
+ *     chatts_tp_set_bulk_release / chatts_tp_bulk_release); tiled prefill weights (chatts_tile_bf16, ChattsLinearArgs.w_tiled /
+ *     planes_tiled, ChattsLayerWeights.*_t). */
 #define CHATTS_ABI_VERSION 9
 int chatts_abi_version(void);
 /* Number of CUs of the current device (grid sizing), or <0. */
@@ -493,6 +495,24 @@ int64_t chatts_tp_max_elems(const ChattsTpComm*);
 /* diagnostic (synchronises: one hipMemcpy): >= 0 status bits - bit 0 = a peer's contribution did not arrive within ~2 s,
  * the results since then are garbage; call chatts_tp_reset on every rank before re-using the comm */
 int chatts_tp_status(ChattsTpComm*);
+/* Release form of the prefill-sized sums (chatts_allreduce_bulk), per communicator.  Two forms publish a workgroup's stores to its peers:
+ * the system-scope fence (__threadfence_system(), round 4) and the LIGHT form (s_waitcnt vmcnt(0): the exchange buffers are uncached,
+ * round 5: 38.5 vs 50.4 us per sum).  The light form has only ever been exercised with all ranks on one device; that a store has reached
+ * a peer's memory ACROSS a link when vmcnt returns is an unproven assumption, and a reordering there is silent wrong sums.  Hence:
+ *   chatts_tp_cross_device   1 = some peer buffer lives on another device than the local one, or its device could not be determined
+ *                            (hipPointerGetAttributes at init); chatts_tp_set_cross_device lets the host say so itself (it knows the ranks'
+ *                            devices; chatts_amd/tp.py gathers their PCI ids).
+ *   chatts_tp_bulk_release   the form the next sum uses: 1 = fence, 0 = light.  Cross-device communicators use the FENCE unless the host
+ *                            has validated the light form on these very links and called chatts_tp_set_bulk_release(c, 0)
+ *                            (P2PExchange.create's first-contact test: >= 64 sums of a rank-dependent pattern, light == fenced element
+ *                            for element on every rank); same-device and loop-back communicators use the light form.
+ *   chatts_tp_set_bulk_release(c, mode)   -1 = by device (default), 0 = light, 1 = fence.  The TP_BULK_FENCE option, when SET,
+ *                            overrides the communicator's mode either way (A/B runs and tests).  The forms interoperate (same
+ *                            flag protocol: they differ in what precedes a rank's flag stores); the host sets one form on all ranks. */
+int chatts_tp_cross_device(const ChattsTpComm*);
+int chatts_tp_set_cross_device(ChattsTpComm*, int cross);
+int chatts_tp_set_bulk_release(ChattsTpComm*, int mode);
+int chatts_tp_bulk_release(const ChattsTpComm*);
 /* zero the local buffer and the call counter (all ranks, then a host barrier, before re-using a comm after an error) */
 int chatts_tp_reset(ChattsTpComm*, chatts_stream_t stream);
 /* The exchange-carrying projections (ChattsLinearArgs.tp_reduce) do not advance the device-resident call counter themselves: the host
