@@ -302,28 +302,37 @@ class options:
 _ENV_ALIASES = {"bf16x2": 0, "bf16": 1}      # CHATTS_GEMM_PRECISION=bf16
 
 
+_ENV_SET = {}      # option name -> value this module last mirrored from the environment
+
+
 def sync_env():
     """Make the options mirror the process environment: every known option NAME takes the value of CHATTS_<NAME> when that variable is
-    set and goes back to unset otherwise.  Called once by load(); tools that flip os.environ between calls call it again.  This is
-    the ONLY place the environment reaches the library: the C side never calls getenv."""
+    set; an option this function set EARLIER goes back to unset when its variable has disappeared.  Options set programmatically
+    (set_option, e.g. ChatTSForCausalLM(precision='bf16') -> GEMM_PRECISION) are left alone unless their variable is set (ADVICE r5:
+    the earlier form cleared the whole table first).  Called once by load(); tools that flip os.environ between calls call it again.
+    This is the ONLY place the environment reaches the library: the C side never calls getenv."""
     lib = _LIB
     if lib is None:
         return
-    lib.chatts_unset_option(None)
     i = 0
     while True:
         n = lib.chatts_option_name(i)
         if n is None:
             break
         i += 1
-        v = os.environ.get("CHATTS_" + n.decode())
+        name = n.decode()
+        v = os.environ.get("CHATTS_" + name)
         if v is None or v == "":
+            if name in _ENV_SET:
+                del _ENV_SET[name]
+                check(lib.chatts_unset_option(n))
             continue
         try:
             iv = _ENV_ALIASES[v] if v in _ENV_ALIASES else int(v)
         except ValueError:
-            raise RuntimeError(f"CHATTS_{n.decode()}={v!r}: tuning options are integers")
+            raise RuntimeError(f"CHATTS_{name}={v!r}: tuning options are integers")
         check(lib.chatts_set_option(n, iv))
+        _ENV_SET[name] = iv
 
 
 def check(rc):

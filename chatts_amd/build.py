@@ -38,19 +38,37 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link the shared library.  Returns the .so path."""
-    os.makedirs(LIBDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "build.stamp")
-    dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
-        return LIB
+# AddressSanitizer on the HOST half of the library only ("ASan host build of the shim"): argument validation, the
+# options table, error strings, geometry choices, handle bookkeeping - everything the C-ABI does before a kernel is enqueued.  GPU ASan
+# needs xnack+ code objects, which this pool refuses; -fno-gpu-sanitize keeps the device code as shipped.
+ASAN_FLAGS = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fsanitize=address",
+              "-fno-gpu-sanitize", "-shared-libsan", "-fno-omit-frame-pointer"]
+ASAN_LIBDIR = os.path.join(HERE, "lib_asan")
+ASAN_LIB = os.path.join(ASAN_LIBDIR, "libchatts_amd_asan.so")
+
+
+def asan_runtime():
+    """path of the shared ASan runtime of the ROCm clang that compiled the library (to LD_PRELOAD into python)"""
+    import glob
+    c = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return c[-1] if c else None
+
+
+def build(force=False, verbose=False, asan=False):
+    """Compile every HIP source for gfx950 and link the shared library.  Returns the .so path.  asan=True: the host-ASan variant
+    (lib_asan/libchatts_amd_asan.so; load it with CHATTS_AMD_LIB=<path> and LD_PRELOAD=asan_runtime(): tests/test_asan_host.py)."""
+    libdir, lib, flags = (ASAN_LIBDIR, ASAN_LIB, ASAN_FLAGS) if asan else (LIBDIR, LIB, FLAGS)
+    os.makedirs(libdir, exist_ok=True)
+    stamp = os.path.join(libdir, "build.stamp")
+    dig = _digest() + ("/asan" if asan else "")
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return lib
     hipcc = _hipcc()
     objs = []
 
     def compile_one(src):
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(libdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, *flags, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -62,14 +80,16 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-ldl"]
+    if asan:
+        cmd += ["-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     with open(stamp, "w") as f:
         f.write(dig)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv))

@@ -18,23 +18,18 @@ void set_error(const char* fmt, ...) {
 
 // tuning options: see common.h.  Plain ints behind relaxed atomics: a host thread may set one while another enqueues (a torn
 // read is impossible; which value a concurrent call sees is the caller's business).
-static const int kOptUnset = -2147483647 - 1;
-static int g_opts[OPT_COUNT];
-static bool g_opts_ready = false;
+// Encoding: 0 = unset (the zero-initialised state: no lazy initialisation, nothing for two first callers to race on - ADVICE r5), otherwise
+// bit 32 set and the value in the low 32 bits.
+static long long g_opts[OPT_COUNT];
+static inline long long opt_pack(int v) { return (1LL << 32) | (long long)(unsigned)v; }
 static const char* const g_opt_names[OPT_COUNT] = {
 #define CHATTS_OPT_NAME(name) #name,
     CHATTS_OPTIONS(CHATTS_OPT_NAME)
 #undef CHATTS_OPT_NAME
 };
-static void opts_init() {
-  if (__atomic_load_n(&g_opts_ready, __ATOMIC_ACQUIRE)) return;
-  for (int i = 0; i < OPT_COUNT; ++i) __atomic_store_n(&g_opts[i], kOptUnset, __ATOMIC_RELAXED);
-  __atomic_store_n(&g_opts_ready, true, __ATOMIC_RELEASE);
-}
 int opt_get(ChattsOpt o, int dflt) {
-  if (!__atomic_load_n(&g_opts_ready, __ATOMIC_ACQUIRE)) return dflt;
-  const int v = __atomic_load_n(&g_opts[o], __ATOMIC_RELAXED);
-  return v == kOptUnset ? dflt : v;
+  const long long v = __atomic_load_n(&g_opts[o], __ATOMIC_RELAXED);
+  return v == 0 ? dflt : (int)(unsigned)(v & 0xffffffffLL);
 }
 
 // roctx ranges (see common.h): resolved once; a missing library leaves both pointers null
@@ -127,29 +122,25 @@ static int opt_index(const char* name) {
 extern "C" int chatts_set_option(const char* name, int value) {
   const int i = opt_index(name);
   CHATTS_REQUIRE(i >= 0, CHATTS_E_BADARG, "set_option: unknown option '%s'", name ? name : "(null)");
-  opts_init();
-  __atomic_store_n(&g_opts[i], value, __ATOMIC_RELAXED);
+  __atomic_store_n(&g_opts[i], opt_pack(value), __ATOMIC_RELAXED);
   return CHATTS_OK;
 }
 extern "C" int chatts_unset_option(const char* name) {
   if (name == nullptr) {      // all of them
-    opts_init();
-    for (int i = 0; i < OPT_COUNT; ++i) __atomic_store_n(&g_opts[i], kOptUnset, __ATOMIC_RELAXED);
+      for (int i = 0; i < OPT_COUNT; ++i) __atomic_store_n(&g_opts[i], 0LL, __ATOMIC_RELAXED);
     return CHATTS_OK;
   }
   const int i = opt_index(name);
   CHATTS_REQUIRE(i >= 0, CHATTS_E_BADARG, "unset_option: unknown option '%s'", name);
-  opts_init();
-  __atomic_store_n(&g_opts[i], kOptUnset, __ATOMIC_RELAXED);
+  __atomic_store_n(&g_opts[i], 0LL, __ATOMIC_RELAXED);
   return CHATTS_OK;
 }
 extern "C" int chatts_get_option(const char* name, int* value, int* is_set) {
   const int i = opt_index(name);
   CHATTS_REQUIRE(i >= 0 && value, CHATTS_E_BADARG, "get_option: unknown option '%s'", name ? name : "(null)");
-  opts_init();
-  const int v = __atomic_load_n(&g_opts[i], __ATOMIC_RELAXED);
-  *value = v == kOptUnset ? 0 : v;
-  if (is_set) *is_set = v != kOptUnset;
+  const long long v = __atomic_load_n(&g_opts[i], __ATOMIC_RELAXED);
+  *value = v == 0 ? 0 : (int)(unsigned)(v & 0xffffffffLL);
+  if (is_set) *is_set = v != 0;
   return CHATTS_OK;
 }
 extern "C" const char* chatts_option_name(int index) { return index >= 0 && index < OPT_COUNT ? g_opt_names[index] : nullptr; }

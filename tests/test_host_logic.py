@@ -231,6 +231,16 @@ def test_tuning_options_table_set_get_unset_and_the_environment_mirror(monkeypat
         assert _lib.get_option("TP_BULK_BLOCKS") == 64 and _lib.get_option("GEMM_PRECISION") == 1
         monkeypatch.delenv("CHATTS_TP_BULK_BLOCKS")
         assert _lib.get_option("TP_BULK_BLOCKS") is None
+        # ... and leaves options set programmatically alone (a model built with precision='bf16' keeps GEMM_PRECISION across a later
+        # sync_env), while an option it mirrored itself follows its variable back to unset
+        monkeypatch.delenv("CHATTS_GEMM_PRECISION")
+        assert _lib.get_option("GEMM_PRECISION") is None
+        _lib.set_option("ATTN_ROWS", 1)
+        monkeypatch.setenv("CHATTS_GEMM_T", "5")
+        assert _lib.get_option("ATTN_ROWS") == 1 and _lib.get_option("GEMM_T") == 5
+        monkeypatch.delenv("CHATTS_GEMM_T")
+        assert _lib.get_option("ATTN_ROWS") == 1 and _lib.get_option("GEMM_T") is None
+        _lib.set_option("ATTN_ROWS", None)
         monkeypatch.setenv("CHATTS_GEMM_SK", "three")
     except RuntimeError as e:
         assert "integers" in str(e)
@@ -239,3 +249,26 @@ def test_tuning_options_table_set_get_unset_and_the_environment_mirror(monkeypat
         raise AssertionError("a non-integer option value must be refused")
     finally:
         lib.chatts_unset_option(None)
+
+
+def test_c_abi_argument_validation_needs_no_gpu():
+    """Everything the C-ABI checks BEFORE it enqueues a kernel is host code: null / mis-shaped arguments come back as error codes with a
+    message, size queries are pure functions.  (Also what tests/test_asan_host.py drives under the host-AddressSanitizer build.)"""
+    lib = _lib.load()
+    la = _lib.LinearArgs()
+    assert lib.chatts_linear(None, None) == _lib.E_BADARG and b"linear" in lib.chatts_last_error()
+    la.m, la.n, la.k = 4, 0, 64
+    assert lib.chatts_linear(ctypes.byref(la), None) < 0
+    assert lib.chatts_tile_bf16_elems(798, 5120) == 800 * 5120 and lib.chatts_tile_bf16_elems(0, 64) == 0
+    assert lib.chatts_tile_bf16(None, 16, 60, 64, None, None) == _lib.E_SHAPE
+    assert lib.chatts_tile_bf16(None, 16, 64, 64, None, None) == _lib.E_BADARG
+    assert lib.chatts_tile_bf16(None, 0, 64, 64, None, None) == 0                        # empty input: nothing to do
+    assert lib.chatts_linear_f16q(None, None) == _lib.E_BADARG
+    assert lib.chatts_split_f16q(None, 4, 100, 100, None, None, None, 100, 1, None) == _lib.E_SHAPE
+    assert lib.chatts_tp_buffer_bytes(9, 1024) == 0 and lib.chatts_tp_buffer_bytes(2, 1024) == 2 * 2 * 1024 * 8 + 256
+    assert lib.chatts_tp_buffer_bytes_bulk(2, 1024, 4096) > lib.chatts_tp_buffer_bytes(2, 1024)
+    assert lib.chatts_tp_bulk_release(None) == -1 and lib.chatts_tp_cross_device(None) == -1
+    assert lib.chatts_tp_set_bulk_release(None, 0) == _lib.E_BADARG and b"tp_set_bulk_release" in lib.chatts_last_error()
+    assert lib.chatts_tp_init(0, 2, None, None, 0, 64) is None and b"tp_init" in lib.chatts_last_error()
+    assert lib.chatts_tp_rank(None) == -1 and lib.chatts_tp_pending(None) == 0
+    assert lib.chatts_option_name(10 ** 6) is None and lib.chatts_option_name(-1) is None
