@@ -854,9 +854,6 @@ static int check_ring_operands(const ChattsLinearArgs* a) {
 }
 static void pick_ring(int m, int n, int k, RingGeom& g) {
   ring_pick(m, n, k, device_cus(), opt_get(OPT_GEMM_T, 0), opt_get(OPT_GEMM_SK, 0), g);
-#ifdef CHATTS_GEMM_PROBE
-  g.ablate = opt_get(OPT_GEMM_ABLATE, 0);
-#endif
 }
 
 // Streaming kernel (2 <= M <= 16 with planes): split-K so that ~2 workgroups per CU are busy, >= 4 K-steps per split.

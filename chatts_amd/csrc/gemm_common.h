@@ -46,7 +46,6 @@ struct RingGeom {
   int F, P;           // 16-row fragments of M, W panels
   int units;          // T * P * sk, ordered (split, panel, M-tile): the M-tiles of a panel are adjacent
   int wpx;            // workgroups per XCD (grid = 8 * wpx)
-  int ablate;         // diagnostic builds (-DCHATTS_GEMM_PROBE) only: 1 = no LDS-DMA, 2 = no fragment reads in the loop, 4 = no MFMAs
 };
 void ring_pick(int m, int n, int k, int cus, int force_t, int force_sk, RingGeom& g);
 int launch_ring(const GemmParams& p, const uint16_t* a_hi, const uint16_t* a_lo, int ldp, const RingGeom& g, bool single, hipStream_t s);

@@ -637,7 +637,6 @@ void f16q_pick(int m, int n, int k, int cus, int force_t, int force_sk, RingGeom
   int wpx = (g.units + 7) / 8;
   if (wpx > slots / 8) wpx = slots / 8;
   g.wpx = wpx;
-  g.ablate = 0;
 }
 
 int launch_f16q(const F16qGemm& q, const RingGeom& g, hipStream_t s) {

@@ -203,7 +203,7 @@ def test_tuning_options_table_set_get_unset_and_the_environment_mirror(monkeypat
     hdr = open(os.path.join(ROOT, "include", "chatts_amd.h")).read()
     doc = hdr[hdr.index("Names (a leading"):hdr.index("int chatts_set_option")]
     documented = set(re.findall(r"\b([A-Z][A-Z0-9]*(?:_[A-Z0-9]+)+)\b", doc)) - {"CHATTS_", "DESIGN"}
-    probes = {"GEMM_ABLATE"}                                   # diagnostic builds only (tools/build_variant.py probe)
+    probes = set()                                             # (the prefill kernel's ablation switch left the table with its probe: tools/probes/gemm_ring_probe.hip)
     assert documented - {"CHATTS_"} <= set(names), documented - set(names)
     assert set(names) - documented <= probes, set(names) - documented
     design = open(os.path.join(ROOT, "DESIGN.md")).read()

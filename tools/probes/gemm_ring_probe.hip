@@ -1,3 +1,7 @@
+// gemm_ring_probe.hip - DIAGNOSTIC VARIANT of chatts_amd/csrc/gemm_ring.hip (not part of the shipped library): the same kernel with the
+// timeline probe and the ablation switches compiled in.  Built by `python tools/build_variant.py probe --replace gemm_ring.hip=tools/probes/gemm_ring_probe.hip`
+// and driven by tools/ring_probe.py (chatts_debug_ring_probe reads the records, chatts_debug_ring_ablate selects an ablation).  Keep in step
+// with the shipped kernel by hand when that changes.
 // gemm_ring.hip - the prefill projection (M >= 96 rows on pre-split bf16 hi / lo planes of A):  C = epilogue(A . W^T), bf16x2.
 // Round 5 rebuild of the LDS-DMA kernel (gemm_dma_kernel, round 1-4).  What the round-5 timeline probe of that kernel showed
 // (tools/gemm_probe.py, profiles/r5_gemm_probe_before.txt) and what this kernel does about it:
@@ -24,6 +28,7 @@
 // chunk c of row r lives at chunk c ^ (((r >> 3) & 1) << 1) (conflict-free for the ds_read_b128 fragment reads; applied on the SOURCE
 // side of the DMA: lane l of a 16-row piece fetches global chunk (l & 3) ^ ((l >> 5) << 1)).
 // Same products and the same per-element summation order over K as the kernels in gemm.hip at equal split-K.
+#define CHATTS_GEMM_PROBE 1
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -39,10 +44,28 @@ constexpr int kRingLds = kRingSlots * kRingHalf;             // 144 KB
 constexpr int kRingThreads = 768, kRingCompute = 8, kRingLoaders = 4;
 
 
+// ---- timeline probe (diagnostic builds only: -DCHATTS_GEMM_PROBE; read by tools/gemm_probe.py through chatts_debug_ring_probe) ---------
+// One 16-word record per workgroup.  Compute wave 0: [0] entry, [1] exit (100 MHz realtime), [2] shader cycles entry -> exit, [3] cycles
+// parked at the half-step barriers, [4] cycles in the epilogues, [5] units << 32 | half-steps, [6] CU id.  Loader wave 0: [8] cycles
+// waiting for its own pieces (vmcnt), [9] cycles parked at barriers, [10] cycles issuing, [11] entry, [12] half-stage 0 landed.
+#ifdef CHATTS_GEMM_PROBE
+constexpr int kRingProbeRecs = 4096;
+__device__ unsigned long long g_ring_probe[kRingProbeRecs * 16];
+#define RPROBE_CLK() __builtin_amdgcn_s_memtime()
+#define RPROBE_RT() __builtin_amdgcn_s_memrealtime()
+#define RPROBE_ADD(var, t0) do { (var) += RPROBE_CLK() - (t0); } while (0)
+#define RABLATE(bit) (ablate & (bit))
+#else
+#define RABLATE(bit) 0
+#define RPROBE_CLK() 0ull
+#define RPROBE_RT() 0ull
+#define RPROBE_ADD(var, t0) do { (void)(t0); } while (0)
+#endif
+
 // SINGLE: the "bf16" speed mode - the lo plane is neither staged nor multiplied (activations rounded to bf16: NOT parity grade)
 template <bool SINGLE>
 __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, const uint16_t* __restrict__ a_hi,
-                                                                 const uint16_t* __restrict__ a_lo, int ldp, RingGeom g) {
+                                                                 const uint16_t* __restrict__ a_lo, int ldp, RingGeom g, int ablate) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,7 +137,7 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
       const size_t koffw = (size_t)hh * wstep, koffa = (size_t)hh * astep;
 #pragma unroll
       for (int h = 0; h < 9; ++h)
-        if (h < np) __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + (h < 4 ? koffw : koffa)), (lptr_t)(base + dst[h]), 16, 0, 0);
+        if (h < np && !RABLATE(1)) __builtin_amdgcn_global_load_lds((gptr_t)(src[h] + (h < 4 ? koffw : koffa)), (lptr_t)(base + dst[h]), 16, 0, 0);
       const int n = np;
       ++gi;
       if (++hh == nh_cur) {
@@ -124,25 +147,43 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
       }
       return n;
     };
+    unsigned long long pr_wait = 0, pr_bar = 0, pr_iss = 0, pr_t;
+    const unsigned long long pr_entry = RPROBE_RT();
     setup(u0);
     issue();
     int q1 = issue(), q2 = issue();
     ring_wait_vmcnt(q1 + q2);                                  // half-stage 0 landed
+    const unsigned long long pr_land = RPROBE_RT();
     __builtin_amdgcn_s_barrier();                              // ... published
     int q3 = issue();                                          // (slot 3 has never been read)
     for (int gh = 0; gh < G; ++gh) {
+      pr_t = RPROBE_CLK();
       ring_wait_vmcnt(q2 + q3);                                // half-stage gh + 1 landed; gh + 2, gh + 3 stay in flight
+      RPROBE_ADD(pr_wait, pr_t);
+      pr_t = RPROBE_CLK();
       __builtin_amdgcn_s_barrier();                            // publishes it; every read of half-stage gh has returned
+      RPROBE_ADD(pr_bar, pr_t);
+      pr_t = RPROBE_CLK();
       const int q4 = issue();                                  // gh + 4 -> the slot of gh
+      RPROBE_ADD(pr_iss, pr_t);
       q1 = q2; q2 = q3; q3 = q4;
     }
     (void)q1;
+#ifdef CHATTS_GEMM_PROBE
+    if (L == 0 && lane == 0 && blockIdx.x < kRingProbeRecs) {
+      unsigned long long* rec = g_ring_probe + (size_t)blockIdx.x * 16;
+      rec[8] = pr_wait; rec[9] = pr_bar; rec[10] = pr_iss; rec[11] = pr_entry; rec[12] = pr_land;
+    }
+#endif
     return;
   }
 
   // ---- compute wave (wm, wn): wave row wm holds f0 (wm = 0) or f - f0 fragments of the tile, 64 columns wn * 64 ..
   const int wm = wave >> 2, wn = wave & 3;
   const int lane_off = (lane & 15) * 64 + ((((lane >> 4) ^ (((lane >> 3) & 1) << 1))) << 4);      // byte offset of this lane's chunk in a 16-row block
+  unsigned long long pc_bar = 0, pc_epi = 0, pc_t;
+  const unsigned long long pc_entry = RPROBE_RT(), pc_clk0 = RPROBE_CLK();
+  int pc_units = 0;
   __builtin_amdgcn_s_barrier();                                // half-stage 0 published
   int gh = 0;
   for (int u = u0; u < uend; u += ustep) {
@@ -174,6 +215,7 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
         for (int i = 0; i < FML; ++i) dst[i] = *reinterpret_cast<const bf16x8_t*>(base + plane * kRingAPlane + a_off + i * 1024);
       };
       auto sweep = [&](const bf16x8_t (&af)[FML], const bf16x8_t (&wfr)[4]) {      // D = W . A^T: operands swapped
+        if (RABLATE(4)) return;
 #pragma unroll
         for (int i = 0; i < FML; ++i)
 #pragma unroll
@@ -185,8 +227,10 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
         if constexpr (!SINGLE) sweep(alo, wcur);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every fragment read of half-stage h has returned
+        pc_t = RPROBE_CLK();
         __builtin_amdgcn_s_barrier();                          // h + 1 is published; the loaders refill the slot of h
-        if (more) {
+        RPROBE_ADD(pc_bar, pc_t);
+        if (more && !RABLATE(2)) {
           const char* nb = slot(h + 1);
           read_w(nb, wnxt);
           if constexpr (!SINGLE) read_a(nb, 1, alo);
@@ -194,7 +238,7 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
         __builtin_amdgcn_sched_barrier(0);
         sweep(ahi, wcur);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) read_a(slot(h + 1), 0, ahi);
+        if (more && !RABLATE(2)) read_a(slot(h + 1), 0, ahi);
       };
       {
         const char* b0 = slot(0);
@@ -220,6 +264,8 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
     }
     gh += r.nh;
 
+    pc_t = RPROBE_CLK();
+    ++pc_units;
     const int tok0 = r.m0 + rowblk * 16, fb0 = r.panel * kRingBN + wn * 64;
     const bool planes = p.c_hi != nullptr;
     if (!p.direct) ring_store<kStRaw, false>(p, acc, fml, tok0, fb0, lane, r.split);
@@ -236,7 +282,16 @@ __global__ __launch_bounds__(kRingThreads) void gemm_ring_kernel(GemmParams p, c
       if (planes) ring_store<kStNone, true>(p, acc, fml, tok0, fb0, lane, 0);
       else ring_store<kStNone, false>(p, acc, fml, tok0, fb0, lane, 0);
     }
+    RPROBE_ADD(pc_epi, pc_t);
   }
+#ifdef CHATTS_GEMM_PROBE
+  if (wave == 0 && lane == 0 && blockIdx.x < kRingProbeRecs) {
+    unsigned long long* rec = g_ring_probe + (size_t)blockIdx.x * 16;
+    rec[0] = pc_entry; rec[1] = RPROBE_RT(); rec[2] = RPROBE_CLK() - pc_clk0; rec[3] = pc_bar; rec[4] = pc_epi;
+    rec[5] = ((unsigned long long)pc_units << 32) | (unsigned)G;
+    rec[6] = (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15ull) << 16) | ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xffffu);
+  }
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
@@ -275,6 +330,7 @@ void ring_pick(int m, int n, int k, int cus, int force_t, int force_sk, RingGeom
   g.wpx = wpx;
 }
 
+static int g_ring_ablate = 0;      // 1 = no LDS-DMA, 2 = no fragment reads in the loop, 4 = no MFMAs (timing only)
 template <bool SINGLE>
 static int launch_ring_t(const GemmParams& p, const uint16_t* a_hi, const uint16_t* a_lo, int ldp, const RingGeom& g, hipStream_t s) {
   static bool configured = false;     // > 64 KB of dynamic LDS must be opted into once
@@ -284,7 +340,7 @@ static int launch_ring_t(const GemmParams& p, const uint16_t* a_hi, const uint16
     CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "gemm_ring: cannot reserve %d bytes of LDS: %s", kRingLds, hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL(gemm_ring_kernel<SINGLE>, dim3(8 * g.wpx), dim3(kRingThreads), kRingLds, s, p, a_hi, a_lo, ldp, g);
+  hipLaunchKernelGGL(gemm_ring_kernel<SINGLE>, dim3(8 * g.wpx), dim3(kRingThreads), kRingLds, s, p, a_hi, a_lo, ldp, g, g_ring_ablate);
   return CHATTS_OK;
 }
 int launch_ring(const GemmParams& p, const uint16_t* a_hi, const uint16_t* a_lo, int ldp, const RingGeom& g, bool single, hipStream_t s) {
@@ -324,3 +380,16 @@ extern "C" int chatts_tile_bf16(const chatts_bf16* src, int rows, int k, int ld,
   return CHATTS_OK;
 }
 
+extern "C" int chatts_debug_ring_ablate(int bits) { chatts::g_ring_ablate = bits; return CHATTS_OK; }
+#ifdef CHATTS_GEMM_PROBE
+// diagnostic builds only (not in include/chatts_amd.h): copy the ring kernel's probe records to the host and clear them
+extern "C" int chatts_debug_ring_probe(void* dst, size_t bytes) {
+  const size_t all = sizeof(unsigned long long) * chatts::kRingProbeRecs * 16;
+  if (bytes > all) bytes = all;
+  if (hipDeviceSynchronize() != hipSuccess) return CHATTS_E_LAUNCH;
+  if (dst && hipMemcpyFromSymbol(dst, HIP_SYMBOL(chatts::g_ring_probe), bytes) != hipSuccess) return CHATTS_E_LAUNCH;
+  void* sym = nullptr;
+  if (hipGetSymbolAddress(&sym, HIP_SYMBOL(chatts::g_ring_probe)) != hipSuccess || hipMemset(sym, 0, all) != hipSuccess) return CHATTS_E_LAUNCH;
+  return CHATTS_OK;
+}
+#endif

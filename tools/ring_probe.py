@@ -15,6 +15,8 @@ from chatts_amd import _lib  # noqa: E402
 lib = _lib.load()
 lib.chatts_debug_ring_probe.restype = C.c_int
 lib.chatts_debug_ring_probe.argtypes = [C.c_void_p, C.c_size_t]
+lib.chatts_debug_ring_ablate.restype = C.c_int
+lib.chatts_debug_ring_ablate.argtypes = [C.c_int]
 DEV = "cuda"
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 798
 SHAPES = {"qkv": (7168, 5120, _lib.EPI_NONE), "o": (5120, 5120, _lib.EPI_RESID), "gate_up": (27648, 5120, _lib.EPI_SWIGLU),
@@ -40,8 +42,9 @@ for name, (n, k, epi) in SHAPES.items():
         for kk in list(os.environ):
             if kk.startswith("CHATTS_GEMM_"):
                 del os.environ[kk]
-        os.environ.update({"CHATTS_GEMM_" + a: str(b) for a, b in env.items()})
+        os.environ.update({"CHATTS_GEMM_" + a: str(b) for a, b in env.items() if a != "ABLATE"})
         _lib.sync_env()
+        lib.chatts_debug_ring_ablate(int(env.get("ABLATE", 0)))
         w = (torch.randn((n, k), device=DEV) * 0.02).to(torch.bfloat16)
         a = torch.randn((M, k), device=DEV)
         hi = a.to(torch.bfloat16)
