@@ -262,7 +262,10 @@ void ring_pick(int m, int n, int k, int cus, int force_t, int force_sk, RingGeom
       const long long rounds = (units + slots - 1) / slots;
       const int steps = (nk + sk - 1) / sk;
       double t = (double)rounds * (steps * step + 9000.0);
-      if (sk > 1) t += 12000.0 + (double)(sk + 2) * m * n * 4.0 / 2500.0;
+      // split-K epilogue: <= 4 slabs take the all-round-trips-at-once form (splitk_epilogue_norm_reg_kernel), more the row-walking one -
+      // measured at down_proj, M = 798 (profiles/r6_ring_geometry_sweep.txt): (T, sk) = (6, 2) 210 us against 224-227 for the (5, 5) the
+      // flat estimate used to pick
+      if (sk > 1) t += sk <= 4 ? 12000.0 + (double)(sk + 2) * m * n * 4.0 / 2500.0 : 24000.0 + (double)(sk + 2) * m * n * 4.0 / 1800.0;
       if (t < best) { best = t; bt = T; bs = sk; }
     }
   }

@@ -19,6 +19,8 @@ M = int(args[0]) if len(args) > 0 else 798
 R = int(args[1]) if len(args) > 1 else 7
 SHAPES = {"qkv": (7168, 5120, _lib.EPI_NONE), "o": (5120, 5120, _lib.EPI_RESID), "gate_up": (27648, 5120, _lib.EPI_SWIGLU),
           "down": (5120, 13824, _lib.EPI_RESID)}
+if os.environ.get("TILED_SHAPES"):
+    SHAPES = {k: v for k, v in SHAPES.items() if k in os.environ["TILED_SHAPES"].split(",")}
 torch.manual_seed(0)
 
 
