@@ -587,15 +587,22 @@ static void launch4_norm(const GemvParams& p, bool norm, int blocks, int threads
   else hipLaunchKernelGGL((gemv4_ldsx_kernel<2, 4, EPI, false>), dim3(blocks), dim3(threads), lds, s, p);
 }
 
-template <int EPI>
-static void launch8_norm(const GemvParams& p, bool norm, int blocks, int threads, size_t lds, hipStream_t s) {
+template <int ROWS, int UNR, int EPI>
+static void launch8_ru(const GemvParams& p, bool norm, int blocks, int threads, size_t lds, hipStream_t s) {
   if (p.w8_format == CHATTS_W8_INT8) {
-    if (norm) hipLaunchKernelGGL((gemv8_ldsx_kernel<2, 2, EPI, true, true>), dim3(blocks), dim3(threads), lds, s, p);
-    else hipLaunchKernelGGL((gemv8_ldsx_kernel<2, 2, EPI, false, true>), dim3(blocks), dim3(threads), lds, s, p);
+    if (norm) hipLaunchKernelGGL((gemv8_ldsx_kernel<ROWS, UNR, EPI, true, true>), dim3(blocks), dim3(threads), lds, s, p);
+    else hipLaunchKernelGGL((gemv8_ldsx_kernel<ROWS, UNR, EPI, false, true>), dim3(blocks), dim3(threads), lds, s, p);
     return;
   }
-  if (norm) hipLaunchKernelGGL((gemv8_ldsx_kernel<2, 2, EPI, true>), dim3(blocks), dim3(threads), lds, s, p);
-  else hipLaunchKernelGGL((gemv8_ldsx_kernel<2, 2, EPI, false>), dim3(blocks), dim3(threads), lds, s, p);
+  if (norm) hipLaunchKernelGGL((gemv8_ldsx_kernel<ROWS, UNR, EPI, true>), dim3(blocks), dim3(threads), lds, s, p);
+  else hipLaunchKernelGGL((gemv8_ldsx_kernel<ROWS, UNR, EPI, false>), dim3(blocks), dim3(threads), lds, s, p);
+}
+template <int EPI>
+static void launch8_norm(const GemvParams& p, bool norm, int rows, int unr, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (rows == 4 && unr == 2) launch8_ru<4, 2, EPI>(p, norm, blocks, threads, lds, s);
+  else if (rows == 4) launch8_ru<4, 1, EPI>(p, norm, blocks, threads, lds, s);
+  else if (unr == 4) launch8_ru<2, 4, EPI>(p, norm, blocks, threads, lds, s);
+  else launch8_ru<2, 2, EPI>(p, norm, blocks, threads, lds, s);
 }
 
 // Waves per workgroup (and workgroups per CU, 0 = whatever fits) of the bf16 GEMV for a shape: the sweep results of
@@ -722,20 +729,36 @@ int launch_gemv(const ChattsLinearArgs* a, hipStream_t s) {
     CHATTS_CHECK_LAUNCH("gemv4_ldsx");
     return CHATTS_OK;
   }
-  if (a->w8 != nullptr) {                       // fp8 weights: 2 rows x 2 chunks of 1024 elements in flight
+  if (a->w8 != nullptr) {                       // 8-bit weights: rows x chunks of 1024 elements in flight per lane (GEMV8_ROWS x GEMV8_UNR)
     const int nchunks8 = (a->k + 1023) / 1024;
     const size_t lds8 = (size_t)nchunks8 * 1024 * 4 + 64 * 4;
-    p.tasks = (units + (swiglu ? 1 : 2) - 1) / (swiglu ? 1 : 2);
-    int blocks8 = (p.tasks + nw - 1) / nw;
-    if (blocks8 > cus * occ) blocks8 = cus * occ;
+    // per shape (kernel trace of the fp8 bench under each geometry, profiles/r6_gemv8_geometry.txt): the vocabulary projection wants 4 rows x 2
+    // chunks in flight (778 MB: 144.8 -> 125.0 us), gate_up 4 rows x 1 (27.8 -> 26.9 us); the shorter launches keep 2 x 2 (4 rows halve
+    // their task count: o / down 11.8 -> 14.5 us, qkv 10.3 -> 13.1)
+    const int rows_auto = (units >= 65536 || (swiglu && a->n >= 16384)) ? 4 : 2, unr_auto = swiglu && a->n >= 16384 ? 1 : 2;
+    int rows8 = opt_get(OPT_GEMV8_ROWS, rows_auto), unr8 = opt_get(OPT_GEMV8_UNR, unr_auto);
+    if (rows8 != 4 || a->tp_reduce) rows8 = 2;          // (the exchange-carrying form pushes 2 rows per task: tp_push_task's lane map)
+    if (rows8 == 4) unr8 = unr8 == 2 ? 2 : 1;
+    else if (unr8 != 4) unr8 = 2;
+    const int upt8 = swiglu ? rows8 / 2 : rows8;
+    p.tasks = (units + upt8 - 1) / upt8;
+    const int nw8 = opt_get(OPT_GEMV8_NW, nw);
+    int occ8 = (int)((150 * 1024) / lds8);
+    if (occ8 > 32 / nw8) occ8 = 32 / nw8;
+    if (occ_auto && occ8 > occ_auto) occ8 = occ_auto;
+    if (occ8 < 1) occ8 = 1;
+    occ8 = opt_get(OPT_GEMV8_OCC, opt_get(OPT_GEMV_OCC, occ8));
+    int blocks8 = (p.tasks + nw8 - 1) / nw8;
+    if (blocks8 > cus * occ8) blocks8 = cus * occ8;
     if (a->tp_reduce) { const int cap = opt_get(OPT_TP_FUSE_BLOCKS, 0); if (cap > 0 && blocks8 > cap) blocks8 = cap; }
     if (blocks8 < 1) blocks8 = 1;
+    const int threads8 = (nw8 >= 1 && nw8 <= 16 ? nw8 : nw) * 64;
     if (a->tp_reduce) p.tp = tp_issue(a->tp_reduce, false);      // (after the last check that can refuse the call: one issue per launch)
     switch (epilogue) {
-      case kEpiResidTp: launch8_norm<kEpiResidTp>(p, false, blocks8, threads, lds8, s); break;
-      case CHATTS_EPI_RESID: launch8_norm<CHATTS_EPI_RESID>(p, norm, blocks8, threads, lds8, s); break;
-      case CHATTS_EPI_SWIGLU: launch8_norm<CHATTS_EPI_SWIGLU>(p, norm, blocks8, threads, lds8, s); break;
-      default: launch8_norm<CHATTS_EPI_NONE>(p, norm, blocks8, threads, lds8, s); break;
+      case kEpiResidTp: launch8_norm<kEpiResidTp>(p, false, rows8, unr8, blocks8, threads8, lds8, s); break;
+      case CHATTS_EPI_RESID: launch8_norm<CHATTS_EPI_RESID>(p, norm, rows8, unr8, blocks8, threads8, lds8, s); break;
+      case CHATTS_EPI_SWIGLU: launch8_norm<CHATTS_EPI_SWIGLU>(p, norm, rows8, unr8, blocks8, threads8, lds8, s); break;
+      default: launch8_norm<CHATTS_EPI_NONE>(p, norm, rows8, unr8, blocks8, threads8, lds8, s); break;
     }
     CHATTS_CHECK_LAUNCH("gemv8_ldsx");
     return CHATTS_OK;

@@ -850,6 +850,35 @@ def test_gemv_fp8_weights_parity(lib, epi, norm, n, k):
     assert rel_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_RESID, _lib.EPI_SWIGLU])
+@pytest.mark.parametrize("n,k", [(1008, 5120), (27648, 5120), (624, 13824)])
+def test_gemv_8bit_geometries_are_bitwise_the_same_sum(lib, monkeypatch, epi, n, k):
+    """GEMV8_ROWS x GEMV8_UNR (rows x 1024-element chunks in flight per lane; per-shape defaults: lm_head 4 x 2, gate_up 4 x 1, else 2 x 2,
+    DESIGN.md 14.5): a row is summed by one wave in the same lane and chunk order whatever the geometry - every form gives the same bits."""
+    from chatts_amd.modeling import quantize_fp8_rows
+    if epi == _lib.EPI_SWIGLU:
+        n = n // 32 * 32
+    a, w, bias, resid, nw = _rand_problem(1, n, k, seed=n + k + epi + 3)
+    q, scale, deq = quantize_fp8_rows(w)
+    ncols = n // 2 if epi == _lib.EPI_SWIGLU else n
+    outs = {}
+    for rows, unr in ((0, 0), (2, 2), (4, 2), (4, 1), (2, 4)):
+        if rows:
+            monkeypatch.setenv("CHATTS_GEMV8_ROWS", str(rows))
+            monkeypatch.setenv("CHATTS_GEMV8_UNR", str(unr))
+        out = torch.full((1, ncols), float("nan"), device=DEV)
+        la = _lib.LinearArgs(a=a.data_ptr(), w=deq.data_ptr(), bias=bias.data_ptr(), resid=resid.data_ptr() if epi == _lib.EPI_RESID else None,
+                             c=out.data_ptr(), norm_w=nw.data_ptr(), norm_eps=1e-6, m=1, n=n, k=k, lda=k, ldw=k, ldc=ncols, epilogue=epi,
+                             workspace=None, workspace_bytes=0, w8=q.data_ptr(), w8_scale=scale.data_ptr(), ldw8=k)
+        _lib.check(lib.chatts_linear(la, st()))
+        torch.cuda.synchronize()
+        outs[(rows, unr)] = out
+    ref = outs[(2, 2)]
+    assert not torch.isnan(ref).any() and rel_err(ref.cpu().numpy(), _ref_linear(a, deq, bias, resid, epi, nw)) < 2e-5
+    for key, out in outs.items():
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), key
+
+
 @pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RESID, _lib.EPI_SWIGLU])
 @pytest.mark.parametrize("m,n,k", [(2, 256, 64), (16, 5120, 5120), (33, 1024, 512), (200, 384, 1024)])
 def test_gemm_fp8_weights_parity(lib, epi, m, n, k):
