@@ -373,7 +373,9 @@ def parity_reference(args):
     key = workload_key(args)
     if key is None:
         return None, None
-    cands = [os.path.join(ROOT, "profiles", f"r{rnd}_parity_{key}_full.json") for rnd in (5, 4, 3)]
+    cands = [os.path.join(ROOT, "profiles", f"r{rnd}_parity_{key}_full.json") for rnd in (6, 5, 4, 3)]
+    if getattr(args, "precision", "bf16x2") == "f16q":      # the opt-in mode's own full-depth run first (its recorded logits errors are its own)
+        cands.insert(0, os.path.join(ROOT, "profiles", f"r6_parity_{key}_f16q_full.json"))
     if args.weights == "bf16" and args.batch <= 1 and getattr(args, "lengths", "uniform") == "uniform":
         cands.append(os.path.join(ROOT, "profiles", f"r2_parity_{key.split('_')[0]}_full.json"))
     for path in cands:
@@ -388,7 +390,7 @@ def parity_reference(args):
 def parity_check(args, toks):
     """Compare the tokens this run generated with the committed full-depth oracle run of the SAME workload.  toks: the token list
     (batch 1) or one list per cache slot (batched workloads: the oracle run records the slots it covered)."""
-    if getattr(args, "precision", "bf16x2") != "bf16x2":
+    if getattr(args, "precision", "bf16x2") not in ("bf16x2", "f16q"):
         return False, {"reason": "speed mode: logits are outside the 1e-3 tolerance by construction (profiles/r2_speed_mode_14b.json, "
                                  "profiles/r4_fp8_speed_mode.json)"}
     if args.layers is not None:
@@ -572,7 +574,7 @@ def main():
     ap.add_argument("--max-ctx", type=int, default=2048, help="KV-cache length (longer prompts, e.g. --series 30, need more)")
     ap.add_argument("--batch", type=int, default=1, help="> 1: continuous-batching workload (BASELINE.json config 5): B prompts decode "
                     "together; a step = one B-wide decode step; value = aggregate tokens/s")
-    ap.add_argument("--precision", default="bf16x2", choices=["bf16x2", "bf16", "fp8"], help="bf16 / fp8 = the optional SPEED modes (bf16: "
+    ap.add_argument("--precision", default="bf16x2", choices=["bf16x2", "bf16", "fp8", "f16q"], help="f16q = the opt-in PARITY-GRADE prefill on the f16 + fp8 matrix pipes (slower; DESIGN.md 14); bf16 / fp8 = the optional SPEED modes (bf16: "
                     "single-pass bf16 activations in the prefill GEMMs; fp8: --weights fp8 only, prefill GEMMs and the TS encoder on the fp8 "
                     "matrix pipe); not parity grade, labelled as such; default bf16x2")
     ap.add_argument("--kv-block", type=int, default=0, help="block-paged KV cache with this many positions per block (0 = one "
@@ -774,10 +776,13 @@ def main():
                    "tp_devices": tp_devices, "tp_status": tp_status, "tp_release": tp_release,
                    "precision": ("bf16 weights; f32 activations, KV cache and accumulation (bf16x2 MFMA split in "
                                  "prefill, exact f32 FMA in decode)") if model.precision == "bf16x2" else
+                                ("PARITY GRADE, opt-in: prefill projections on the f16q split (f16 MFMA + block-scaled e4m3 MFMA, chatts_linear_f16q), "
+                                 "everything else as the default; slower than the default (DESIGN.md 14)") if model.precision == "f16q" else
                                 ("SPEED MODE precision=bf16 - NOT the parity-grade line: prefill GEMMs multiply bf16-rounded activations "
                                  "(one MFMA pass), logits ~3e-2 of the default mode (profiles/r2_speed_mode_14b.json); decode as in the default"),
                    "first_tokens": toks[:8],
-                   "weight_bytes_decode_stream": step_bytes, "weight_bytes_tiled_prefill_copies": model.tiled_weight_bytes_local()},
+                   "weight_bytes_decode_stream": step_bytes, "weight_bytes_tiled_prefill_copies": model.tiled_weight_bytes_local(),
+                   "weight_bytes_f16q_copies": model.f16q_weight_bytes_local()},
         "ttft_ms_p50": ttft, "ts_encode_ms_p50": median(enc_ms),
         "decode_hbm_gbs_per_gpu": step_bytes / (dt / args.steps) / 1e9,
         "decode_hbm_frac_of_8TBs": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,

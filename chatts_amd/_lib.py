@@ -75,7 +75,10 @@ class LayerWeights(C.Structure):
                 ("down8_scale", c_void_p),
                 ("qkv4", c_void_p), ("qkv4_sz", c_void_p), ("o4", c_void_p), ("o4_sz", c_void_p), ("gate_up4", c_void_p),
                 ("gate_up4_sz", c_void_p), ("down4", c_void_p), ("down4_sz", c_void_p), ("w4_group", c_int),
-                ("qkv_t", c_void_p), ("o_t", c_void_p), ("gate_up_t", c_void_p), ("down_t", c_void_p)]
+                ("qkv_t", c_void_p), ("o_t", c_void_p), ("gate_up_t", c_void_p), ("down_t", c_void_p),
+                ("qkv16", c_void_p), ("qkv_q8", c_void_p), ("qkv_q8e", c_void_p), ("o16", c_void_p), ("o_q8", c_void_p), ("o_q8e", c_void_p),
+                ("gate_up16", c_void_p), ("gate_up_q8", c_void_p), ("gate_up_q8e", c_void_p),
+                ("down16", c_void_p), ("down_q8", c_void_p), ("down_q8e", c_void_p)]
 
 
 class PrefillSegment(C.Structure):
@@ -136,6 +139,7 @@ SIGNATURES = {
     "chatts_linear_f16q_workspace": (c_size_t, [c_int, c_int, c_int]),
     "chatts_linear_f16q": (c_int, [C.POINTER(LinearF16qArgs), c_void_p]),
     "chatts_decoder_set_prefill_fp8": (c_int, [c_void_p, c_int]),
+    "chatts_decoder_set_prefill_f16q": (c_int, [c_void_p, c_int]),
     "chatts_tile_bf16_elems": (c_size_t, [c_int, c_int]),
     "chatts_tile_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "chatts_split_bf16x2": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),

@@ -38,6 +38,8 @@ struct ChattsDecoder {
   bool sampling = false;    // token selection of the decode steps: greedy argmax, or the sampler with `sa`
   ChattsSamplingArgs sa{};
   ChattsTpComm* tp = nullptr;   // tensor-parallel exchange (borrowed); required by the whole-step entry points when tp_world > 1
+  bool prefill_f16q = false; // opt-in parity-grade mode (chatts_decoder_set_prefill_f16q): prefill chunks of >= 96 rows on the f16 + e4m3 operand split
+  bool normed_q = false;    // the f16q planes A already hold RMSNorm(x) for the projection that comes next (layer_part_f16q only)
   bool prefill_fp8 = false; // SPEED MODE (chatts_decoder_set_prefill_fp8): prefill chunks of >= 16 rows multiply fp8 x fp8 (gemm_fp8.hip)
   bool fuse_tp = false;     // set by chatts_decoder_decode_step: the M == 1 o_proj / down_proj GEMVs carry the exchange in their own launch
   bool tp_fused = false;    // ... and whether the last layer part's projection did (otherwise the caller launches chatts_allreduce)
@@ -108,6 +110,8 @@ extern "C" int chatts_split_bf16x2(const float* x, int m, int k, int ldx, chatts
   return launch_split_bf16x2(x, m, k, ldx, hi, lo, ld_planes, as_stream(stream));
 }
 
+constexpr int kF16qMinRows = 96;      // f16q mode: chunks below this take the default kernels (also parity grade)
+
 extern "C" size_t chatts_decoder_workspace(const ChattsDecoderConfig* c, int t_max, int n_splits_max) {
   if (!c) return 0;
   size_t ws = 0;
@@ -116,7 +120,8 @@ extern "C" size_t chatts_decoder_workspace(const ChattsDecoderConfig* c, int t_m
                             {c->hidden, c->inter}};
   for (int t = 2; t <= t_max; ++t) {   // geometry depends on M; take the max over all M (cheap: <= t_max iterations)
     for (auto& s : shapes) {
-      const size_t w = gemm_workspace(t, s[0], s[1]);
+      size_t w = gemm_workspace(t, s[0], s[1]);
+      if (t >= kF16qMinRows && s[1] % 128 == 0) { const size_t wq = chatts_linear_f16q_workspace(t, s[0], s[1]); if (wq > w) w = wq; }
       if (w > ws) ws = w;
     }
   }
@@ -298,6 +303,95 @@ extern "C" int chatts_decoder_set_prefill_fp8(ChattsDecoder* d, int on) {
   return CHATTS_OK;
 }
 
+// ---- OPT-IN, PARITY GRADE: a prefill chunk's layer half on the f16q operand split (gemm_f16q.hip) -------------------------------------
+// The four projections multiply f16 high parts on the f16 MFMA and e4m3 residuals x e4m3 weights on the block-scaled fp8 MFMA; every
+// activation matrix between them travels as f16q planes written by its producer (RMSNorm, attention output split, SwiGLU epilogue, the
+// residual projections' post-norm).  Scratch: the bf16 plane buffers re-typed - pair 0 / pair 1 = (f16 hi | e4m3 lo, then the e8m0 scales).
+extern "C" int chatts_decoder_set_prefill_f16q(ChattsDecoder* d, int on) {
+  CHATTS_REQUIRE(d, CHATTS_E_BADARG, "decoder_set_prefill_f16q: null decoder");
+  if (on) {
+    const ChattsDecoderConfig& c = d->cfg;
+    for (const ChattsLayerWeights& lw : d->layers)
+      CHATTS_REQUIRE(lw.qkv16 && lw.qkv_q8 && lw.qkv_q8e && lw.o16 && lw.o_q8 && lw.o_q8e && lw.gate_up16 && lw.gate_up_q8 && lw.gate_up_q8e &&
+                         lw.down16 && lw.down_q8 && lw.down_q8e, CHATTS_E_BADARG, "decoder_set_prefill_f16q: a layer has no f16q weight copies");
+    CHATTS_REQUIRE(c.hidden % 128 == 0 && c.inter % 128 == 0, CHATTS_E_SHAPE, "decoder_set_prefill_f16q: hidden / inter must be multiples of 128");
+    CHATTS_REQUIRE(d->b.planes_hi && d->b.planes_lo && d->b.planes2_hi && d->b.planes2_lo && d->b.t_max >= 1, CHATTS_E_BADARG,
+                   "decoder_set_prefill_f16q: the plane buffers are needed as scratch");
+    CHATTS_REQUIRE(!d->prefill_fp8, CHATTS_E_BADARG, "decoder_set_prefill_f16q: the fp8 speed mode is on");
+  }
+  d->prefill_f16q = on != 0;
+  d->normed_q = false;
+  return CHATTS_OK;
+}
+
+struct F16qBuf { chatts_f16* hi; uint8_t* lo8; uint8_t* sc; };
+static F16qBuf f16q_buf(const ChattsDecoder* d, int pair) {
+  const ChattsDecoderConfig& c = d->cfg;
+  int maxdim = c.hidden > c.inter ? c.hidden : c.inter;
+  if (c.n_q * kHeadDim > maxdim) maxdim = c.n_q * kHeadDim;
+  const size_t plane = (size_t)d->b.t_max * maxdim;            // elements of one bf16 plane = bytes of the e4m3 plane
+  F16qBuf b;
+  b.hi = reinterpret_cast<chatts_f16*>(pair ? d->b.planes2_hi : d->b.planes_hi);
+  b.lo8 = reinterpret_cast<uint8_t*>(pair ? d->b.planes2_lo : d->b.planes_lo);
+  b.sc = b.lo8 + plane;
+  return b;
+}
+
+static int layer_part_f16q(ChattsDecoder* d, int layer, int part, int t, int pos0, const int32_t* pos0_dev, chatts_stream_t stream) {
+  StageRange stage(part == 0 ? "chatts.layer.attn.f16q" : "chatts.layer.mlp.f16q");
+  const ChattsDecoderConfig& c = d->cfg;
+  const ChattsLayerWeights& lw = d->layers[layer];
+  const bool tp = c.tp_world > 1;
+  const int H = c.hidden, na = c.n_q * kHeadDim, qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim;
+  const F16qBuf A = f16q_buf(d, 0), B = f16q_buf(d, 1);
+  d->normed = false;
+  d->tp_fused = false;
+  int rc;
+  auto base = [&](ChattsLinearF16qArgs& q, const F16qBuf& in, int k, const chatts_f16* w16, const uint8_t* w8, const uint8_t* w8e, int n) {
+    q = ChattsLinearF16qArgs{};
+    q.a_hi = in.hi; q.a_lo8 = in.lo8; q.a_scale = in.sc; q.ld_a = k; q.ld_scale = k / 128;
+    q.w16 = w16; q.w8 = w8; q.w8_exp = w8e; q.ldw = k; q.m = t; q.n = n; q.k = k;
+    q.workspace = d->b.workspace; q.workspace_bytes = d->b.workspace_bytes;
+  };
+  // a residual projection also writes RMSNorm(x) for the projection after it - only inside the entry points that run the layers back to back
+  auto post = [&](ChattsLinearF16qArgs& q, const float* next_norm_w) {
+    if (!d->chain || tp || !next_norm_w) return;
+    q.post_norm_w = next_norm_w; q.post_norm_eps = c.rms_eps;
+    q.post_hi = A.hi; q.post_lo8 = A.lo8; q.post_scale = A.sc; q.ld_post = H; q.ld_pscale = H / 128;
+    d->normed_q = true;
+  };
+  ChattsLinearF16qArgs q;
+  if (part == 0) {
+    if (!d->normed_q && (rc = chatts_rmsnorm_f16q(d->b.x, lw.input_norm, A.hi, A.lo8, A.sc, H, H / 128, t, H, c.rms_eps, stream)) != 0) return rc;
+    d->normed_q = false;
+    base(q, A, H, lw.qkv16, lw.qkv_q8, lw.qkv_q8e, qkv_n);
+    q.bias = lw.qkv_bias; q.c = d->b.qkv; q.ldc = qkv_n; q.epilogue = CHATTS_EPI_NONE;
+    if ((rc = chatts_linear_f16q(&q, stream)) != 0) return rc;
+    ChattsKvCache kc = layer_cache(d, layer, d->cur_seq);
+    if ((rc = chatts_rope_kv_write(d->b.qkv, t, c.n_q, c.n_kv, lw.q_norm, lw.k_norm, c.rms_eps, d->w.cos_tab, d->w.sin_tab, pos0, pos0_dev,
+                                   &kc, stream)) != 0) return rc;
+    if ((rc = attention_impl(d->b.qkv, t, c.n_q, c.n_kv, pos0, pos0_dev, &kc, d->b.attn, nullptr, nullptr, 1, d->b.workspace,
+                             d->b.workspace_bytes, stream)) != 0) return rc;
+    if ((rc = chatts_split_f16q(d->b.attn, t, na, na, A.hi, A.lo8, A.sc, na, na / 128, stream)) != 0) return rc;
+    base(q, A, na, lw.o16, lw.o_q8, lw.o_q8e, H);
+    q.ldc = H;
+    if (tp) { q.c = d->b.delta; q.epilogue = CHATTS_EPI_NONE; }
+    else { q.c = d->b.x; q.resid = d->b.x; q.epilogue = CHATTS_EPI_RESID; post(q, lw.post_norm); }
+    return chatts_linear_f16q(&q, stream);
+  }
+  if (!d->normed_q && (rc = chatts_rmsnorm_f16q(d->b.x, lw.post_norm, A.hi, A.lo8, A.sc, H, H / 128, t, H, c.rms_eps, stream)) != 0) return rc;
+  d->normed_q = false;
+  base(q, A, H, lw.gate_up16, lw.gate_up_q8, lw.gate_up_q8e, 2 * c.inter);
+  q.epilogue = CHATTS_EPI_SWIGLU; q.ldc = c.inter;
+  q.c_hi = B.hi; q.c_lo8 = B.lo8; q.c_scale = B.sc; q.ld_cplanes = c.inter; q.ld_cscale = c.inter / 128;
+  if ((rc = chatts_linear_f16q(&q, stream)) != 0) return rc;
+  base(q, B, c.inter, lw.down16, lw.down_q8, lw.down_q8e, H);
+  q.ldc = H;
+  if (tp) { q.c = d->b.delta; q.epilogue = CHATTS_EPI_NONE; }
+  else { q.c = d->b.x; q.resid = d->b.x; q.epilogue = CHATTS_EPI_RESID; post(q, layer + 1 < c.n_layers ? d->layers[layer + 1].input_norm : nullptr); }
+  return chatts_linear_f16q(&q, stream);
+}
+
 static int layer_part_fp8(ChattsDecoder* d, int layer, int part, int t, int pos0, const int32_t* pos0_dev, chatts_stream_t stream) {
   const ChattsDecoderConfig& c = d->cfg;
   const ChattsLayerWeights& lw = d->layers[layer];
@@ -348,6 +442,8 @@ extern "C" int chatts_decoder_layer_part(ChattsDecoder* d, int layer, int part, 
                  "decoder_layer_part: bad arguments");
   CHATTS_REQUIRE(t >= 1 && t <= d->b.t_max, CHATTS_E_SHAPE, "decoder_layer_part: t=%d exceeds buffers (%d)", t, d->b.t_max);
   if (d->prefill_fp8 && t >= 16) return layer_part_fp8(d, layer, part, t, pos0, pos0_dev, stream);      // speed mode, prefill chunks only
+  if (d->prefill_f16q && t >= kF16qMinRows) return layer_part_f16q(d, layer, part, t, pos0, pos0_dev, stream);
+  d->normed_q = false;        // (a following f16q half recomputes its norm: planes 0 are about to hold bf16 data)
   StageRange stage(part == 0 ? "chatts.layer.attn" : "chatts.layer.mlp");
   const ChattsDecoderConfig& c = d->cfg;
   const ChattsLayerWeights& lw = d->layers[layer];
@@ -562,7 +658,7 @@ extern "C" int chatts_decoder_logits_batched(ChattsDecoder* d, int batch, float*
   la.workspace = d->b.workspace; la.workspace_bytes = d->b.workspace_bytes;
   la.w8 = d->w.lm_head8; la.w8_scale = d->w.lm_head8_scale; la.ldw8 = c.hidden; la.w8_format = d->cfg.w8_format;
   int rc = norm_into(d, d->w.final_norm, &la, stream);      // binds planes a fused epilogue already wrote (d->normed), or launches the norm
-  d->normed = false;
+  d->normed = false; d->normed_q = false;
   if (rc) return rc;
   return chatts_linear(&la, stream);
 }
@@ -588,7 +684,7 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
   if ((rc = chatts_embed_token_batched(token_dev, batch, d->w.embed, embed_offset(d), embed_rows(d), c.hidden, d->b.x,
                                        stream)) != 0) return rc;
   d->chain = true;               // layers run back to back: a projection may write the next one's normed operand
-  d->normed = false;
+  d->normed = false; d->normed_q = false;
   const int64_t nx = (int64_t)batch * c.hidden;
   for (int l = 0; l < c.n_layers && rc == CHATTS_OK; ++l) {
     rc = chatts_decoder_layer_part_batched(d, l, 0, batch, pos_dev, n_splits, stream);
@@ -597,7 +693,7 @@ extern "C" int chatts_decoder_decode_step_batched(ChattsDecoder* d, int batch, i
     if (tp && rc == CHATTS_OK && !d->tp_fused) rc = chatts_allreduce(d->tp, d->b.delta, d->b.x, d->b.x, nx, stream);     // ... and down_proj
   }
   d->chain = false;
-  if (rc) { d->normed = false; return rc; }
+  if (rc) { d->normed = false; d->normed_q = false; return rc; }
   if ((rc = chatts_decoder_logits_batched(d, batch, logits_all, stream)) != 0) return rc;
   return chatts_decoder_select_tokens(d, logits_all, batch, c.vocab_local, token_dev, token_logit_dev, out_tokens, out_stride, step_dev,
                                       pos_dev, c.max_ctx - 1, nullptr, stream);
@@ -624,7 +720,7 @@ extern "C" int chatts_decoder_prefill(ChattsDecoder* d, int t, int pos0, chatts_
   StageRange stage("chatts.prefill");
   const bool tp = d->cfg.tp_world > 1;
   d->chain = true;
-  d->normed = false;
+  d->normed = false; d->normed_q = false;
   int rc = CHATTS_OK;
   for (int l = 0; l < d->cfg.n_layers && rc == CHATTS_OK; ++l) {
     rc = chatts_decoder_layer_part(d, l, 0, t, pos0, nullptr, 1, stream);
@@ -633,7 +729,7 @@ extern "C" int chatts_decoder_prefill(ChattsDecoder* d, int t, int pos0, chatts_
     if (tp && rc == CHATTS_OK) rc = tp_sum_into_x(d, t, stream);
   }
   d->chain = false;
-  d->normed = false;
+  d->normed = false; d->normed_q = false;
   return rc;
 }
 
@@ -692,7 +788,7 @@ extern "C" int chatts_decoder_prefill_last(ChattsDecoder* d, int t, int pos0, ch
   StageRange stage("chatts.prefill_last");
   const bool tp = d->cfg.tp_world > 1;
   d->chain = true;
-  d->normed = false;
+  d->normed = false; d->normed_q = false;
   int rc = CHATTS_OK;
   const int L = d->cfg.n_layers;
   for (int l = 0; l + 1 < L && rc == CHATTS_OK; ++l) {
@@ -713,7 +809,7 @@ extern "C" int chatts_decoder_prefill_last(ChattsDecoder* d, int t, int pos0, ch
     }
   } else if (rc == CHATTS_OK) rc = layer_last_row(d, L - 1, t, pos0, stream);
   d->chain = false;
-  d->normed = false;
+  d->normed = false; d->normed_q = false;
   // the last row's o_proj / down_proj carried their exchange without advancing the device-side call counter (host-counted epochs):
   // settle it here, so that whatever runs next on this communicator - a replayed decode graph above all - starts from a flushed count
   if (tp && d->tp) { const int frc = chatts_tp_flush_epochs(d->tp, stream); if (rc == CHATTS_OK) rc = frc; }
@@ -733,7 +829,7 @@ static int layer_part0_packed(ChattsDecoder* d, int layer, int t, const ChattsPr
   const bool f8 = d->prefill_fp8 && t >= 16;          // speed mode: qkv and o_proj as fp8 x fp8 GEMMs (layer_part_fp8's arithmetic)
   ChattsLinearArgs la{};
   if (f8) {
-    d->normed = false;
+    d->normed = false; d->normed_q = false;
     uint8_t* a8 = reinterpret_cast<uint8_t*>(d->b.planes_hi);
     if ((rc = chatts_quantize_rows_fp8(d->b.x, t, H, H, lw.input_norm, c.rms_eps, a8, H, d->b.xn, stream)) != 0) return rc;
     ChattsLinearFp8Args f{};
@@ -795,14 +891,14 @@ extern "C" int chatts_decoder_prefill_packed(ChattsDecoder* d, const ChattsPrefi
   CHATTS_REQUIRE(t <= d->b.t_max, CHATTS_E_SHAPE, "decoder_prefill_packed: %d rows exceed buffers (%d)", t, d->b.t_max);
   StageRange stage("chatts.prefill_packed");
   d->chain = true;
-  d->normed = false;
+  d->normed = false; d->normed_q = false;
   int rc = CHATTS_OK;
   for (int l = 0; l < d->cfg.n_layers && rc == CHATTS_OK; ++l) {
     rc = layer_part0_packed(d, l, t, segs, n_segs, stream);
     if (rc == CHATTS_OK) rc = chatts_decoder_layer_part(d, l, 1, t, 0, nullptr, 1, stream);
   }
   d->chain = false;
-  d->normed = false;
+  d->normed = false; d->normed_q = false;
   return rc;
 }
 

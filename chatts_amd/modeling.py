@@ -111,8 +111,12 @@ class ChatTSForCausalLM:
         # "fp8" = SPEED mode on the CDNA4 fp8 matrix pipe (needs weight_format="fp8", BASELINE.json config 5): prefill chunks and the
         # TS encoder quantise their activations per row to e4m3 and multiply fp8 x fp8 (v_mfma_scale_f32_16x16x128_f8f6f4: 4x less
         # matrix time than bf16x2), logits ~1e-2 from the default; decode steps are unchanged.  Per model, not process-wide.
-        if precision not in (None, "bf16x2", "bf16", "fp8"):
-            raise ValueError("precision must be None / 'bf16x2' (parity grade), 'bf16' or 'fp8' (speed modes)")
+        # "f16q" = PARITY GRADE like the default, on other matrix pipes: prefill chunks of >= 96 rows multiply an f16 high part
+        # on the f16 MFMA and an e4m3 residual x e4m3 weights on the CDNA4 block-scaled fp8 MFMA (1.5 instead of 2 pass-equivalents per
+        # product; logits ~1.3e-4 of the float32 oracle against ~5e-5).  Measured SLOWER than the default (the kernel is paced by its
+        # operand feed, which the split does not shrink) and costs 3 more bytes per weight: opt-in, never the default.  Per model.
+        if precision not in (None, "bf16x2", "bf16", "fp8", "f16q"):
+            raise ValueError("precision must be None / 'bf16x2' or 'f16q' (parity grade), 'bf16' or 'fp8' (speed modes)")
         if precision == "fp8" and weight_format != "fp8":
             raise ValueError("precision='fp8' multiplies the fp8 weight copies: it needs weight_format='fp8'")
         if precision is not None:
@@ -148,7 +152,7 @@ class ChatTSForCausalLM:
         # pieces then read consecutive memory; bit-identical results, prefill projections -4 %, profiles/r6_tiled_check.txt).  None = when
         # a prefill chunk can reach that kernel (>= 96 rows) and CHATTS_TILED_WEIGHTS != 0; costs the bf16 weight bytes once more.
         if prefill_tiled_weights is None:
-            prefill_tiled_weights = self.t_max >= 96 and os.environ.get("CHATTS_TILED_WEIGHTS", "1") != "0"
+            prefill_tiled_weights = self.t_max >= 96 and os.environ.get("CHATTS_TILED_WEIGHTS", "1") != "0" and self.precision != "f16q"
         self.prefill_tiled_weights = bool(prefill_tiled_weights)
         self._tiled = []                         # per layer: {projection: tiled copy}
         self.use_graph = use_graph
@@ -417,10 +421,26 @@ class ChatTSForCausalLM:
                         _lib.check(lib.chatts_tile_bf16(w.data_ptr(), rows, k, k, out.data_ptr(), _lib.stream_ptr()))
                         tiled[name] = out
             self._tiled.append(tiled)
+        self._f16q = []
+        for lw in self.layers:
+            qd = {}
+            if self.precision == "f16q":
+                for name in ("qkv", "o", "gate_up", "down"):
+                    w = lw[name]
+                    rows, k = w.shape
+                    if k % 128 or not w.is_contiguous():
+                        raise ValueError(f"precision='f16q' needs K % 128 == 0 for every projection ({name}: K={k})")
+                    w16 = torch.empty((rows, k), dtype=torch.float16, device=dev)
+                    w8 = torch.empty((rows, k), dtype=torch.uint8, device=dev)
+                    w8e = torch.empty((rows,), dtype=torch.uint8, device=dev)
+                    _lib.check(lib.chatts_weights_f16q(w.data_ptr(), rows, k, k, w16.data_ptr(), w8.data_ptr(), w8e.data_ptr(), k, _lib.stream_ptr()))
+                    qd[name] = (w16, w8, w8e)
+            self._f16q.append(qd)
         arr = (_lib.LayerWeights * L)()
         for i, lw in enumerate(self.layers):
             tl = self._tiled[i]
-            arr[i] = _lib.LayerWeights(qkv_t=_lib.ptr(tl.get("qkv")), o_t=_lib.ptr(tl.get("o")), gate_up_t=_lib.ptr(tl.get("gate_up")),
+            fq = {f"{n}{suf}": _lib.ptr(t3[j]) for n, t3 in self._f16q[i].items() for j, suf in enumerate(("16", "_q8", "_q8e"))}
+            arr[i] = _lib.LayerWeights(**fq, qkv_t=_lib.ptr(tl.get("qkv")), o_t=_lib.ptr(tl.get("o")), gate_up_t=_lib.ptr(tl.get("gate_up")),
                                        down_t=_lib.ptr(tl.get("down")),
                                        input_norm=_lib.ptr(lw["input_norm"]), qkv=_lib.ptr(lw["qkv"]),
                                        qkv_bias=_lib.ptr(lw.get("qkv_bias")), q_norm=_lib.ptr(lw.get("q_norm")),
@@ -460,6 +480,8 @@ class ChatTSForCausalLM:
         if self.precision == "fp8":              # speed mode: prefill chunks and the TS encoder on the fp8 matrix pipe
             _lib.check(lib.chatts_decoder_set_prefill_fp8(self._decoder, 1))
             self.ts_encoder.set_precision("fp8")
+        if self.precision == "f16q":             # parity-grade prefill on the f16 + fp8 matrix pipes (the TS encoder keeps bf16x2)
+            _lib.check(lib.chatts_decoder_set_prefill_f16q(self._decoder, 1))
         if plan.world > 1 and self.use_p2p and getattr(self.comm, "dist", None) is not None and self._tp is None:
             from .tp import P2PExchange
             ex, err = None, None
@@ -522,6 +544,10 @@ class ChatTSForCausalLM:
     def tiled_weight_bytes_local(self):
         """Bytes of the prefill kernel's tiled weight copies on this rank (resident beside the tensors weight_bytes_local() counts)."""
         return sum(t.numel() * t.element_size() for tl in self._tiled for t in tl.values())
+
+    def f16q_weight_bytes_local(self):
+        """Bytes of the f16q weight copies (precision='f16q' only)"""
+        return sum(t.numel() * t.element_size() for qd in self._f16q for t3 in qd.values() for t in t3)
 
     # ---------------------------------------------------------------------------------------------
     # vLLM-plugin-shaped hooks (same names/order as chatts_vllm.py:538-610)

@@ -46,7 +46,7 @@ const char* chatts_last_error(void);
  *     environment); ChattsLinearArgs.tile_counters, ChattsDecoderBuffers.tile_counters and CHATTS_TILE_COUNTERS removed (the in-launch
  *     split-K fix-up they served was measured slower twice); chatts_tp_flush_epochs;
  *  9: the f16q operand format of the prefill projections (chatts_split_f16q / chatts_weights_f16q / chatts_rmsnorm_f16q /
- *     chatts_linear_f16q: an experiment kept for its numbers, NOT a decoder path - DESIGN.md section 14);
+ *     chatts_linear_f16q, ChattsLayerWeights.*16 / *_q8 / *_q8e, chatts_decoder_set_prefill_f16q: an opt-in, parity-grade, SLOWER prefill mode - DESIGN.md section 14);
  *     the tensor-parallel exchange's release form per communicator (chatts_tp_cross_device / chatts_tp_set_cross_device /
  *     chatts_tp_set_bulk_release / chatts_tp_bulk_release); tiled prefill weights (chatts_tile_bf16, ChattsLinearArgs.w_tiled /
  *     planes_tiled, ChattsLayerWeights.*_t). */
@@ -573,6 +573,12 @@ typedef struct ChattsLayerWeights {
   /* optional copies of the four bf16 matrices in the tiled layout of chatts_tile_bf16 (ChattsLinearArgs.w_tiled): the operand feed of the
    * prefill kernel reads them as consecutive memory; every other kernel keeps streaming the row-major tensors.  NULL = row-major only. */
   const chatts_bf16* qkv_t; const chatts_bf16* o_t; const chatts_bf16* gate_up_t; const chatts_bf16* down_t;
+  /* optional f16q copies (chatts_weights_f16q: f16 [N, K], e4m3 [N, K], e8m0 row exponent [N]) of the four matrices: the operands of
+   * chatts_decoder_set_prefill_f16q.  NULL otherwise. */
+  const chatts_f16* qkv16; const uint8_t* qkv_q8; const uint8_t* qkv_q8e;
+  const chatts_f16* o16; const uint8_t* o_q8; const uint8_t* o_q8e;
+  const chatts_f16* gate_up16; const uint8_t* gate_up_q8; const uint8_t* gate_up_q8e;
+  const chatts_f16* down16; const uint8_t* down_q8; const uint8_t* down_q8e;
 } ChattsLayerWeights;
 
 typedef struct ChattsDecoderConfig {
@@ -657,6 +663,12 @@ int chatts_decoder_layer_part_add(ChattsDecoder*, int add_delta, int layer, int 
  * qkv8 / o8 / gate_up8 / down8 in e4m3 (w8_format FP8) and K multiples of 128.  NOT parity grade (~1e-2 on logits); decode steps,
  * attention, norms, KV cache and logits are unchanged.  Returns CHATTS_E_BADARG when the copies are missing. */
 int chatts_decoder_set_prefill_fp8(ChattsDecoder*, int on);
+/* OPT-IN, PARITY GRADE, SLOWER than the default: prefill chunks of >= 96 rows run their four projections on the f16q
+ * operand split (chatts_linear_f16q: f16 high part on v_mfma_f32_16x16x32_f16 + e4m3 residual x e4m3 weights on the CDNA4 block-scaled
+ * v_mfma_scale_f32_16x16x128_f8f6f4) instead of the bf16 hi / lo split - the fp8 matrix pipe at float32 grade (logits ~1.3e-4 of the
+ * float32 oracle at full depth against ~5e-5 for the default; bar 1e-3).  Needs every layer's f16q weight copies, hidden / inter / n_q * 128
+ * multiples of 128, the plane buffers as scratch.  RoPE, cache, attention, residual stream and all decode steps are unchanged. */
+int chatts_decoder_set_prefill_f16q(ChattsDecoder* d, int on);
 
 /* Attach the tensor-parallel exchange (tp_world > 1): chatts_decoder_decode_step(_batched) then run whole TP steps on the
  * stream - partial o_proj / down_proj sums are all-reduced into the residual stream by chatts_allreduce, tokens are agreed on

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--oracle-slots", default="0", help="--batch > 1: cache slots the oracle recomputes (comma separated)")
     ap.add_argument("--new", type=int, default=9, help="first token + decode steps compared")
     ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--precision", default=None, choices=[None, "bf16x2", "f16q"], help="f16q: the opt-in parity-grade prefill on the f16 + fp8 matrix pipes")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--out", default="gpurun_out/r3_parity_full.json")
     args = ap.parse_args()
@@ -66,7 +67,7 @@ def main():
     T = len(ids) - 2 * len(lengths) + sum((L + 15) // 16 for L in lengths)
     max_ctx = max(2048, -(-(T + args.new + 16) // 256) * 256)
     model = ChatTSForCausalLM.from_synthetic(cfg, seed=0, max_ctx=max_ctx, max_prefill_tokens=1024, weight_format=args.weights,
-                                             max_batch=B)
+                                             max_batch=B, precision=args.precision)
     model.use_graph = True
 
     # ---- HIP path, driven like bench.py ---------------------------------------------------------------------
