@@ -134,7 +134,7 @@ def main():
                                                 weights=args.weights, batch=B))
     res = {
         "what": "full-depth parity of a bench.py workload: HIP path vs CPU float32 oracle (layer-streamed)",
-        "workload_key": key, "model": args.model, "layers": cfg.num_hidden_layers, "series": args.series,
+        "workload_key": key, "precision": args.precision or "bf16x2", "model": args.model, "layers": cfg.num_hidden_layers, "series": args.series,
         "length": None if args.lengths == "mixed" else args.length, "lengths": lengths, "batch": B, "weights": args.weights,
         "prompt_tokens": per_slot[str(slots[0])]["prompt_tokens"], "seed": 0, "tolerance": 1e-3,
         "max_step_logits_rel_err": worst_rel, "max_abs_err_over_max_logit": worst_abs,
