@@ -142,7 +142,7 @@ __device__ __forceinline__ void f16q_store_swiglu(const F16qGemm& q, const f32x4
 // MAXFML: the largest per-wave fragment count this instantiation carries (tiles of <= 2 MAXFML fragments).  The 5-fragment form needs ~40
 // registers more (accumulators + e4m3 fragments); tiles of <= 8 fragments run the leaner instantiation.
 template <int MAXFML>
-__global__ __launch_bounds__(kQThreads) void gemm_f16q_kernel(F16qGemm q, RingGeom g, int opt_early) {
+__global__ __launch_bounds__(kQThreads) void gemm_f16q_kernel(F16qGemm q, RingGeom g) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const GemmParams& p = q.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -276,7 +276,6 @@ __global__ __launch_bounds__(kQThreads) void gemm_f16q_kernel(F16qGemm q, RingGe
 
   // ---- compute side: wave (wm, wn) holds f0 (wm = 0) or f - f0 fragments of the tile x 64 columns wn * 64 .. ------------------------------
   const int wm = wave >> 2, wn = wave & 3;
-  (void)opt_early;
   const int lane_off = (lane & 15) * 64 + ((((lane >> 4) ^ (((lane >> 3) & 1) << 1))) << 4);      // this lane's 16-byte chunk in a 16-row f16 block
   const int f8_off = ((lane >> 5) & 1) * 256 + (lane & 15) * 16 + ((lane >> 4) & 1) * 8;           // this lane's 8 bytes in an e4m3 fragment
   setup(u0);
@@ -647,9 +646,9 @@ int launch_f16q(const F16qGemm& q, const RingGeom& g, hipStream_t s) {
     CHATTS_REQUIRE(e == hipSuccess, CHATTS_E_LAUNCH, "gemm_f16q: cannot reserve %d bytes of LDS: %s", kQLds, hipGetErrorString(e));
     configured = true;
   }
-  const int fmax = (g.F + g.T - 1) / g.T, stagger = opt_get(OPT_F16Q_STAGGER, 1);
-  if (fmax <= 8) hipLaunchKernelGGL(gemm_f16q_kernel<4>, dim3(8 * g.wpx), dim3(kQThreads), kQLds, s, q, g, stagger);
-  else hipLaunchKernelGGL(gemm_f16q_kernel<5>, dim3(8 * g.wpx), dim3(kQThreads), kQLds, s, q, g, stagger);
+  const int fmax = (g.F + g.T - 1) / g.T;
+  if (fmax <= 8) hipLaunchKernelGGL(gemm_f16q_kernel<4>, dim3(8 * g.wpx), dim3(kQThreads), kQLds, s, q, g);
+  else hipLaunchKernelGGL(gemm_f16q_kernel<5>, dim3(8 * g.wpx), dim3(kQThreads), kQLds, s, q, g);
   return CHATTS_OK;
 }
 

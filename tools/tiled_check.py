@@ -18,7 +18,9 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 M = int(args[0]) if len(args) > 0 else 798
 R = int(args[1]) if len(args) > 1 else 7
 SHAPES = {"qkv": (7168, 5120, _lib.EPI_NONE), "o": (5120, 5120, _lib.EPI_RESID), "gate_up": (27648, 5120, _lib.EPI_SWIGLU),
-          "down": (5120, 13824, _lib.EPI_RESID)}
+          "down": (5120, 13824, _lib.EPI_RESID), "ts": (5120, 5120, _lib.EPI_GELU)}
+if not os.environ.get("TILED_SHAPES"):
+    SHAPES.pop("ts")
 if os.environ.get("TILED_SHAPES"):
     SHAPES = {k: v for k, v in SHAPES.items() if k in os.environ["TILED_SHAPES"].split(",")}
 torch.manual_seed(0)
@@ -71,7 +73,7 @@ def run(c, v):
         la.w_tiled = c["wt"].data_ptr()
     if v == "wa":
         la.a_hi, la.a_lo, la.planes_tiled = c["hit"].data_ptr(), c["lot"].data_ptr(), 1
-    if c["epi"] == _lib.EPI_SWIGLU:
+    if c["epi"] in (_lib.EPI_SWIGLU, _lib.EPI_GELU):
         la.c = None
         la.c_hi, la.c_lo, la.ld_cplanes = c["phi_" + v].data_ptr(), c["plo_" + v].data_ptr(), c["ncols"]
     if c["epi"] == _lib.EPI_RESID:
@@ -81,6 +83,8 @@ def run(c, v):
 
 
 VARIANTS = (("rm", "row-major"), ("w", "W tiled"), ("wa", "W + planes tiled"))
+if os.environ.get("TILED_VARIANTS"):
+    VARIANTS = tuple(v for v in VARIANTS if v[0] in os.environ["TILED_VARIANTS"].split(","))
 cases = {name: prep(n, k, epi, name) for name, (n, k, epi) in SHAPES.items()}
 for name, c in cases.items():
     ok_layout = bool((tile_ref(c["w"]).view(torch.int16) == c["wt"].view(torch.int16)).all()) and \
@@ -89,14 +93,14 @@ for name, c in cases.items():
         run(c, v)
     torch.cuda.synchronize()
     same = {}
-    for v in ("w", "wa"):
-        keys = ["out_"] if c["epi"] != _lib.EPI_SWIGLU else ["phi_", "plo_"]
+    for v in [x for x, _ in VARIANTS if x != "rm"]:
+        keys = ["out_"] if c["epi"] not in (_lib.EPI_SWIGLU, _lib.EPI_GELU) else ["phi_", "plo_"]
         if c["epi"] == _lib.EPI_RESID:
             keys += ["nhi_", "nlo_"]
         same[v] = all(bool((c[k + v].view(torch.int16 if c[k + v].dtype == torch.bfloat16 else torch.int32) ==
                             c[k + "rm"].view(torch.int16 if c[k + v].dtype == torch.bfloat16 else torch.int32)).all()) for k in keys)
     nz = float(c["out_rm"].abs().sum() + c["phi_rm"].float().abs().sum())
-    print(f"{name:8s} tiled layout == restatement: {ok_layout}   outputs bit-identical to row-major: W tiled {same['w']}, W + planes tiled {same['wa']}  (|out| {nz:.3e})", flush=True)
+    print(f"{name:8s} tiled layout == restatement: {ok_layout}   outputs bit-identical to row-major: {same}  (|out| {nz:.3e})", flush=True)
 
 res = {(s, v): [] for s in SHAPES for v, _ in VARIANTS}
 for rnd in range(R + 1):
