@@ -178,11 +178,20 @@ class P2PExchange:
                 x = torch.zeros(n, dtype=torch.float32, device="cuda")
                 self.all_reduce_bulk(parts[comm.rank], x)
                 bad += int(not torch.equal(x, want))
-        bad += int(self.status() != 0)
+        torch.cuda.synchronize()
+        stalled = self.status() != 0
+        bad += int(stalled)
         if os.environ.get("CHATTS_TP_INJECT_RELEASE_MISMATCH", "0") == "1":
             bad += 1
-        allbad = [None] * comm.world
-        comm.dist.all_gather_object(allbad, bad, group=comm.group)
+        gathered = [None] * comm.world
+        comm.dist.all_gather_object(gathered, (bad, stalled), group=comm.group)
+        allbad = [b for b, _ in gathered]
+        if any(st for _, st in gathered):
+            # a peer's contribution timed out somewhere: the exchange buffers hold garbage from then on - zero them and the call counters on
+            # EVERY rank before anything else uses the communicator (include/chatts_amd.h: chatts_tp_reset), then meet
+            _lib.check(self.lib.chatts_tp_reset(self.handle, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            comm.barrier()
         if any(allbad):
             self.set_bulk_release("fence")
             self.release_note = f"fence (first contact: {sum(1 for b in allbad if b)} of {comm.world} ranks saw a light-release sum differ or a peer time out)"

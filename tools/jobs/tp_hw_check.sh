@@ -26,14 +26,15 @@ import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 ok = d["parity_checked"] and d["n_gpus"] == d["config"]["rccl_world_size"] and "p2p" in (d["config"]["tp_exchange"] or "")
 print("     n_gpus", d["n_gpus"], "tokens/s", round(d["value"], 1), "ttft_ms", round(d["ttft_ms_p50"], 1), "exchange:", d["config"]["tp_exchange"], "parity_checked", d["parity_checked"])
+print("     release form of the prefill-sized sums (P2PExchange.first_contact, round 6):", d["config"]["tp_release"])
 sys.exit(0 if ok else 1)
 PY
   rc=$?; fi
   say $rc "bench.py --gpus $W (TP=$W decode graph + p2p exchange, oracle tokens)" "$O/4_bench_tp$W.err"
 done
-# 4b. if step 4 ran but parity_checked came out false: repeat it with the conservative release of the prefill-sized all-reduce
-#     (CHATTS_TP_BULK_FENCE=1: __threadfence_system() before the flags instead of draining the stores to the uncached exchange areas -
-#     DESIGN.md section 13.4; both forms pass every single-device test, neither has crossed a link)
+# 4b. the same with the release form FORCED each way (round 6: step 4's form was decided by the first-contact test - "light (validated ...)"
+#     or "fence (...)", printed above; CHATTS_TP_BULK_FENCE=1 / 0 overrides it: compare ttft_ms / parity_checked.  Forcing 0 on a node whose
+#     first-contact test chose the fence is expected to FAIL parity - that is the test's finding, not a bug of this script)
 for W in 2 "$N"; do
   [ "$W" -le "$N" ] || continue
   CHATTS_TP_BULK_FENCE=1 timeout 900 python bench.py --gpus "$W" --no-cpu-baseline --steps 16 --warmup 4 > "$O/4b_bench_tp${W}_fence.json" 2> "$O/4b_bench_tp${W}_fence.err"
