@@ -178,7 +178,7 @@ struct StageRange {
   X(GEMM_STREAM_MB) X(GEMM_STREAM_MB_WAVES) X(EPI_V4) X(EPI_NORM_Q) X(EPI_NORM_REG) X(POST_NORM_SMALL_M) X(ROPE_FUSE) X(ATTN_BF16X3) X(ATTN_EXACT) X(EPI_NORM_Q_GROUPS)  \
   X(ATTN_PLANES) X(ATTN_XCD) X(ATTN_ROWS) X(ATTN_KSPLIT) X(ARGMAX_2STAGE) X(TS_F32_PATH) X(KV_ROUND) X(TP_FUSE) X(TP_FUSE_BLOCKS)       \
   X(TP_BULK_BLOCKS) X(TP_BULK_THREADS) X(TP_BULK_FENCE) X(TP_AR_BLOCKS) X(GEMV_ROWS) X(GEMV_UNR) X(GEMV_NW) X(GEMV_OCC) X(GEMV_BLOCKS) X(GEMV_LDSPAD) X(GEMV_KS) X(FP8_BM) \
-  X(FP8_ORDER) X(GEMV8_ROWS) X(GEMV8_UNR) X(GEMV8_NW) X(GEMV8_OCC)
+  X(FP8_ORDER) X(GEMV8_ROWS) X(GEMV8_UNR) X(GEMV8_NW) X(GEMV8_OCC) X(TS_L0_FUSED)
 enum ChattsOpt {
 #define CHATTS_OPT_ENUM(name) OPT_##name,
   CHATTS_OPTIONS(CHATTS_OPT_ENUM)

@@ -4,6 +4,7 @@
 // torch ops per series; here one wave per series for the mask reduction and one wave per patch for
 // the feature row, no host sync.
 #include "common.h"
+#include "gemm_common.h"
 
 namespace chatts {
 
@@ -146,6 +147,153 @@ __global__ __launch_bounds__(256) void ts_normalise_kernel(const double* __restr
 
 }  // namespace chatts
 
+// ---- patchify + the first MLP layer in ONE launch (round 6; VERDICT r5 next #3a) -------------------------------------------------------
+// out0[p, n] = GELU(feat[p, :] . W0[n, :] + b0[n]) written as bf16 hi / lo planes - the operand of layer 1.  The separate form cost a
+// patchify launch (5.5 us) plus a 20-workgroup run of the prefill kernel for 3 MB of weights (13 us: K = 320 is ten half-steps of
+// pipeline fill).  Here a workgroup of 4 waves owns 128 patch rows x 32 output columns; wave w builds the activation fragments of its
+// two 16-row blocks IN REGISTERS, straight from the series / position table (the feature row never exists in memory), loads its W0
+// fragments straight from L2 (3 MB, shared by everybody) and issues the same MFMAs in the same order as the prefill kernel does
+// (per 32 K-values: lo pass, then hi pass; operands swapped, D = W . A^T): bit-identical planes.  No LDS, no barrier.
+namespace chatts {
+__device__ __forceinline__ float ts_feature(const ChattsPatchifyArgs& a, const float2* row, int vl, float last, int t0, int k) {
+  const int ps = a.patch_size;
+  if (a.mode == 1) {
+    if (k < ps) { const int t = t0 + k; return t < vl ? row[t].x : last; }
+    const int q = k - ps;
+    if (q >= ps * a.emb_dim) return 0.f;
+    const int j = q / a.emb_dim, e = q - j * a.emb_dim;
+    const int t = t0 + j;
+    return a.pos_table[(size_t)(t < vl ? t : a.max_seq_len) * a.emb_dim + e];
+  }
+  if (a.mode == 2) {
+    if (k >= 2 * ps) return 0.f;
+    const int t = t0 + (k >> 1);
+    if (!(k & 1)) return t < vl ? row[t].x : last;
+    const int den = a.max_valid_len - 1 > 1 ? a.max_valid_len - 1 : 1;
+    return t < vl ? (float)t / (float)den : -1.0f;
+  }
+  if (k >= ps) return 0.f;
+  const int t = t0 + k;
+  return t < vl ? row[t].x : last;
+}
+
+// the 8 consecutive features k0 .. k0 + 7 of one patch row (k0 % 8 == 0).  Mode 1 with patch size and embedding width multiples of 8 (every
+// shipped config: 16 / 16): the group lies wholly inside the value part or inside ONE position's embedding row - two 16-byte loads, one
+// division per group instead of eight
+__device__ __forceinline__ void ts_feature8(const ChattsPatchifyArgs& a, const float2* row, int vl, float last, int t0, int k0, float (&v)[8]) {
+  const int ps = a.patch_size;
+  if (a.mode == 1 && (ps & 7) == 0 && (a.emb_dim & 7) == 0) {
+    if (k0 < ps) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int t = t0 + k0 + q; v[q] = t < vl ? row[t].x : last; }
+      return;
+    }
+    const int q0 = k0 - ps;
+    if (q0 >= ps * a.emb_dim) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = 0.f;
+      return;
+    }
+    const int j = q0 / a.emb_dim, e0 = q0 - j * a.emb_dim;
+    const int t = t0 + j;
+    const float* src = a.pos_table + (size_t)(t < vl ? t : a.max_seq_len) * a.emb_dim + e0;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = ts_feature(a, row, vl, last, t0, k0 + q);
+}
+
+template <int KSTEPS>      // K-steps of 32 (feature count rounded up): compiled per count so that every load is in flight at once
+__global__ __launch_bounds__(256) void ts_layer0_kernel(ChattsPatchifyArgs a, const uint16_t* __restrict__ w0, int ldw, const float* __restrict__ b0,
+                                                         int hidden, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int ld_out) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 32, r0 = blockIdx.y * 128 + wave * 32;
+  const int frow = lane & 15, kc = lane >> 4;                  // this lane's row of a 16-row block, and its 8 K-values of a 32-deep step
+  // the two patch rows this lane feeds (one per 16-row block), clamped to the last real row (stores are masked)
+  const float2* rowp[2];
+  int vl[2], t0[2];
+  float last[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    int p = r0 + b * 16 + frow;
+    if (p > a.total_patches - 1) p = a.total_patches - 1;
+    int lo = 0, hi = a.n_series;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.row_off[mid] <= p) lo = mid; else hi = mid;
+    }
+    vl[b] = a.valid_len[lo];
+    t0[b] = (p - a.row_off[lo]) * a.patch_size;
+    rowp[b] = reinterpret_cast<const float2*>(a.series) + (size_t)lo * a.lmax;
+    last[b] = rowp[b][vl[b] - 1].x;
+  }
+  // W0 fragments: rows n0 + 16 j + frow, K-values 32 s + 8 kc ..; all KSTEPS x 2 loads issued before the first use
+  bf16x8_t wf[KSTEPS][2];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      wf[s][j] = *reinterpret_cast<const bf16x8_t*>(w0 + (size_t)(n0 + j * 16 + frow) * ldw + s * 32 + kc * 8);
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    bf16x8_t ahi[2], alo[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float v[8];
+      ts_feature8(a, rowp[b], vl[b], last[b], t0[b], s * 32 + kc * 8, v);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        uint16_t h, l;
+        split_bf16x2(v[q], h, l);
+        ahi[b][q] = __builtin_bit_cast(__bf16, h);
+        alo[b][q] = __builtin_bit_cast(__bf16, l);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], alo[b], acc[b][j], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], ahi[b], acc[b][j], 0, 0, 0);
+  }
+  // lane holds D[feature n0 + 16 j + 4 kc + r][token r0 + 16 b + frow]: bias, exact-erf GELU, split, 8-byte stores (ring_store's arithmetic)
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int tok = r0 + b * 16 + frow;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int fb = n0 + j * 16 + kc * 4;
+      const f32x4 bias = b0 ? *reinterpret_cast<const f32x4*>(b0 + fb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      bf16x4_t hv, lv;
+      {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = gelu_erf_f(acc[b][j][r] + bias[r]);
+          const __bf16 h = (__bf16)v;
+          hv[r] = h;
+          lv[r] = (__bf16)(v - (float)h);
+        }
+      }
+      if (tok < a.total_patches && fb < hidden) {
+        *reinterpret_cast<bf16x4_t*>(out_hi + (size_t)tok * ld_out + fb) = hv;
+        *reinterpret_cast<bf16x4_t*>(out_lo + (size_t)tok * ld_out + fb) = lv;
+      }
+    }
+  }
+}
+}  // namespace chatts
+
 using namespace chatts;
 
 extern "C" int chatts_ts_normalise(const double* raw, const int32_t* lengths, int n_series, int lmax, float* enc, double* stats,
@@ -217,11 +365,43 @@ extern "C" int chatts_ts_encode(const float* series, const int32_t* row_off, con
   auto hi_of = [&](float* buf) { return reinterpret_cast<chatts_bf16*>(buf); };
   auto lo_of = [&](float* buf, int k) { return reinterpret_cast<chatts_bf16*>(buf) + (size_t)P * k; };
   if (planes) { pa.out = nullptr; pa.out_hi = hi_of(feat); pa.out_lo = lo_of(feat, w->in_features_pad); }
-  int rc = chatts_ts_patchify(&pa, stream);
-  if (rc) return rc;
+  int rc;
   float* cur = feat;
   int k = w->in_features_pad;
-  for (int l = 0; l < w->num_layers; ++l) {
+  int l0 = 0;
+  // patchify + layer 0 as one launch (ts_layer0_kernel) when layer 0 is a hidden layer of the plane path: its GELU output goes out as the
+  // planes layer 1 reads; the feature matrix is never written.  TS_L0_FUSED=0 keeps the two-launch form (bit-identical).
+  const int feat_n = w->mode == 1 ? w->patch_size * (1 + w->emb_dim) : (w->mode == 2 ? 2 * w->patch_size : w->patch_size);
+  const int ksteps = (feat_n + 31) / 32;
+  if (planes && w->num_layers >= 2 && H % 32 == 0 && ksteps >= 1 && ksteps <= 10 && ksteps * 32 <= w->in_features_pad && h0 &&
+      ((uintptr_t)w->w[0] % 16) == 0 && ((uintptr_t)w->b[0] % 16) == 0 && ((uintptr_t)w->pos_table % 16) == 0 && opt_get(OPT_TS_L0_FUSED, 1) != 0) {
+    CHATTS_REQUIRE(pa.series && pa.row_off && pa.valid_len && (w->mode != 1 || (pa.pos_table && w->emb_dim > 0 && w->max_seq_len > 0)), CHATTS_E_BADARG,
+                   "ts_encode: null series / offsets / position table");
+    const dim3 grid(H / 32, (P + 127) / 128), block(256);
+    uint16_t* oh = hi_of(h0);
+    uint16_t* ol = lo_of(h0, H);
+#define CHATTS_TS_L0(KS) hipLaunchKernelGGL((ts_layer0_kernel<KS>), grid, block, 0, as_stream(stream), pa, w->w[0], w->in_features_pad, w->b[0], H, oh, ol, H)
+    switch (ksteps) {
+      case 1: CHATTS_TS_L0(1); break;
+      case 2: CHATTS_TS_L0(2); break;
+      case 3: CHATTS_TS_L0(3); break;
+      case 4: CHATTS_TS_L0(4); break;
+      case 5: CHATTS_TS_L0(5); break;
+      case 6: CHATTS_TS_L0(6); break;
+      case 7: CHATTS_TS_L0(7); break;
+      case 8: CHATTS_TS_L0(8); break;
+      case 9: CHATTS_TS_L0(9); break;
+      default: CHATTS_TS_L0(10); break;
+    }
+#undef CHATTS_TS_L0
+    CHATTS_CHECK_LAUNCH("ts_layer0");
+    cur = h0;
+    k = H;
+    l0 = 1;
+  } else {
+    if ((rc = chatts_ts_patchify(&pa, stream)) != 0) return rc;
+  }
+  for (int l = l0; l < w->num_layers; ++l) {
     const bool last = l == w->num_layers - 1;
     float* dst = last ? out : ((l & 1) ? h1 : h0);
     ChattsLinearArgs la{};

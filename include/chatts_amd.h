@@ -62,7 +62,7 @@ int chatts_device_cus(void);
  * GEMM_BM GEMM_PRECISION (1 = the bf16 speed mode) GEMM_PLANES_MIN_M GEMM_STREAM GEMM_STREAM_STAGES GEMM_STREAM_WAVES GEMM_STREAM_MB
  * GEMM_STREAM_MB_WAVES EPI_V4 EPI_NORM_Q EPI_NORM_Q_GROUPS EPI_NORM_REG POST_NORM_SMALL_M ROPE_FUSE ATTN_BF16X3 ATTN_EXACT ATTN_PLANES ATTN_XCD ATTN_ROWS ATTN_KSPLIT ARGMAX_2STAGE
  * TS_F32_PATH KV_ROUND TP_FUSE TP_FUSE_BLOCKS TP_BULK_BLOCKS TP_BULK_THREADS TP_BULK_FENCE TP_AR_BLOCKS GEMV_ROWS GEMV_UNR GEMV_NW GEMV_OCC GEMV_BLOCKS GEMV_LDSPAD GEMV_KS
- * FP8_BM FP8_ORDER GEMV8_ROWS GEMV8_UNR GEMV8_NW GEMV8_OCC (DESIGN.md section 11 says what each selects and where it was measured).  A set / unset is a relaxed atomic store: safe
+ * FP8_BM FP8_ORDER GEMV8_ROWS GEMV8_UNR GEMV8_NW GEMV8_OCC TS_L0_FUSED (DESIGN.md section 11 says what each selects and where it was measured).  A set / unset is a relaxed atomic store: safe
  * beside running calls, which see either value.  chatts_unset_option(NULL) clears all.  chatts_option_name(i) enumerates (NULL at the end). */
 int chatts_set_option(const char* name, int value);
 int chatts_unset_option(const char* name);

@@ -155,6 +155,34 @@ def test_ts_encoder_plane_path_equals_float32_path(lib, monkeypatch, hidden, len
     assert torch.equal(hi, want_hi) and torch.equal(lo, (f32 - want_hi.float()).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("mode", ["pos_emb", "pos_idx", "raw"])
+@pytest.mark.parametrize("hidden,lengths", [(1024, [17]), (1024, [100, 256, 1]), (5120, [256] * 8), (1024, [1000, 64, 1024] * 3), (4096, [33] * 5)])
+def test_ts_encoder_fused_layer0_is_bitwise_the_two_launch_form(lib, monkeypatch, mode, hidden, lengths):
+    """ts_layer0_kernel (patchify + first MLP layer in one launch: activation fragments built in registers from the series / position
+    table, W0 fragments straight from L2, the prefill kernel's MFMA order) against CHATTS_TS_L0_FUSED=0 (feature planes written, layer 0
+    through chatts_linear): the encoder output is bit-identical - 2 .. 200 patch rows (16-row block tails, several 128-row tiles), the three
+    feature modes of TimeSeriesEmbedding (chatts_vllm.py:61-91)."""
+    from chatts_amd.ts_encoder import TimeSeriesEmbedding
+    cfg = dict(patch_size=16, num_layers=3, hidden_size=hidden, num_features=2, max_sequence_length=2048,
+               use_position_embedding=mode == "pos_emb", use_position_idx=mode == "pos_idx", embedding_dim=16)
+    enc = TimeSeriesEmbedding(cfg, device=DEV)
+    enc.load_synthetic([s for s in synth.ts_encoder_specs(type("C", (), {"ts": cfg})())], 5)
+    rng = np.random.default_rng(len(lengths) + hidden)
+    lmax = max(lengths)
+    x = np.zeros((len(lengths), 2 * lmax, 1), dtype=np.float32)
+    for i, L in enumerate(lengths):
+        x[i, 0:2 * L:2, 0] = rng.standard_normal(L)
+        x[i, 1:2 * L:2, 0] = 1.0
+    xd = torch.from_numpy(x).to(DEV)
+    a, _ = enc(xd, valid_lengths=lengths)
+    a = a.clone()
+    monkeypatch.setenv("CHATTS_TS_L0_FUSED", "0")
+    b, _ = enc(xd, valid_lengths=lengths)
+    torch.cuda.synchronize()
+    assert a.shape == b.shape == (sum((L + 15) // 16 for L in lengths), hidden) and torch.isfinite(a).all()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def test_ts_encoder_empty_and_errors(lib):
     from chatts_amd.ts_encoder import TimeSeriesEmbedding
     cfg = dict(patch_size=16, num_layers=2, hidden_size=64, num_features=2, max_sequence_length=64,
