@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void ts_normalise_kernel(const double* __restr
 // ---- patchify + the first MLP layer in ONE launch (round 6; VERDICT r5 next #3a) -------------------------------------------------------
 // out0[p, n] = GELU(feat[p, :] . W0[n, :] + b0[n]) written as bf16 hi / lo planes - the operand of layer 1.  The separate form cost a
 // patchify launch (5.5 us) plus a 20-workgroup run of the prefill kernel for 3 MB of weights (13 us: K = 320 is ten half-steps of
-// pipeline fill).  Here a workgroup of 4 waves owns 128 patch rows x 32 output columns; wave w builds the activation fragments of its
-// two 16-row blocks IN REGISTERS, straight from the series / position table (the feature row never exists in memory), loads its W0
+// pipeline fill).  Here a one-wave workgroup owns 16 patch rows x 64 output columns; it builds the activation fragments of its
+// 16-row block IN REGISTERS, straight from the series / position table (the feature row never exists in memory), loads its W0
 // fragments straight from L2 (3 MB, shared by everybody) and issues the same MFMAs in the same order as the prefill kernel does
 // (per 32 K-values: lo pass, then hi pass; operands swapped, D = W . A^T): bit-identical planes.  No LDS, no barrier.
 namespace chatts {
@@ -177,118 +177,133 @@ __device__ __forceinline__ float ts_feature(const ChattsPatchifyArgs& a, const f
   return t < vl ? row[t].x : last;
 }
 
-// the 8 consecutive features k0 .. k0 + 7 of one patch row (k0 % 8 == 0).  Mode 1 with patch size and embedding width multiples of 8 (every
-// shipped config: 16 / 16): the group lies wholly inside the value part or inside ONE position's embedding row - two 16-byte loads, one
-// division per group instead of eight
-__device__ __forceinline__ void ts_feature8(const ChattsPatchifyArgs& a, const float2* row, int vl, float last, int t0, int k0, float (&v)[8]) {
+// the 8 consecutive features k0 .. k0 + 7 of one patch row (k0 % 8 == 0), LOADS ONLY and branch-free per lane: the tail value "last valid
+// value" is row[vl - 1], i.e. the load index is clamped instead of selecting afterwards; out-of-range groups load a valid address and
+// are zeroed.  MODE is compile time (the generic per-element form of ts_feature would put every mode's code, with its divisions, into each
+// of the 18 groups of a lane).  Mode 1 needs patch size and embedding width multiples of 8 (every shipped config: 16 / 16): a group then
+// lies wholly inside the value part or inside ONE position's embedding row - two 16-byte loads, one division per group.
+template <int MODE>
+__device__ __forceinline__ void ts_feature8(const ChattsPatchifyArgs& a, const float2* row, int vl, int t0, int k0, float (&v)[8]) {
   const int ps = a.patch_size;
-  if (a.mode == 1 && (ps & 7) == 0 && (a.emb_dim & 7) == 0) {
+  if constexpr (MODE == 1) {
     if (k0 < ps) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { const int t = t0 + k0 + q; v[q] = t < vl ? row[t].x : last; }
-      return;
+      for (int q = 0; q < 8; ++q) { const int t = t0 + k0 + q; v[q] = row[t < vl ? t : vl - 1].x; }
+    } else {
+      const int q0 = k0 - ps;
+      const bool ok = q0 < ps * a.emb_dim;
+      const int j = ok ? q0 / a.emb_dim : 0, e0 = ok ? q0 - j * a.emb_dim : 0;
+      const int t = t0 + j;
+      const float* src = a.pos_table + (size_t)(t < vl ? t : a.max_seq_len) * a.emb_dim + e0;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+      const float m = ok ? 1.f : 0.f;
+      v[0] = x0.x * m; v[1] = x0.y * m; v[2] = x0.z * m; v[3] = x0.w * m; v[4] = x1.x * m; v[5] = x1.y * m; v[6] = x1.z * m; v[7] = x1.w * m;
     }
-    const int q0 = k0 - ps;
-    if (q0 >= ps * a.emb_dim) {
+  } else if constexpr (MODE == 2) {      // (value, position) pairs: k even = value of t0 + k / 2, k odd = t / max(1, max_vl - 1) or -1
+    const bool ok = k0 < 2 * ps;
+    const int den = a.max_valid_len - 1 > 1 ? a.max_valid_len - 1 : 1;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = 0.f;
-      return;
+    for (int q = 0; q < 4; ++q) {
+      const int t = t0 + (ok ? (k0 >> 1) + q : 0);
+      const float x = row[t < vl ? t : vl - 1].x;
+      v[2 * q] = ok ? x : 0.f;
+      v[2 * q + 1] = ok ? (t < vl ? (float)t / (float)den : -1.0f) : 0.f;
     }
-    const int j = q0 / a.emb_dim, e0 = q0 - j * a.emb_dim;
-    const int t = t0 + j;
-    const float* src = a.pos_table + (size_t)(t < vl ? t : a.max_seq_len) * a.emb_dim + e0;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
-    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-    return;
+  } else {
+    const bool ok = k0 < ps;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int t = t0 + (ok ? k0 + q : 0); const float x = row[t < vl ? t : vl - 1].x; v[q] = ok ? x : 0.f; }
   }
-#pragma unroll
-  for (int q = 0; q < 8; ++q) v[q] = ts_feature(a, row, vl, last, t0, k0 + q);
 }
 
-template <int KSTEPS>      // K-steps of 32 (feature count rounded up): compiled per count so that every load is in flight at once
-__global__ __launch_bounds__(256) void ts_layer0_kernel(ChattsPatchifyArgs a, const uint16_t* __restrict__ w0, int ldw, const float* __restrict__ b0,
+template <int KSTEPS, int MODE, int NJ = 2>      // NJ: 16-column fragments per wave;  K-steps of 32 (feature count rounded up) and the feature mode: compiled in, so that every load is in flight at once
+__global__ __launch_bounds__(64) void ts_layer0_kernel(ChattsPatchifyArgs a, const uint16_t* __restrict__ w0, int ldw, const float* __restrict__ b0,
                                                          int hidden, uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int ld_out) {
   typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = blockIdx.x * 32, r0 = blockIdx.y * 128 + wave * 32;
+  // workgroup = ONE wave = 16 patch rows x 64 output columns (no LDS, no barrier: nothing to share): it builds (and splits) one activation
+  // fragment per K-step and re-uses it for four W fragments; P = 128, H = 5120: 640 independent waves over 256 CUs
+  const int lane = threadIdx.x & 63;
+  const int n0 = blockIdx.x * (16 * NJ), r0 = blockIdx.y * 16;
   const int frow = lane & 15, kc = lane >> 4;                  // this lane's row of a 16-row block, and its 8 K-values of a 32-deep step
-  // the two patch rows this lane feeds (one per 16-row block), clamped to the last real row (stores are masked)
-  const float2* rowp[2];
-  int vl[2], t0[2];
-  float last[2];
+  if (r0 >= a.total_patches) return;                           // (wave-uniform: a block wholly beyond the last patch row)
+  // W0 fragments first: rows n0 + 16 j + frow, K-values 32 s + 8 kc ..; all KSTEPS x 4 loads are independent of everything else
+  bf16x8_t wf[KSTEPS][NJ];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    int p = r0 + b * 16 + frow;
-    if (p > a.total_patches - 1) p = a.total_patches - 1;
-    int lo = 0, hi = a.n_series;
+  for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      int wr = n0 + j * 16 + frow;
+      if (wr > hidden - 1) wr = hidden - 1;
+      wf[s][j] = *reinterpret_cast<const bf16x8_t*>(w0 + (size_t)wr * ldw + s * 32 + kc * 8);
+    }
+  // the patch row this lane feeds, clamped to the last real row (stores are masked).  Its series: up to 63 series - lane i holds
+  // row_off[i] / valid_len[i] (ONE round trip), the search is a wave-uniform walk over lanes and two ds_bpermute; more series - the
+  // binary search of ts_patchify_kernel (log2 N dependent round trips)
+  const int nser = a.n_series;
+  const int my_off = a.row_off[lane <= nser ? lane : nser];
+  const int my_vl = a.valid_len[lane < nser ? lane : nser - 1];
+  int p = r0 + frow;
+  if (p > a.total_patches - 1) p = a.total_patches - 1;
+  int sidx = 0, off = 0, vl = 0;
+  if (nser <= 63) {
+    for (int i = 1; i < nser; ++i) sidx += __builtin_amdgcn_readlane(my_off, i) <= p ? 1 : 0;
+    off = __shfl(my_off, sidx, 64);
+    vl = __shfl(my_vl, sidx, 64);
+  } else {
+    int lo = 0, hi = nser;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
       if (a.row_off[mid] <= p) lo = mid; else hi = mid;
     }
-    vl[b] = a.valid_len[lo];
-    t0[b] = (p - a.row_off[lo]) * a.patch_size;
-    rowp[b] = reinterpret_cast<const float2*>(a.series) + (size_t)lo * a.lmax;
-    last[b] = rowp[b][vl[b] - 1].x;
+    sidx = lo;
+    off = a.row_off[lo];
+    vl = a.valid_len[lo];
   }
-  // W0 fragments: rows n0 + 16 j + frow, K-values 32 s + 8 kc ..; all KSTEPS x 2 loads issued before the first use
-  bf16x8_t wf[KSTEPS][2];
+  const int t0 = (p - off) * a.patch_size;
+  const float2* rowp = reinterpret_cast<const float2*>(a.series) + (size_t)sidx * a.lmax;
+  // every feature load of the block before the first use
+  float raw[KSTEPS][8];
 #pragma unroll
-  for (int s = 0; s < KSTEPS; ++s)
+  for (int s = 0; s < KSTEPS; ++s) ts_feature8<MODE>(a, rowp, vl, t0, s * 32 + kc * 8, raw[s]);
+  f32x4 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      wf[s][j] = *reinterpret_cast<const bf16x8_t*>(w0 + (size_t)(n0 + j * 16 + frow) * ldw + s * 32 + kc * 8);
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < KSTEPS; ++s) {
-    bf16x8_t ahi[2], alo[2];
+    bf16x8_t ahi, alo;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      float v[8];
-      ts_feature8(a, rowp[b], vl[b], last[b], t0[b], s * 32 + kc * 8, v);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        uint16_t h, l;
-        split_bf16x2(v[q], h, l);
-        ahi[b][q] = __builtin_bit_cast(__bf16, h);
-        alo[b][q] = __builtin_bit_cast(__bf16, l);
-      }
+    for (int q = 0; q < 8; ++q) {
+      uint16_t h, l;
+      split_bf16x2(raw[s][q], h, l);
+      ahi[q] = __builtin_bit_cast(__bf16, h);
+      alo[q] = __builtin_bit_cast(__bf16, l);
     }
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], alo, acc[j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], alo[b], acc[b][j], 0, 0, 0);
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], ahi[b], acc[b][j], 0, 0, 0);
+    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], ahi, acc[j], 0, 0, 0);
   }
-  // lane holds D[feature n0 + 16 j + 4 kc + r][token r0 + 16 b + frow]: bias, exact-erf GELU, split, 8-byte stores (ring_store's arithmetic)
+  // lane holds D[feature n0 + 16 j + 4 kc + r][token r0 + frow]: bias, exact-erf GELU, split, 8-byte stores (ring_store's arithmetic)
+  const int tok = r0 + frow;
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int tok = r0 + b * 16 + frow;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int fb = n0 + j * 16 + kc * 4;
-      const f32x4 bias = b0 ? *reinterpret_cast<const f32x4*>(b0 + fb) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      bf16x4_t hv, lv;
-      {
+  for (int j = 0; j < NJ; ++j) {
+    const int fb = n0 + j * 16 + kc * 4;
+    const int fbc = fb < hidden ? fb : 0;
+    const f32x4 bias = b0 ? *reinterpret_cast<const f32x4*>(b0 + fbc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x4_t hv, lv;
+    {
 #pragma clang fp contract(off)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = gelu_erf_f(acc[b][j][r] + bias[r]);
-          const __bf16 h = (__bf16)v;
-          hv[r] = h;
-          lv[r] = (__bf16)(v - (float)h);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const float v = gelu_erf_f(acc[j][r] + bias[r]);
+        const __bf16 h = (__bf16)v;
+        hv[r] = h;
+        lv[r] = (__bf16)(v - (float)h);
       }
-      if (tok < a.total_patches && fb < hidden) {
-        *reinterpret_cast<bf16x4_t*>(out_hi + (size_t)tok * ld_out + fb) = hv;
-        *reinterpret_cast<bf16x4_t*>(out_lo + (size_t)tok * ld_out + fb) = lv;
-      }
+    }
+    if (tok < a.total_patches && fb < hidden) {
+      *reinterpret_cast<bf16x4_t*>(out_hi + (size_t)tok * ld_out + fb) = hv;
+      *reinterpret_cast<bf16x4_t*>(out_lo + (size_t)tok * ld_out + fb) = lv;
     }
   }
 }
@@ -373,25 +388,32 @@ extern "C" int chatts_ts_encode(const float* series, const int32_t* row_off, con
   // planes layer 1 reads; the feature matrix is never written.  TS_L0_FUSED=0 keeps the two-launch form (bit-identical).
   const int feat_n = w->mode == 1 ? w->patch_size * (1 + w->emb_dim) : (w->mode == 2 ? 2 * w->patch_size : w->patch_size);
   const int ksteps = (feat_n + 31) / 32;
-  if (planes && w->num_layers >= 2 && H % 32 == 0 && ksteps >= 1 && ksteps <= 10 && ksteps * 32 <= w->in_features_pad && h0 &&
+  const bool l0_shape = w->mode == 1 ? (w->patch_size % 8 == 0 && w->emb_dim % 8 == 0 && ksteps <= 10) : (w->patch_size % 8 == 0 && ksteps <= 2);
+  if (planes && w->num_layers >= 2 && H % 16 == 0 && ksteps >= 1 && l0_shape && ksteps * 32 <= w->in_features_pad && h0 &&
       ((uintptr_t)w->w[0] % 16) == 0 && ((uintptr_t)w->b[0] % 16) == 0 && ((uintptr_t)w->pos_table % 16) == 0 && opt_get(OPT_TS_L0_FUSED, 1) != 0) {
     CHATTS_REQUIRE(pa.series && pa.row_off && pa.valid_len && (w->mode != 1 || (pa.pos_table && w->emb_dim > 0 && w->max_seq_len > 0)), CHATTS_E_BADARG,
                    "ts_encode: null series / offsets / position table");
-    const dim3 grid(H / 32, (P + 127) / 128), block(256);
+    const dim3 grid((H + 31) / 32, (P + 15) / 16), block(64);      // (NJ = 2: 32 columns per wave)
     uint16_t* oh = hi_of(h0);
     uint16_t* ol = lo_of(h0, H);
-#define CHATTS_TS_L0(KS) hipLaunchKernelGGL((ts_layer0_kernel<KS>), grid, block, 0, as_stream(stream), pa, w->w[0], w->in_features_pad, w->b[0], H, oh, ol, H)
-    switch (ksteps) {
-      case 1: CHATTS_TS_L0(1); break;
-      case 2: CHATTS_TS_L0(2); break;
-      case 3: CHATTS_TS_L0(3); break;
-      case 4: CHATTS_TS_L0(4); break;
-      case 5: CHATTS_TS_L0(5); break;
-      case 6: CHATTS_TS_L0(6); break;
-      case 7: CHATTS_TS_L0(7); break;
-      case 8: CHATTS_TS_L0(8); break;
-      case 9: CHATTS_TS_L0(9); break;
-      default: CHATTS_TS_L0(10); break;
+#define CHATTS_TS_L0(KS, MD) hipLaunchKernelGGL((ts_layer0_kernel<KS, MD>), grid, block, 0, as_stream(stream), pa, w->w[0], w->in_features_pad, w->b[0], H, oh, ol, H)
+    if (w->mode == 1) {
+      switch (ksteps) {
+        case 1: CHATTS_TS_L0(1, 1); break;
+        case 2: CHATTS_TS_L0(2, 1); break;
+        case 3: CHATTS_TS_L0(3, 1); break;
+        case 4: CHATTS_TS_L0(4, 1); break;
+        case 5: CHATTS_TS_L0(5, 1); break;
+        case 6: CHATTS_TS_L0(6, 1); break;
+        case 7: CHATTS_TS_L0(7, 1); break;
+        case 8: CHATTS_TS_L0(8, 1); break;
+        case 9: CHATTS_TS_L0(9, 1); break;
+        default: CHATTS_TS_L0(10, 1); break;
+      }
+    } else if (w->mode == 2) {
+      if (ksteps == 1) CHATTS_TS_L0(1, 2); else CHATTS_TS_L0(2, 2);
+    } else {
+      if (ksteps == 1) CHATTS_TS_L0(1, 0); else CHATTS_TS_L0(2, 0);
     }
 #undef CHATTS_TS_L0
     CHATTS_CHECK_LAUNCH("ts_layer0");
