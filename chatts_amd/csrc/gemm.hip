@@ -981,7 +981,9 @@ int launch_gemm(const ChattsLinearArgs* a_in, hipStream_t s, const RopeFuse* rop
     else if (a->m > 16) rc = w8x ? launch_stream_t<4, false, 2, 8>(p, a, sk, s) : launch_stream_t<4, false, 2>(p, a, sk, s);     // 4 x 24 KB
     else if (a->w8 && a->w8_format == CHATTS_W8_INT8)
       rc = stages == 3 ? launch_stream_t<3, true, 1, 4, true>(p, a, sk, s) : launch_stream_t<4, true, 1, 4, true>(p, a, sk, s);
-    else if (a->w8 && opt_get(OPT_GEMM_STREAM_WAVES, 4) == 8)
+    // fp8 W: eight waves per workgroup since round 6 (kernel trace of config 5 per geometry, profiles/r6_cfg5_stream_geometry.txt: gate_up 30.0 -> 29.2,
+    // o / down 11.8 -> 11.1, qkv 10.3 -> 9.7, lm_head 153 -> 141 us; bit-identical to four waves)
+    else if (a->w8 && opt_get(OPT_GEMM_STREAM_WAVES, 8) == 8)
       rc = stages == 3 ? launch_stream_t<3, true, 1, 8>(p, a, sk, s) : launch_stream_t<4, true, 1, 8>(p, a, sk, s);
     else if (a->w8) rc = stages == 3 ? launch_stream_t<3, true>(p, a, sk, s) : launch_stream_t<4, true>(p, a, sk, s);
     else if (stages == 3) rc = launch_stream_t<3, false>(p, a, sk, s);
