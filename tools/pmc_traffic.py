@@ -61,7 +61,7 @@ def headline(db, cmd, src):
     name, grid, wg, n, kib, us = max(rows, key=lambda r: r[4])            # gate_up: the SwiGLU GEMV with the most bytes
     inter = 13824
     d = load()
-    d.update({"source": f"{src} ({cmd}, MI355X, round 5)", "code_digest": code_digest(GEMV_FILES), "code_files": GEMV_FILES,
+    d.update({"source": f"{src} ({cmd}, MI355X, round 6)", "code_digest": code_digest(GEMV_FILES), "code_files": GEMV_FILES,
               "kernel": f"gemv_ldsx_kernel<2,2,SWIGLU,NORM> (gate_up_proj, grid {grid} = {grid // wg} workgroups x {wg} threads)",
               "launches_counted": n, "fetch_size_kib_per_launch": round(kib, 1), "gfx950_fetch_correction": 2.0,
               "write_bytes_per_launch": inter * 4, "hbm_bytes_per_launch": int(kib * 1024 * 2 + inter * 4), "avg_us_under_pmc": round(us, 2)})
@@ -81,7 +81,7 @@ def ts(db, cmd, src):
         per_kernel.append({"kernel": name.split("(")[0].replace("void chatts::", "")[:80], "grid": grid, "launches_per_call": round(n / calls, 2),
                            "fetch_bytes_per_call": int(b), "avg_us_under_pmc": round(us, 2)})
     d = load()
-    d["ts_encoder"] = {"source": f"{src} ({cmd}, MI355X, round 5)", "code_digest": code_digest(TS_FILES), "code_files": TS_FILES,
+    d["ts_encoder"] = {"source": f"{src} ({cmd}, MI355X, round 6)", "code_digest": code_digest(TS_FILES), "code_files": TS_FILES,
                        "workload": "8 series x 256 steps (P = 128 patches), chatts_ts_encode", "calls_counted": calls,
                        "hbm_fetch_bytes_per_call": int(total), "algorithmic_bytes_per_call": 215257152,
                        "ratio": round(total / 215257152, 3), "per_kernel": per_kernel}
@@ -99,7 +99,7 @@ def batched(db, cmd, src, key="14b_8x1024_fp8_b16"):
     d = load()
     inter, B = 13824, 16
     d.setdefault("batched", {})[key] = {
-        "source": f"{src} ({cmd}, MI355X, round 5)", "code_digest": code_digest(BATCHED_FILES), "code_files": BATCHED_FILES,
+        "source": f"{src} ({cmd}, MI355X, round 6)", "code_digest": code_digest(BATCHED_FILES), "code_files": BATCHED_FILES,
         "kernel": f"{gu[0].split('(')[0].replace('void chatts::', '')} (gate_up_proj + SwiGLU, M = {B}, grid {gu[1]})",
         "fetch_size_kib_per_launch": round(gu[4], 1), "gfx950_fetch_correction": 2.0, "write_bytes_per_launch": B * inter * 2 * 2,
         "hbm_bytes_per_launch": int(gu[4] * 1024 * 2 + B * inter * 4), "algorithmic_bytes_per_launch": 143208448,
