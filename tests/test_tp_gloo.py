@@ -188,3 +188,97 @@ def test_tensor_parallel_serving_followers_replay_the_leader():
     assert [a[1] for a in adds] == ["a <ts><ts/>", "b", "c"]
     assert adds[0][3] == ("temperature", "timeseries")                                        # no callback crossed the wire
     assert sum(1 for e in logs[0] if e[0] == "step") >= 4
+
+
+# ---- the release-form decision of the bulk sums (P2PExchange.first_contact), driven on CPU -----------------------------------------------
+class _FakeExchange:
+    """P2PExchange with its device-facing hooks replaced: the bulk sum is a gloo all-reduce, optionally corrupted under the light form on
+    one rank, the status word and the library's knobs are Python attributes.  first_contact itself is the shipped method."""
+
+    def __init__(self, comm, ident, corrupt_light_on=None, stall_on=None, forced=None, lib_cross=False):
+        self.comm, self.ident, self.corrupt, self.stall, self.forced, self.lib_cross = comm, ident, corrupt_light_on, stall_on, forced, lib_cross
+        self.bulk_elems, self.release_note, self.mode, self.cross_set, self.resets = 1 << 12, None, None, False, 0
+
+    _tensor_device = "cpu"
+
+    def device_identity(self):
+        return self.ident
+
+    def _set_cross_device(self):
+        self.cross_set = True
+
+    def _library_saw_cross_device(self):
+        return self.lib_cross
+
+    def _forced_release_option(self):
+        return self.forced
+
+    def _reset_after_stall(self):
+        self.resets += 1
+
+    def set_bulk_release(self, mode):
+        self.mode = mode
+
+    def bulk_release(self):
+        return "fence" if (self.forced == 1 or (self.forced is None and self.mode == "fence")) else "light"
+
+    def status(self):
+        return 1 if self.stall == self.comm.rank else 0
+
+    def all_reduce_bulk(self, inp, x):
+        s = inp.clone()
+        dist.all_reduce(s)
+        if self.mode == "light" and self.corrupt == self.comm.rank:
+            s[7] += 1.0                           # one element of one sum on one rank arrives wrong
+        x += s
+        return x
+
+
+def _first_contact_worker(rank, world, port, q):
+    from chatts_amd.tp import P2PExchange
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("CHATTS_TP_ASSUME_CROSS_DEVICE", "CHATTS_TP_INJECT_RELEASE_MISMATCH"):
+        os.environ.pop(k, None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = Comm()
+        out = {}
+        cases = {"same_device": dict(ident=("host", "gpu0")),
+                 "cross_ok": dict(ident=("host", f"gpu{rank}")),
+                 "cross_light_wrong_on_rank1": dict(ident=("host", f"gpu{rank}"), corrupt_light_on=1),
+                 "cross_peer_stalled_on_rank0": dict(ident=("host", f"gpu{rank}"), stall_on=0),
+                 "forced_fence": dict(ident=("host", f"gpu{rank}"), forced=1),
+                 "library_unsure": dict(ident=("host", "gpu0"), lib_cross=True)}
+        for name, kw in cases.items():
+            ex = _FakeExchange(comm, **kw)
+            P2PExchange.first_contact(ex, comm, rounds=4)
+            out[name] = (ex.release_note, ex.mode, ex.cross_set, ex.resets)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_first_contact_decides_the_release_form_identically_on_every_rank():
+    """chatts_amd.tp.P2PExchange.first_contact (the guard every serving path runs when it builds its exchange): ranks that share a device
+    keep the light release untested; ranks on different devices run the test sums and get the light form only if EVERY rank saw every
+    sum exact under both forms - one wrong element on one rank, or one timed-out peer (then every rank also resets its buffers), leaves
+    the fence on ALL ranks; TP_BULK_FENCE set wins; a library that could not place a peer buffer counts as cross-device."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_first_contact_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for name in res[0]:
+        assert res[0][name][:2] == res[1][name][:2], (name, res[0][name], res[1][name])      # same verdict, same note, on both ranks
+    r = res[0]
+    assert r["same_device"][0] == "light (all ranks on one device)" and r["same_device"][1] is None and not r["same_device"][2]
+    assert r["cross_ok"][0].startswith("light (validated at first contact: 4 sums") and r["cross_ok"][1] == "light" and r["cross_ok"][2]
+    assert r["cross_light_wrong_on_rank1"][0].startswith("fence (first contact: 1 of 2 ranks") and r["cross_light_wrong_on_rank1"][1] == "fence"
+    assert r["cross_peer_stalled_on_rank0"][1] == "fence" and res[0]["cross_peer_stalled_on_rank0"][3] == 1 and res[1]["cross_peer_stalled_on_rank0"][3] == 1
+    assert r["forced_fence"][0] == "fence (TP_BULK_FENCE=1 set)" and r["forced_fence"][1] is None
+    assert r["library_unsure"][0].startswith("light (validated") and not r["library_unsure"][2]
