@@ -373,13 +373,15 @@ static int ptr_device(const void* p) {
   return a.device;
 }
 static void tp_classify_peers(ChattsTpComm* c) {
-  const int mine = ptr_device(c->p.peer[c->p.rank]);
-  for (int r = 0; r < c->p.world; ++r) {
-    if (r == c->p.rank) continue;
-    const int d = ptr_device(c->p.peer[r]);
-    if (mine < 0 || d < 0 || d != mine) c->cross_device = 1;
-    else c->shared_device = 1;
-  }
+  // over ALL pairs of ranks, not only the ones involving this rank: every rank must arrive at the same two flags (the bulk sum's grid
+  // follows from them and its flags are per workgroup) - also when the ranks are spread unevenly over the devices
+  int dev[kMaxWorld];
+  for (int r = 0; r < c->p.world; ++r) dev[r] = ptr_device(c->p.peer[r]);
+  for (int i = 0; i < c->p.world; ++i)
+    for (int j = i + 1; j < c->p.world; ++j) {
+      if (dev[i] < 0 || dev[j] < 0 || dev[i] != dev[j]) c->cross_device = 1;
+      else c->shared_device = 1;
+    }
 }
 
 extern "C" size_t chatts_tp_buffer_bytes(int world, int64_t max_elems) {
