@@ -739,6 +739,7 @@ extern "C" int chatts_decoder_prefill(ChattsDecoder* d, int t, int pos0, chatts_
 // and the MLP as weight-streaming GEMVs.  Saves one layer's attention + o / gate_up / down GEMMs (~0.9 of 44 ms at the
 // benchmark prompt).  The result lives in row 0 of x (rows 1.. are stale).
 static int layer_last_row(ChattsDecoder* d, int layer, int t, int pos0, chatts_stream_t stream) {
+  d->normed_q = false;      // (f16q mode: the last layer runs the default kernels)
   const ChattsDecoderConfig& c = d->cfg;
   const ChattsLayerWeights& lw = d->layers[layer];
   const int H = c.hidden, qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim;
@@ -826,6 +827,7 @@ static int layer_part0_packed(ChattsDecoder* d, int layer, int t, const ChattsPr
   const ChattsLayerWeights& lw = d->layers[layer];
   const int H = c.hidden, qkv_n = (c.n_q + 2 * c.n_kv) * kHeadDim, na = c.n_q * kHeadDim;
   int rc;
+  d->normed_q = false;      // (f16q mode: this half runs the default kernels and is about to overwrite planes 0 - the next MLP half recomputes its norm)
   const bool f8 = d->prefill_fp8 && t >= 16;          // speed mode: qkv and o_proj as fp8 x fp8 GEMMs (layer_part_fp8's arithmetic)
   ChattsLinearArgs la{};
   if (f8) {

@@ -145,3 +145,30 @@ def test_f16q_prefill_mode_matches_oracle(preset, lengths):
     assert worst["f16q"] < 1e-3, worst
     assert worst["f16q"] < 3e-4, worst                                       # what the split delivers (few layers: far below)
     assert not torch.equal(hid["f16q"], hid[None])                           # the mode really ran other arithmetic than the default
+
+
+def test_f16q_mode_with_packed_multi_prompt_prefill_matches_oracle():
+    """precision='f16q' under continuous batching: several prompts prefilled in ONE packed pass of > 96 rows - the attention half of a layer
+    runs the default kernels per segment (layer_part0_packed), the MLP half the f16q projections, and the plane buffers change their type in
+    between: every request must still produce the oracle's tokens (a stale 'planes already normed' flag across that boundary would not)."""
+    from chatts_amd import config as cfgmod, synth
+    from chatts_amd.modeling import ChatTSForCausalLM
+    from chatts_amd.processing import ChatTSProcessor
+    from oracle import pipeline, synth as osynth
+    from tests.util import chat_prompt, random_walk_series
+    cfg = cfgmod.preset("tiny-qwen2")
+    proc = ChatTSProcessor.from_pretrained(cfg)
+    sd = osynth.state_dict(synth.all_specs(cfg), 5)
+    rng = np.random.default_rng(21)
+    specs = [[256, 256], [100, 256], [256], [64, 64, 64]]
+    reqs, wants = [], []
+    for lengths in specs:
+        series = [random_walk_series(rng, L) for L in lengths]
+        inp = proc(text=[chat_prompt(lengths)], timeseries=series, return_tensors="pt")
+        ids = inp["input_ids"][0].tolist()
+        reqs.append((ids, inp["timeseries"], list(lengths)))
+        wants.append(pipeline.generate(cfg, sd, ids, inp["timeseries"].numpy(), 6)["tokens"])
+    m = ChatTSForCausalLM.from_synthetic(cfg, seed=5, max_ctx=512, max_prefill_tokens=512, max_batch=4, precision="f16q")
+    outs = m.generate_batch(reqs, max_new_tokens=6, eos_token_id=None, sync_every=3)
+    assert outs == wants
+    assert m.prefix_stats.get("packed_prefills", 0) >= 1
