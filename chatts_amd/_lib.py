@@ -59,7 +59,7 @@ class LinearF16qArgs(C.Structure):
                 ("epilogue", c_int), ("c_hi", c_void_p), ("c_lo8", c_void_p), ("c_scale", c_void_p), ("ld_cplanes", c_int),
                 ("ld_cscale", c_int), ("post_norm_w", c_void_p), ("post_norm_eps", c_float), ("post_hi", c_void_p),
                 ("post_lo8", c_void_p), ("post_scale", c_void_p), ("ld_post", c_int), ("ld_pscale", c_int),
-                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("planes_tiled", c_int), ("w_tiled", c_int)]
 
 
 class KvCache(C.Structure):
@@ -133,9 +133,11 @@ SIGNATURES = {
     "chatts_linear": (c_int, [C.POINTER(LinearArgs), c_void_p]),
     "chatts_quantize_rows_fp8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "chatts_linear_fp8": (c_int, [C.POINTER(LinearFp8Args), c_void_p]),
-    "chatts_split_f16q": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "chatts_split_f16q": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "chatts_weights_f16q": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "chatts_rmsnorm_f16q": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "chatts_rmsnorm_f16q": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "chatts_tile_e4m3_bytes": (c_size_t, [c_int, c_int]),
+    "chatts_tile_e4m3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "chatts_linear_f16q_workspace": (c_size_t, [c_int, c_int, c_int]),
     "chatts_linear_f16q": (c_int, [C.POINTER(LinearF16qArgs), c_void_p]),
     "chatts_decoder_set_prefill_fp8": (c_int, [c_void_p, c_int]),

@@ -313,7 +313,7 @@ extern "C" int chatts_decoder_set_prefill_f16q(ChattsDecoder* d, int on) {
     const ChattsDecoderConfig& c = d->cfg;
     for (const ChattsLayerWeights& lw : d->layers)
       CHATTS_REQUIRE(lw.qkv16 && lw.qkv_q8 && lw.qkv_q8e && lw.o16 && lw.o_q8 && lw.o_q8e && lw.gate_up16 && lw.gate_up_q8 && lw.gate_up_q8e &&
-                         lw.down16 && lw.down_q8 && lw.down_q8e, CHATTS_E_BADARG, "decoder_set_prefill_f16q: a layer has no f16q weight copies");
+                         lw.down16 && lw.down_q8 && lw.down_q8e, CHATTS_E_BADARG, "decoder_set_prefill_f16q: a layer has no (tiled) f16q weight copies");
     CHATTS_REQUIRE(c.hidden % 128 == 0 && c.inter % 128 == 0, CHATTS_E_SHAPE, "decoder_set_prefill_f16q: hidden / inter must be multiples of 128");
     CHATTS_REQUIRE(d->b.planes_hi && d->b.planes_lo && d->b.planes2_hi && d->b.planes2_lo && d->b.t_max >= 1, CHATTS_E_BADARG,
                    "decoder_set_prefill_f16q: the plane buffers are needed as scratch");
@@ -329,7 +329,8 @@ static F16qBuf f16q_buf(const ChattsDecoder* d, int pair) {
   const ChattsDecoderConfig& c = d->cfg;
   int maxdim = c.hidden > c.inter ? c.hidden : c.inter;
   if (c.n_q * kHeadDim > maxdim) maxdim = c.n_q * kHeadDim;
-  const size_t plane = (size_t)d->b.t_max * maxdim;            // elements of one bf16 plane = bytes of the e4m3 plane
+  const size_t plane = (size_t)((d->b.t_max + 31) / 32 * 32) * maxdim;      // elements of one bf16 plane (rows rounded up to 32: the tiled planes
+                                                                           // hold whole 16-row blocks) = bytes of the e4m3 plane
   F16qBuf b;
   b.hi = reinterpret_cast<chatts_f16*>(pair ? d->b.planes2_hi : d->b.planes_hi);
   b.lo8 = reinterpret_cast<uint8_t*>(pair ? d->b.planes2_lo : d->b.planes_lo);
@@ -352,6 +353,7 @@ static int layer_part_f16q(ChattsDecoder* d, int layer, int part, int t, int pos
     q.a_hi = in.hi; q.a_lo8 = in.lo8; q.a_scale = in.sc; q.ld_a = k; q.ld_scale = k / 128;
     q.w16 = w16; q.w8 = w8; q.w8_exp = w8e; q.ldw = k; q.m = t; q.n = n; q.k = k;
     q.workspace = d->b.workspace; q.workspace_bytes = d->b.workspace_bytes;
+    q.planes_tiled = 1; q.w_tiled = 1;      // every plane set and both weight copies in the kernel's own 1 KB / 512 B block order
   };
   // a residual projection also writes RMSNorm(x) for the projection after it - only inside the entry points that run the layers back to back
   auto post = [&](ChattsLinearF16qArgs& q, const float* next_norm_w) {
@@ -362,7 +364,7 @@ static int layer_part_f16q(ChattsDecoder* d, int layer, int part, int t, int pos
   };
   ChattsLinearF16qArgs q;
   if (part == 0) {
-    if (!d->normed_q && (rc = chatts_rmsnorm_f16q(d->b.x, lw.input_norm, A.hi, A.lo8, A.sc, H, H / 128, t, H, c.rms_eps, stream)) != 0) return rc;
+    if (!d->normed_q && (rc = chatts_rmsnorm_f16q(d->b.x, lw.input_norm, A.hi, A.lo8, A.sc, H, H / 128, t, H, c.rms_eps, 1, stream)) != 0) return rc;
     d->normed_q = false;
     base(q, A, H, lw.qkv16, lw.qkv_q8, lw.qkv_q8e, qkv_n);
     q.bias = lw.qkv_bias; q.c = d->b.qkv; q.ldc = qkv_n; q.epilogue = CHATTS_EPI_NONE;
@@ -372,14 +374,14 @@ static int layer_part_f16q(ChattsDecoder* d, int layer, int part, int t, int pos
                                    &kc, stream)) != 0) return rc;
     if ((rc = attention_impl(d->b.qkv, t, c.n_q, c.n_kv, pos0, pos0_dev, &kc, d->b.attn, nullptr, nullptr, 1, d->b.workspace,
                              d->b.workspace_bytes, stream)) != 0) return rc;
-    if ((rc = chatts_split_f16q(d->b.attn, t, na, na, A.hi, A.lo8, A.sc, na, na / 128, stream)) != 0) return rc;
+    if ((rc = chatts_split_f16q(d->b.attn, t, na, na, A.hi, A.lo8, A.sc, na, na / 128, 1, stream)) != 0) return rc;
     base(q, A, na, lw.o16, lw.o_q8, lw.o_q8e, H);
     q.ldc = H;
     if (tp) { q.c = d->b.delta; q.epilogue = CHATTS_EPI_NONE; }
     else { q.c = d->b.x; q.resid = d->b.x; q.epilogue = CHATTS_EPI_RESID; post(q, lw.post_norm); }
     return chatts_linear_f16q(&q, stream);
   }
-  if (!d->normed_q && (rc = chatts_rmsnorm_f16q(d->b.x, lw.post_norm, A.hi, A.lo8, A.sc, H, H / 128, t, H, c.rms_eps, stream)) != 0) return rc;
+  if (!d->normed_q && (rc = chatts_rmsnorm_f16q(d->b.x, lw.post_norm, A.hi, A.lo8, A.sc, H, H / 128, t, H, c.rms_eps, 1, stream)) != 0) return rc;
   d->normed_q = false;
   base(q, A, H, lw.gate_up16, lw.gate_up_q8, lw.gate_up_q8e, 2 * c.inter);
   q.epilogue = CHATTS_EPI_SWIGLU; q.ldc = c.inter;

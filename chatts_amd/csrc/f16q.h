@@ -45,6 +45,23 @@ struct F16qPlanes {
   uint8_t* lo8;      // [M, ld]
   uint8_t* sc;       // [M, ldsc]   ldsc >= K / 128
   int ld, ldsc;
+  int tiled;         // hi / lo8 in the TILED layout (below) over a matrix of `ld` columns (then ld = K exactly); the scales stay row-major
 };
+
+// TILED planes: what an LDS-DMA piece of gemm_f16q_kernel deposits is consecutive memory (profiles/r6_feed_probe.txt: 27-30 B per clock and
+// CU against 18 for 64-byte and 10-12 for 32-byte row slices).  Blocks of 16 rows x 32 K-values at index (row / 16) * (K / 32) + k / 32:
+//   hi   1 KB per block: 16-byte chunk (8 values) c of row r at position l = 4 r + (c ^ ((r >> 3) << 1)), r = row % 16, c = (k / 8) % 4
+//        (chatts_tile_bf16's order: the XOR is the fragment reads' bank swizzle)
+//   lo8  512 B per block: bytes 16 h .. 16 h + 15 of row r (h = (k / 16) % 2) at position 16 h + r
+// Element offsets of the 4 consecutive values k .. k + 3 (k % 4 == 0) of `row`:
+__device__ __forceinline__ size_t f16q_hi_off(const F16qPlanes& o, int row, int k) {
+  if (!o.tiled) return (size_t)row * o.ld + k;
+  const int r = row & 15, c = (k >> 3) & 3;
+  return ((size_t)(row >> 4) * (o.ld >> 5) + (k >> 5)) * 512 + (size_t)(((r << 2) | (c ^ ((r >> 3) << 1))) << 3) + (k & 7);
+}
+__device__ __forceinline__ size_t f16q_lo_off(const F16qPlanes& o, int row, int k) {
+  if (!o.tiled) return (size_t)row * o.ld + k;
+  return ((size_t)(row >> 4) * (o.ld >> 5) + (k >> 5)) * 512 + (size_t)(((((k >> 4) & 1) << 4) | (row & 15)) << 4) + (k & 15);
+}
 
 }  // namespace chatts

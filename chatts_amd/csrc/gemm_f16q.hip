@@ -47,14 +47,17 @@ struct F16qGemm {
   const uint8_t* a_lo8;
   const uint8_t* a_sc;
   int lda, ldsc;
+  int a_tiled;             // a_hi / a_lo8 in the tiled plane layout of f16q.h (lda == K)
   const _Float16* w16;
   const uint8_t* w8;
   const uint8_t* w8e;      // e8m0 byte per W row
   int ldw;
+  int w_tiled;             // w16 in the layout of chatts_tile_bf16 (16-bit elements), w8 in that of chatts_tile_e4m3: a piece = 1 KB of memory
   _Float16* c_hi;          // SwiGLU output in the f16q format (down_proj's operand), or null
   uint8_t* c_lo8;
   uint8_t* c_sc;
   int ldcp, ldcsc;
+  int c_tiled;             // the SwiGLU plane output goes out tiled (over ldcp = N / 2 columns)
 };
 
 // Both MFMAs as inline asm with the accumulator TIED (D = C in place).  Through the builtins hipcc (ROCm 7.2) gave most products a
@@ -80,6 +83,7 @@ __device__ __forceinline__ void f16q_store_swiglu(const F16qGemm& q, const f32x4
                                                   int panel, char* smem) {
   const GemmParams& p = q.g;
   const int tl = lane & 15, fq = (lane >> 4) * 4;
+  const F16qPlanes cp{q.c_hi, q.c_lo8, q.c_sc, q.ldcp, q.ldcsc, q.c_tiled};
   float* scr = reinterpret_cast<float*>(smem + kQScr);
   f32x4 bg[2], bu[2];
 #pragma unroll
@@ -129,8 +133,8 @@ __device__ __forceinline__ void f16q_store_swiglu(const F16qGemm& q, const f32x4
           const int fb = fb0 + h * 32 + fq;
           const int ocol = (fb >> 5) * 16 + fq;
           if (fb + 19 < p.n) {
-            *reinterpret_cast<f16x4_t*>(q.c_hi + (size_t)tok * q.ldcp + ocol) = hv[i][h];
-            *reinterpret_cast<uint32_t*>(q.c_lo8 + (size_t)tok * q.ldcp + ocol) = f16q_pack4(lo[i][h][0], lo[i][h][1], lo[i][h][2], lo[i][h][3], inv);
+            *reinterpret_cast<f16x4_t*>(q.c_hi + f16q_hi_off(cp, tok, ocol)) = hv[i][h];
+            *reinterpret_cast<uint32_t*>(q.c_lo8 + f16q_lo_off(cp, tok, ocol)) = f16q_pack4(lo[i][h][0], lo[i][h][1], lo[i][h][2], lo[i][h][3], inv);
           }
         }
         if ((wave & 3) == 0 && lane < 16) q.c_sc[(size_t)tok * q.ldcsc + panel] = (uint8_t)f16q_byte(E);
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(kQThreads) void gemm_f16q_kernel(F16qGemm q, RingGe
   const char* const b_ahi = reinterpret_cast<const char*>(q.a_hi);
   const char* const b_w8 = reinterpret_cast<const char*>(q.w8);
   const char* const b_a8 = reinterpret_cast<const char*>(q.a_lo8);
+  const int nkt = p.k >> 5;                                      // half-stages of the whole K (tiled operands)
   const int pcA = wave == 2 ? 0 : (wave == 5 ? 1 : (wave == 6 ? 2 : -1));
   uint32_t o_w16[2], o_ahi[2], o_w8 = 0, o_a8 = 0, o_asc = 0, o_wsc = 0;
   int n_ahi = 0, n_a8 = 0, n_asc = 0, nh_cur = 0, hh = 0, ucur = u0;
@@ -175,23 +180,48 @@ __global__ __launch_bounds__(kQThreads) void gemm_f16q_kernel(F16qGemm q, RingGe
     const int n0 = r.panel * kRingPanel;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      int wr = n0 + (wave + 8 * h) * 16 + prow;
-      if (wr > p.n - 1) wr = p.n - 1;
-      o_w16[h] = (uint32_t)(((size_t)wr * q.ldw + r.kbeg) * 2 + gchunk * 16);
+      if (q.w_tiled) {
+        int rb = (n0 >> 4) + wave + 8 * h;
+        const int rbmax = ((p.n + 15) >> 4) - 1;
+        if (rb > rbmax) rb = rbmax;
+        o_w16[h] = (uint32_t)(((size_t)rb * nkt + (r.kbeg >> 5)) * 1024 + lane * 16);
+      } else {
+        int wr = n0 + (wave + 8 * h) * 16 + prow;
+        if (wr > p.n - 1) wr = p.n - 1;
+        o_w16[h] = (uint32_t)(((size_t)wr * q.ldw + r.kbeg) * 2 + gchunk * 16);
+      }
       const int fr = wave + 8 * h;
-      int am = r.m0 + fr * 16 + prow;
-      if (am > p.m - 1) am = p.m - 1;
-      o_ahi[h] = (uint32_t)(((size_t)am * q.lda + r.kbeg) * 2 + gchunk * 16);
+      if (q.a_tiled) {
+        const int fb = (r.m0 >> 4) + (fr < r.f ? fr : r.f - 1);
+        o_ahi[h] = (uint32_t)(((size_t)fb * nkt + (r.kbeg >> 5)) * 1024 + lane * 16);
+      } else {
+        int am = r.m0 + fr * 16 + prow;
+        if (am > p.m - 1) am = p.m - 1;
+        o_ahi[h] = (uint32_t)(((size_t)am * q.lda + r.kbeg) * 2 + gchunk * 16);
+      }
     }
     n_ahi = r.f > wave + 8 ? 2 : (r.f > wave ? 1 : 0);
     {
-      int wr = n0 + (2 * wave + f8frag) * 16 + f8row;
-      if (wr > p.n - 1) wr = p.n - 1;
-      o_w8 = (uint32_t)((size_t)wr * q.ldw + r.kbeg + f8half * 16);
+      if (q.w_tiled) {
+        int pb = (n0 >> 5) + wave;
+        const int pbmax = ((p.n + 31) >> 5) - 1;
+        if (pb > pbmax) pb = pbmax;
+        o_w8 = (uint32_t)(((size_t)pb * nkt + (r.kbeg >> 5)) * 1024 + lane * 16);
+      } else {
+        int wr = n0 + (2 * wave + f8frag) * 16 + f8row;
+        if (wr > p.n - 1) wr = p.n - 1;
+        o_w8 = (uint32_t)((size_t)wr * q.ldw + r.kbeg + f8half * 16);
+      }
       const int pr = 7 - wave;
-      int am = r.m0 + (2 * pr + f8frag) * 16 + f8row;
-      if (am > p.m - 1) am = p.m - 1;
-      o_a8 = (uint32_t)((size_t)am * q.lda + r.kbeg + f8half * 16);
+      if (q.a_tiled) {
+        int fr = 2 * pr + f8frag;
+        if (fr > r.f - 1) fr = r.f - 1;
+        o_a8 = (uint32_t)(((size_t)((r.m0 >> 4) + fr) * nkt + (r.kbeg >> 5)) * 512 + (lane & 31) * 16);
+      } else {
+        int am = r.m0 + (2 * pr + f8frag) * 16 + f8row;
+        if (am > p.m - 1) am = p.m - 1;
+        o_a8 = (uint32_t)((size_t)am * q.lda + r.kbeg + f8half * 16);
+      }
       n_a8 = 2 * pr < r.f ? 1 : 0;
     }
     n_asc = (pcA >= 0 && pcA * 64 < r.f * 16) ? 1 : 0;
@@ -215,7 +245,8 @@ __global__ __launch_bounds__(kQThreads) void gemm_f16q_kernel(F16qGemm q, RingGe
   // bytes (a group's first quarter); 7 = W scale bytes (a unit's first half-stage).
   bool live = true;
   char* ibase = smem;
-  uint32_t ik16 = 0, ik8 = 0;
+  uint32_t ik16 = 0, ik8 = 0, ikw16 = 0, ikw8 = 0;
+  const uint32_t wstep16 = q.w_tiled ? 1024u : 64u, wstep8 = q.w_tiled ? 1024u : 32u, astep16 = q.a_tiled ? 1024u : 64u, astep8 = q.a_tiled ? 512u : 32u;
   auto issue_begin = [&](auto fast_c) {
     constexpr bool FAST = decltype(fast_c)::value;
     if constexpr (!FAST) {
@@ -227,15 +258,17 @@ __global__ __launch_bounds__(kQThreads) void gemm_f16q_kernel(F16qGemm q, RingGe
       live = ucur < uend;
     }
     ibase = smem + (gi & (kQSlots - 1)) * kQSlot;
-    ik16 = (uint32_t)hh * 64u;
-    ik8 = (uint32_t)hh * 32u;
+    ik16 = (uint32_t)hh * astep16;
+    ik8 = (uint32_t)hh * astep8;
+    ikw16 = (uint32_t)hh * wstep16;
+    ikw8 = (uint32_t)hh * wstep8;
   };
   auto piece = [&](auto p_c, auto sq_c) {
     constexpr int P = decltype(p_c)::value, SQ = decltype(sq_c)::value;
     if (!live) return;
-    if constexpr (P == 0) __builtin_amdgcn_global_load_lds((gptr_t)(b_w16 + o_w16[0] + ik16), (lptr_t)(ibase + kQW16 + wave * 1024), 16, 0, 0);
-    if constexpr (P == 1) __builtin_amdgcn_global_load_lds((gptr_t)(b_w16 + o_w16[1] + ik16), (lptr_t)(ibase + kQW16 + (wave + 8) * 1024), 16, 0, 0);
-    if constexpr (P == 2) __builtin_amdgcn_global_load_lds((gptr_t)(b_w8 + o_w8 + ik8), (lptr_t)(ibase + kQW8 + wave * 1024), 16, 0, 0);
+    if constexpr (P == 0) __builtin_amdgcn_global_load_lds((gptr_t)(b_w16 + o_w16[0] + ikw16), (lptr_t)(ibase + kQW16 + wave * 1024), 16, 0, 0);
+    if constexpr (P == 1) __builtin_amdgcn_global_load_lds((gptr_t)(b_w16 + o_w16[1] + ikw16), (lptr_t)(ibase + kQW16 + (wave + 8) * 1024), 16, 0, 0);
+    if constexpr (P == 2) __builtin_amdgcn_global_load_lds((gptr_t)(b_w8 + o_w8 + ikw8), (lptr_t)(ibase + kQW8 + wave * 1024), 16, 0, 0);
     if constexpr (P == 3) { if (n_ahi > 0) __builtin_amdgcn_global_load_lds((gptr_t)(b_ahi + o_ahi[0] + ik16), (lptr_t)(ibase + kQAhi + wave * 1024), 16, 0, 0); }
     if constexpr (P == 4) { if (n_ahi > 1) __builtin_amdgcn_global_load_lds((gptr_t)(b_ahi + o_ahi[1] + ik16), (lptr_t)(ibase + kQAhi + (wave + 8) * 1024), 16, 0, 0); }
     if constexpr (P == 5) { if (n_a8) __builtin_amdgcn_global_load_lds((gptr_t)(b_a8 + o_a8 + ik8), (lptr_t)(ibase + kQA8 + (7 - wave) * 1024), 16, 0, 0); }
@@ -473,8 +506,8 @@ __global__ __launch_bounds__(256) void split_f16q_kernel(const float* __restrict
     amax = half_wave_max(amax);
     const int E = f16q_exp(amax);
     if (live) {
-      *reinterpret_cast<f16x4_t*>(o.hi + (size_t)row * o.ld + col) = hv;
-      *reinterpret_cast<uint32_t*>(o.lo8 + (size_t)row * o.ld + col) = f16q_pack4(lo[0], lo[1], lo[2], lo[3], f16q_inv(E));
+      *reinterpret_cast<f16x4_t*>(o.hi + f16q_hi_off(o, row, col)) = hv;
+      *reinterpret_cast<uint32_t*>(o.lo8 + f16q_lo_off(o, row, col)) = f16q_pack4(lo[0], lo[1], lo[2], lo[3], f16q_inv(E));
       if ((threadIdx.x & 31) == 0) o.sc[(size_t)row * o.ldsc + (col >> 7)] = (uint8_t)f16q_byte(E);
     }
   }
@@ -510,6 +543,22 @@ __global__ __launch_bounds__(256) void weights_f16q_kernel(const uint16_t* __res
 }
 
 
+// e4m3 [rows, k] row-major -> the tiled layout of the f16q kernel's e4m3 pieces: block (b = row / 32, t = k / 32) is the 1 KB at
+// ((b * k / 32) + t) * 1 KB; inside it the 16-byte chunk at position l (0 .. 63) holds row 32 b + (l >> 5) * 16 + (l & 15), bytes
+// 32 t + ((l >> 4) & 1) * 16 .. + 15 - the order in which the lanes of a fragment-pair piece deposit it.  Rows beyond the matrix repeat the last.
+__global__ __launch_bounds__(256) void tile_e4m3_kernel(const uint8_t* __restrict__ src, int rows, int k, int ld, uint8_t* __restrict__ dst) {
+  const int nkt = k >> 5;
+  const size_t chunks = (size_t)((rows + 31) >> 5) * nkt * 64;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (size_t)gridDim.x * 256) {
+    const int l = (int)(i & 63);
+    const size_t blk = i >> 6;
+    const int t = (int)(blk % nkt);
+    int row = (int)(blk / nkt) * 32 + (l >> 5) * 16 + (l & 15);
+    if (row > rows - 1) row = rows - 1;
+    *reinterpret_cast<u32x4*>(dst + i * 16) = *reinterpret_cast<const u32x4*>(src + (size_t)row * ld + t * 32 + ((l >> 4) & 1) * 16);
+  }
+}
+
 // one row's 4 consecutive values of this thread -> the row's f16q planes (a 128-value block = this thread's half-wave; every lane of the
 // half-wave must call, `live` says whether its columns exist)
 __device__ __forceinline__ void f16q_put4(const F16qPlanes& o, int row, int col, const float (&v)[4], bool live) {
@@ -526,8 +575,8 @@ __device__ __forceinline__ void f16q_put4(const F16qPlanes& o, int row, int col,
   amax = half_wave_max(live ? amax : 0.f);
   const int E = f16q_exp(amax);
   if (live) {
-    *reinterpret_cast<f16x4_t*>(o.hi + (size_t)row * o.ld + col) = hv;
-    *reinterpret_cast<uint32_t*>(o.lo8 + (size_t)row * o.ld + col) = f16q_pack4(lo[0], lo[1], lo[2], lo[3], f16q_inv(E));
+    *reinterpret_cast<f16x4_t*>(o.hi + f16q_hi_off(o, row, col)) = hv;
+    *reinterpret_cast<uint32_t*>(o.lo8 + f16q_lo_off(o, row, col)) = f16q_pack4(lo[0], lo[1], lo[2], lo[3], f16q_inv(E));
     if ((threadIdx.x & 31) == 0) o.sc[(size_t)row * o.ldsc + (col >> 7)] = (uint8_t)f16q_byte(E);
   }
 }
@@ -657,13 +706,14 @@ int launch_f16q(const F16qGemm& q, const RingGeom& g, hipStream_t s) {
 using namespace chatts;
 
 extern "C" int chatts_split_f16q(const float* x, int m, int k, int ldx, chatts_f16* hi, uint8_t* lo8, uint8_t* scale, int ld_planes, int ld_scale,
-                                 chatts_stream_t stream) {
+                                 int tiled, chatts_stream_t stream) {
+  CHATTS_REQUIRE(!tiled || ld_planes == k, CHATTS_E_SHAPE, "split_f16q: tiled planes need ld_planes == K");
   CHATTS_REQUIRE(m >= 0 && k > 0 && k % kF16qBlock == 0, CHATTS_E_SHAPE, "split_f16q: m=%d k=%d (K must be a multiple of 128)", m, k);
   if (m == 0) return CHATTS_OK;
   CHATTS_REQUIRE(x && hi && lo8 && scale, CHATTS_E_BADARG, "split_f16q: null pointer");
   CHATTS_REQUIRE(ldx >= k && ldx % 4 == 0 && ld_planes >= k && ld_planes % 16 == 0 && ld_scale >= k / kF16qBlock && ((uintptr_t)x % 16) == 0 &&
                      ((uintptr_t)hi % 16) == 0 && ((uintptr_t)lo8 % 16) == 0, CHATTS_E_SHAPE, "split_f16q: leading dimensions / alignment");
-  F16qPlanes o{reinterpret_cast<_Float16*>(hi), lo8, scale, ld_planes, ld_scale};
+  F16qPlanes o{reinterpret_cast<_Float16*>(hi), lo8, scale, ld_planes, ld_scale, tiled};
   hipLaunchKernelGGL(split_f16q_kernel, dim3(m), dim3(256), 0, as_stream(stream), x, k, ldx, o);
   CHATTS_CHECK_LAUNCH("split_f16q");
   return CHATTS_OK;
@@ -685,7 +735,7 @@ extern "C" int chatts_weights_f16q(const chatts_bf16* w, int n, int k, int ldw, 
 static int f16q_splitk_epilogue(const ChattsLinearF16qArgs* a, int sk, hipStream_t s) {
   CHATTS_REQUIRE(sk <= 4 && a->n <= 8192 && a->n % 4 == 0 && a->epilogue != CHATTS_EPI_SWIGLU && a->epilogue != CHATTS_EPI_GELU, CHATTS_E_SHAPE,
                  "linear_f16q: split-K epilogue handles <= 4 slabs of <= 8192 columns (EPI_NONE / EPI_RESID); got sk=%d n=%d", sk, a->n);
-  F16qPlanes o{reinterpret_cast<_Float16*>(a->post_hi), a->post_lo8, a->post_scale, a->ld_post, a->ld_pscale};
+  F16qPlanes o{reinterpret_cast<_Float16*>(a->post_hi), a->post_lo8, a->post_scale, a->ld_post, a->ld_pscale, a->planes_tiled};
   if (a->post_norm_w)
     CHATTS_REQUIRE(o.hi && o.lo8 && o.sc && a->n % kF16qBlock == 0 && a->ld_post >= a->n && a->ld_post % 4 == 0 && a->ld_pscale >= a->n / kF16qBlock,
                    CHATTS_E_SHAPE, "linear_f16q: post-norm planes need hi / lo8 / scale, N %% 128 == 0, ld_post >= N");
@@ -706,13 +756,27 @@ static int f16q_splitk_epilogue(const ChattsLinearF16qArgs* a, int sk, hipStream
   return CHATTS_OK;
 }
 
+extern "C" size_t chatts_tile_e4m3_bytes(int rows, int k) { return rows > 0 && k > 0 ? (size_t)((rows + 31) / 32) * 32 * k : 0; }
+
+extern "C" int chatts_tile_e4m3(const uint8_t* src, int rows, int k, int ld, uint8_t* dst, chatts_stream_t stream) {
+  CHATTS_REQUIRE(rows >= 0 && k > 0 && k % 32 == 0 && ld >= k && ld % 16 == 0, CHATTS_E_SHAPE, "tile_e4m3: rows=%d k=%d ld=%d (K %% 32 == 0, ld %% 16 == 0)", rows, k, ld);
+  if (rows == 0) return CHATTS_OK;
+  CHATTS_REQUIRE(src && dst && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, CHATTS_E_BADARG, "tile_e4m3: null / unaligned pointer");
+  const size_t chunks = chatts_tile_e4m3_bytes(rows, k) / 16;
+  const unsigned blocks = (unsigned)((chunks + 255) / 256 < 16384 ? (chunks + 255) / 256 : 16384);
+  hipLaunchKernelGGL(tile_e4m3_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, rows, k, ld, dst);
+  CHATTS_CHECK_LAUNCH("tile_e4m3");
+  return CHATTS_OK;
+}
+
 extern "C" int chatts_rmsnorm_f16q(const float* x, const float* w, chatts_f16* hi, uint8_t* lo8, uint8_t* scale, int ld_planes, int ld_scale, int t,
-                                   int hidden, float eps, chatts_stream_t stream) {
+                                   int hidden, float eps, int tiled, chatts_stream_t stream) {
+  CHATTS_REQUIRE(!tiled || ld_planes == hidden, CHATTS_E_SHAPE, "rmsnorm_f16q: tiled planes need ld_planes == hidden");
   CHATTS_REQUIRE(t >= 0 && hidden > 0 && hidden % kF16qBlock == 0, CHATTS_E_SHAPE, "rmsnorm_f16q: t=%d hidden=%d (a multiple of 128)", t, hidden);
   if (t == 0) return CHATTS_OK;
   CHATTS_REQUIRE(x && w && hi && lo8 && scale, CHATTS_E_BADARG, "rmsnorm_f16q: null pointer");
   CHATTS_REQUIRE(ld_planes >= hidden && ld_planes % 4 == 0 && ld_scale >= hidden / kF16qBlock, CHATTS_E_SHAPE, "rmsnorm_f16q: leading dimensions");
-  F16qPlanes o{reinterpret_cast<_Float16*>(hi), lo8, scale, ld_planes, ld_scale};
+  F16qPlanes o{reinterpret_cast<_Float16*>(hi), lo8, scale, ld_planes, ld_scale, tiled};
   hipLaunchKernelGGL(rmsnorm_f16q_kernel, dim3(t), dim3(256), 0, as_stream(stream), x, w, hidden, eps, o);
   CHATTS_CHECK_LAUNCH("rmsnorm_f16q");
   return CHATTS_OK;
@@ -732,6 +796,10 @@ extern "C" int chatts_linear_f16q(const ChattsLinearF16qArgs* a, chatts_stream_t
   CHATTS_REQUIRE(a->a_hi && a->a_lo8 && a->a_scale && a->w16 && a->w8 && a->w8_exp, CHATTS_E_BADARG, "linear_f16q: null operand");
   CHATTS_REQUIRE(a->k % kF16qBlock == 0 && a->n % 16 == 0 && (a->epilogue != CHATTS_EPI_SWIGLU || a->n % 256 == 0), CHATTS_E_SHAPE,
                  "linear_f16q: K=%d must be a multiple of 128, N=%d of 16 (SwiGLU: 256)", a->k, a->n);
+  CHATTS_REQUIRE(!a->w_tiled || a->ldw == a->k, CHATTS_E_SHAPE, "linear_f16q: tiled weights need ldw == K");
+  CHATTS_REQUIRE(!a->planes_tiled || (a->ld_a == a->k && (!a->c_hi || a->ld_cplanes == (a->epilogue == CHATTS_EPI_SWIGLU ? a->n / 2 : a->n)) &&
+                                      (!a->post_norm_w || a->ld_post == a->n)), CHATTS_E_SHAPE,
+                 "linear_f16q: tiled planes need ld_a == K, ld_cplanes == the output width, ld_post == N");
   CHATTS_REQUIRE(a->ld_a >= a->k && a->ld_a % 16 == 0 && a->ldw >= a->k && a->ldw % 16 == 0 && a->ld_scale >= a->k / kF16qBlock &&
                      ((uintptr_t)a->a_hi % 16) == 0 && ((uintptr_t)a->a_lo8 % 16) == 0 && ((uintptr_t)a->w16 % 16) == 0 && ((uintptr_t)a->w8 % 16) == 0,
                  CHATTS_E_SHAPE, "linear_f16q: operand leading dimensions (multiples of 16) / 16-byte alignment");
@@ -768,12 +836,12 @@ extern "C" int chatts_linear_f16q(const ChattsLinearF16qArgs* a, chatts_stream_t
     q.g.c = a->c;
   }
   q.a_hi = reinterpret_cast<const _Float16*>(a->a_hi); q.a_lo8 = a->a_lo8; q.a_sc = a->a_scale; q.lda = a->ld_a; q.ldsc = a->ld_scale;
-  q.w16 = reinterpret_cast<const _Float16*>(a->w16); q.w8 = a->w8; q.w8e = a->w8_exp; q.ldw = a->ldw;
+  q.w16 = reinterpret_cast<const _Float16*>(a->w16); q.w8 = a->w8; q.w8e = a->w8_exp; q.ldw = a->ldw; q.w_tiled = a->w_tiled; q.a_tiled = a->planes_tiled; q.c_tiled = a->planes_tiled;
   q.c_hi = reinterpret_cast<_Float16*>(a->c_hi); q.c_lo8 = a->c_lo8; q.c_sc = a->c_scale; q.ldcp = a->ld_cplanes; q.ldcsc = a->ld_cscale;
   if (const int rc = launch_f16q(q, g, as_stream(stream))) return rc;
   CHATTS_CHECK_LAUNCH("gemm_f16q");
   if (sk > 1) return f16q_splitk_epilogue(a, sk, as_stream(stream));
   if (a->post_norm_w)
-    return chatts_rmsnorm_f16q(a->c, a->post_norm_w, a->post_hi, a->post_lo8, a->post_scale, a->ld_post, a->ld_pscale, a->m, a->n, a->post_norm_eps, stream);
+    return chatts_rmsnorm_f16q(a->c, a->post_norm_w, a->post_hi, a->post_lo8, a->post_scale, a->ld_post, a->ld_pscale, a->m, a->n, a->post_norm_eps, a->planes_tiled, stream);
   return CHATTS_OK;
 }

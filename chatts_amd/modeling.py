@@ -386,7 +386,7 @@ class ChatTSForCausalLM:
             "act": torch.zeros((self.t_max, plan.inter), **f32), "delta": torch.zeros((self.t_max, H), **f32),
             "logits": torch.zeros(plan.vocab, **f32),
             # two pairs of bf16 hi / lo planes (prefill: LDS-DMA GEMM operands; pair 0 = projection input, pair 1 = SwiGLU out)
-            "planes": torch.zeros((4, self.t_max, max(H, plan.nq * d, plan.inter)), dtype=torch.bfloat16, device=dev),
+            "planes": torch.zeros((4, (self.t_max + 31) // 32 * 32, max(H, plan.nq * d, plan.inter)), dtype=torch.bfloat16, device=dev),   # (rows: whole 16-row blocks for the tiled f16q planes)
             "ws": torch.zeros(ws_bytes, dtype=torch.uint8, device=dev),
             # decode-loop state lives on the device so a captured step can be replayed
             "pos_all": torch.zeros(MB, dtype=torch.int32, device=dev), "step_all": torch.zeros(MB, dtype=torch.int32, device=dev),
@@ -434,7 +434,12 @@ class ChatTSForCausalLM:
                     w8 = torch.empty((rows, k), dtype=torch.uint8, device=dev)
                     w8e = torch.empty((rows,), dtype=torch.uint8, device=dev)
                     _lib.check(lib.chatts_weights_f16q(w.data_ptr(), rows, k, k, w16.data_ptr(), w8.data_ptr(), w8e.data_ptr(), k, _lib.stream_ptr()))
-                    qd[name] = (w16, w8, w8e)
+                    # ... stored in the kernel's own block order: an LDS-DMA piece is 1 KB of consecutive memory
+                    w16t = torch.empty(int(lib.chatts_tile_bf16_elems(rows, k)), dtype=torch.float16, device=dev)
+                    w8t = torch.empty(int(lib.chatts_tile_e4m3_bytes(rows, k)), dtype=torch.uint8, device=dev)
+                    _lib.check(lib.chatts_tile_bf16(w16.data_ptr(), rows, k, k, w16t.data_ptr(), _lib.stream_ptr()))
+                    _lib.check(lib.chatts_tile_e4m3(w8.data_ptr(), rows, k, k, w8t.data_ptr(), _lib.stream_ptr()))
+                    qd[name] = (w16t, w8t, w8e)
             self._f16q.append(qd)
         arr = (_lib.LayerWeights * L)()
         for i, lw in enumerate(self.layers):

@@ -282,13 +282,23 @@ typedef struct ChattsLinearF16qArgs {
   int ld_post, ld_pscale;
   void* workspace;
   size_t workspace_bytes;
+  int planes_tiled;          /* EVERY plane set of this call - a_hi / a_lo8, the SwiGLU output c_hi / c_lo8, post_hi / post_lo8 - is in the TILED plane
+                              * layout (csrc/f16q.h: blocks of 16 rows x 32 K-values, hi 1 KB in chatts_tile_bf16's order, lo8 512 B = two 16-byte
+                              * halves per row; leading dimensions = the matrix widths; buffers hold ceil(M / 16) * 16 rows); scales stay row-major */
+  int w_tiled;               /* w16 / w8 are in the tiled layouts of chatts_tile_bf16 (as 16-bit elements) / chatts_tile_e4m3 (ldw == K): every
+                              * LDS-DMA piece of the weights is 1 KB of consecutive memory; bit-identical results */
 } ChattsLinearF16qArgs;
 int chatts_split_f16q(const float* x, int m, int k, int ldx, chatts_f16* hi, uint8_t* lo8, uint8_t* scale, int ld_planes, int ld_scale,
-                      chatts_stream_t stream);
+                      int tiled, chatts_stream_t stream);
 int chatts_weights_f16q(const chatts_bf16* w, int n, int k, int ldw, chatts_f16* w16, uint8_t* w8, uint8_t* w8_exp, int ld_out,
                         chatts_stream_t stream);
 int chatts_rmsnorm_f16q(const float* x, const float* w, chatts_f16* hi, uint8_t* lo8, uint8_t* scale, int ld_planes, int ld_scale, int t,
-                        int hidden, float eps, chatts_stream_t stream);
+                        int hidden, float eps, int tiled, chatts_stream_t stream);
+/* e4m3 [rows, ld] row-major (K % 32 == 0) -> the tiled layout of the f16q kernel's e4m3 pieces: block (b = row / 32, t = k / 32) is the 1 KB at
+ * ((b * K / 32) + t) * 1 KB; the 16-byte chunk at position l holds row 32 b + (l >> 5) * 16 + (l & 15), bytes 32 t + ((l >> 4) & 1) * 16 .. + 15.
+ * dst holds chatts_tile_e4m3_bytes(rows, k) = ceil(rows / 32) * 32 * k bytes; rows beyond the matrix repeat the last row. */
+size_t chatts_tile_e4m3_bytes(int rows, int k);
+int chatts_tile_e4m3(const uint8_t* src, int rows, int k, int ld, uint8_t* dst, chatts_stream_t stream);
 size_t chatts_linear_f16q_workspace(int m, int n, int k);
 int chatts_linear_f16q(const ChattsLinearF16qArgs* a, chatts_stream_t stream);
 
@@ -573,8 +583,8 @@ typedef struct ChattsLayerWeights {
   /* optional copies of the four bf16 matrices in the tiled layout of chatts_tile_bf16 (ChattsLinearArgs.w_tiled): the operand feed of the
    * prefill kernel reads them as consecutive memory; every other kernel keeps streaming the row-major tensors.  NULL = row-major only. */
   const chatts_bf16* qkv_t; const chatts_bf16* o_t; const chatts_bf16* gate_up_t; const chatts_bf16* down_t;
-  /* optional f16q copies (chatts_weights_f16q: f16 [N, K], e4m3 [N, K], e8m0 row exponent [N]) of the four matrices: the operands of
-   * chatts_decoder_set_prefill_f16q.  NULL otherwise. */
+  /* optional f16q copies of the four matrices, TILED (chatts_weights_f16q, then chatts_tile_bf16 on the f16 copy and chatts_tile_e4m3 on the
+   * e4m3 copy; e8m0 row exponent [N]): the operands of chatts_decoder_set_prefill_f16q.  NULL otherwise. */
   const chatts_f16* qkv16; const uint8_t* qkv_q8; const uint8_t* qkv_q8e;
   const chatts_f16* o16; const uint8_t* o_q8; const uint8_t* o_q8e;
   const chatts_f16* gate_up16; const uint8_t* gate_up_q8; const uint8_t* gate_up_q8e;
@@ -667,7 +677,7 @@ int chatts_decoder_set_prefill_fp8(ChattsDecoder*, int on);
  * operand split (chatts_linear_f16q: f16 high part on v_mfma_f32_16x16x32_f16 + e4m3 residual x e4m3 weights on the CDNA4 block-scaled
  * v_mfma_scale_f32_16x16x128_f8f6f4) instead of the bf16 hi / lo split - the fp8 matrix pipe at float32 grade (logits ~1.3e-4 of the
  * float32 oracle at full depth against ~5e-5 for the default; bar 1e-3).  Needs every layer's f16q weight copies, hidden / inter / n_q * 128
- * multiples of 128, the plane buffers as scratch.  RoPE, cache, attention, residual stream and all decode steps are unchanged. */
+ * multiples of 128, the plane buffers as scratch (each holding ceil(t_max / 32) * 32 rows of max(hidden, inter, n_q * 128) bf16 elements).  RoPE, cache, attention, residual stream and all decode steps are unchanged. */
 int chatts_decoder_set_prefill_f16q(ChattsDecoder* d, int on);
 
 /* Attach the tensor-parallel exchange (tp_world > 1): chatts_decoder_decode_step(_batched) then run whole TP steps on the

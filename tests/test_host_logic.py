@@ -264,7 +264,7 @@ def test_c_abi_argument_validation_needs_no_gpu():
     assert lib.chatts_tile_bf16(None, 16, 64, 64, None, None) == _lib.E_BADARG
     assert lib.chatts_tile_bf16(None, 0, 64, 64, None, None) == 0                        # empty input: nothing to do
     assert lib.chatts_linear_f16q(None, None) == _lib.E_BADARG
-    assert lib.chatts_split_f16q(None, 4, 100, 100, None, None, None, 100, 1, None) == _lib.E_SHAPE
+    assert lib.chatts_split_f16q(None, 4, 100, 100, None, None, None, 100, 1, 0, None) == _lib.E_SHAPE
     assert lib.chatts_tp_buffer_bytes(9, 1024) == 0 and lib.chatts_tp_buffer_bytes(2, 1024) == 2 * 2 * 1024 * 8 + 256
     assert lib.chatts_tp_buffer_bytes_bulk(2, 1024, 4096) > lib.chatts_tp_buffer_bytes(2, 1024)
     assert lib.chatts_tp_bulk_release(None) == -1 and lib.chatts_tp_cross_device(None) == -1

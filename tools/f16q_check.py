@@ -37,11 +37,27 @@ def prep(n, k, epi, name):
     c["qhi"] = torch.empty((M, k), dtype=torch.float16, device=DEV)
     c["qlo"] = torch.empty((M, k), dtype=torch.uint8, device=DEV)
     c["qsc"] = torch.empty((M, k // 128), dtype=torch.uint8, device=DEV)
-    _lib.check(lib.chatts_split_f16q(a.data_ptr(), M, k, k, c["qhi"].data_ptr(), c["qlo"].data_ptr(), c["qsc"].data_ptr(), k, k // 128, st.cuda_stream))
+    _lib.check(lib.chatts_split_f16q(a.data_ptr(), M, k, k, c["qhi"].data_ptr(), c["qlo"].data_ptr(), c["qsc"].data_ptr(), k, k // 128, 0, st.cuda_stream))
     c["w16"] = torch.empty((n, k), dtype=torch.float16, device=DEV)
     c["w8"] = torch.empty((n, k), dtype=torch.uint8, device=DEV)
     c["w8e"] = torch.empty((n,), dtype=torch.uint8, device=DEV)
     _lib.check(lib.chatts_weights_f16q(w.data_ptr(), n, k, k, c["w16"].data_ptr(), c["w8"].data_ptr(), c["w8e"].data_ptr(), k, st.cuda_stream))
+    c["w16t"] = torch.empty(lib.chatts_tile_bf16_elems(n, k), dtype=torch.float16, device=DEV)
+    c["w8t"] = torch.empty(lib.chatts_tile_e4m3_bytes(n, k), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.chatts_tile_bf16(c["w16"].data_ptr(), n, k, k, c["w16t"].data_ptr(), st.cuda_stream))
+    _lib.check(lib.chatts_tile_e4m3(c["w8"].data_ptr(), n, k, k, c["w8t"].data_ptr(), st.cuda_stream))
+    c["out_qt"] = torch.zeros((M, c["ncols"]), device=DEV)
+    # tiled activation planes (blocks of 16 rows: buffers hold ceil(M / 16) * 16 rows)
+    M16 = (M + 15) // 16 * 16
+    c["thi"] = torch.zeros((M16, k), dtype=torch.float16, device=DEV)
+    c["tlo"] = torch.zeros((M16, k), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.chatts_split_f16q(a.data_ptr(), M, k, k, c["thi"].data_ptr(), c["tlo"].data_ptr(), c["qsc"].data_ptr(), k, k // 128, 1, st.cuda_stream))
+    c["out_qa"] = torch.zeros((M, c["ncols"]), device=DEV)
+    nc16 = c["ncols"]
+    c["tchi"] = torch.zeros((M16, nc16), dtype=torch.float16, device=DEV)
+    c["tclo"] = torch.zeros((M16, nc16), dtype=torch.uint8, device=DEV)
+    c["tnhi"] = torch.zeros((M16, n), dtype=torch.float16, device=DEV)
+    c["tnlo"] = torch.zeros((M16, n), dtype=torch.uint8, device=DEV)
     nc = c["ncols"]
     c["resid"] = torch.randn((M, nc), device=DEV)
     c["bias"] = torch.randn((n,), device=DEV) if name == "qkv" else None
@@ -74,17 +90,19 @@ def run_bf16x2(c):
     _lib.check(lib.chatts_linear(la, st.cuda_stream))
 
 
-def run_f16q(c):
-    qa = _lib.LinearF16qArgs(a_hi=c["qhi"].data_ptr(), a_lo8=c["qlo"].data_ptr(), a_scale=c["qsc"].data_ptr(), ld_a=c["k"], ld_scale=c["k"] // 128,
-                             w16=c["w16"].data_ptr(), w8=c["w8"].data_ptr(), w8_exp=c["w8e"].data_ptr(), ldw=c["k"], bias=_lib.ptr(c["bias"]),
-                             resid=c["resid"].data_ptr() if c["epi"] == _lib.EPI_RESID else None, c=c["out_q"].data_ptr(), m=M, n=c["n"], k=c["k"],
+def run_f16q(c, tiled=False, atiled=False):
+    qa = _lib.LinearF16qArgs(a_hi=c["thi" if atiled else "qhi"].data_ptr(), a_lo8=c["tlo" if atiled else "qlo"].data_ptr(), a_scale=c["qsc"].data_ptr(), ld_a=c["k"], ld_scale=c["k"] // 128,
+                             planes_tiled=1 if atiled else 0,
+                             w16=c["w16t" if tiled else "w16"].data_ptr(), w8=c["w8t" if tiled else "w8"].data_ptr(), w8_exp=c["w8e"].data_ptr(), ldw=c["k"],
+                             w_tiled=1 if tiled else 0, bias=_lib.ptr(c["bias"]),
+                             resid=c["resid"].data_ptr() if c["epi"] == _lib.EPI_RESID else None, c=c["out_qa" if atiled else ("out_qt" if tiled else "out_q")].data_ptr(), m=M, n=c["n"], k=c["k"],
                              ldc=c["ncols"], epilogue=c["epi"], workspace=c["wsp"].data_ptr(), workspace_bytes=c["wsp"].numel())
     if c["epi"] == _lib.EPI_SWIGLU and not c.get("plain"):
         qa.c = None
-        qa.c_hi, qa.c_lo8, qa.c_scale, qa.ld_cplanes, qa.ld_cscale = c["chi"].data_ptr(), c["clo"].data_ptr(), c["csc"].data_ptr(), c["ncols"], c["ncols"] // 128
+        qa.c_hi, qa.c_lo8, qa.c_scale, qa.ld_cplanes, qa.ld_cscale = c["tchi" if atiled else "chi"].data_ptr(), c["tclo" if atiled else "clo"].data_ptr(), c["csc"].data_ptr(), c["ncols"], c["ncols"] // 128
     if c["epi"] == _lib.EPI_RESID:
         qa.post_norm_w, qa.post_norm_eps = c["nw"].data_ptr(), 1e-6
-        qa.post_hi, qa.post_lo8, qa.post_scale, qa.ld_post, qa.ld_pscale = c["qnhi"].data_ptr(), c["qnlo"].data_ptr(), c["qnsc"].data_ptr(), c["n"], c["n"] // 128
+        qa.post_hi, qa.post_lo8, qa.post_scale, qa.ld_post, qa.ld_pscale = c["tnhi" if atiled else "qnhi"].data_ptr(), c["tnlo" if atiled else "qnlo"].data_ptr(), c["qnsc"].data_ptr(), c["n"], c["n"] // 128
     _lib.check(lib.chatts_linear_f16q(qa, st.cuda_stream))
 
 
@@ -103,8 +121,11 @@ if CHECK:
         # GEMM (float32 output forms) against the float64 product of the dequantised operands, and against the true float32 product
         c["plain"] = True
         run_f16q(c)
+        run_f16q(c, tiled=True)
+        run_f16q(c, tiled=True, atiled=True)
         run_bf16x2(c)
         torch.cuda.synchronize()
+        tiled_same = bool((c["out_q"].view(torch.int32) == c["out_qt"].view(torch.int32)).all()) and bool((c["out_q"].view(torch.int32) == c["out_qa"].view(torch.int32)).all())
         ref = f16q_ref.gemm(c["qhi"], c["qlo"], c["qsc"], c["w16"], c["w8"], c["w8e"])
         true = c["a"].double() @ c["w"].double().t()
         if c["bias"] is not None:
@@ -117,7 +138,7 @@ if CHECK:
                 return (torch.nn.functional.silu(v[:, :, 0]) * v[:, :, 1]).reshape(M, c["n"] // 2)
             ref, true = sw(ref), sw(true)
         line = f"{name:8s} producers {'ok' if all(prod.values()) else prod}  f16q vs its float64 reference {rel(c['out_q'], ref):.2e}  vs the true product {rel(c['out_q'], true):.2e}" \
-               f"  (bf16x2 vs true {rel(c['out'], true):.2e})"
+               f"  (bf16x2 vs true {rel(c['out'], true):.2e})  tiled weights / planes bit-identical: {tiled_same}"
         c["plain"] = False
         if c["epi"] == _lib.EPI_SWIGLU:          # plane output: bit-exact against the split of the float32 output
             run_f16q(c)
@@ -132,10 +153,11 @@ if CHECK:
             line += f"  post-norm planes: scale bytes equal {float((es == c['qnsc']).float().mean()):.4f}  max|hi - ref| {dh:.2e}"
         print(line, flush=True)
 
-res = {(s, a): [] for s in SHAPES for a in ("bf16x2", "f16q")}
+ARMS = (("bf16x2", run_bf16x2), ("f16q", run_f16q), ("f16q W tiled", lambda c: run_f16q(c, tiled=True)), ("f16q all tiled", lambda c: run_f16q(c, tiled=True, atiled=True)))
+res = {(s, a): [] for s in SHAPES for a, _ in ARMS}
 for rnd in range(R + 1):
     for sname, c in cases.items():
-        for aname, fn in (("bf16x2", run_bf16x2), ("f16q", run_f16q)):
+        for aname, fn in ARMS:
             fn(c)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -146,7 +168,7 @@ for rnd in range(R + 1):
             torch.cuda.synchronize()
             if rnd > 0:
                 res[(sname, aname)].append(e0.elapsed_time(e1) * 1e3 / 3)
-tot = {"bf16x2": 0.0, "f16q": 0.0}
+tot = {a: 0.0 for a, _ in ARMS}
 for sname in SHAPES:
     line = f"{sname:8s}"
     for aname in tot:
