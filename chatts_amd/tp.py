@@ -123,13 +123,17 @@ class P2PExchange:
 
     @staticmethod
     def device_identity():
-        """what tells two ranks' GPUs apart: host + the device's uuid (or PCI address)"""
+        """what tells two ranks' GPUs apart: host + everything this process knows about its device - uuid and PCI address when torch
+        exposes them, and always the device index together with the visibility masks it is relative to (one process per GPU under a
+        launcher: the indices differ even where uuid / PCI fields are missing).  Equal identities = the same device; anything else is
+        treated as another device (the conservative side: fence, or the light form after the test sums)."""
+        import os
         import socket
-        props = torch.cuda.get_device_properties(torch.cuda.current_device())
-        ident = getattr(props, "uuid", None)
-        if ident is None:
-            ident = tuple(getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
-        return (socket.gethostname(), str(ident))
+        idx = torch.cuda.current_device()
+        props = torch.cuda.get_device_properties(idx)
+        pci = tuple(getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        masks = tuple(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"))
+        return (socket.gethostname(), str(getattr(props, "uuid", None)), pci, idx, masks)
 
     def bulk_release(self):
         """'fence' | 'light': the form the next bulk sum uses (chatts_tp_bulk_release)"""
