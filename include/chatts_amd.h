@@ -251,7 +251,9 @@ int chatts_linear(const ChattsLinearArgs* args, chatts_stream_t stream);
  *   E + 127 = one e8m0 byte per row and 128 consecutive K-values [M, ld_scale]: the smallest power of two with max|lo| / 2^E <= 448 (127 for
  *   an all-zero block).  Weights: an f16 copy of the bf16 matrix (exact for 2^-17 <= |w| <= 65504) and an e4m3 copy with ONE power-of-two
  *   scale per row (byte E + 127, the same rule over the row).  C = epilogue(hi . W16^T + (q 2^E) . (W8 2^Ew)^T), float32 accumulate.
- * chatts_split_f16q: float32 [M, K] -> planes (K % 128 == 0).  chatts_weights_f16q: bf16 [N, K] -> (w16, w8, w8_exp), ld_out % 16 == 0.
+ * chatts_split_f16q: float32 [M, K] -> planes (K % 128 == 0); tiled != 0 (also chatts_rmsnorm_f16q's): hi / lo8 in the TILED plane layout
+ * (ChattsLinearF16qArgs.planes_tiled; ld_planes == K; buffers of ceil(M / 16) * 16 rows).  chatts_weights_f16q: bf16 [N, K] -> (w16, w8, w8_exp), ld_out % 16 == 0;
+ * chatts_tile_bf16 (on w16, as 16-bit elements) and chatts_tile_e4m3 (on w8) turn them into the kernel's block order (w_tiled).
  * chatts_rmsnorm_f16q: chatts_rmsnorm's arithmetic with the row written as planes.  chatts_linear_f16q: the GEMM (M >= 1; meant for
  * prefill chunks); epilogues of chatts_linear; SWIGLU may write its result as planes (c_hi / c_lo8 / c_scale: the next projection's
  * operand) instead of float32 c; EPI_NONE / EPI_RESID may additionally write RMSNorm(c) as planes (post_*), fused into the split-K
