@@ -410,9 +410,18 @@ class ChatTSForCausalLM:
                 self._kv.retire(sl)
                 self._push_kv_row(sl)
         self._tiled = []
+        tile_ok = self.prefill_tiled_weights
         for lw in self.layers:
             tiled = {}
-            if self.prefill_tiled_weights:
+            if tile_ok:
+                # the copies are an optimisation: never let them take the memory the KV cache / activations of a large configuration need
+                need = sum(lw[n].numel() * 2 for n in ("qkv", "o", "gate_up", "down"))
+                free = torch.cuda.mem_get_info(dev)[0]
+                if free < need + (8 << 30):
+                    import warnings
+                    warnings.warn(f"prefill_tiled_weights: {free / 2**30:.1f} GiB free - layers {len(self._tiled)}.. keep the row-major weights only")
+                    tile_ok = False
+            if tile_ok:
                 for name in ("qkv", "o", "gate_up", "down"):
                     w = lw[name]
                     rows, k = w.shape
